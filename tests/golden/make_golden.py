@@ -1,0 +1,431 @@
+#!/usr/bin/env python3
+"""Generate the golden parity fixtures under tests/golden/ by IMPORTING the reference.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    PYTHONPATH=tools/refshim:/root/reference python tests/golden/make_golden.py
+
+`tools/refshim` holds an identity-decorator `numba` stand-in so the reference's
+pure-Python jitted bodies run unmodified.  Nothing from the reference is copied:
+this script drives the reference's public functions and records inputs/outputs.
+
+Fixtures:
+  g1_movegen.npz   seeded random playouts through azalea.game.hex.HexGame
+  g2_flip.npz      HexGame.flip_player_board_moves on random padded batches
+  g3_forward_*.npz HexNetwork.forward (weights + inputs + value/logprob)
+  g4_search_*.npz  SearchTree.search with stub networks: evaluation tape + tree dump
+  g5_game_*.npz    play_game([AzaleaAgent(Policy(stub))]) full self-play traces
+  g6_collate.npz   prep.torch_batch_replays on a small ReplayDataFrame
+"""
+import os
+import sys
+import zlib
+
+import numpy as np
+
+np.seterr(over="ignore")
+import torch  # noqa: E402
+
+import azalea  # noqa: E402,F401
+from azalea import mcts as ref_mcts  # noqa: E402
+from azalea import prep as ref_prep  # noqa: E402
+from azalea.azalea_agent import AzaleaAgent  # noqa: E402
+from azalea.fnv1a import fnv1a  # noqa: E402
+from azalea.game.hex import HexGame  # noqa: E402
+from azalea.network import HexNetwork  # noqa: E402
+from azalea.play_game import play_game  # noqa: E402
+from azalea.policy import Policy  # noqa: E402
+from azalea.search_tree import SearchTree  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(1)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote %-28s %8.1f KB" % (name, os.path.getsize(path) / 1024.0))
+
+
+# --------------------------------------------------------------------------- G1
+def random_playout(n, rng):
+    """Play uniformly random legal moves through the reference game until it ends."""
+    g = HexGame(n)
+    moves, results, nlegal, lhash = [], [], [], []
+    while True:
+        st = g.state
+        if st.result:
+            break
+        lm = st.legal_moves
+        nlegal.append(len(lm))
+        lhash.append(zlib.crc32(lm.astype(np.int32).tobytes()))
+        mv = int(lm[rng.randint(len(lm))])
+        g.step(mv)
+        moves.append(mv)
+        results.append(g.state.result)
+    return moves, results, nlegal, lhash, g.state.board.copy()
+
+
+def make_g1():
+    rng = np.random.RandomState(20240101)
+    out = {}
+    for n, count in ((11, 300), (13, 60), (5, 100), (3, 40)):
+        cells = n * n
+        mv = np.zeros((count, cells), np.int16)
+        res = np.zeros((count, cells), np.int8)
+        nl = np.zeros((count, cells), np.int16)
+        lh = np.zeros((count, cells), np.uint32)
+        ln = np.zeros(count, np.int16)
+        fb = np.zeros((count, n, n), np.int8)
+        for i in range(count):
+            m, r, k, h, b = random_playout(n, rng)
+            ln[i] = len(m)
+            mv[i, :len(m)] = m
+            res[i, :len(m)] = r
+            nl[i, :len(m)] = k
+            lh[i, :len(m)] = h
+            fb[i] = b
+        out.update({"moves_%d" % n: mv, "result_%d" % n: res, "nlegal_%d" % n: nl,
+                    "legalcrc_%d" % n: lh, "length_%d" % n: ln, "final_%d" % n: fb})
+    save("g1_movegen.npz", **out)
+
+
+# --------------------------------------------------------------------------- G2
+def make_g2():
+    rng = np.random.RandomState(7)
+    out = {}
+    for n in (5, 11, 13):
+        b = rng.randint(0, 3, size=(16, n, n)).astype(np.int32)
+        k = n * n
+        moves = np.zeros((16, k), np.int32)
+        for i in range(16):
+            empt = np.flatnonzero(b[i].ravel() == 0).astype(np.int32) + 1
+            # ragged: keep a random-length ascending prefix-subset, zero padded
+            keep = empt[: rng.randint(0, len(empt) + 1)]
+            moves[i, :len(keep)] = keep
+        fb, fm = HexGame.flip_player_board_moves(b, moves)
+        out.update({"board_%d" % n: b, "moves_%d" % n: moves,
+                    "fboard_%d" % n: np.ascontiguousarray(fb).astype(np.int32),
+                    "fmoves_%d" % n: fm.astype(np.int32)})
+    save("g2_flip.npz", **out)
+
+
+# --------------------------------------------------------------------------- G3
+def positions_from_playouts(n, count, rng):
+    """Network inputs as mcts.evaluate_batch builds them: non-terminal states, boards of
+    second-player-to-move rows flipped to the first player's view, legal moves padded."""
+    states = []
+    while len(states) < count:
+        g = HexGame(n)
+        stop = rng.randint(0, n * n)
+        for _ in range(stop):
+            st = g.state
+            if st.result:
+                break
+            lm = st.legal_moves
+            g.step(int(lm[rng.randint(len(lm))]))
+        st = g.state
+        if not st.result:
+            states.append(st)
+    batch = ref_prep.batch_games(states)
+    board = batch["board"].copy()
+    lm = batch["legal_moves"].copy()
+    flip = batch["color"] == 1
+    board[flip], lm[flip] = HexGame.flip_player_board_moves(board[flip], lm[flip])
+    return board.astype(np.int32), lm.astype(np.int32), batch["color"].astype(np.int32)
+
+
+def build_net(n, blocks, chans, seed):
+    torch.manual_seed(seed)
+    net = HexNetwork(board_size=n, num_blocks=blocks, base_chans=chans)
+    # non-trivial BatchNorm statistics / affine so BN folding is really exercised
+    g = torch.Generator().manual_seed(seed + 1)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) * 1.5 + 0.25)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) * 1.0 + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    net.eval()
+    # modern torch: the reference's permute leaves a channels_last view that .view() rejects;
+    # hand the stem an equivalent NCHW-contiguous tensor (same values) via a forward hook.
+    net.encoder.register_forward_hook(
+        lambda mod, inp, out: out.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1))
+    return net
+
+
+def make_g3():
+    rng = np.random.RandomState(33)
+    for tag, n, blocks, chans, count in (("11_6x64", 11, 6, 64, 96),
+                                         ("13_2x32", 13, 2, 32, 32),
+                                         ("5_1x8", 5, 1, 8, 32)):
+        net = build_net(n, blocks, chans, seed=1000 + n)
+        board, lm, color = positions_from_playouts(n, count, rng)
+        with torch.no_grad():
+            o = net.run({"board": torch.tensor(board), "legal_moves": torch.tensor(lm)})
+        arrays = {"w:" + k: v.detach().numpy() for k, v in net.state_dict().items()}
+        arrays.update(board=board, legal_moves=lm, color=color,
+                      value=o["value"].numpy(), moves_logprob=o["moves_logprob"].numpy(),
+                      cfg=np.array([n, blocks, chans], np.int32))
+        save("g3_forward_%s.npz" % tag, **arrays)
+
+
+# --------------------------------------------------------------------------- stub nets
+class StubNet:
+    """Duck-typed azalea Network: .device, .eval(), .run(batch) -> value, moves_logprob.
+
+    mode 'uniform0'   : logits 0 (uniform priors), value 0
+    mode 'uniformhash': logits 0, value = (fnv1a(board) & 0xffff)/32768 - 1
+    mode 'hashprior'  : logits from a hash of (board, tile), value from the board hash
+    Padding is masked with -99 and log_softmax taken over the padded row, as the real net does.
+    """
+    device = torch.device("cpu")
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def eval(self):
+        return self
+
+    def run(self, batch, compute_loss=False):
+        board = batch["board"].numpy().astype(np.int32)
+        lm = batch["legal_moves"].numpy()
+        B, K = lm.shape
+        value = np.zeros(B, np.float32)
+        logit = np.zeros((B, K), np.float32)
+        for i in range(B):
+            h = int(fnv1a(board[i].ravel()))
+            if self.mode != "uniform0":
+                value[i] = np.float32((h & 0xFFFF) / 32768.0 - 1.0)
+            if self.mode == "hashprior":
+                for j in range(K):
+                    t = int(lm[i, j])
+                    if t:
+                        x = (h ^ (t * 2654435761)) & 0xFFFFFFFF
+                        x = (x * 2246822519) & 0xFFFFFFFF
+                        logit[i, j] = np.float32(((x >> 13) & 0xFF) / 64.0)
+        logit_t = torch.tensor(logit)
+        logit_t.masked_fill_(torch.tensor(lm == 0), -99)
+        lp = torch.log_softmax(logit_t, dim=1)
+        return dict(value=torch.tensor(value), moves_logprob=lp)
+
+
+class Tape:
+    """Records every mcts.evaluate_batch result in call order (the 'evaluation tape')."""
+
+    def __init__(self):
+        self.values, self.nch, self.priors, self.boards, self.colors = [], [], [], [], []
+        self._orig = ref_mcts.evaluate_batch
+
+    def __enter__(self):
+        def wrapped(game, net, states, rng):
+            value, num_children, prior = self._orig(game, net, states, rng)
+            for i, st in enumerate(states):
+                self.values.append(np.float32(value[i]))
+                self.nch.append(int(num_children[i]))
+                self.priors.append(np.asarray(prior[i, :num_children[i]], np.float32).copy())
+                self.boards.append(st.board.astype(np.int8).copy())
+                self.colors.append(int(st.color))
+            return value, num_children, prior
+        ref_mcts.evaluate_batch = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        ref_mcts.evaluate_batch = self._orig
+
+    def arrays(self, prefix=""):
+        off = np.zeros(len(self.priors) + 1, np.int64)
+        off[1:] = np.cumsum([len(p) for p in self.priors])
+        flat = np.concatenate(self.priors) if self.priors else np.zeros(0, np.float32)
+        return {prefix + "tape_value": np.array(self.values, np.float32),
+                prefix + "tape_nch": np.array(self.nch, np.int32),
+                prefix + "tape_prior": flat.astype(np.float32),
+                prefix + "tape_off": off,
+                prefix + "tape_board": np.array(self.boards, np.int8),
+                prefix + "tape_color": np.array(self.colors, np.int8)}
+
+
+def dump_tree(tree, prefix=""):
+    n = tree.num_nodes
+    return {prefix + "num_nodes": np.int64(n), prefix + "root_id": np.int64(tree.root_id),
+            prefix + "parent": tree.parent[:n].copy(),
+            prefix + "first_child": tree.first_child[:n].copy(),
+            prefix + "num_children": tree.num_children[:n].copy(),
+            prefix + "num_visits": tree.num_visits[:n].copy(),
+            prefix + "total_value": tree.total_value[:n].copy(),
+            prefix + "prior_prob": tree.prior_prob[:n].copy()}
+
+
+class NoiseRecorder:
+    """Wraps a RandomState so the dirichlet draws the search consumed can be stored."""
+
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(seed)
+        self.noise = []
+
+    def dirichlet(self, alpha):
+        x = self.rs.dirichlet(alpha)
+        self.noise.append(x.copy())
+        return x
+
+    def multinomial(self, *a, **k):
+        return self.rs.multinomial(*a, **k)
+
+
+def play_prefix(n, nplies, seed):
+    rng = np.random.RandomState(seed)
+    g = HexGame(n)
+    played = []
+    for _ in range(nplies):
+        st = g.state
+        if st.result:
+            break
+        mv = int(st.legal_moves[rng.randint(len(st.legal_moves))])
+        g.step(mv)
+        if g.state.result:  # keep the search root non-terminal: stop before the winning move
+            g = HexGame(n)
+            for m in played:
+                g.step(m)
+            break
+        played.append(mv)
+    return g, np.array(played, np.int32)
+
+
+def make_g4():
+    # (tag, n, prefix plies, prefix seed, sims, batch, c_puct, mode, noise eps, alpha, rng seed, follow-up moves)
+    cases = [
+        ("a_11_empty_s40_u0", 11, 0, 0, 40, 10, 0.5, "uniform0", 0.0, 0.03, 0, 0),
+        ("b_11_empty_s400_uh", 11, 0, 0, 400, 10, 0.5, "uniformhash", 0.0, 0.03, 0, 0),
+        ("c_11_p30_s400_hp", 11, 30, 5, 400, 10, 0.75, "hashprior", 0.0, 0.03, 0, 0),
+        ("d_11_p100_s400_uh", 11, 100, 6, 400, 10, 0.5, "uniformhash", 0.0, 0.03, 0, 0),
+        ("e_11_p90_s40_hp", 11, 90, 8, 40, 10, 0.5, "hashprior", 0.0, 0.03, 0, 0),
+        ("f_5_p12_s100_uh", 5, 12, 9, 100, 10, 0.5, "uniformhash", 0.0, 0.03, 0, 0),
+        ("g_13_empty_s40_hp", 13, 0, 0, 40, 10, 0.5, "hashprior", 0.0, 0.03, 0, 0),
+        ("h_11_empty_s40_noise", 11, 0, 0, 40, 10, 0.5, "hashprior", 0.25, 0.03, 1234, 0),
+        ("i_11_p40_s60_noise_b7", 11, 40, 11, 60, 7, 0.75, "uniformhash", 0.25, 0.3, 99, 0),
+        ("j_11_p20_s100_moves", 11, 20, 12, 100, 10, 0.5, "hashprior", 0.0, 0.03, 0, 3),
+        ("k_5_p15_s100_moves", 5, 15, 13, 100, 10, 0.5, "uniformhash", 0.0, 0.03, 0, 3),
+    ]
+    for (tag, n, npre, pseed, sims, bs, c, mode, eps, alpha, rseed, follow) in cases:
+        game, prefix = play_prefix(n, npre, pseed)
+        net = StubNet(mode)
+        tree = SearchTree()
+        rng = NoiseRecorder(rseed)
+        arrays = dict(cfg_n=np.int32(n), cfg_sims=np.int32(sims), cfg_batch=np.int32(bs),
+                      cfg_c=np.float64(c), cfg_eps=np.float64(eps), cfg_alpha=np.float64(alpha),
+                      cfg_seed=np.int64(rseed), prefix_moves=prefix,
+                      mode=np.array(mode), follow=np.int32(follow))
+        for step in range(follow + 1):
+            pre = "s%d_" % step
+            n_noise_before = len(rng.noise)
+            with Tape() as tape:
+                probs, value, metrics = tree.search(
+                    game, net, num_simulations=sims, temperature=1.0,
+                    exploration_coef=c, exploration_noise_scale=eps,
+                    exploration_noise_alpha=alpha, batch_size=bs, rng=rng)
+            arrays.update(tape.arrays(pre))
+            arrays.update(dump_tree(tree, pre))
+            arrays[pre + "probs"] = probs.astype(np.float64)
+            arrays[pre + "value"] = np.float32(value)
+            arrays[pre + "search_value"] = np.float64(metrics["search_value"])
+            arrays[pre + "root_board"] = game.state.board.astype(np.int8)
+            arrays[pre + "legal_moves"] = game.state.legal_moves.astype(np.int32)
+            noise = rng.noise[n_noise_before:]
+            if noise:
+                arrays[pre + "noise"] = np.array(noise, np.float64)
+            if step < follow:
+                # deterministic follow-up: most visited root child (lowest index on ties)
+                stats = tree.root.move_stats
+                move_id = int(np.argmax(stats.num_visits))
+                lm = game.state.legal_moves
+                arrays[pre + "move_id"] = np.int32(move_id)
+                tree.move(move_id)
+                game.step(int(lm[move_id]))
+                if game.state.result:
+                    arrays["follow"] = np.int32(step)
+                    break
+        save("g4_search_%s.npz" % tag, **arrays)
+
+
+# --------------------------------------------------------------------------- G5 / G6
+def make_policy(mode, n, sims, bs, c, depth, alpha, eps, temp):
+    p = Policy()
+    p.net = StubNet(mode)
+    p.network_type = "stub"
+    p.board_size = n
+    p.num_blocks = 0
+    p.base_chans = 0
+    p.simulations = sims
+    p.search_batch_size = bs
+    p.exploration_coef = c
+    p.exploration_depth = depth
+    p.exploration_noise_alpha = alpha
+    p.exploration_noise_scale = eps
+    p.exploration_temperature = temp
+    return p
+
+
+def make_g5_g6():
+    frames = {}
+    cases = [
+        ("a_7_s20", 7, 20, 10, 0.5, 5, 0.03, 0.25, 1.0, "hashprior", 4242, True, True),
+        ("b_11_s40", 11, 40, 10, 0.5, 15, 0.03, 0.25, 1.0, "uniformhash", 777, True, True),
+        ("c_5_s30_greedy", 5, 30, 10, 0.75, 3, 0.3, 0.25, 1.0, "hashprior", 31337, False, False),
+        ("d_9_s50_nonoise", 9, 50, 10, 0.5, 8, 0.03, 0.25, 0.5, "hashprior", 2718, True, False),
+    ]
+    for (tag, n, sims, bs, c, depth, alpha, eps, temp, mode, seed, sampling, explore) in cases:
+        policy = make_policy(mode, n, sims, bs, c, depth, alpha, eps, temp)
+        policy.settings["move_sampling"] = sampling
+        policy.settings["move_exploration"] = explore
+        agent = AzaleaAgent(lambda n=n: HexGame(n), policy=policy, device="cpu")
+        agent.seed(seed)
+        result, frame, metrics = play_game([agent], collect_data=True)
+        P = len(frame)
+        K = n * n
+        board = np.zeros((P, n, n), np.int8)
+        color = np.zeros(P, np.int8)
+        nlegal = np.zeros(P, np.int16)
+        lmoves = np.zeros((P, K), np.int16)
+        mprob = np.zeros((P, K), np.float32)
+        for i in range(P):
+            st = frame.state[i]
+            k = len(st.legal_moves)
+            board[i] = st.board
+            color[i] = st.color
+            nlegal[i] = k
+            lmoves[i, :k] = st.legal_moves
+            mprob[i, :k] = frame.moves_prob[i]
+            assert st.result == 0 and frame.moves_prob[i].dtype == np.float32
+        mnames = sorted(k for k in metrics if k != "seconds_per_game")
+        save("g5_game_%s.npz" % tag,
+             cfg_n=np.int32(n), cfg_sims=np.int32(sims), cfg_batch=np.int32(bs),
+             cfg_c=np.float64(c), cfg_depth=np.int32(depth), cfg_alpha=np.float64(alpha),
+             cfg_eps=np.float64(eps), cfg_temp=np.float64(temp), mode=np.array(mode),
+             cfg_seed=np.int64(seed), cfg_sampling=np.bool_(sampling), cfg_explore=np.bool_(explore),
+             result=np.int32(result), board=board, color=color, nlegal=nlegal,
+             legal_moves=lmoves, moves_prob=mprob, reward=np.array(frame.reward, np.float32),
+             metric_names=np.array(mnames), metric_values=np.array([float(metrics[k]) for k in mnames]))
+        frames[tag] = frame
+
+    # G6: the reference collate over a ragged slice of one recorded game
+    frame = frames["a_7_s20"]
+    idx = [0, 3, 7, len(frame) - 1, len(frame) // 2]
+    recs = [frame[i] for i in idx]
+    tb = ref_prep.torch_batch_replays(recs)
+    save("g6_collate.npz", idx=np.array(idx, np.int32),
+         **{"out_" + k: v.numpy() for k, v in tb.items()},
+         **{"dtype_" + k: np.array(str(v.numpy().dtype)) for k, v in tb.items()})
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    if "g1" in which:
+        make_g1()
+    if "g2" in which:
+        make_g2()
+    if "g3" in which:
+        make_g3()
+    if "g4" in which:
+        make_g4()
+    if "g5" in which:
+        make_g5_g6()
