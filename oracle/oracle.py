@@ -1,0 +1,390 @@
+"""ctypes front-end of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product (azalea_amd) never does.  See oracle.h for what each C function restates.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+MAXC = 19 * 19
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+class _Hex(C.Structure):
+    _fields_ = [("n", C.c_int32), ("color", C.c_int32), ("winner", C.c_int32),
+                ("board", C.c_int32 * MAXC)]
+
+
+class _Tree(C.Structure):
+    _fields_ = [("cap", C.c_int64), ("num_nodes", C.c_int64), ("root_id", C.c_int32),
+                ("parent", C.POINTER(C.c_int32)), ("first_child", C.POINTER(C.c_int32)),
+                ("num_children", C.POINTER(C.c_int32)), ("num_visits", C.POINTER(C.c_float)),
+                ("total_value", C.POINTER(C.c_float)), ("prior_prob", C.POINTER(C.c_float))]
+
+
+class _SearchCfg(C.Structure):
+    _fields_ = [("simulations", C.c_int32), ("batch_size", C.c_int32), ("c_puct", C.c_double),
+                ("noise_scale", C.c_double), ("noise", C.POINTER(C.c_double)),
+                ("noise_rows", C.c_int64)]
+
+
+class SearchStats(C.Structure):
+    _fields_ = [("search_value", C.c_double), ("n_select", C.c_int64), ("n_eval", C.c_int64),
+                ("sum_depth", C.c_int64), ("sum_k_interior", C.c_int64),
+                ("sum_k_leaf", C.c_int64), ("n_terminal_evals", C.c_int64),
+                ("status", C.c_int32)]
+
+
+class _UniformCtx(C.Structure):
+    _fields_ = [("hash_value", C.c_int), ("prior_by_k", C.POINTER(C.c_float))]
+
+
+class _TapeCtx(C.Structure):
+    _fields_ = [("value", C.POINTER(C.c_float)), ("nch", C.POINTER(C.c_int32)),
+                ("prior", C.POINTER(C.c_float)), ("off", C.POINTER(C.c_int64)),
+                ("pos", C.c_int64), ("len", C.c_int64), ("mismatch", C.c_int32)]
+
+
+class BenchCfg(C.Structure):
+    _fields_ = [("n", C.c_int32), ("simulations", C.c_int32), ("batch_size", C.c_int32),
+                ("n_games", C.c_int32), ("n_threads", C.c_int32), ("max_plies", C.c_int32),
+                ("use_net", C.c_int32), ("c_puct", C.c_double), ("noise_scale", C.c_double),
+                ("noise_alpha", C.c_double), ("temperature", C.c_double),
+                ("exploration_depth", C.c_int32), ("seed", C.c_uint64)]
+
+
+class BenchOut(C.Structure):
+    _fields_ = [("games", C.c_int64), ("plies", C.c_int64), ("selects", C.c_int64),
+                ("evals", C.c_int64), ("seconds", C.c_double)]
+
+
+EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                      C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float))
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.ohex_init.argtypes = [C.POINTER(_Hex), C.c_int]
+        L.ohex_legal_moves.argtypes = [C.POINTER(_Hex), C.POINTER(C.c_int32)]
+        L.ohex_result.argtypes = [C.POINTER(_Hex)]
+        L.ohex_step.argtypes = [C.POINTER(_Hex), C.c_int]
+        L.ohex_check_win.argtypes = [C.POINTER(C.c_int32), C.c_int, C.c_int]
+        L.ohex_flip_board_moves.argtypes = [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                            C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.otree_new.restype = C.POINTER(_Tree)
+        L.otree_new.argtypes = [C.c_int64]
+        L.otree_free.argtypes = [C.POINTER(_Tree)]
+        L.otree_reset.argtypes = [C.POINTER(_Tree)]
+        L.otree_move.argtypes = [C.POINTER(_Tree), C.c_int]
+        L.osearch.argtypes = [C.POINTER(_Tree), C.POINTER(_Hex), C.c_void_p, C.c_void_p,
+                              C.POINTER(_SearchCfg), C.POINTER(SearchStats)]
+        L.ofnv1a.restype = C.c_uint32
+        L.ofnv1a.argtypes = [C.POINTER(C.c_int32), C.c_int]
+        L.onet_new.restype = C.c_void_p
+        L.onet_new.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.onet_free.argtypes = [C.c_void_p]
+        L.onet_set.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64]
+        L.onet_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.obench_selfplay.argtypes = [C.POINTER(BenchCfg), C.c_void_p, C.POINTER(BenchOut)]
+        _lib = L
+    return _lib
+
+
+def _i32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _f32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def fnv1a(seq):
+    a = np.ascontiguousarray(seq, np.int32)
+    return int(lib().ofnv1a(_i32p(a), a.size))
+
+
+class Hex:
+    """azalea.game.hex.HexGame restated (hex.py:19-70) over the C rules."""
+
+    def __init__(self, n=11):
+        self.n = n
+        self.g = _Hex()
+        lib().ohex_init(C.byref(self.g), n)
+
+    def copy(self):
+        h = Hex.__new__(Hex)
+        h.n = self.n
+        h.g = _Hex()
+        C.memmove(C.byref(h.g), C.byref(self.g), C.sizeof(_Hex))
+        return h
+
+    @property
+    def board(self):
+        return np.array(self.g.board[: self.n * self.n], np.int32).reshape(self.n, self.n)
+
+    def set_board(self, board, color, winner=0):
+        flat = np.asarray(board, np.int32).ravel()
+        for i, v in enumerate(flat):
+            self.g.board[i] = int(v)
+        self.g.color = color
+        self.g.winner = winner
+
+    @property
+    def color(self):
+        """0 = first player to move, 1 = second (HexGameState.color, hex.py:56)."""
+        return self.g.color - 1
+
+    @property
+    def result(self):
+        return lib().ohex_result(C.byref(self.g))
+
+    def legal_moves(self):
+        out = np.zeros(self.n * self.n, np.int32)
+        k = lib().ohex_legal_moves(C.byref(self.g), _i32p(out))
+        return out[:k].copy()
+
+    def step(self, move):
+        if lib().ohex_step(C.byref(self.g), int(move)) != 0:
+            raise ValueError("illegal move %d" % move)
+
+
+def check_win(board, tile):
+    b = np.ascontiguousarray(board, np.int32)
+    return lib().ohex_check_win(_i32p(b), b.shape[0], int(tile))
+
+
+def flip_board_moves(board, moves):
+    """HexGame.flip_player_board_moves (hex.py:89-122) for one board or a batch."""
+    board = np.ascontiguousarray(board, np.int32)
+    moves = np.ascontiguousarray(moves, np.int32)
+    single = board.ndim == 2
+    b3 = board[None] if single else board
+    m2 = moves[None] if single else moves
+    fb = np.zeros_like(b3)
+    fm = np.zeros_like(m2)
+    n = b3.shape[-1]
+    for i in range(len(b3)):
+        bi, mi = np.ascontiguousarray(b3[i]), np.ascontiguousarray(m2[i])
+        fbi, fmi = np.zeros_like(bi), np.zeros_like(mi)
+        lib().ohex_flip_board_moves(n, _i32p(bi), _i32p(mi), mi.size, _i32p(fbi), _i32p(fmi))
+        fb[i], fm[i] = fbi, fmi
+    return (fb[0], fm[0]) if single else (fb, fm)
+
+
+class Tree:
+    """azalea.search_tree.SearchTree storage (search_tree.py:43-71)."""
+
+    def __init__(self, cap=1 << 20):
+        self.t = lib().otree_new(cap)
+        self.cap = cap
+
+    def __del__(self):
+        if getattr(self, "t", None) is not None and _lib is not None:
+            _lib.otree_free(self.t)
+            self.t = None
+
+    def reset(self):
+        lib().otree_reset(self.t)
+
+    def move(self, move_id):
+        lib().otree_move(self.t, int(move_id))
+
+    @property
+    def num_nodes(self):
+        return int(self.t.contents.num_nodes)
+
+    @property
+    def root_id(self):
+        return int(self.t.contents.root_id)
+
+    def _arr(self, name, dtype):
+        n = self.num_nodes
+        ptr = getattr(self.t.contents, name)
+        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+    def dump(self):
+        return {"num_nodes": self.num_nodes, "root_id": self.root_id,
+                "parent": self._arr("parent", np.int32),
+                "first_child": self._arr("first_child", np.int32),
+                "num_children": self._arr("num_children", np.int32),
+                "num_visits": self._arr("num_visits", np.float32),
+                "total_value": self._arr("total_value", np.float32),
+                "prior_prob": self._arr("prior_prob", np.float32)}
+
+    def root_stats(self):
+        """(num_visits, total_value, prior) of the root's children (search_tree.py:192-204,
+        values NOT negated here) and the root's own (visits, value)."""
+        d = self.dump()
+        r = d["root_id"]
+        fc, k = d["first_child"][r], d["num_children"][r]
+        sl = slice(fc, fc + max(k, 0))
+        return (d["num_visits"][sl], d["total_value"][sl], d["prior_prob"][sl],
+                d["num_visits"][r], d["total_value"][r])
+
+
+class UniformEval:
+    def __init__(self, hash_value=False, prior_by_k=None):
+        self.table = None if prior_by_k is None else np.ascontiguousarray(prior_by_k, np.float32)
+        self.ctx = _UniformCtx(int(hash_value),
+                               _f32p(self.table) if self.table is not None else None)
+        self.fn = C.cast(lib().oeval_uniform, C.c_void_p)
+        self.ctxp = C.cast(C.pointer(self.ctx), C.c_void_p)
+
+
+class TapeEval:
+    def __init__(self, value, nch, prior, off):
+        self.value = np.ascontiguousarray(value, np.float32)
+        self.nch = np.ascontiguousarray(nch, np.int32)
+        self.prior = np.ascontiguousarray(prior, np.float32)
+        self.off = np.ascontiguousarray(off, np.int64)
+        self.ctx = _TapeCtx(_f32p(self.value), _i32p(self.nch), _f32p(self.prior),
+                            self.off.ctypes.data_as(C.POINTER(C.c_int64)), 0, len(self.value), 0)
+        self.fn = C.cast(lib().oeval_tape, C.c_void_p)
+        self.ctxp = C.cast(C.pointer(self.ctx), C.c_void_p)
+
+    @property
+    def mismatch(self):
+        return bool(self.ctx.mismatch)
+
+    @property
+    def consumed(self):
+        return int(self.ctx.pos)
+
+
+class Net:
+    """azalea.network.HexNetwork inference forward (network.py:120-152) in C."""
+
+    def __init__(self, n, blocks, chans, state):
+        self.n, self.blocks, self.chans = n, blocks, chans
+        self.h = lib().onet_new(n, blocks, chans)
+        for name, arr in state.items():
+            if name.endswith("num_batches_tracked"):
+                continue
+            a = np.ascontiguousarray(np.asarray(arr), np.float32)
+            lib().onet_set(self.h, name.encode(), _f32p(a), a.size)
+        self.fn = C.cast(lib().oeval_net, C.c_void_p)
+        self.ctxp = C.c_void_p(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.onet_free(self.h)
+            self.h = None
+
+    def forward(self, boards, legal_moves):
+        boards = np.ascontiguousarray(boards, np.int32)
+        lm = np.ascontiguousarray(legal_moves, np.int32)
+        B, K = lm.shape
+        value = np.zeros(B, np.float32)
+        logprob = np.zeros((B, K), np.float32)
+        lib().onet_forward(self.h, B, K, _i32p(boards), _i32p(lm), _f32p(value), _f32p(logprob))
+        return value, logprob
+
+
+class CallbackEval:
+    """Python evaluator: fn(boards[B,n,n], legal_moves[B,K]) -> (value[B], prior[B,K])."""
+
+    def __init__(self, fn):
+        def trampoline(ctx, n, B, K, boards, moves, value, prior):
+            b = np.ctypeslib.as_array(boards, shape=(B, n, n)).copy()
+            m = np.ctypeslib.as_array(moves, shape=(B, K)).copy()
+            v, p = fn(b, m)
+            np.ctypeslib.as_array(value, shape=(B,))[:] = np.asarray(v, np.float32)
+            np.ctypeslib.as_array(prior, shape=(B, K))[:] = np.asarray(p, np.float32)
+        self._cb = EVAL_FN(trampoline)
+        self.fn = C.cast(self._cb, C.c_void_p)
+        self.ctxp = C.c_void_p(0)
+
+
+def search(tree, game, evaluator, simulations, batch_size=10, c_puct=1.0, noise_scale=0.0,
+           noise=None):
+    """mcts.sample_paths (mcts.py:258-293) on the oracle tree; returns SearchStats."""
+    cfg = _SearchCfg(simulations, batch_size, c_puct, noise_scale, None, 0)
+    if noise_scale:
+        noise = np.ascontiguousarray(noise, np.float64)
+        cfg.noise = noise.ctypes.data_as(C.POINTER(C.c_double))
+        cfg.noise_rows = noise.shape[0]
+    st = SearchStats()
+    lib().osearch(tree.t, C.byref(game.g), evaluator.fn, evaluator.ctxp, C.byref(cfg), C.byref(st))
+    return st
+
+
+def as_distribution(counts, temperature=1.0):
+    """search_tree.py:327-344, restated with the same numpy calls (host-side arithmetic)."""
+    counts = np.asarray(counts, np.float32)
+    with np.errstate(divide="ignore"):
+        log_pi = np.log(counts.clip(min=1))
+    log_pi[counts == 0] = -np.inf
+    if temperature:
+        log_pi = log_pi / temperature
+    else:
+        log_pi[log_pi < log_pi.max()] = -np.inf
+    log_pi = log_pi.astype(np.float64)
+    log_z = np.logaddexp.reduce(log_pi)
+    return np.exp(log_pi - log_z)
+
+
+def play_game(n, evaluator, *, simulations, batch_size, c_puct, exploration_depth, noise_alpha,
+              noise_scale, temperature, seed, move_sampling=True, move_exploration=True,
+              tree_cap=1 << 22, max_plies=300):
+    """One self-play game: play_game.py:44-67 over Policy.choose_action (policy.py:132-168),
+    with AzaleaAgent.seed's policy.seed(seed + 1) convention (azalea_agent.py:41-44)."""
+    rng = np.random.RandomState(seed + 1)
+    game, tree = Hex(n), Tree(tree_cap)
+    rows = []
+    ply = 0
+    sel = (simulations // batch_size + 1) * batch_size
+    while ply < max_plies and not game.result:
+        T = temperature if move_sampling else 0.0
+        eps = noise_scale if (move_sampling and move_exploration) else 0.0
+        if ply >= exploration_depth:
+            T = 0.0
+        lm = game.legal_moves()
+        noise = None
+        if eps:
+            noise = np.array([rng.dirichlet(np.full(len(lm), noise_alpha)) for _ in range(sel)])
+        st = search(tree, game, evaluator, simulations, batch_size, c_puct, eps, noise)
+        if st.status:
+            raise RuntimeError("SearchTreeFull")
+        nv, tv, pp, rv, rt = tree.root_stats()
+        probs = as_distribution(nv, T)
+        move_id = int(np.argmax(rng.multinomial(1, probs)))
+        rows.append(dict(board=game.board, color=game.color, legal_moves=lm,
+                         moves_prob=probs.astype(np.float32), move=int(lm[move_id]),
+                         value=np.float32(rt) / np.float32(rv), search_value=st.search_value,
+                         num_nodes=tree.num_nodes))
+        tree.move(move_id)
+        game.step(int(lm[move_id]))
+        ply += 1
+    result = game.result or 2
+    reward = np.full(len(rows), result - 2.0, np.float32)
+    reward[1::2] *= -1
+    return result, rows, reward
+
+
+def bench_selfplay(n, simulations, batch_size, n_games, n_threads, net=None, c_puct=0.5,
+                   noise_scale=0.25, noise_alpha=0.03, temperature=1.0, exploration_depth=15,
+                   seed=0xBAD5EED5, max_plies=300):
+    cfg = BenchCfg(n, simulations, batch_size, n_games, n_threads, max_plies,
+                   1 if net is not None else 0, c_puct, noise_scale, noise_alpha, temperature,
+                   exploration_depth, seed)
+    out = BenchOut()
+    lib().obench_selfplay(C.byref(cfg), net.h if net is not None else None, C.byref(out))
+    return dict(games=out.games, plies=out.plies, selects=out.selects, evals=out.evals,
+                seconds=out.seconds)
