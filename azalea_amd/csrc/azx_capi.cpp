@@ -1,0 +1,775 @@
+// azx_capi.cpp -- host side of the C ABI declared in include/azx.h.
+// Owns the device arenas, sequences the kernels on one HIP stream per engine, and converts
+// between the reference's data model (six tree arrays, ragged legal-move lists) and the
+// engine's HBM layout.  No CPU fallback: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/azx.h"
+#include "azx_dev.h"
+#include "mcts_kernels.h"
+#include "net.h"
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHECK(expr)                                                                    \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return fail(AZX_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),  \
+                        __FILE__, __LINE__);                                              \
+    } while (0)
+
+struct azx_engine {
+    azx_config cfg;
+    DevEngine d;
+    hipStream_t stream = nullptr;
+    int num_batches = 0;
+    int selects_per_search = 0;
+    std::vector<void *> allocs;
+    // gather buffers
+    int32_t *g_k = nullptr, *g_legal = nullptr, *g_nn = nullptr;
+    float *g_cv = nullptr, *g_cw = nullptr, *g_cp = nullptr, *g_rv = nullptr, *g_rw = nullptr,
+          *g_sv = nullptr;
+    double *noise_dev = nullptr;
+    size_t noise_cap = 0;
+    float *prior_table_dev = nullptr;
+    int32_t *moveids_dev = nullptr;
+    int32_t *slots_dev = nullptr, *moves_dev = nullptr, *nmoves_dev = nullptr;
+    size_t moves_cap = 0;
+    // external evaluator bookkeeping
+    bool ext_active = false;
+    int ext_batches_done = 0;
+    std::vector<int> ext_order;                 // eval indices sorted by (slot, leaf)
+    std::vector<std::vector<int>> ext_cells;    // original legal cells per sorted entry
+    // play mode
+    bool play_ready = false;
+    int64_t q_alloc = 0;
+    std::vector<void *> q_allocs;
+    // timing
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    AzxNet *net = nullptr;
+};
+
+template <typename T>
+static int dev_alloc(azx_engine *e, T **p, size_t count, bool zero = true) {
+    void *q = nullptr;
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    hipError_t err = hipMalloc(&q, bytes);
+    if (err != hipSuccess)
+        return fail(AZX_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(err));
+    if (zero) {
+        err = hipMemsetAsync(q, 0, bytes, e->stream);
+        if (err != hipSuccess) return fail(AZX_EHIP, "hipMemset failed: %s", hipGetErrorString(err));
+    }
+    e->allocs.push_back(q);
+    *p = reinterpret_cast<T *>(q);
+    return AZX_OK;
+}
+
+#define TRY(expr)            \
+    do {                     \
+        int _rc = (expr);    \
+        if (_rc) return _rc; \
+    } while (0)
+
+extern "C" const char *azx_last_error(void) { return g_err.c_str(); }
+extern "C" int azx_version(void) { return 1; }
+
+extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
+    if (!cfg || !out) return fail(AZX_EINVAL, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(AZX_ENODEV, "no HIP device visible: the engine has no CPU fallback");
+    if (cfg->board_size < 2 || cfg->board_size > AZX_MAX_BOARD)
+        return fail(AZX_EINVAL, "board_size %d outside [2, %d]", cfg->board_size, AZX_MAX_BOARD);
+    if (cfg->n_games < 1) return fail(AZX_EINVAL, "n_games must be >= 1");
+    if (cfg->search_batch_size < 1 || cfg->search_batch_size > AZX_MAX_BATCH)
+        return fail(AZX_EINVAL, "search_batch_size %d outside [1, %d]", cfg->search_batch_size,
+                    AZX_MAX_BATCH);
+    if (cfg->simulations < 0) return fail(AZX_EINVAL, "simulations must be >= 0");
+    if (cfg->evaluator < AZX_EVAL_RESNET || cfg->evaluator > AZX_EVAL_EXTERNAL)
+        return fail(AZX_EINVAL, "unknown evaluator %d", cfg->evaluator);
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(AZX_EINVAL, "device %d not in [0, %d)", cfg->device, ndev);
+    HIPCHECK(hipSetDevice(cfg->device));
+
+    azx_engine *e = new azx_engine();
+    e->cfg = *cfg;
+    HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    DevEngine &d = e->d;
+    memset(&d, 0, sizeof d);
+    d.N = cfg->board_size;
+    d.ncells = d.N * d.N;
+    d.G = cfg->n_games;
+    d.bs = cfg->search_batch_size;
+    d.slots = d.ncells <= 128 ? 2 : 3;
+    d.c_puct = cfg->exploration_coef;
+    d.evaluator = cfg->evaluator;
+    d.flags = cfg->flags;
+    d.seed = cfg->seed;
+    d.noise_alpha = (float)cfg->noise_alpha;
+    d.noise_scale = 0.0;
+    d.exploration_depth = cfg->exploration_depth;
+    d.temperature = (float)cfg->temperature;
+    e->num_batches = cfg->simulations / cfg->search_batch_size + 1;   // mcts.py:268
+    e->selects_per_search = e->num_batches * cfg->search_batch_size;
+    // arena capacity: enough for one move's growth on top of a carried subtree by default
+    int cap = cfg->nodes_per_game;
+    if (cap <= 0) cap = 2 * (e->selects_per_search + 1) * d.ncells + 1024;
+    d.cap = cap;
+
+    const size_t G = d.G, bs = d.bs, E = G * bs;
+    const size_t pstride = d.ncells + (d.ncells & 1);
+    int rc = AZX_OK;
+#define A(ptr, count) if (!rc) rc = dev_alloc(e, &ptr, (count))
+    A(d.cells, G * d.slots * 64);
+    A(d.ghdr, G);
+    A(d.thdr, G);
+    if (!rc) rc = dev_alloc(e, &d.arena[0], G * (size_t)cap, false);
+    if (cfg->flags & AZX_FLAG_NO_COMPACT) d.arena[1] = d.arena[0];
+    else if (!rc) rc = dev_alloc(e, &d.arena[1], G * (size_t)cap, false);
+    A(d.leaf_node, E); A(d.leaf_len, E); A(d.leaf_eval, E); A(d.leaf_link, E);
+    A(d.leaf_mask, E * 4); A(d.path, E * pstride);
+    A(d.ev_board, E * AZX_CELL_STRIDE); A(d.ev_src, E); A(d.ev_flip, E);
+    A(d.ev_value, E); A(d.ev_prior, E * AZX_CELL_STRIDE); A(d.n_eval, 4);
+    A(d.counters, CTR_COUNT); A(d.q_count, 2); A(d.next_uid, 2); A(d.stat_sums, 8);
+    A(e->g_k, G); A(e->g_legal, G * d.ncells); A(e->g_nn, G);
+    A(e->g_cv, G * d.ncells); A(e->g_cw, G * d.ncells); A(e->g_cp, G * d.ncells);
+    A(e->g_rv, G); A(e->g_rw, G); A(e->g_sv, G);
+    A(e->moveids_dev, G); A(e->slots_dev, G); A(e->nmoves_dev, G);
+#undef A
+    if (rc) { azx_destroy(e); return rc; }
+    if (cfg->evaluator == AZX_EVAL_RESNET) {
+        rc = azx_net_create(&e->net, d.N, cfg->num_blocks, cfg->base_chans, (int)E, e->stream);
+        if (rc) { g_err = azx_net_error(); azx_destroy(e); return rc; }
+    }
+    *out = e;
+    // all slots start as fresh games with uids 0..G-1
+    azx_launch_reset(d, nullptr, d.G, nullptr, nullptr, 0, 1, e->stream);
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    return AZX_OK;
+}
+
+extern "C" void azx_destroy(azx_engine *e) {
+    if (!e) return;
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->net) azx_net_destroy(e->net);
+    for (void *p : e->allocs) (void)hipFree(p);
+    for (void *p : e->q_allocs) (void)hipFree(p);
+    for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" void *azx_stream(azx_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+extern "C" int azx_set_weights(azx_engine *e, int n_tensors, const char *const *names,
+                               const void *const *ptrs, const int64_t *counts, int on_device) {
+    if (!e) return fail(AZX_EINVAL, "null engine");
+    if (!e->net) return fail(AZX_ESTATE, "engine was not created with AZX_EVAL_RESNET");
+    int rc = azx_net_set_weights(e->net, n_tensors, names, ptrs, counts, on_device);
+    if (rc) g_err = azx_net_error();
+    return rc;
+}
+
+extern "C" int azx_set_prior_table(azx_engine *e, const float *prior_by_k, int count) {
+    if (!e || !prior_by_k) return fail(AZX_EINVAL, "null argument");
+    if (count < e->d.ncells + 1) return fail(AZX_EINVAL, "prior table needs %d entries", e->d.ncells + 1);
+    if (!e->prior_table_dev) TRY(dev_alloc(e, &e->prior_table_dev, (size_t)e->d.ncells + 1));
+    HIPCHECK(hipMemcpyAsync(e->prior_table_dev, prior_by_k, sizeof(float) * (e->d.ncells + 1),
+                            hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    e->d.prior_by_k = e->prior_table_dev;
+    return AZX_OK;
+}
+
+extern "C" int azx_reset(azx_engine *e, const int32_t *slots, int n_slots, const int32_t *moves,
+                         const int32_t *n_moves, int stride) {
+    if (!e) return fail(AZX_EINVAL, "null engine");
+    DevEngine &d = e->d;
+    if (!slots) n_slots = d.G;
+    if (n_slots < 1 || n_slots > d.G) return fail(AZX_EINVAL, "n_slots %d outside [1, %d]", n_slots, d.G);
+    if (slots) {
+        for (int i = 0; i < n_slots; ++i)
+            if (slots[i] < 0 || slots[i] >= d.G) return fail(AZX_EINVAL, "slot %d out of range", slots[i]);
+        HIPCHECK(hipMemcpyAsync(e->slots_dev, slots, sizeof(int32_t) * n_slots, hipMemcpyHostToDevice, e->stream));
+    }
+    if (moves) {
+        if (!n_moves || stride < 1) return fail(AZX_EINVAL, "moves given without n_moves/stride");
+        const size_t need = (size_t)n_slots * stride;
+        if (need > e->moves_cap) {
+            TRY(dev_alloc(e, &e->moves_dev, need));
+            e->moves_cap = need;
+        }
+        // validate on the host: the device step assumes legal moves (hex.py:173-176 asserts)
+        for (int i = 0; i < n_slots; ++i) {
+            if (n_moves[i] < 0 || n_moves[i] > stride) return fail(AZX_EINVAL, "n_moves[%d] out of range", i);
+            std::vector<char> used(d.ncells, 0);
+            for (int p = 0; p < n_moves[i]; ++p) {
+                const int mv = moves[(size_t)i * stride + p];
+                if (mv < 1 || mv > d.ncells || used[mv - 1]) return fail(AZX_EINVAL, "illegal move %d", mv);
+                used[mv - 1] = 1;
+            }
+        }
+        HIPCHECK(hipMemcpyAsync(e->moves_dev, moves, sizeof(int32_t) * need, hipMemcpyHostToDevice, e->stream));
+        HIPCHECK(hipMemcpyAsync(e->nmoves_dev, n_moves, sizeof(int32_t) * n_slots, hipMemcpyHostToDevice, e->stream));
+    }
+    azx_launch_reset(d, slots ? e->slots_dev : nullptr, n_slots, moves ? e->moves_dev : nullptr,
+                     moves ? e->nmoves_dev : nullptr, stride, 1, e->stream);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    e->ext_active = false;
+    return AZX_OK;
+}
+
+// ---- timing of the tree kernels (roofline: algorithmic bytes / measured launch time) --------
+static void time_begin(azx_engine *e) {
+    if (e->ev_used + 2 > e->ev_pool.size()) {
+        if (e->ev_pool.size() >= 1 << 16) return;
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        e->ev_pool.push_back(a);
+        e->ev_pool.push_back(b);
+    }
+    (void)hipEventRecord(e->ev_pool[e->ev_used], e->stream);
+}
+static void time_end(azx_engine *e) {
+    if (e->ev_used + 2 > e->ev_pool.size()) return;
+    (void)hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream);
+    e->ev_used += 2;
+}
+static void time_collect(azx_engine *e, double *seconds, int64_t *launches) {
+    for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->ev_pool[i], e->ev_pool[i + 1]) == hipSuccess) {
+            *seconds += ms * 1e-3;
+            *launches += 1;
+        }
+    }
+    e->ev_used = 0;
+}
+
+static int upload_noise(azx_engine *e, const double *noise, int n_select, int noise_stride,
+                        double noise_scale) {
+    DevEngine &d = e->d;
+    d.noise = nullptr;
+    d.device_noise = 0;
+    d.noise_scale = noise_scale;
+    d.n_select = n_select;
+    d.noise_stride = noise_stride;
+    if (noise_scale == 0.0) return AZX_OK;
+    if (!noise) { d.device_noise = 1; return AZX_OK; }
+    if (n_select < e->selects_per_search)
+        return fail(AZX_EINVAL, "noise has %d rows, a search consumes %d", n_select, e->selects_per_search);
+    const size_t need = (size_t)d.G * n_select * noise_stride;
+    if (need > e->noise_cap) {
+        TRY(dev_alloc(e, &e->noise_dev, need, false));
+        e->noise_cap = need;
+    }
+    HIPCHECK(hipMemcpyAsync(e->noise_dev, noise, sizeof(double) * need, hipMemcpyHostToDevice, e->stream));
+    d.noise = e->noise_dev;
+    return AZX_OK;
+}
+
+// one whole search on the stream (no host sync) for the device-side evaluators
+static int enqueue_search(azx_engine *e, bool timed) {
+    DevEngine &d = e->d;
+    if (d.evaluator == AZX_EVAL_UNIFORM || d.evaluator == AZX_EVAL_UNIFORM_HASH) {
+        if (timed) time_begin(e);
+        azx_launch_mcts(d, MODE_BEGIN | MODE_INLINE, e->num_batches, e->stream);
+        if (timed) time_end(e);
+        return AZX_OK;
+    }
+    if (d.evaluator == AZX_EVAL_RESNET) {
+        if (!azx_net_ready(e->net)) return fail(AZX_ESTATE, "azx_set_weights has not been called");
+        HIPCHECK(hipMemsetAsync(d.n_eval, 0, sizeof(int32_t), e->stream));
+        if (timed) time_begin(e);
+        azx_launch_mcts(d, MODE_BEGIN, e->num_batches, e->stream);
+        if (timed) time_end(e);
+        azx_net_eval(e->net, d, e->stream);
+        for (int b = 0; b < e->num_batches; ++b) {
+            HIPCHECK(hipMemsetAsync(d.n_eval, 0, sizeof(int32_t), e->stream));
+            if (timed) time_begin(e);
+            azx_launch_mcts(d, MODE_APPLY | MODE_SELECT, e->num_batches, e->stream);
+            if (timed) time_end(e);
+            azx_net_eval(e->net, d, e->stream);
+        }
+        if (timed) time_begin(e);
+        azx_launch_mcts(d, MODE_APPLY, e->num_batches, e->stream);
+        if (timed) time_end(e);
+        return AZX_OK;
+    }
+    return fail(AZX_ESTATE, "evaluator %d has no device pipeline", d.evaluator);
+}
+
+extern "C" int azx_search(azx_engine *e, const double *noise, int n_select, int noise_stride,
+                          double noise_scale) {
+    if (!e) return fail(AZX_EINVAL, "null engine");
+    if (e->d.evaluator == AZX_EVAL_EXTERNAL)
+        return fail(AZX_ESTATE, "AZX_EVAL_EXTERNAL: drive azx_search_begin/step instead");
+    TRY(upload_noise(e, noise, n_select, noise_stride, noise_scale));
+    TRY(enqueue_search(e, false));
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    return AZX_OK;
+}
+
+static int read_pending(azx_engine *e, int *n_pending) {
+    int32_t n = 0;
+    HIPCHECK(hipMemcpyAsync(&n, e->d.n_eval, sizeof n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    *n_pending = n;
+    return AZX_OK;
+}
+
+extern "C" int azx_search_begin(azx_engine *e, const double *noise, int n_select, int noise_stride,
+                                double noise_scale, int *n_pending) {
+    if (!e || !n_pending) return fail(AZX_EINVAL, "null argument");
+    if (e->d.evaluator != AZX_EVAL_EXTERNAL && e->d.evaluator != AZX_EVAL_RESNET)
+        return fail(AZX_ESTATE, "phase API needs AZX_EVAL_EXTERNAL (or RESNET)");
+    TRY(upload_noise(e, noise, n_select, noise_stride, noise_scale));
+    HIPCHECK(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), e->stream));
+    azx_launch_mcts(e->d, MODE_BEGIN, e->num_batches, e->stream);
+    HIPCHECK(hipGetLastError());
+    e->ext_active = true;
+    e->ext_batches_done = 0;
+    return read_pending(e, n_pending);
+}
+
+extern "C" int azx_search_step(azx_engine *e, int *n_pending, int *done) {
+    if (!e || !n_pending || !done) return fail(AZX_EINVAL, "null argument");
+    if (!e->ext_active) return fail(AZX_ESTATE, "azx_search_step without azx_search_begin");
+    HIPCHECK(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), e->stream));
+    if (e->ext_batches_done < e->num_batches) {
+        azx_launch_mcts(e->d, MODE_APPLY | MODE_SELECT, e->num_batches, e->stream);
+        e->ext_batches_done += 1;
+        *done = 0;
+    } else {
+        azx_launch_mcts(e->d, MODE_APPLY, e->num_batches, e->stream);
+        e->ext_active = false;
+        *done = 1;
+    }
+    HIPCHECK(hipGetLastError());
+    return read_pending(e, n_pending);
+}
+
+static int flip_cell(int cell, int N) {   // hex.py:107-111 (r,c) -> (N-1-c, N-1-r)
+    const int r = cell / N, c = cell % N;
+    return (N - 1 - c) * N + (N - 1 - r);
+}
+
+extern "C" int azx_get_leaves(azx_engine *e, int cap, int32_t *boards, int32_t *legal_moves,
+                              int32_t *slot, int32_t *k, int *n_out) {
+    if (!e || !n_out) return fail(AZX_EINVAL, "null argument");
+    DevEngine &d = e->d;
+    int n = 0;
+    TRY(read_pending(e, &n));
+    if (n > cap) return fail(AZX_EINVAL, "%d pending leaves, caller capacity %d", n, cap);
+    *n_out = n;
+    e->ext_order.clear();
+    e->ext_cells.clear();
+    if (n == 0) return AZX_OK;
+    std::vector<uint8_t> hb((size_t)n * AZX_CELL_STRIDE);
+    std::vector<int32_t> hsrc(n), hflip(n);
+    HIPCHECK(hipMemcpyAsync(hb.data(), d.ev_board, hb.size(), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipMemcpyAsync(hsrc.data(), d.ev_src, sizeof(int32_t) * n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipMemcpyAsync(hflip.data(), d.ev_flip, sizeof(int32_t) * n, hipMemcpyDeviceToHost, e->stream));
+    const size_t E = (size_t)d.G * d.bs;
+    std::vector<uint64_t> hmask(E * 4);
+    HIPCHECK(hipMemcpyAsync(hmask.data(), d.leaf_mask, sizeof(uint64_t) * hmask.size(), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return hsrc[a] < hsrc[b]; });
+    e->ext_order = order;
+    e->ext_cells.resize(n);
+    for (int j = 0; j < n; ++j) {
+        const int ev = order[j], src = hsrc[ev];
+        std::vector<int> &cells = e->ext_cells[j];
+        for (int c = 0; c < d.ncells; ++c)
+            if ((hmask[(size_t)src * 4 + (c >> 6)] >> (c & 63)) & 1ull) cells.push_back(c);
+        if (slot) slot[j] = src / d.bs;
+        if (k) k[j] = (int)cells.size();
+        if (boards)
+            for (int c = 0; c < d.ncells; ++c)
+                boards[(size_t)j * d.ncells + c] = hb[(size_t)ev * AZX_CELL_STRIDE + c];
+        if (legal_moves) {
+            for (int c = 0; c < d.ncells; ++c) legal_moves[(size_t)j * d.ncells + c] = 0;
+            for (size_t i = 0; i < cells.size(); ++i)
+                legal_moves[(size_t)j * d.ncells + i] =
+                    (hflip[ev] ? flip_cell(cells[i], d.N) : cells[i]) + 1;
+        }
+    }
+    return AZX_OK;
+}
+
+extern "C" int azx_put_evals(azx_engine *e, int n, const float *value, const float *prior) {
+    if (!e || (n && (!value || !prior))) return fail(AZX_EINVAL, "null argument");
+    DevEngine &d = e->d;
+    if (n != (int)e->ext_order.size())
+        return fail(AZX_ESTATE, "azx_put_evals(%d) does not match %zu pending leaves", n, e->ext_order.size());
+    if (n == 0) return AZX_OK;
+    std::vector<float> hv(n), hp((size_t)n * AZX_CELL_STRIDE, 0.0f);
+    for (int j = 0; j < n; ++j) {
+        const int ev = e->ext_order[j];
+        hv[ev] = value[j];
+        const std::vector<int> &cells = e->ext_cells[j];
+        for (size_t i = 0; i < cells.size(); ++i)
+            hp[(size_t)ev * AZX_CELL_STRIDE + cells[i]] = prior[(size_t)j * d.ncells + i];
+    }
+    HIPCHECK(hipMemcpyAsync(d.ev_value, hv.data(), sizeof(float) * n, hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(hipMemcpyAsync(d.ev_prior, hp.data(), sizeof(float) * hp.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    return AZX_OK;
+}
+
+extern "C" int azx_get_root(azx_engine *e, int32_t *k, int32_t *legal_moves, float *child_visits,
+                            float *child_value, float *child_prior, float *root_visits,
+                            float *root_value, int32_t *num_nodes, float *search_value) {
+    if (!e) return fail(AZX_EINVAL, "null engine");
+    DevEngine &d = e->d;
+    const size_t G = d.G, GC = G * d.ncells;
+    HIPCHECK(hipMemsetAsync(e->g_legal, 0, sizeof(int32_t) * GC, e->stream));
+    HIPCHECK(hipMemsetAsync(e->g_cv, 0, sizeof(float) * GC, e->stream));
+    HIPCHECK(hipMemsetAsync(e->g_cw, 0, sizeof(float) * GC, e->stream));
+    HIPCHECK(hipMemsetAsync(e->g_cp, 0, sizeof(float) * GC, e->stream));
+    azx_launch_gather_root(d, e->g_k, e->g_legal, e->g_cv, e->g_cw, e->g_cp, e->g_rv, e->g_rw,
+                           e->g_nn, e->g_sv, e->stream);
+    HIPCHECK(hipGetLastError());
+#define D2H(dst, src, bytes) if (dst) HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream))
+    D2H(k, e->g_k, sizeof(int32_t) * G);
+    D2H(legal_moves, e->g_legal, sizeof(int32_t) * GC);
+    D2H(child_visits, e->g_cv, sizeof(float) * GC);
+    D2H(child_value, e->g_cw, sizeof(float) * GC);
+    D2H(child_prior, e->g_cp, sizeof(float) * GC);
+    D2H(root_visits, e->g_rv, sizeof(float) * G);
+    D2H(root_value, e->g_rw, sizeof(float) * G);
+    D2H(num_nodes, e->g_nn, sizeof(int32_t) * G);
+    D2H(search_value, e->g_sv, sizeof(float) * G);
+#undef D2H
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    if (search_value) {   // mcts.py:291
+        const float denom = (float)(e->num_batches * d.bs);
+        for (size_t g = 0; g < G; ++g) search_value[g] = search_value[g] / denom;
+    }
+    return AZX_OK;
+}
+
+extern "C" int azx_get_games(azx_engine *e, int32_t *board, int32_t *color, int32_t *result,
+                             int32_t *ply) {
+    if (!e) return fail(AZX_EINVAL, "null engine");
+    DevEngine &d = e->d;
+    const size_t G = d.G;
+    std::vector<uint32_t> hc(G * d.slots * 64);
+    std::vector<GameHdr> hh(G);
+    HIPCHECK(hipMemcpyAsync(hc.data(), d.cells, sizeof(uint32_t) * hc.size(), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipMemcpyAsync(hh.data(), d.ghdr, sizeof(GameHdr) * G, hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    for (size_t g = 0; g < G; ++g) {
+        if (board)
+            for (int c = 0; c < d.ncells; ++c)
+                board[g * d.ncells + c] = (int32_t)(hc[g * d.slots * 64 + c] & 3u);
+        if (color) color[g] = hh[g].color - 1;                                    // hex.py:56
+        if (result) result[g] = hh[g].winner ? (hh[g].winner == 2 ? 1 : 3) : 0;   // hex.py:161-170
+        if (ply) ply[g] = hh[g].ply;
+    }
+    return AZX_OK;
+}
+
+extern "C" int azx_advance(azx_engine *e, const int32_t *move_ids) {
+    if (!e || !move_ids) return fail(AZX_EINVAL, "null argument");
+    DevEngine &d = e->d;
+    HIPCHECK(hipMemcpyAsync(e->moveids_dev, move_ids, sizeof(int32_t) * d.G, hipMemcpyHostToDevice, e->stream));
+    azx_launch_advance(d, e->moveids_dev, 0, e->stream);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    e->ext_active = false;
+    return AZX_OK;
+}
+
+extern "C" int azx_tree_dump(azx_engine *e, int slot, int cap, int32_t *parent, int32_t *first_child,
+                             int32_t *num_children, float *num_visits, float *total_value,
+                             float *prior_prob, int32_t *num_nodes, int32_t *root_id) {
+    if (!e || !num_nodes || !root_id) return fail(AZX_EINVAL, "null argument");
+    DevEngine &d = e->d;
+    if (slot < 0 || slot >= d.G) return fail(AZX_EINVAL, "slot %d out of range", slot);
+    TreeHdr th;
+    HIPCHECK(hipMemcpyAsync(&th, d.thdr + slot, sizeof th, hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    *num_nodes = th.num_nodes;
+    *root_id = th.root_id;
+    if (th.num_nodes > cap) return fail(AZX_EINVAL, "tree has %d nodes, caller capacity %d", th.num_nodes, cap);
+    std::vector<Node> nodes(th.num_nodes);
+    HIPCHECK(hipMemcpyAsync(nodes.data(), d.arena[th.arena] + (size_t)slot * d.cap,
+                            sizeof(Node) * nodes.size(), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    // rebuild the reference's six arrays (search_tree.py:48-55): parent and num_children are
+    // implied by the layout (children of a k-move node are k consecutive ids, each with k-1)
+    const int n = th.num_nodes;
+    std::vector<int32_t> par(n, -1), kk(n, -1);
+    kk[0] = th.k0;
+    for (int v = 0; v < n; ++v) {
+        const Node &nd = nodes[v];
+        int fc = -1, nc = -1;
+        if (nd.link >= 0) {
+            fc = nd.link;
+            nc = kk[v];
+            for (int j = 0; j < nc && fc + j < n; ++j) { par[fc + j] = v; kk[fc + j] = nc - 1; }
+        } else if (nd.link <= -2) {
+            fc = -2 - nd.link;
+            nc = 0;
+        }
+        if (first_child) first_child[v] = fc;
+        if (num_children) num_children[v] = nc;
+        if (num_visits) num_visits[v] = nd.nv;
+        if (total_value) total_value[v] = nd.tv;
+        if (prior_prob) prior_prob[v] = nd.pp;
+    }
+    if (parent) for (int v = 0; v < n; ++v) parent[v] = par[v];
+    return AZX_OK;
+}
+
+extern "C" int azx_forward(azx_engine *e, int B, int K, const int32_t *boards,
+                           const int32_t *legal_moves, float *value, float *moves_logprob) {
+    if (!e) return fail(AZX_EINVAL, "null engine");
+    if (!e->net) return fail(AZX_ESTATE, "engine was not created with AZX_EVAL_RESNET");
+    int rc = azx_net_forward_host(e->net, B, K, boards, legal_moves, value, moves_logprob, e->stream);
+    if (rc) g_err = azx_net_error();
+    return rc;
+}
+
+extern "C" int azx_hex_replay(int device, int board_size, int n_games, const int32_t *moves,
+                              const int32_t *length, int stride, int32_t *result_out,
+                              int32_t *nlegal_out, uint64_t *empties_out, int32_t *final_board) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(AZX_ENODEV, "no HIP device visible: the engine has no CPU fallback");
+    if (board_size < 2 || board_size > AZX_MAX_BOARD) return fail(AZX_EINVAL, "bad board_size");
+    if (n_games < 1 || stride < 1 || !moves || !length) return fail(AZX_EINVAL, "bad argument");
+    HIPCHECK(hipSetDevice(device));
+    const int ncells = board_size * board_size;
+    for (int g = 0; g < n_games; ++g) {
+        if (length[g] < 0 || length[g] > stride) return fail(AZX_EINVAL, "length[%d] out of range", g);
+        std::vector<char> used(ncells, 0);
+        for (int p = 0; p < length[g]; ++p) {
+            const int mv = moves[(size_t)g * stride + p];
+            if (mv < 1 || mv > ncells || used[mv - 1]) return fail(AZX_EINVAL, "illegal move %d in game %d", mv, g);
+            used[mv - 1] = 1;
+        }
+    }
+    const size_t gs = (size_t)n_games * stride;
+    int32_t *dm = nullptr, *dl = nullptr, *dr = nullptr, *dn = nullptr, *df = nullptr;
+    uint64_t *de = nullptr;
+    HIPCHECK(hipMalloc(&dm, sizeof(int32_t) * gs));
+    HIPCHECK(hipMalloc(&dl, sizeof(int32_t) * n_games));
+    HIPCHECK(hipMalloc(&dr, sizeof(int32_t) * gs));
+    HIPCHECK(hipMalloc(&dn, sizeof(int32_t) * gs));
+    HIPCHECK(hipMalloc(&de, sizeof(uint64_t) * gs * 4));
+    HIPCHECK(hipMalloc(&df, sizeof(int32_t) * (size_t)n_games * ncells));
+    HIPCHECK(hipMemset(dr, 0, sizeof(int32_t) * gs));
+    HIPCHECK(hipMemset(dn, 0, sizeof(int32_t) * gs));
+    HIPCHECK(hipMemset(de, 0, sizeof(uint64_t) * gs * 4));
+    HIPCHECK(hipMemcpy(dm, moves, sizeof(int32_t) * gs, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dl, length, sizeof(int32_t) * n_games, hipMemcpyHostToDevice));
+    azx_launch_hex_replay(board_size, n_games, dm, dl, stride, dr, dn, de, df, nullptr);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipDeviceSynchronize());
+    if (result_out) HIPCHECK(hipMemcpy(result_out, dr, sizeof(int32_t) * gs, hipMemcpyDeviceToHost));
+    if (nlegal_out) HIPCHECK(hipMemcpy(nlegal_out, dn, sizeof(int32_t) * gs, hipMemcpyDeviceToHost));
+    if (empties_out) HIPCHECK(hipMemcpy(empties_out, de, sizeof(uint64_t) * gs * 4, hipMemcpyDeviceToHost));
+    if (final_board) HIPCHECK(hipMemcpy(final_board, df, sizeof(int32_t) * (size_t)n_games * ncells, hipMemcpyDeviceToHost));
+    (void)hipFree(dm); (void)hipFree(dl); (void)hipFree(dr); (void)hipFree(dn); (void)hipFree(de); (void)hipFree(df);
+    return AZX_OK;
+}
+
+// ---- throughput mode ------------------------------------------------------------------------
+static int play_setup(azx_engine *e, int64_t q_rows, int ring) {
+    DevEngine &d = e->d;
+    if (!e->play_ready) {
+        const size_t rows = (size_t)d.G * d.ncells;
+        TRY(dev_alloc(e, &d.row_board, rows * AZX_CELL_STRIDE));
+        TRY(dev_alloc(e, &d.row_prob, rows * AZX_CELL_STRIDE));
+        TRY(dev_alloc(e, &d.row_k, rows));
+        e->play_ready = true;
+    }
+    if (q_rows > e->q_alloc) {
+        (void)hipStreamSynchronize(e->stream);
+        for (void *p : e->q_allocs) (void)hipFree(p);
+        e->q_allocs.clear();
+        auto qa = [&](void **p, size_t bytes) -> int {
+            hipError_t err = hipMalloc(p, bytes);
+            if (err != hipSuccess) return fail(AZX_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+            e->q_allocs.push_back(*p);
+            return AZX_OK;
+        };
+        TRY(qa((void **)&d.q_board, (size_t)q_rows * AZX_CELL_STRIDE));
+        TRY(qa((void **)&d.q_prob, (size_t)q_rows * AZX_CELL_STRIDE * sizeof(float)));
+        TRY(qa((void **)&d.q_color, (size_t)q_rows * sizeof(int32_t)));
+        TRY(qa((void **)&d.q_k, (size_t)q_rows * sizeof(int32_t)));
+        TRY(qa((void **)&d.q_reward, (size_t)q_rows * sizeof(float)));
+        TRY(qa((void **)&d.q_uid, (size_t)q_rows * sizeof(int64_t)));
+        e->q_alloc = q_rows;
+    }
+    d.q_cap = e->q_alloc;
+    d.q_ring = ring;
+    HIPCHECK(hipMemsetAsync(d.q_count, 0, sizeof(unsigned long long), e->stream));
+    return AZX_OK;
+}
+
+struct CounterSnap {
+    unsigned long long c[CTR_COUNT];
+    double s[8];
+};
+
+static int snap_counters(azx_engine *e, CounterSnap *s) {
+    HIPCHECK(hipMemcpyAsync(s->c, e->d.counters, sizeof s->c, hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipMemcpyAsync(s->s, e->d.stat_sums, sizeof s->s, hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    return AZX_OK;
+}
+
+static void fill_stats(const CounterSnap &a, const CounterSnap &b, azx_play_stats *st) {
+    st->games = (int64_t)(b.c[CTR_GAMES] - a.c[CTR_GAMES]);
+    st->game_errors = (int64_t)(b.c[CTR_ERRORS] - a.c[CTR_ERRORS]);
+    st->plies = (int64_t)(b.c[CTR_PLIES] - a.c[CTR_PLIES]);
+    st->selects = (int64_t)(b.c[CTR_SELECTS] - a.c[CTR_SELECTS]);
+    st->evals = (int64_t)(b.c[CTR_EVALS] - a.c[CTR_EVALS]);
+    st->sum_depth = (int64_t)(b.c[CTR_SUM_DEPTH] - a.c[CTR_SUM_DEPTH]);
+    st->sum_k_interior = (int64_t)(b.c[CTR_SUM_K_INT] - a.c[CTR_SUM_K_INT]);
+    st->sum_k_leaf = (int64_t)(b.c[CTR_SUM_K_LEAF] - a.c[CTR_SUM_K_LEAF]);
+    st->sum_search_value = b.s[0] - a.s[0];
+    st->sum_root_width = b.s[1] - a.s[1];
+    st->sum_action_logprob = b.s[2] - a.s[2];
+    st->sum_reward_last = b.s[3] - a.s[3];
+}
+
+static int enqueue_ply(azx_engine *e) {
+    TRY(enqueue_search(e, true));
+    azx_launch_choose(e->d, e->stream);
+    azx_launch_advance(e->d, nullptr, 1, e->stream);
+    return AZX_OK;
+}
+
+extern "C" int azx_play_steps(azx_engine *e, int64_t plies, azx_play_stats *stats) {
+    if (!e || !stats) return fail(AZX_EINVAL, "null argument");
+    if (e->d.evaluator == AZX_EVAL_EXTERNAL) return fail(AZX_ESTATE, "play mode needs a device evaluator");
+    memset(stats, 0, sizeof *stats);
+    TRY(play_setup(e, std::max<int64_t>(e->q_alloc, 1 << 16), 1));
+    TRY(upload_noise(e, nullptr, 0, 0, e->cfg.noise_scale));
+    CounterSnap a, b;
+    TRY(snap_counters(e, &a));
+    hipEvent_t t0, t1;
+    HIPCHECK(hipEventCreate(&t0));
+    HIPCHECK(hipEventCreate(&t1));
+    HIPCHECK(hipEventRecord(t0, e->stream));
+    for (int64_t p = 0; p < plies; ++p) TRY(enqueue_ply(e));
+    HIPCHECK(hipEventRecord(t1, e->stream));
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, t0, t1));
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    TRY(snap_counters(e, &b));
+    fill_stats(a, b, stats);
+    stats->positions = (int64_t)(b.c[CTR_ROWS] - a.c[CTR_ROWS]);
+    stats->seconds = ms * 1e-3;
+    time_collect(e, &stats->mcts_seconds, &stats->mcts_launches);
+    return AZX_OK;
+}
+
+extern "C" int azx_play(azx_engine *e, int64_t min_positions, int64_t max_plies, int64_t cap,
+                        int32_t *board, int32_t *color, int32_t *nlegal, float *moves_prob,
+                        float *reward, int64_t *game_uid, azx_play_stats *stats) {
+    if (!e || !stats) return fail(AZX_EINVAL, "null argument");
+    if (e->d.evaluator == AZX_EVAL_EXTERNAL) return fail(AZX_ESTATE, "play mode needs a device evaluator");
+    DevEngine &d = e->d;
+    memset(stats, 0, sizeof *stats);
+    const int64_t worst = min_positions + (int64_t)d.G * d.ncells;
+    if (cap < worst)
+        return fail(AZX_EINVAL, "cap %lld < min_positions + n_games*cells = %lld (whole games only)",
+                    (long long)cap, (long long)worst);
+    TRY(play_setup(e, worst, 0));
+    TRY(upload_noise(e, nullptr, 0, 0, e->cfg.noise_scale));
+    CounterSnap a, b;
+    TRY(snap_counters(e, &a));
+    hipEvent_t t0, t1;
+    HIPCHECK(hipEventCreate(&t0));
+    HIPCHECK(hipEventCreate(&t1));
+    HIPCHECK(hipEventRecord(t0, e->stream));
+    unsigned long long rows = 0;
+    for (int64_t p = 0; (max_plies <= 0 || p < max_plies) && (int64_t)rows < min_positions; ++p) {
+        TRY(enqueue_ply(e));
+        HIPCHECK(hipMemcpyAsync(&rows, d.q_count, sizeof rows, hipMemcpyDeviceToHost, e->stream));
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    }
+    HIPCHECK(hipEventRecord(t1, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, t0, t1));
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    TRY(snap_counters(e, &b));
+    fill_stats(a, b, stats);
+    stats->positions = (int64_t)rows;
+    stats->seconds = ms * 1e-3;
+    time_collect(e, &stats->mcts_seconds, &stats->mcts_launches);
+    if (rows == 0) return AZX_OK;
+    const size_t n = (size_t)rows;
+    std::vector<uint8_t> hb(n * AZX_CELL_STRIDE);
+    std::vector<float> hp(n * AZX_CELL_STRIDE);
+    HIPCHECK(hipMemcpyAsync(hb.data(), d.q_board, hb.size(), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipMemcpyAsync(hp.data(), d.q_prob, hp.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (color) HIPCHECK(hipMemcpyAsync(color, d.q_color, n * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    if (nlegal) HIPCHECK(hipMemcpyAsync(nlegal, d.q_k, n * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    if (reward) HIPCHECK(hipMemcpyAsync(reward, d.q_reward, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (game_uid) HIPCHECK(hipMemcpyAsync(game_uid, d.q_uid, n * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    for (size_t r = 0; r < n; ++r) {
+        if (board)
+            for (int c = 0; c < d.ncells; ++c) board[r * d.ncells + c] = hb[r * AZX_CELL_STRIDE + c];
+        if (moves_prob)
+            for (int c = 0; c < d.ncells; ++c) moves_prob[r * d.ncells + c] = hp[r * AZX_CELL_STRIDE + c];
+    }
+    return AZX_OK;
+}
+
+// ---- float32 arithmetic self-test hook (tests): IEEE sqrt/divide and no FMA contraction ----
+extern "C" int azx_selftest_arith(int device, int n, const float *a, const float *b, float *sq,
+                                  float *dv, float *mul) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(AZX_ENODEV, "no HIP device visible");
+    HIPCHECK(hipSetDevice(device));
+    float *da, *db, *ds, *dd, *dm;
+    HIPCHECK(hipMalloc(&da, n * 4)); HIPCHECK(hipMalloc(&db, n * 4)); HIPCHECK(hipMalloc(&ds, n * 4));
+    HIPCHECK(hipMalloc(&dd, n * 4)); HIPCHECK(hipMalloc(&dm, n * 4));
+    HIPCHECK(hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice));
+    azx_launch_arith(da, db, ds, dd, dm, n, nullptr);
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(sq, ds, n * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(dv, dd, n * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(mul, dm, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(ds); (void)hipFree(dd); (void)hipFree(dm);
+    return AZX_OK;
+}

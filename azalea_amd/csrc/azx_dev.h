@@ -1,0 +1,205 @@
+// azx_dev.h -- device-side data model shared by the tree and network kernels (gfx950 only).
+//
+// HBM layout, per game slot g (see DESIGN.md "Data layout"):
+//   cells[g][SLOTS*64]  u32 per board cell: bits0-1 colour (0 empty, 1 X, 2 O),
+//                       bits2-3 edge flags of the cell's group (low edge / high edge),
+//                       bits8..  group label (cell index of the stone that last merged it).
+//                       One wavefront owns one game; lane l holds cells l, l+64, l+128.
+//   arena[a][g][cap]    Node (16 B): {num_visits, total_value, prior_prob, link}.
+//                       link >= 0: first child id (children are contiguous, in ascending
+//                       tile order); -1: unevaluated; <= -2: terminal (first_child value
+//                       the reference would hold = -2 - link).  The reference's parent[] and
+//                       num_children[] (search_tree.py:48-50) are implied: a Hex node with k
+//                       legal moves has children with k-1, and paths are recorded on descent.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/azx.h"
+
+#define AZX_LINK_UNEVAL (-1)
+#define AZX_LINK_TERM(fc) (-2 - (fc))
+#define AZX_LABEL_NONE 0x3FFFFFu
+
+struct alignas(16) Node {
+    float nv;      // num_visits   (float32 on purpose: search_tree.py:53)
+    float tv;      // total_value  (own perspective, search_tree.py:37-38)
+    float pp;      // prior_prob   (parent's perspective, search_tree.py:39-40)
+    int32_t link;
+};
+
+struct alignas(64) TreeHdr {
+    int32_t num_nodes;
+    int32_t root_id;
+    int32_t root_k;        // legal moves at the root
+    int32_t k0;            // legal moves at node 0 (for the six-array dump)
+    int32_t arena;         // which ping-pong arena holds the live tree
+    int32_t status;        // 0 ok, 1 SearchTreeFull
+    int32_t batches_left;  // select batches still to run in the current search
+    int32_t pending;       // leaves selected and waiting for expand/backup
+    int32_t pending_root;  // the pending leaf is the root evaluation (no backup)
+    int32_t select_count;  // select_leaf calls so far in this search (noise row index)
+    float   search_value;  // mcts.py:287 accumulator (float32)
+    int32_t pad[5];
+};
+
+struct alignas(64) GameHdr {
+    int32_t color;     // side to move, 1 = X, 2 = O
+    int32_t winner;    // 0 / 1 / 2
+    int32_t ply;
+    int32_t active;    // slot takes part in search/advance
+    int64_t uid;       // global game index (seeds the device RNG stream)
+    int32_t move_id;   // device-chosen child index of the last azx_play step
+    int32_t n_rows;    // replay rows this game has written so far
+    int32_t pad[8];
+};
+
+enum {   // counters[] slots
+    CTR_SELECTS = 0, CTR_SUM_DEPTH, CTR_SUM_K_INT, CTR_SUM_K_LEAF, CTR_EVALS, CTR_TERM_EVALS,
+    CTR_GAMES, CTR_ERRORS, CTR_PLIES, CTR_ROWS, CTR_COUNT = 16
+};
+
+struct DevEngine {
+    int32_t N, ncells, G, bs, cap, slots;
+    float c_puct;
+    int32_t evaluator, flags;
+    // games
+    uint32_t *cells;        // [G][slots*64]
+    GameHdr *ghdr;          // [G]
+    // trees
+    Node *arena[2];         // [G][cap] each
+    TreeHdr *thdr;          // [G]
+    // per-leaf scratch of the batch in flight
+    int32_t *leaf_node;     // [G][bs]
+    int32_t *leaf_len;      // [G][bs] path length (nodes below the root)
+    int32_t *leaf_eval;     // [G][bs] index into ev_* or -1 (terminal)
+    int32_t *leaf_link;     // [G][bs] the leaf's link when it was selected (-1 or terminal code)
+    uint64_t *leaf_mask;    // [G][bs][4] empties bitmask at the leaf (original frame)
+    int32_t *path;          // [G][bs][ncells]
+    // evaluation requests / results (packed by atomic counter)
+    uint8_t *ev_board;      // [E][AZX_CELL_STRIDE] network input (first player's view)
+    int32_t *ev_src;        // [E] g*bs + i
+    int32_t *ev_flip;       // [E] 1 if the board was flipped (mover is O)
+    float *ev_value;        // [E]
+    float *ev_prior;        // [E][AZX_CELL_STRIDE] by ORIGINAL cell index
+    int32_t *n_eval;        // [1]
+    // noise (parity: host rows; throughput: device RNG)
+    const double *noise;    // [G][n_select][noise_stride] or null
+    int32_t n_select, noise_stride;
+    double noise_scale;
+    float noise_alpha;
+    int32_t device_noise;
+    uint64_t seed;
+    const float *prior_by_k;   // [ncells+1] or null
+    unsigned long long *counters;
+    // throughput mode (azx_play): per-slot replay rows of the game in progress ...
+    int32_t exploration_depth;
+    float temperature;
+    uint8_t *row_board;     // [G][ncells][AZX_CELL_STRIDE] absolute colours before the move
+    float *row_prob;        // [G][ncells][AZX_CELL_STRIDE] moves_prob dense by child index
+    int32_t *row_k;         // [G][ncells]
+    // ... and the output queue finished games are appended to (whole games only)
+    int64_t q_cap;
+    int32_t q_ring;         // 1: wrap around instead of stalling (bench)
+    uint8_t *q_board;       // [Q][AZX_CELL_STRIDE]
+    float *q_prob;          // [Q][AZX_CELL_STRIDE]
+    int32_t *q_color, *q_k; // [Q]
+    float *q_reward;        // [Q]
+    int64_t *q_uid;         // [Q]
+    unsigned long long *q_count;   // [1] rows appended
+    unsigned long long *next_uid;  // [1]
+    double *stat_sums;      // [8] search_value, root_width, action_logprob, reward_last
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- Hex rules on one wavefront: azalea/game/hex.py:137-231 ------------------------------
+// The reference flood-fills the last mover's group (hex.py:204-231); here every cell carries
+// its group's label and edge flags, so placing a stone is one O(1) wave-parallel relabel
+// (a union of <= 6 neighbouring groups) and the win test is "merged flags == both edges".
+template <int SLOTS>
+struct HexWave {
+    uint32_t c[SLOTS];
+    int color;    // 1 = X to move, 2 = O (hex.py:148)
+    int winner;   // hex.py:149
+
+    __device__ __forceinline__ void load(const uint32_t *p, int lane) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) c[s] = p[s * 64 + lane];
+    }
+    __device__ __forceinline__ void store(uint32_t *p, int lane) const {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) p[s * 64 + lane] = c[s];
+    }
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) c[s] = 0;
+        color = 1;
+        winner = 0;
+    }
+    // wave-uniform read of one cell
+    __device__ __forceinline__ uint32_t read_cell(int cell) const {
+        const int s = cell >> 6, ln = cell & 63;
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            uint32_t t = __builtin_amdgcn_readlane(c[i], ln);
+            if (s == i) v = t;
+        }
+        return v;
+    }
+    // empties bitmask, slot s (hex.py:151-159: legal moves are the empty cells while winner==0)
+    __device__ __forceinline__ uint64_t empties(int s, int lane, int ncells) const {
+        return __ballot(((c[s] & 3u) == 0u) && (s * 64 + lane < ncells));
+    }
+    // hex.py:172-179 step + :204-231 check_win.  `cell` must be wave-uniform, empty, winner==0.
+    __device__ __forceinline__ void step(int cell, int N, int lane) {
+        const int col = color;
+        const int r = cell / N, q = cell - r * N;
+        const int e = (col == 1) ? r : q;            // colour 1 tracks rows, 2 columns
+        uint32_t flags = (e == 0 ? 1u : 0u) | (e == N - 1 ? 2u : 0u);
+        uint32_t labs[6];
+        const int dr[6] = {-1, -1, 0, 0, 1, 1};      // hex.py:190-195 neighbour order
+        const int dc[6] = {0, 1, -1, 1, -1, 0};
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+            const int nr = r + dr[d], nc = q + dc[d];
+            uint32_t lab = AZX_LABEL_NONE;
+            if (nr >= 0 && nr < N && nc >= 0 && nc < N) {
+                const uint32_t v = read_cell(nr * N + nc);
+                if ((int)(v & 3u) == col) {
+                    flags |= (v >> 2) & 3u;
+                    lab = v >> 8;
+                }
+            }
+            labs[d] = lab;
+        }
+        const uint32_t nv = (uint32_t)col | (flags << 2) | ((uint32_t)cell << 8);
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const uint32_t v = c[s];
+            const uint32_t lb = v >> 8;
+            const bool same = (int)(v & 3u) == col;
+            const bool hit = same && (lb == labs[0] || lb == labs[1] || lb == labs[2] ||
+                                      lb == labs[3] || lb == labs[4] || lb == labs[5]);
+            const bool mine = (s * 64 + lane) == cell;
+            c[s] = (mine || hit) ? nv : v;
+        }
+        winner = (flags == 3u) ? col : 0;
+        color = 3 - col;
+    }
+};

@@ -1,0 +1,1065 @@
+// mcts_kernels.hip -- Hex movegen + flat-array PUCT search kernels for gfx950 (MI355X).
+//
+// One 64-lane wavefront owns one concurrent game.  The board lives in registers (lane l
+// holds cells l, l+64[, l+128]), the children of the node being scored are read with one
+// coalesced 16-byte load per lane, PUCT argmax / visit sums are wave reductions, and the
+// Hex win test is an O(1) wave-parallel group relabel (see HexWave in azx_dev.h).
+//
+// Restates (bit-exact in float32, compile with -ffp-contract=off):
+//   azalea/mcts.py:46-76 select_batch, :79-92 apply_virtual_loss, :95-116 select_leaf,
+//   :119-136 score_actions, :139-152 deduplicate_leaves, :155-217 evaluate_batch (host half),
+//   :226-239 expand_batch, :242-255 backup_batch, :258-293 sample_paths;
+//   azalea/search_tree.py:59-71 reset, :115-132 move, :254-274 create_child_nodes;
+//   azalea/game/hex.py:137-231 rules, :72-122 perspective flip.
+#include "azx_dev.h"
+#include "mcts_kernels.h"
+
+__device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
+
+// numpy's float32 pairwise add-reduce for n < 128 (np.sum over the batch values, mcts.py:287)
+__device__ inline float np_sum_f32(const float *a, int n) {
+    if (n < 8) {
+        float r = 0.0f;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    float r[8];
+    int i;
+    for (i = 0; i < 8; ++i) r[i] = a[i];
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+// ---- Philox4x32-10 counter RNG (device noise + move sampling in throughput mode) ----------
+struct Philox {
+    uint32_t k0, k1;
+    __device__ __forceinline__ void gen(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                        uint32_t out[4]) const {
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ a, n1 = (uint32_t)p1;
+            const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ b, n3 = (uint32_t)p0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            a += 0x9E3779B9u; b += 0xBB67AE85u;
+        }
+        out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    }
+};
+__device__ __forceinline__ float u01(uint32_t x) { return ((x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ Philox game_rng(const DevEngine &E, int64_t uid) {
+    Philox ph;
+    const uint64_t s = E.seed + (uint64_t)uid;
+    ph.k0 = (uint32_t)s;
+    ph.k1 = (uint32_t)(s >> 32) ^ 0x5bd1e995u;
+    return ph;
+}
+
+// log of a Gamma(alpha) variate, alpha < 1 (Marsaglia-Tsang on alpha+1, boosted by U^(1/alpha))
+__device__ inline float log_gamma_variate(const Philox &ph, uint32_t c0, uint32_t c1, uint32_t c2,
+                                          float alpha) {
+    const float d = alpha + 1.0f - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
+    float lg = 0.0f;
+    for (uint32_t t = 0; t < 64; ++t) {
+        uint32_t r[4];
+        ph.gen(c0, c1, c2, t, r);
+        const float u1 = u01(r[0]), u2 = u01(r[1]);
+        const float x = sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
+        float v = 1.0f + c * x;
+        if (v <= 0.0f) continue;
+        v = v * v * v;
+        const float u = u01(r[2]);
+        if (__logf(u) < 0.5f * x * x + d - d * v + d * __logf(v)) {
+            lg = __logf(d * v) + __logf(u01(r[3])) / alpha;
+            break;
+        }
+    }
+    return lg;
+}
+
+template <int SLOTS>
+struct Masks {
+    uint64_t m[SLOTS];
+    int base[SLOTS];
+    int k;
+};
+
+template <int SLOTS>
+__device__ __forceinline__ Masks<SLOTS> make_masks(const HexWave<SLOTS> &h, int lane, int ncells) {
+    Masks<SLOTS> mk;
+    int k = 0;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        mk.m[s] = h.empties(s, lane, ncells);
+        mk.base[s] = k;
+        k += popc64(mk.m[s]);
+    }
+    mk.k = h.winner ? 0 : k;   // hex.py:152-153: no legal moves once there is a winner
+    return mk;
+}
+
+__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+
+// read-modify-write of (num_visits, total_value) along a recorded path: lane d handles path
+// element d.  `with_root` prepends the root (backup only, mcts.py:253).  The value added at
+// the LEAF is leaf_amount; with `alternate` its sign flips at every step towards the root
+// (mcts.py:252).  Visits get +dv everywhere.
+__device__ __forceinline__ void path_rmw(Node *arena, const int32_t *path_s, int len, int root_id,
+                                         bool with_root, float leaf_amount, bool alternate,
+                                         float dv, int lane) {
+    const int total = len + (with_root ? 1 : 0);
+    for (int b0 = 0; b0 < total; b0 += 64) {
+        const int d = b0 + lane;
+        if (d < total) {
+            const int id = with_root ? (d == 0 ? root_id : path_s[d - 1]) : path_s[d];
+            const int dist = total - 1 - d;              // 0 at the leaf
+            const float a = (alternate && (dist & 1)) ? -leaf_amount : leaf_amount;
+            float2 *p = reinterpret_cast<float2 *>(arena + id);
+            float2 x = *p;
+            x.x += dv;
+            x.y += a;
+            *p = x;
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_mem_sync() {
+    // global stores of this wave must be visible to later loads issued by OTHER lanes of it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// source cell of output cell o after the perspective flip (hex.py:72-87)
+__device__ __forceinline__ int flip_src(int o, int N) {
+    const int i = o / N, j = o - i * N;
+    return (N - 1 - j) * N + (N - 1 - i);
+}
+
+struct Lds {
+    int32_t *path;        // [AZX_MAX_BATCH][ncells]
+    uint64_t *mask;       // [AZX_MAX_BATCH][4]
+    unsigned char *colors;// [AZX_MAX_BATCH][AZX_CELL_STRIDE] absolute colours at the leaf
+    int32_t *node, *len, *link, *term, *mover, *uidx;   // [AZX_MAX_BATCH]
+    float *value;         // [AZX_MAX_BATCH]
+};
+
+size_t azx_mcts_lds_bytes(int ncells) {
+    size_t b = (size_t)AZX_MAX_BATCH * (ncells + (ncells & 1)) * 4;   // path
+    b += AZX_MAX_BATCH * 4 * 8;                                        // mask
+    b += AZX_MAX_BATCH * AZX_CELL_STRIDE;                              // colors
+    b += AZX_MAX_BATCH * 4 * 7;                                        // small arrays
+    return b + 64;
+}
+
+__device__ __forceinline__ Lds carve_lds(unsigned char *raw, int ncells) {
+    Lds L;
+    L.path = reinterpret_cast<int32_t *>(raw);
+    L.mask = reinterpret_cast<uint64_t *>(L.path + AZX_MAX_BATCH * (ncells + (ncells & 1)));
+    L.colors = reinterpret_cast<unsigned char *>(L.mask + AZX_MAX_BATCH * 4);
+    L.node = reinterpret_cast<int32_t *>(L.colors + AZX_MAX_BATCH * AZX_CELL_STRIDE);
+    L.len = L.node + AZX_MAX_BATCH;
+    L.link = L.len + AZX_MAX_BATCH;
+    L.term = L.link + AZX_MAX_BATCH;
+    L.mover = L.term + AZX_MAX_BATCH;
+    L.uidx = L.mover + AZX_MAX_BATCH;
+    L.value = reinterpret_cast<float *>(L.uidx + AZX_MAX_BATCH);
+    return L;
+}
+
+// ============================================================================================
+// The search kernel.  mode = MODE_* bits (mcts_kernels.h).
+// ============================================================================================
+template <int SLOTS>
+__global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batches) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x;
+    const int N = E.N, ncells = E.ncells, bs = E.bs;
+    const int pstride = ncells + (ncells & 1);
+    GameHdr *gh = E.ghdr + g;
+    if (!gh->active) return;
+    TreeHdr *th = E.thdr + g;
+    const Lds L = carve_lds(smem_raw, ncells);
+
+    int num_nodes = th->num_nodes;
+    const int root_id = th->root_id;
+    int status = th->status;
+    int batches_left = th->batches_left;
+    int pending = th->pending;
+    int pending_root = th->pending_root;
+    int select_count = th->select_count;
+    float search_value = th->search_value;
+    Node *arena = E.arena[th->arena] + (size_t)g * E.cap;
+
+    HexWave<SLOTS> root;
+    root.load(E.cells + (size_t)g * SLOTS * 64, lane);
+    root.color = gh->color;
+    root.winner = gh->winner;
+    const int ply = gh->ply;
+    const Masks<SLOTS> rootmk = make_masks<SLOTS>(root, lane, ncells);
+
+    unsigned long long c_selects = 0, c_depth = 0, c_kint = 0, c_kleaf = 0, c_evals = 0, c_term = 0;
+    const bool inline_eval = (mode & MODE_INLINE) != 0;
+    const float c32 = E.c_puct;
+    const float keep32 = (float)(1.0 - E.noise_scale);   // python float -> f32 (weak scalar)
+    const Philox ph = game_rng(E, gh->uid);
+
+    if (mode & MODE_BEGIN) {
+        batches_left = num_batches;
+        select_count = 0;
+        search_value = 0.0f;
+        pending = 0;
+        pending_root = 0;
+    }
+
+    // ---- create_child_nodes (search_tree.py:254-274) for one leaf; returns false when full
+    auto expand = [&](int node, int lnk, bool terminal, const uint64_t *lm,
+                      const float *prior_row, float prior_const) -> bool {
+        if (lnk != AZX_LINK_UNEVAL) return true;          // re-selected terminal: mcts.py:237
+        int k = 0;
+        int base[SLOTS];
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) { base[s] = k; k += popc64(lm[s]); }
+        if (terminal) k = 0;
+        if (num_nodes + k > E.cap) { status = 1; return false; }   // SearchTreeFull
+        const int fc = num_nodes;
+        num_nodes += k;
+        if (k > 0) {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                if ((lm[s] >> lane) & 1ull) {
+                    const int cell = s * 64 + lane;
+                    const int rk = base[s] + popc64(lm[s] & lanemask_lt(lane));
+                    Node nd;
+                    nd.nv = 0.0f;
+                    nd.tv = 0.0f;
+                    nd.pp = prior_row ? prior_row[cell] : prior_const;
+                    nd.link = AZX_LINK_UNEVAL;
+                    arena[fc + rk] = nd;
+                }
+            }
+            c_kleaf += (unsigned long long)k;
+        }
+        if (lane == 0) arena[node].link = (k > 0) ? fc : AZX_LINK_TERM(fc);
+        return true;
+    };
+
+    // ---- emit one evaluation request: network-input board (flipped for O) ----------------
+    auto emit_request = [&](int e, int src_index, const unsigned char *colors, int mover) {
+        const bool flip = mover == 2;                       // state.color == 1: mcts.py:178
+        for (int o = lane; o < AZX_CELL_STRIDE; o += 64) {
+            unsigned char v = 0;
+            if (o < ncells) {
+                const int src = flip ? flip_src(o, N) : o;
+                v = colors[src];
+                if (flip && v) v = 3 - v;
+            }
+            E.ev_board[(size_t)e * AZX_CELL_STRIDE + o] = v;
+        }
+        if (lane == 0) {
+            E.ev_src[e] = src_index;
+            E.ev_flip[e] = flip ? 1 : 0;
+        }
+    };
+
+    // fnv1a of the network-input board (parity stub value, tests/golden/make_golden.py)
+    auto hash_value = [&](const unsigned char *colors, int mover) -> float {
+        const bool flip = mover == 2;
+        uint32_t h = 0x811c9dc5u;
+        // each int32 contributes its low byte then three zero bytes: h = (h ^ b) * p^4
+        const uint32_t p = 0x01000193u, p4 = p * p * p * p;
+        for (int o = 0; o < ncells; ++o) {
+            const int src = flip ? flip_src(o, N) : o;
+            uint32_t v = colors[src];
+            if (flip && v) v = 3 - v;
+            h = (h ^ v) * p4;
+        }
+        return (float)((double)(h & 0xffffu) / 32768.0 - 1.0);
+    };
+
+    auto inline_prior = [&](int k) -> float {
+        return E.prior_by_k ? E.prior_by_k[k] : 1.0f / (float)k;
+    };
+
+    // =================================== BEGIN: root evaluation (mcts.py:272-273) ========
+    if ((mode & MODE_BEGIN) && status == 0) {
+        const int root_link = arena[root_id].link;
+        if (root_link == AZX_LINK_UNEVAL) {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int cell = s * 64 + lane;
+                if (cell < ncells) L.colors[cell] = (unsigned char)(root.c[s] & 3u);
+            }
+            lds_sync();
+            if (inline_eval) {
+                expand(root_id, AZX_LINK_UNEVAL, root.winner != 0, rootmk.m, nullptr,
+                       rootmk.k ? inline_prior(rootmk.k) : 0.0f);
+                c_evals += 1;
+                wave_mem_sync();
+            } else {
+                int e = 0;
+                if (lane == 0) e = atomicAdd(E.n_eval, 1);
+                e = __builtin_amdgcn_readfirstlane(e);
+                emit_request(e, g * bs + 0, L.colors, root.color);
+                if (lane == 0) {
+                    const size_t lb = (size_t)g * bs;
+                    E.leaf_node[lb] = root_id;
+                    E.leaf_len[lb] = 0;
+                    E.leaf_eval[lb] = e;
+                    E.leaf_link[lb] = AZX_LINK_UNEVAL;
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) E.leaf_mask[lb * 4 + s] = rootmk.m[s];
+                }
+                pending = 1;
+                pending_root = 1;
+                c_evals += 1;
+            }
+        }
+    }
+
+    // =================================== APPLY: expand + backup pending leaves ============
+    if ((mode & MODE_APPLY) && pending > 0 && status == 0) {
+        const size_t lb = (size_t)g * bs;
+        for (int i = 0; i < pending; ++i) {
+            const int node = E.leaf_node[lb + i];
+            const int len = E.leaf_len[lb + i];
+            const int ev = E.leaf_eval[lb + i];
+            const int lnk = E.leaf_link[lb + i];
+            uint64_t lm[SLOTS];
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) lm[s] = E.leaf_mask[(lb + i) * 4 + s];
+            const int32_t *pth = E.path + (lb + i) * (size_t)pstride;
+            for (int d = lane; d < len; d += 64) L.path[d] = pth[d];
+            lds_sync();
+            const bool terminal = ev < 0;
+            float v = -1.0f;                                   // mcts.py:194-195
+            if (!terminal) v = E.ev_value[ev];
+            if (!expand(node, lnk, terminal, lm,
+                        terminal ? nullptr : E.ev_prior + (size_t)ev * AZX_CELL_STRIDE, 0.0f))
+                break;
+            if (!pending_root) {
+                path_rmw(arena, L.path, len, root_id, true, v, true, 1.0f, lane);   // mcts.py:247-255
+                if (lane == 0) L.value[i] = v;
+            }
+            wave_mem_sync();
+            lds_sync();
+        }
+        if (!pending_root && status == 0) {
+            lds_sync();
+            search_value += np_sum_f32(L.value, pending);       // mcts.py:287
+        }
+        pending = 0;
+        pending_root = 0;
+    }
+
+    // =================================== SELECT (+ inline evaluate/expand/backup) =========
+    const bool do_select = (mode & (MODE_SELECT | MODE_INLINE)) != 0;
+    while (do_select && batches_left > 0 && status == 0 && pending == 0) {
+        const int root_link = arena[root_id].link;
+        if (root_link < 0) break;   // unevaluated or terminal root: nothing to search
+
+        // ---- select_batch: bs sequential descents with virtual loss (mcts.py:62-70) ----
+        for (int i = 0; i < bs; ++i) {
+            HexWave<SLOTS> cur = root;                        // snapshot/restore, search_tree.py:150-154
+            int link = root_link;
+            int depth = 0, node = root_id, child_link = 0;
+            bool at_root = true;
+            for (;;) {
+                const Masks<SLOTS> mk = make_masks<SLOTS>(cur, lane, ncells);
+                // ---- children statistics: one 16-byte load per legal move --------------
+                float4 st[SLOTS];
+                int rk[SLOTS];
+                float sumn = 0.0f;
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    const bool empty = (mk.m[s] >> lane) & 1ull;
+                    rk[s] = mk.base[s] + popc64(mk.m[s] & lanemask_lt(lane));
+                    st[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (empty) {
+                        st[s] = *reinterpret_cast<const float4 *>(arena + link + rk[s]);
+                        sumn += st[s].x;
+                    }
+                }
+                sumn = wave_sum(sumn);                         // exact: visit counts are integers
+                const float sq = sqrtf(sumn);                  // mcts.py:132
+                // ---- Dirichlet noise at the root only (mcts.py:126-131, :114) ----------
+                float nz[SLOTS];
+                const bool noisy = at_root && E.noise_scale != 0.0;
+                if (noisy && E.device_noise) {
+                    float lg[SLOTS];
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) {
+                        lg[s] = -3.0e38f;
+                        if ((mk.m[s] >> lane) & 1ull) {
+                            lg[s] = log_gamma_variate(ph, (uint32_t)(s * 64 + lane),
+                                                      (uint32_t)select_count, (uint32_t)ply,
+                                                      E.noise_alpha);
+                            mx = fmaxf(mx, lg[s]);
+                        }
+                    }
+                    mx = wave_max(mx);
+                    float sw = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) {
+                        nz[s] = ((mk.m[s] >> lane) & 1ull) ? __expf(lg[s] - mx) : 0.0f;
+                        sw += nz[s];
+                    }
+                    sw = wave_sum(sw);
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) nz[s] = nz[s] / sw;
+                }
+                // ---- score_actions (mcts.py:119-136), op by op in float32 --------------
+                float best = -INFINITY;
+                int best_cell = 0x7fffffff;
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    if ((mk.m[s] >> lane) & 1ull) {
+                        float P = st[s].z;
+                        if (noisy) {
+                            const float kept = keep32 * P;
+                            if (E.device_noise) {
+                                P = kept + (float)E.noise_scale * nz[s];
+                            } else {
+                                const double *row = E.noise +
+                                    ((size_t)g * E.n_select + select_count) * E.noise_stride;
+                                P = (float)((double)kept + E.noise_scale * row[rk[s]]);
+                            }
+                        }
+                        const float nvj = st[s].x;
+                        const float gap = sq / (1.0f + nvj);              // mcts.py:132
+                        const float U = (c32 * P) * gap;                  // mcts.py:133
+                        const float W = -st[s].y;                         // search_tree.py:203
+                        const float Q = W / fmaxf(nvj, 1.0f);             // mcts.py:134
+                        const float score = Q + U;                        // mcts.py:135
+                        const int cell = s * 64 + lane;
+                        if (score > best || (score == best && cell < best_cell)) {
+                            best = score;
+                            best_cell = cell;
+                        }
+                    }
+                }
+                // np.argmax: highest score, lowest index on ties (mcts.py:112)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ob = __shfl_xor(best, o, 64);
+                    const int oc = __shfl_xor(best_cell, o, 64);
+                    if (ob > best || (ob == best && oc < best_cell)) { best = ob; best_cell = oc; }
+                }
+                best_cell = __builtin_amdgcn_readfirstlane(best_cell);
+                const int bl = best_cell & 63, bsl = best_cell >> 6;
+                int child_rank = 0;
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    const int r_ = __builtin_amdgcn_readlane(rk[s], bl);
+                    const int l_ = __builtin_amdgcn_readlane(__float_as_int(st[s].w), bl);
+                    if (s == bsl) { child_rank = r_; child_link = l_; }
+                }
+                c_depth += 1;
+                c_kint += (unsigned long long)mk.k;
+                node = link + child_rank;
+                if (lane == 0) L.path[i * pstride + depth] = node;
+                cur.step(best_cell, N, lane);                  // search_tree.py:306-308
+                depth += 1;
+                at_root = false;
+                if (child_link < 0) break;                     // leaf: unevaluated or terminal
+                link = child_link;
+            }
+            select_count += 1;
+            c_selects += 1;
+            // record the leaf (mcts.py:69-70) ...
+            const Masks<SLOTS> lmk = make_masks<SLOTS>(cur, lane, ncells);
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int cell = s * 64 + lane;
+                if (cell < ncells) L.colors[i * AZX_CELL_STRIDE + cell] = (unsigned char)(cur.c[s] & 3u);
+            }
+            if (lane == 0) {
+                L.node[i] = node;
+                L.len[i] = depth;
+                L.link[i] = child_link;
+                L.term[i] = cur.winner != 0;
+                L.mover[i] = cur.color;
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) L.mask[i * 4 + s] = lmk.m[s];
+            }
+            lds_sync();
+            // ... and apply the virtual loss to its path (mcts.py:68, :79-92)
+            path_rmw(arena, L.path + i * pstride, depth, root_id, false, 1.0f, false, 1.0f, lane);
+            wave_mem_sync();
+        }
+        // undo the virtual losses in list order (mcts.py:72)
+        for (int i = 0; i < bs; ++i) {
+            path_rmw(arena, L.path + i * pstride, L.len[i], root_id, false, -1.0f, false, -1.0f, lane);
+            wave_mem_sync();
+        }
+        // deduplicate_leaves: keep first occurrence by node id (mcts.py:139-152)
+        int nu = 0;
+        for (int i = 0; i < bs; ++i) {
+            bool dup = false;
+            for (int j = 0; j < i; ++j) dup = dup || (L.node[j] == L.node[i]);
+            if (!dup) {
+                if (lane == 0) L.uidx[nu] = i;
+                nu += 1;
+            }
+        }
+        lds_sync();
+        batches_left -= 1;
+
+        if (inline_eval) {
+            // evaluate_batch + expand_batch + backup_batch for the inline (uniform) evaluator
+            for (int u = 0; u < nu; ++u) {
+                const int i = L.uidx[u];
+                const bool terminal = L.term[i] != 0;
+                uint64_t lm[SLOTS];
+                int k = 0;
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) { lm[s] = L.mask[i * 4 + s]; k += popc64(lm[s]); }
+                float v = -1.0f;
+                if (!terminal) {
+                    v = (E.evaluator == AZX_EVAL_UNIFORM_HASH)
+                            ? hash_value(L.colors + i * AZX_CELL_STRIDE, L.mover[i]) : 0.0f;
+                    c_evals += 1;
+                } else {
+                    c_term += 1;
+                }
+                if (!expand(L.node[i], L.link[i], terminal, lm, nullptr,
+                            (!terminal && k) ? inline_prior(k) : 0.0f))
+                    break;
+                path_rmw(arena, L.path + i * pstride, L.len[i], root_id, true, v, true, 1.0f, lane);
+                if (lane == 0) L.value[u] = v;
+                wave_mem_sync();
+            }
+            lds_sync();
+            if (status == 0) search_value += np_sum_f32(L.value, nu);   // mcts.py:287
+        } else {
+            // hand the unique leaves to the evaluator: scratch + packed requests
+            int n_nt = 0;
+            for (int u = 0; u < nu; ++u) n_nt += L.term[L.uidx[u]] ? 0 : 1;
+            int e0 = 0;
+            if (lane == 0 && n_nt) e0 = atomicAdd(E.n_eval, n_nt);
+            e0 = __builtin_amdgcn_readfirstlane(e0);
+            const size_t lb = (size_t)g * bs;
+            int e = e0;
+            for (int u = 0; u < nu; ++u) {
+                const int i = L.uidx[u];
+                const bool terminal = L.term[i] != 0;
+                const int len = L.len[i];
+                int32_t *pth = E.path + (lb + u) * (size_t)pstride;
+                for (int d = lane; d < len; d += 64) pth[d] = L.path[i * pstride + d];
+                if (lane == 0) {
+                    E.leaf_node[lb + u] = L.node[i];
+                    E.leaf_len[lb + u] = len;
+                    E.leaf_link[lb + u] = L.link[i];
+                    E.leaf_eval[lb + u] = terminal ? -1 : e;
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) E.leaf_mask[(lb + u) * 4 + s] = L.mask[i * 4 + s];
+                }
+                if (!terminal) {
+                    emit_request(e, g * bs + u, L.colors + i * AZX_CELL_STRIDE, L.mover[i]);
+                    e += 1;
+                    c_evals += 1;
+                } else {
+                    c_term += 1;
+                }
+            }
+            pending = nu;
+        }
+    }
+
+    // =================================== epilogue ========================================
+    if (lane == 0) {
+        th->num_nodes = num_nodes;
+        th->status = status;
+        th->batches_left = batches_left;
+        th->pending = pending;
+        th->pending_root = pending_root;
+        th->select_count = select_count;
+        th->search_value = search_value;
+        if (c_selects) atomicAdd(E.counters + CTR_SELECTS, c_selects);
+        if (c_depth) atomicAdd(E.counters + CTR_SUM_DEPTH, c_depth);
+        if (c_kint) atomicAdd(E.counters + CTR_SUM_K_INT, c_kint);
+        if (c_kleaf) atomicAdd(E.counters + CTR_SUM_K_LEAF, c_kleaf);
+        if (c_evals) atomicAdd(E.counters + CTR_EVALS, c_evals);
+        if (c_term) atomicAdd(E.counters + CTR_TERM_EVALS, c_term);
+    }
+}
+
+// ============================================================================================
+// reset + replay: HexGame.reset / step (hex.py:47-49, :172-179), SearchTree.reset
+// (search_tree.py:59-71).  One wavefront per listed slot.
+// ============================================================================================
+template <int SLOTS>
+__device__ __forceinline__ void tree_reset(const DevEngine &E, int g, TreeHdr *th, int k, int lane) {
+    Node *arena = E.arena[th->arena] + (size_t)g * E.cap;
+    if (lane == 0) {
+        Node nd;
+        nd.nv = 0.0f; nd.tv = 0.0f; nd.pp = 1.0f; nd.link = AZX_LINK_UNEVAL;
+        arena[0] = nd;
+        th->num_nodes = 1;
+        th->root_id = 0;
+        th->root_k = k;
+        th->k0 = k;
+        th->status = 0;
+        th->batches_left = 0;
+        th->pending = 0;
+        th->pending_root = 0;
+        th->select_count = 0;
+        th->search_value = 0.0f;
+    }
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(64) void k_reset(DevEngine E, const int32_t *slots, int n_slots,
+                                              const int32_t *moves, const int32_t *n_moves,
+                                              int stride, int assign_uid) {
+    const int lane = threadIdx.x;
+    const int idx = blockIdx.x;
+    if (idx >= n_slots) return;
+    const int g = slots ? slots[idx] : idx;
+    HexWave<SLOTS> h;
+    h.clear();
+    int ply = 0;
+    if (moves) {
+        const int nm = n_moves[idx];
+        for (int p = 0; p < nm; ++p) {
+            const int mv = moves[(size_t)idx * stride + p];
+            h.step(mv - 1, E.N, lane);
+            ply += 1;
+        }
+    }
+    h.store(E.cells + (size_t)g * SLOTS * 64, lane);
+    const Masks<SLOTS> mk = make_masks<SLOTS>(h, lane, E.ncells);
+    GameHdr *gh = E.ghdr + g;
+    TreeHdr *th = E.thdr + g;
+    if (lane == 0) {
+        gh->color = h.color;
+        gh->winner = h.winner;
+        gh->ply = ply;
+        gh->active = 1;
+        gh->move_id = -1;
+        gh->n_rows = 0;
+        if (assign_uid) gh->uid = (int64_t)atomicAdd(E.next_uid, 1ull);
+        th->arena = 0;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    tree_reset<SLOTS>(E, g, th, mk.k, lane);
+}
+
+// ============================================================================================
+// advance: HexGame.step + SearchTree.move (hex.py:172-179, search_tree.py:115-132), with the
+// kept subtree compacted into the other arena (the reference never reclaims nodes).
+// In play mode a finished game is appended to the output queue and the slot restarts.
+// ============================================================================================
+template <int SLOTS>
+__global__ __launch_bounds__(64) void k_advance(DevEngine E, const int32_t *move_ids, int play_mode) {
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x;
+    GameHdr *gh = E.ghdr + g;
+    TreeHdr *th = E.thdr + g;
+    if (!gh->active) return;
+    int status = th->status;
+    const int mid = move_ids ? move_ids[g] : gh->move_id;
+    if (mid < 0 && status == 0) return;
+
+    HexWave<SLOTS> h;
+    h.load(E.cells + (size_t)g * SLOTS * 64, lane);
+    h.color = gh->color;
+    h.winner = gh->winner;
+    int ply = gh->ply;
+    bool finished = false, errored = status != 0;
+
+    if (!errored) {
+        const Masks<SLOTS> mk = make_masks<SLOTS>(h, lane, E.ncells);
+        // the mid-th legal move in ascending tile order (search_tree.py:306)
+        int cell = -1;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const bool empty = (mk.m[s] >> lane) & 1ull;
+            const int rk = mk.base[s] + popc64(mk.m[s] & lanemask_lt(lane));
+            const uint64_t hit = __ballot(empty && rk == mid);
+            if (hit) cell = s * 64 + (int)__ffsll((long long)hit) - 1;
+        }
+        if (cell < 0) return;   // illegal move_id: leave the slot untouched
+        h.step(cell, E.N, lane);
+        ply += 1;
+        h.store(E.cells + (size_t)g * SLOTS * 64, lane);
+        const Masks<SLOTS> nmk = make_masks<SLOTS>(h, lane, E.ncells);
+        finished = h.winner != 0;
+
+        // ---- SearchTree.move (search_tree.py:115-132) ----
+        Node *src = E.arena[th->arena] + (size_t)g * E.cap;
+        const int root_id = th->root_id;
+        const int root_link = src[root_id].link;
+        int child = -1, clink = AZX_LINK_UNEVAL;
+        if (root_link >= 0) {
+            child = root_link + mid;
+            clink = src[child].link;
+        }
+        if (child < 0 || clink == AZX_LINK_UNEVAL) {
+            tree_reset<SLOTS>(E, g, th, nmk.k, lane);           // step to the unknown
+        } else if (E.flags & AZX_FLAG_NO_COMPACT) {
+            if (lane == 0) { th->root_id = child; th->root_k = nmk.k; }
+        } else {
+            // Cheney copy of the kept subtree, level by level (children of a level-L node: kL)
+            Node *dst = E.arena[th->arena ^ 1] + (size_t)g * E.cap;
+            if (lane == 0) dst[0] = src[child];
+            wave_mem_sync();
+            int n_new = 1, lvl_start = 0, lvl_end = 1, kL = nmk.k;
+            while (lvl_start < lvl_end && kL > 0) {
+                for (int i0 = lvl_start; i0 < lvl_end; i0 += 64) {
+                    const int i = i0 + lane;
+                    int oldfc = -1;
+                    if (i < lvl_end) oldfc = dst[i].link;
+                    const bool has = oldfc >= 0;
+                    const uint64_t hm = __ballot(has);
+                    const int newfc = n_new + kL * popc64(hm & lanemask_lt(lane));
+                    if (has) dst[i].link = newfc;
+                    uint64_t rem = hm;
+                    while (rem) {
+                        const int l = (int)__ffsll((long long)rem) - 1;
+                        rem &= rem - 1;
+                        const int o = __builtin_amdgcn_readlane(oldfc, l);
+                        const int nf = __builtin_amdgcn_readlane(newfc, l);
+                        for (int j = lane; j < kL; j += 64) dst[nf + j] = src[o + j];
+                    }
+                    n_new += kL * popc64(hm);
+                    wave_mem_sync();
+                }
+                lvl_start = lvl_end;
+                lvl_end = n_new;
+                kL -= 1;
+            }
+            if (lane == 0) {
+                th->arena ^= 1;
+                th->num_nodes = n_new;
+                th->root_id = 0;
+                th->root_k = nmk.k;
+                th->k0 = nmk.k;
+            }
+        }
+        if (lane == 0) {
+            gh->color = h.color;
+            gh->winner = h.winner;
+            gh->ply = ply;
+            gh->move_id = -1;
+            atomicAdd(E.counters + CTR_PLIES, 1ull);
+        }
+    }
+
+    if (!play_mode || !(finished || errored)) return;
+
+    // ---- play mode: harvest the finished game (play_game.py:59-67) and restart the slot ----
+    const int rows = gh->n_rows;
+    bool restart = true;
+    if (finished) {
+        const int result = h.winner == 2 ? 1 : 3;              // hex.py:161-170
+        unsigned long long pos = 0;
+        if (lane == 0) pos = atomicAdd(E.q_count, (unsigned long long)rows);
+        pos = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(pos >> 32)) << 32) |
+              (unsigned int)__builtin_amdgcn_readfirstlane((int)pos);
+        if (!E.q_ring && pos + rows > (unsigned long long)E.q_cap) {
+            // queue full: give the reservation back and park the slot until the host drains
+            if (lane == 0) { atomicAdd(E.q_count, (unsigned long long)(-(long long)rows)); gh->active = 0; }
+            restart = false;
+        } else {
+            for (int r = 0; r < rows; ++r) {
+                const size_t q = (size_t)((pos + r) % (unsigned long long)E.q_cap);
+                const size_t sr = ((size_t)g * E.ncells + r) * AZX_CELL_STRIDE;
+                for (int o = lane; o < AZX_CELL_STRIDE / 4; o += 64)
+                    reinterpret_cast<uint32_t *>(E.q_board + q * AZX_CELL_STRIDE)[o] =
+                        reinterpret_cast<const uint32_t *>(E.row_board + sr)[o];
+                for (int o = lane; o < AZX_CELL_STRIDE; o += 64)
+                    E.q_prob[q * AZX_CELL_STRIDE + o] = E.row_prob[sr + o];
+                if (lane == 0) {
+                    E.q_color[q] = r & 1;
+                    E.q_k[q] = E.row_k[(size_t)g * E.ncells + r];
+                    float rew = (float)(result - 2);           // play_game.py:64-65
+                    if (r & 1) rew = -rew;
+                    E.q_reward[q] = rew;
+                    E.q_uid[q] = gh->uid;
+                }
+            }
+            if (lane == 0) {
+                atomicAdd(E.counters + CTR_GAMES, 1ull);
+                atomicAdd(E.counters + CTR_ROWS, (unsigned long long)rows);
+                float last = (float)(result - 2);
+                if ((rows - 1) & 1) last = -last;
+                atomicAdd(E.stat_sums + 3, (double)last);       // metrics['reward']
+            }
+        }
+    } else {
+        if (lane == 0) atomicAdd(E.counters + CTR_ERRORS, 1ull);   // parallel_player.py:73-76
+    }
+    if (restart) {
+        HexWave<SLOTS> z;
+        z.clear();
+        z.store(E.cells + (size_t)g * SLOTS * 64, lane);
+        if (lane == 0) {
+            gh->color = 1;
+            gh->winner = 0;
+            gh->ply = 0;
+            gh->move_id = -1;
+            gh->n_rows = 0;
+            gh->uid = (int64_t)atomicAdd(E.next_uid, 1ull);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        tree_reset<SLOTS>(E, g, th, E.ncells, lane);
+    }
+}
+
+// ============================================================================================
+// root statistics: root.move_stats (search_tree.py:192-204) dense by child index
+// ============================================================================================
+template <int SLOTS>
+__global__ __launch_bounds__(64) void k_gather_root(DevEngine E, int32_t *k_out, int32_t *legal,
+                                                    float *cv, float *cw, float *cp, float *rv,
+                                                    float *rw, int32_t *nn, float *sv) {
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x;
+    GameHdr *gh = E.ghdr + g;
+    TreeHdr *th = E.thdr + g;
+    HexWave<SLOTS> h;
+    h.load(E.cells + (size_t)g * SLOTS * 64, lane);
+    h.color = gh->color;
+    h.winner = gh->winner;
+    const Masks<SLOTS> mk = make_masks<SLOTS>(h, lane, E.ncells);
+    const Node *arena = E.arena[th->arena] + (size_t)g * E.cap;
+    const Node rootn = arena[th->root_id];
+    const size_t ob = (size_t)g * E.ncells;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        if (((mk.m[s] >> lane) & 1ull) && mk.k > 0) {
+            const int rk = mk.base[s] + popc64(mk.m[s] & lanemask_lt(lane));
+            if (legal) legal[ob + rk] = s * 64 + lane + 1;
+            if (rootn.link >= 0) {
+                const Node c = arena[rootn.link + rk];
+                if (cv) cv[ob + rk] = c.nv;
+                if (cw) cw[ob + rk] = c.tv;
+                if (cp) cp[ob + rk] = c.pp;
+            }
+        }
+    }
+    if (lane == 0) {
+        if (k_out) k_out[g] = mk.k;
+        if (rv) rv[g] = rootn.nv;
+        if (rw) rw[g] = rootn.tv;
+        if (nn) nn[g] = th->num_nodes;
+        if (sv) sv[g] = th->search_value;
+    }
+}
+
+// ============================================================================================
+// throughput mode: Policy.choose_action's move draw (policy.py:142-160) + play_game's data
+// collection (play_game.py:81-98) on the device.  as_distribution (search_tree.py:327-344):
+// T>0: p ~ n^(1/T); T==0: uniform over the most-visited children.
+// ============================================================================================
+template <int SLOTS>
+__global__ __launch_bounds__(64) void k_choose(DevEngine E) {
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x;
+    GameHdr *gh = E.ghdr + g;
+    TreeHdr *th = E.thdr + g;
+    if (!gh->active || th->status != 0) return;
+    HexWave<SLOTS> h;
+    h.load(E.cells + (size_t)g * SLOTS * 64, lane);
+    h.color = gh->color;
+    h.winner = gh->winner;
+    const Masks<SLOTS> mk = make_masks<SLOTS>(h, lane, E.ncells);
+    const Node *arena = E.arena[th->arena] + (size_t)g * E.cap;
+    const Node rootn = arena[th->root_id];
+    if (rootn.link < 0 || mk.k == 0) return;
+    const int ply = gh->ply;
+    const float T = (ply >= E.exploration_depth) ? 0.0f : E.temperature;   // policy.py:142-149
+
+    float nv[SLOTS], w[SLOTS];
+    int rk[SLOTS];
+    float mx = 0.0f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        nv[s] = 0.0f;
+        rk[s] = mk.base[s] + popc64(mk.m[s] & lanemask_lt(lane));
+        if ((mk.m[s] >> lane) & 1ull) nv[s] = arena[rootn.link + rk[s]].nv;
+        mx = fmaxf(mx, nv[s]);
+    }
+    mx = wave_max(mx);
+    float tot = 0.0f;
+    int width = 0;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const bool empty = (mk.m[s] >> lane) & 1ull;
+        float x = 0.0f;
+        if (empty) {
+            if (T > 0.0f) x = (nv[s] > 0.0f) ? (T == 1.0f ? nv[s] : __powf(nv[s], 1.0f / T)) : 0.0f;
+            else x = (nv[s] == mx) ? 1.0f : 0.0f;
+            width += nv[s] > 0.0f;
+        }
+        w[s] = x;
+        tot += x;
+    }
+    tot = wave_sum(tot);
+    width = wave_sum_i(width);
+    // inclusive prefix sums in child order (slot-major, lane-minor)
+    uint32_t r[4];
+    game_rng(E, gh->uid).gen(0xC0FFEEu, (uint32_t)ply, 0u, 0x4D4F5645u, r);
+    const float target = u01(r[0]) * tot;
+    float run = 0.0f;
+    int chosen = -1;
+    float chosen_w = 0.0f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        float inc = w[s];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        const float cum = run + inc;
+        const bool cand = ((mk.m[s] >> lane) & 1ull) && w[s] > 0.0f && cum > target;
+        const uint64_t cm = __ballot(cand);
+        if (cm && chosen < 0) {
+            const int l = (int)__ffsll((long long)cm) - 1;
+            chosen = __builtin_amdgcn_readlane(rk[s], l);
+            chosen_w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[s]), l));
+        }
+        run += __shfl(inc, 63, 64);
+    }
+    if (chosen < 0) {   // rounding left the target at the very top: take the last positive child
+#pragma unroll
+        for (int s = SLOTS - 1; s >= 0; --s) {
+            const uint64_t cm = __ballot(((mk.m[s] >> lane) & 1ull) && w[s] > 0.0f);
+            if (cm && chosen < 0) {
+                const int l = 63 - __clzll((long long)cm);
+                chosen = __builtin_amdgcn_readlane(rk[s], l);
+                chosen_w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[s]), l));
+            }
+        }
+    }
+    // replay row (play_game.py:92-94): pre-move board and moves_prob
+    const int row = gh->n_rows;
+    const size_t rb = ((size_t)g * E.ncells + row) * AZX_CELL_STRIDE;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int cell = s * 64 + lane;
+        if (cell < AZX_CELL_STRIDE) E.row_board[rb + cell] = (unsigned char)(h.c[s] & 3u);
+        if ((mk.m[s] >> lane) & 1ull) E.row_prob[rb + rk[s]] = w[s] / tot;
+    }
+    for (int o = mk.k + lane; o < AZX_CELL_STRIDE; o += 64) E.row_prob[rb + o] = 0.0f;
+    if (lane == 0) {
+        E.row_k[(size_t)g * E.ncells + row] = mk.k;
+        gh->n_rows = row + 1;
+        gh->move_id = chosen;
+        atomicAdd(E.stat_sums + 0, (double)(th->search_value));
+        atomicAdd(E.stat_sums + 1, (double)width);
+        atomicAdd(E.stat_sums + 2, (double)__logf(chosen_w / tot));
+    }
+}
+
+// ============================================================================================
+// rules only: replay move lists, reporting per-ply result / legal count / empties mask
+// ============================================================================================
+template <int SLOTS>
+__global__ __launch_bounds__(64) void k_hex_replay(int N, int n_games, const int32_t *moves,
+                                                   const int32_t *length, int stride,
+                                                   int32_t *result_out, int32_t *nlegal_out,
+                                                   uint64_t *empties_out, int32_t *final_board) {
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x;
+    if (g >= n_games) return;
+    const int ncells = N * N;
+    HexWave<SLOTS> h;
+    h.clear();
+    const int len = length[g];
+    for (int p = 0; p < len; ++p) {
+        const Masks<SLOTS> mk = make_masks<SLOTS>(h, lane, ncells);
+        const size_t o = (size_t)g * stride + p;
+        if (lane == 0) {
+            nlegal_out[o] = mk.k;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) empties_out[o * 4 + s] = (s < SLOTS && mk.k) ? mk.m[s < SLOTS ? s : 0] : 0ull;
+        }
+        h.step(moves[o] - 1, N, lane);
+        if (lane == 0) result_out[o] = h.winner ? (h.winner == 2 ? 1 : 3) : 0;   // hex.py:161-170
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int cell = s * 64 + lane;
+        if (cell < ncells) final_board[(size_t)g * ncells + cell] = (int32_t)(h.c[s] & 3u);
+    }
+}
+
+// ---- float32 arithmetic self-test: sqrt / divide must be IEEE correctly rounded -------------
+__global__ void k_arith(const float *a, const float *b, float *sq, float *dv, float *mul, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        sq[i] = sqrtf(a[i]);
+        dv[i] = a[i] / (1.0f + b[i]);
+        mul[i] = (0.75f * a[i]) * b[i] + a[i];
+    }
+}
+
+// ============================================================================================
+// host-side launchers (called from azx_capi.cpp)
+// ============================================================================================
+#define DISPATCH_SLOTS(slots, CALL)                         \
+    do {                                                    \
+        if ((slots) <= 2) { CALL(2); }                      \
+        else { CALL(3); }                                   \
+    } while (0)
+
+void azx_launch_mcts(const DevEngine &E, int mode, int num_batches, hipStream_t st) {
+    const size_t lds = azx_mcts_lds_bytes(E.ncells);
+#define CALL(S) hipLaunchKernelGGL((k_mcts<S>), dim3(E.G), dim3(64), lds, st, E, mode, num_batches)
+    DISPATCH_SLOTS(E.slots, CALL);
+#undef CALL
+}
+
+void azx_launch_reset(const DevEngine &E, const int32_t *slots, int n_slots, const int32_t *moves,
+                      const int32_t *n_moves, int stride, int assign_uid, hipStream_t st) {
+#define CALL(S) hipLaunchKernelGGL((k_reset<S>), dim3(n_slots), dim3(64), 0, st, E, slots, n_slots, moves, n_moves, stride, assign_uid)
+    DISPATCH_SLOTS(E.slots, CALL);
+#undef CALL
+}
+
+void azx_launch_advance(const DevEngine &E, const int32_t *move_ids, int play_mode, hipStream_t st) {
+#define CALL(S) hipLaunchKernelGGL((k_advance<S>), dim3(E.G), dim3(64), 0, st, E, move_ids, play_mode)
+    DISPATCH_SLOTS(E.slots, CALL);
+#undef CALL
+}
+
+void azx_launch_gather_root(const DevEngine &E, int32_t *k_out, int32_t *legal, float *cv, float *cw,
+                            float *cp, float *rv, float *rw, int32_t *nn, float *sv, hipStream_t st) {
+#define CALL(S) hipLaunchKernelGGL((k_gather_root<S>), dim3(E.G), dim3(64), 0, st, E, k_out, legal, cv, cw, cp, rv, rw, nn, sv)
+    DISPATCH_SLOTS(E.slots, CALL);
+#undef CALL
+}
+
+void azx_launch_choose(const DevEngine &E, hipStream_t st) {
+#define CALL(S) hipLaunchKernelGGL((k_choose<S>), dim3(E.G), dim3(64), 0, st, E)
+    DISPATCH_SLOTS(E.slots, CALL);
+#undef CALL
+}
+
+void azx_launch_hex_replay(int N, int n_games, const int32_t *moves, const int32_t *length, int stride,
+                           int32_t *result_out, int32_t *nlegal_out, uint64_t *empties_out,
+                           int32_t *final_board, hipStream_t st) {
+    const int slots = (N * N + 63) / 64;
+#define CALL(S) hipLaunchKernelGGL((k_hex_replay<S>), dim3(n_games), dim3(64), 0, st, N, n_games, moves, length, stride, result_out, nlegal_out, empties_out, final_board)
+    DISPATCH_SLOTS(slots, CALL);
+#undef CALL
+}
+
+void azx_launch_arith(const float *a, const float *b, float *sq, float *dv, float *mul, int n,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(k_arith, dim3((n + 255) / 256), dim3(256), 0, st, a, b, sq, dv, mul, n);
+}

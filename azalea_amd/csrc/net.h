@@ -1,0 +1,20 @@
+// net.h -- HexNetwork inference forward on gfx950 (net_kernels.hip): interface used by azx_capi.cpp
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "azx_dev.h"
+
+struct AzxNet;
+
+int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hipStream_t st);
+void azx_net_destroy(AzxNet *net);
+const char *azx_net_error();
+int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void *const *ptrs,
+                        const int64_t *counts, int on_device);
+bool azx_net_ready(const AzxNet *net);
+// evaluate the packed requests ev_board[0 .. *d.n_eval) -> ev_value, ev_prior (by original cell)
+void azx_net_eval(AzxNet *net, const DevEngine &d, hipStream_t st);
+// Network.run on host arrays (network.py:87-105): value[B], moves_logprob[B][K]
+int azx_net_forward_host(AzxNet *net, int B, int K, const int32_t *boards,
+                         const int32_t *legal_moves, float *value, float *logprob, hipStream_t st);

@@ -1,0 +1,249 @@
+"""Thin numpy front-end over the C ABI (include/azx.h): one Engine = one azx_engine handle.
+
+Everything here is plumbing: arrays in, arrays out.  The search, the rules and the network
+forward all run in libazx_hip.so on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (EVAL_EXTERNAL, EVAL_RESNET, EVAL_UNIFORM, EVAL_UNIFORM_HASH,  # noqa: F401
+                   FLAG_NO_COMPACT, AzxError, Config, PlayStats, check)
+
+
+def _p(a, ctype):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
+
+
+class Engine:
+    def __init__(self, board_size=11, n_games=1, simulations=400, search_batch_size=10,
+                 exploration_coef=0.5, exploration_depth=15, noise_alpha=0.03, noise_scale=0.25,
+                 temperature=1.0, evaluator=EVAL_UNIFORM, num_blocks=6, base_chans=64,
+                 nodes_per_game=0, flags=0, device=0, seed=0xBAD5EED5):
+        self.L = _lib.lib()
+        self.cfg = Config(board_size, n_games, simulations, search_batch_size,
+                          float(np.float32(exploration_coef)), exploration_depth, noise_alpha,
+                          noise_scale, temperature, evaluator, num_blocks, base_chans,
+                          nodes_per_game, flags, device, seed)
+        self.h = C.c_void_p()
+        check(self.L.azx_create(C.byref(self.cfg), C.byref(self.h)))
+        self.n = board_size
+        self.cells = board_size * board_size
+        self.G = n_games
+        self.bs = search_batch_size
+        self.num_batches = simulations // search_batch_size + 1          # mcts.py:268
+        self.selects_per_search = self.num_batches * search_batch_size
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.azx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- set-up -------------------------------------------------------------------------
+    def set_prior_table(self, table):
+        t = np.ascontiguousarray(table, np.float32)
+        check(self.L.azx_set_prior_table(self.h, _p(t, C.c_float), t.size))
+
+    def set_weights(self, tensors, on_device=False):
+        """tensors: {state_dict name: contiguous fp32 numpy array} or {name: (ptr, count)}."""
+        names, ptrs, counts, keep = [], [], [], []
+        for name, t in tensors.items():
+            if name.endswith("num_batches_tracked"):
+                continue
+            if isinstance(t, tuple):
+                ptr, cnt = t
+            else:
+                a = np.ascontiguousarray(t, np.float32)
+                keep.append(a)
+                ptr, cnt = a.ctypes.data, a.size
+            names.append(name.encode())
+            ptrs.append(ptr)
+            counts.append(cnt)
+        n = len(names)
+        c_names = (C.c_char_p * n)(*names)
+        c_ptrs = (C.c_void_p * n)(*ptrs)
+        c_counts = (C.c_int64 * n)(*counts)
+        check(self.L.azx_set_weights(self.h, n, c_names, c_ptrs, c_counts, 1 if on_device else 0))
+
+    def reset(self, slots=None, moves=None):
+        """Reset slots (all by default); `moves` = list of move lists replayed per slot."""
+        s = None if slots is None else np.ascontiguousarray(slots, np.int32)
+        ns = self.G if s is None else len(s)
+        if moves is None:
+            check(self.L.azx_reset(self.h, _p(s, C.c_int32), ns, None, None, 0))
+            return
+        stride = max(1, max(len(m) for m in moves))
+        mv = np.zeros((ns, stride), np.int32)
+        nm = np.zeros(ns, np.int32)
+        for i, m in enumerate(moves):
+            mv[i, :len(m)] = m
+            nm[i] = len(m)
+        check(self.L.azx_reset(self.h, _p(s, C.c_int32), ns, _p(mv, C.c_int32), _p(nm, C.c_int32), stride))
+
+    # ---- search -------------------------------------------------------------------------
+    def search(self, noise=None, noise_scale=0.0):
+        """noise: float64 [G, n_select, stride] host Dirichlet rows, or None."""
+        if noise is not None:
+            nz = np.ascontiguousarray(noise, np.float64)
+            assert nz.ndim == 3 and nz.shape[0] == self.G
+            check(self.L.azx_search(self.h, _p(nz, C.c_double), nz.shape[1], nz.shape[2], noise_scale))
+        else:
+            check(self.L.azx_search(self.h, None, 0, 0, noise_scale))
+
+    def search_begin(self, noise=None, noise_scale=0.0):
+        n = C.c_int(0)
+        if noise is not None:
+            nz = np.ascontiguousarray(noise, np.float64)
+            check(self.L.azx_search_begin(self.h, _p(nz, C.c_double), nz.shape[1], nz.shape[2],
+                                          noise_scale, C.byref(n)))
+        else:
+            check(self.L.azx_search_begin(self.h, None, 0, 0, noise_scale, C.byref(n)))
+        return n.value
+
+    def search_step(self):
+        n, done = C.c_int(0), C.c_int(0)
+        check(self.L.azx_search_step(self.h, C.byref(n), C.byref(done)))
+        return n.value, bool(done.value)
+
+    def get_leaves(self):
+        cap = self.G * self.bs
+        boards = np.zeros((cap, self.n, self.n), np.int32)
+        lm = np.zeros((cap, self.cells), np.int32)
+        slot = np.zeros(cap, np.int32)
+        k = np.zeros(cap, np.int32)
+        n = C.c_int(0)
+        check(self.L.azx_get_leaves(self.h, cap, _p(boards, C.c_int32), _p(lm, C.c_int32),
+                                    _p(slot, C.c_int32), _p(k, C.c_int32), C.byref(n)))
+        n = n.value
+        return boards[:n], lm[:n], slot[:n], k[:n]
+
+    def put_evals(self, value, prior):
+        v = np.ascontiguousarray(value, np.float32)
+        p = np.zeros((len(v), self.cells), np.float32)
+        pr = np.asarray(prior, np.float32)
+        if len(v):
+            p[:, :pr.shape[1]] = pr
+        check(self.L.azx_put_evals(self.h, len(v), _p(v, C.c_float), _p(p, C.c_float)))
+
+    def search_external(self, evaluate, noise=None, noise_scale=0.0):
+        """Drive one search with a host evaluator: evaluate(boards, legal_moves, slot, k) ->
+        (value[n], prior[n, >=max k]).  Mirrors mcts.sample_paths' call order."""
+        n = self.search_begin(noise, noise_scale)
+        while True:
+            if n:
+                b, lm, slot, k = self.get_leaves()
+                v, p = evaluate(b, lm, slot, k)
+                self.put_evals(v, p)
+            n, done = self.search_step()
+            if done:
+                break
+
+    # ---- results ------------------------------------------------------------------------
+    def get_root(self):
+        G, Cn = self.G, self.cells
+        out = dict(k=np.zeros(G, np.int32), legal_moves=np.zeros((G, Cn), np.int32),
+                   child_visits=np.zeros((G, Cn), np.float32),
+                   child_value=np.zeros((G, Cn), np.float32),
+                   child_prior=np.zeros((G, Cn), np.float32), root_visits=np.zeros(G, np.float32),
+                   root_value=np.zeros(G, np.float32), num_nodes=np.zeros(G, np.int32),
+                   search_value=np.zeros(G, np.float32))
+        check(self.L.azx_get_root(
+            self.h, _p(out["k"], C.c_int32), _p(out["legal_moves"], C.c_int32),
+            _p(out["child_visits"], C.c_float), _p(out["child_value"], C.c_float),
+            _p(out["child_prior"], C.c_float), _p(out["root_visits"], C.c_float),
+            _p(out["root_value"], C.c_float), _p(out["num_nodes"], C.c_int32),
+            _p(out["search_value"], C.c_float)))
+        return out
+
+    def get_games(self):
+        G = self.G
+        board = np.zeros((G, self.n, self.n), np.int32)
+        color, result, ply = (np.zeros(G, np.int32) for _ in range(3))
+        check(self.L.azx_get_games(self.h, _p(board, C.c_int32), _p(color, C.c_int32),
+                                   _p(result, C.c_int32), _p(ply, C.c_int32)))
+        return dict(board=board, color=color, result=result, ply=ply)
+
+    def advance(self, move_ids):
+        m = np.ascontiguousarray(move_ids, np.int32)
+        assert m.shape == (self.G,)
+        check(self.L.azx_advance(self.h, _p(m, C.c_int32)))
+
+    def tree_dump(self, slot=0, cap=None):
+        if cap is None:
+            cap = int(self.get_root()["num_nodes"][slot]) + 8
+        arrs = dict(parent=np.zeros(cap, np.int32), first_child=np.zeros(cap, np.int32),
+                    num_children=np.zeros(cap, np.int32), num_visits=np.zeros(cap, np.float32),
+                    total_value=np.zeros(cap, np.float32), prior_prob=np.zeros(cap, np.float32))
+        nn, rid = C.c_int32(0), C.c_int32(0)
+        check(self.L.azx_tree_dump(
+            self.h, slot, cap, _p(arrs["parent"], C.c_int32), _p(arrs["first_child"], C.c_int32),
+            _p(arrs["num_children"], C.c_int32), _p(arrs["num_visits"], C.c_float),
+            _p(arrs["total_value"], C.c_float), _p(arrs["prior_prob"], C.c_float),
+            C.byref(nn), C.byref(rid)))
+        out = {k: v[:nn.value].copy() for k, v in arrs.items()}
+        out["num_nodes"], out["root_id"] = nn.value, rid.value
+        return out
+
+    def forward(self, boards, legal_moves):
+        b = np.ascontiguousarray(boards, np.int32)
+        lm = np.ascontiguousarray(legal_moves, np.int32)
+        B, K = lm.shape
+        value = np.zeros(B, np.float32)
+        logprob = np.zeros((B, K), np.float32)
+        check(self.L.azx_forward(self.h, B, K, _p(b, C.c_int32), _p(lm, C.c_int32),
+                                 _p(value, C.c_float), _p(logprob, C.c_float)))
+        return value, logprob
+
+    # ---- throughput mode ------------------------------------------------------------------
+    def play(self, min_positions, max_plies=0):
+        cap = int(min_positions) + self.G * self.cells
+        board = np.zeros((cap, self.n, self.n), np.int32)
+        color = np.zeros(cap, np.int32)
+        nlegal = np.zeros(cap, np.int32)
+        prob = np.zeros((cap, self.cells), np.float32)
+        reward = np.zeros(cap, np.float32)
+        uid = np.zeros(cap, np.int64)
+        st = PlayStats()
+        check(self.L.azx_play(self.h, int(min_positions), int(max_plies), cap,
+                              _p(board, C.c_int32), _p(color, C.c_int32), _p(nlegal, C.c_int32),
+                              _p(prob, C.c_float), _p(reward, C.c_float), _p(uid, C.c_int64),
+                              C.byref(st)))
+        n = st.positions
+        return dict(board=board[:n], color=color[:n], nlegal=nlegal[:n], moves_prob=prob[:n],
+                    reward=reward[:n], game_uid=uid[:n]), st.as_dict()
+
+    def play_steps(self, plies):
+        st = PlayStats()
+        check(self.L.azx_play_steps(self.h, int(plies), C.byref(st)))
+        return st.as_dict()
+
+
+def hex_replay(board_size, moves, lengths, device=0):
+    """azx_hex_replay: per-ply result / legal count / empties mask for many move lists."""
+    mv = np.ascontiguousarray(moves, np.int32)
+    ln = np.ascontiguousarray(lengths, np.int32)
+    G, stride = mv.shape
+    res = np.zeros((G, stride), np.int32)
+    nl = np.zeros((G, stride), np.int32)
+    em = np.zeros((G, stride, 4), np.uint64)
+    fb = np.zeros((G, board_size, board_size), np.int32)
+    check(_lib.lib().azx_hex_replay(device, board_size, G, _p(mv, C.c_int32), _p(ln, C.c_int32),
+                                    stride, _p(res, C.c_int32), _p(nl, C.c_int32),
+                                    _p(em, C.c_uint64), _p(fb, C.c_int32)))
+    return res, nl, em, fb
+
+
+def selftest_arith(a, b, device=0):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    sq, dv, mul = (np.zeros_like(a) for _ in range(3))
+    check(_lib.lib().azx_selftest_arith(device, a.size, _p(a, C.c_float), _p(b, C.c_float),
+                                        _p(sq, C.c_float), _p(dv, C.c_float), _p(mul, C.c_float)))
+    return sq, dv, mul

@@ -1,0 +1,196 @@
+/*
+ * azx.h -- C ABI of the MI355X-native batched Hex self-play engine (libazx_hip.so).
+ *
+ * This is the drop-in boundary for azalea's MCTS self-play hot path.  The reference
+ * (jseppanen/azalea) has no FFI layer: its seam is the duck-typed Python surface
+ * Player.read / Policy.choose_action / SearchTree.search.  Each entry point below names
+ * the reference interface (file:line under azalea/) it replaces; azalea_amd/ binds them
+ * with ctypes and INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only (no torch types).  Every function returns
+ * 0 on success or a negative AZX_E* code; azx_last_error() gives the message.  Host
+ * buffers are caller-allocated.  An engine handle is NOT thread-safe: one host thread
+ * per handle, all device work stream-ordered on the engine's own HIP stream, calls block.
+ *
+ * Units follow the reference: a "move" is flat tile index + 1 (0 = padding,
+ * game/hex.py:151-159); a "move_id"/child index i is the i-th legal move in ascending
+ * tile order (search_tree.py:298-308); colour 1 = X/first player, 2 = O.
+ */
+#ifndef AZX_H
+#define AZX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZX_MAX_BOARD 13          /* 11x11 and 13x13 are the BASELINE configs */
+#define AZX_MAX_CELLS (AZX_MAX_BOARD * AZX_MAX_BOARD)
+#define AZX_CELL_STRIDE 192       /* per-position row stride of dense [*, cells] buffers */
+#define AZX_MAX_BATCH 16          /* search_batch_size upper bound */
+
+enum {
+    AZX_OK = 0,
+    AZX_EINVAL = -1,     /* bad argument / configuration */
+    AZX_EHIP = -2,       /* HIP runtime failure (message has the hipError string) */
+    AZX_ENOMEM = -3,
+    AZX_ESTATE = -4,     /* call sequence error (e.g. apply without select) */
+    AZX_ENODEV = -5      /* no MI355X visible: there is no CPU fallback */
+};
+
+/* evaluator = what plays the role of Network.run inside mcts.evaluate_batch (mcts.py:202-215) */
+enum {
+    AZX_EVAL_RESNET = 0,    /* HexNetwork forward on device (network.py:134-152) */
+    AZX_EVAL_UNIFORM = 1,   /* uniform priors 1/k, value 0, evaluated inline (BASELINE config 2) */
+    AZX_EVAL_UNIFORM_HASH = 2, /* parity stub: prior_by_k table + fnv1a value hash, inline */
+    AZX_EVAL_EXTERNAL = 3   /* host supplies value/priors per leaf between select and apply */
+};
+
+enum {
+    AZX_FLAG_NO_COMPACT = 1  /* keep the reference's never-free arena + moving root_id
+                                (search_tree.py:115-132) instead of compacting on advance */
+};
+
+typedef struct {
+    int32_t board_size;          /* N: policy.py:51 */
+    int32_t n_games;             /* concurrent game slots on this GPU */
+    int32_t simulations;         /* policy.py:55 */
+    int32_t search_batch_size;   /* policy.py:56 (<= AZX_MAX_BATCH) */
+    float   exploration_coef;    /* c_puct, policy.py:57 (f32: numpy weak-scalar semantics) */
+    int32_t exploration_depth;   /* policy.py:58 */
+    double  noise_alpha;         /* policy.py:59 */
+    double  noise_scale;         /* policy.py:60 */
+    double  temperature;         /* policy.py:61 */
+    int32_t evaluator;           /* AZX_EVAL_* */
+    int32_t num_blocks;          /* policy.py:52 (resnet only) */
+    int32_t base_chans;          /* policy.py:53 (resnet only; 64 or multiples of 32) */
+    int32_t nodes_per_game;      /* tree arena capacity per game (SearchTreeFull beyond it) */
+    int32_t flags;               /* AZX_FLAG_* */
+    int32_t device;              /* HIP device ordinal */
+    uint64_t seed;               /* base seed; game uid u draws from stream seed+u */
+} azx_config;
+
+typedef struct azx_engine azx_engine;
+
+const char *azx_last_error(void);
+int azx_version(void);
+
+/* Policy.initialize / Policy.reset (policy.py:36-63, :76-80): allocate device arenas. */
+int azx_create(const azx_config *cfg, azx_engine **out);
+void azx_destroy(azx_engine *e);
+
+/* Policy.net weights (policy.py:65-74, network.py:42-61,:120-132): copy + pack the
+ * state_dict tensors.  names[i] are state_dict keys; ptrs[i] point at contiguous fp32 data,
+ * on the device (torch tensor.data_ptr()) when on_device != 0, else on the host. */
+int azx_set_weights(azx_engine *e, int n_tensors, const char *const *names,
+                    const void *const *ptrs, const int64_t *counts, int on_device);
+
+/* AZX_EVAL_UNIFORM_HASH only: prior_by_k[k] = the f32 prior a k-move position gets. */
+int azx_set_prior_table(azx_engine *e, const float *prior_by_k, int count);
+
+/* HexGame.reset + SearchTree.reset (hex.py:47-49, search_tree.py:59-71) for the listed
+ * slots (NULL = all), then replay `n_moves[i]` moves from `moves` (row stride `stride`). */
+int azx_reset(azx_engine *e, const int32_t *slots, int n_slots, const int32_t *moves,
+              const int32_t *n_moves, int stride);
+
+/* ---- one search, split the way mcts.sample_paths is (mcts.py:258-293) ------------------ */
+
+/* SearchTree.search for every active slot from its current root (search_tree.py:73-113).
+ * noise: NULL -> no noise if noise_scale==0, else device RNG Dirichlet (throughput mode);
+ * else host Dirichlet draws [n_games][n_select][noise_stride] f64, one row per select_leaf
+ * (mcts.py:126-131) -- parity mode keeps numpy's RandomState on the host.
+ * With AZX_EVAL_EXTERNAL this returns AZX_ESTATE: drive the phases below instead. */
+int azx_search(azx_engine *e, const double *noise, int n_select, int noise_stride,
+               double noise_scale);
+
+/* external-evaluator phases (parity tests; also how a custom network would plug in):
+ *   begin -> [pending>0: get_leaves, put_evals] -> repeat { step -> get_leaves -> put_evals }
+ * azx_search_begin emits the root evaluation requests (mcts.py:272-273),
+ * azx_search_step applies the pending evaluations (expand mcts.py:226-239, backup :242-255)
+ * and, if batches remain, selects the next batch (mcts.py:46-76).  *n_pending receives the
+ * number of positions waiting for evaluation; *done is 1 when all batches are applied. */
+int azx_search_begin(azx_engine *e, const double *noise, int n_select, int noise_stride,
+                     double noise_scale, int *n_pending);
+int azx_search_step(azx_engine *e, int *n_pending, int *done);
+/* pending positions in (slot, leaf order) order: boards[n][cells] int32 already flipped to
+ * the first player's view (mcts.py:178-181), legal_moves[n][cells] padded with 0 (flipped
+ * tiles, original order), slot[n], k[n]. */
+int azx_get_leaves(azx_engine *e, int cap, int32_t *boards, int32_t *legal_moves,
+                   int32_t *slot, int32_t *k, int *n_out);
+/* value[n], prior[n][cells] (prior j = child j, first k entries) in the same order */
+int azx_put_evals(azx_engine *e, int n, const float *value, const float *prior);
+
+/* ---- results ---------------------------------------------------------------------------- */
+
+/* root.move_stats + root stats (search_tree.py:106-112, :192-204): per slot, child arrays
+ * [n_games][cells] dense by child index (first k valid). Any pointer may be NULL. */
+int azx_get_root(azx_engine *e, int32_t *k, int32_t *legal_moves, float *child_visits,
+                 float *child_value, float *child_prior, float *root_visits,
+                 float *root_value, int32_t *num_nodes, float *search_value);
+
+/* game state per slot: HexGame.state (hex.py:55-60): board [n_games][cells] int32,
+ * color (0/1), result (0/1/3), ply. */
+int azx_get_games(azx_engine *e, int32_t *board, int32_t *color, int32_t *result,
+                  int32_t *ply);
+
+/* Policy.execute_action + HexGame.step (policy.py:170-176, hex.py:172-179): per slot the
+ * chosen child index (move_id), or -1 to leave the slot untouched. */
+int azx_advance(azx_engine *e, const int32_t *move_ids);
+
+/* raw tree of one slot in the reference's six-array model (search_tree.py:48-55) */
+int azx_tree_dump(azx_engine *e, int slot, int cap, int32_t *parent, int32_t *first_child,
+                  int32_t *num_children, float *num_visits, float *total_value,
+                  float *prior_prob, int32_t *num_nodes, int32_t *root_id);
+
+/* ---- network only: Network.run inference branch (network.py:87-91,:103-105) ------------- */
+int azx_forward(azx_engine *e, int B, int K, const int32_t *boards,
+                const int32_t *legal_moves, float *value, float *moves_logprob);
+
+/* ---- rules only: HexGameImpl.step/legal_moves/result over move lists (hex.py:151-179) --- */
+/* moves[n_games][stride]; outputs per ply p < length: result after the move, number of
+ * legal moves before it, and the empties bitmask before it (4 x u64 per ply).
+ * board_size need not match any engine. */
+int azx_hex_replay(int device, int board_size, int n_games, const int32_t *moves,
+                   const int32_t *length, int stride, int32_t *result_out,
+                   int32_t *nlegal_out, uint64_t *empties_out, int32_t *final_board);
+
+/* ---- throughput mode: Player.read (parallel_player.py:24-28, :41-52) -------------------- */
+typedef struct {
+    int64_t positions;        /* rows written */
+    int64_t games;            /* games finished (metrics['games']) */
+    int64_t game_errors;      /* SearchTreeFull games skipped (parallel_player.py:73-76) */
+    int64_t plies;            /* engine moves executed over all slots */
+    int64_t selects;          /* select_leaf calls */
+    int64_t evals;            /* positions evaluated */
+    int64_t sum_depth, sum_k_interior, sum_k_leaf;   /* roofline byte model inputs */
+    double  sum_search_value, sum_root_width, sum_action_logprob, sum_reward_last;
+    double  seconds;          /* device time of the call (hipEvents on the engine stream) */
+    double  mcts_seconds;     /* device time in the tree kernels */
+    int64_t mcts_launches;
+} azx_play_stats;
+
+/* Self-play until >= min_positions rows from FINISHED games are available (whole games
+ * only, like batch_examples) or max_plies engine steps have run (0 = unbounded).
+ * Rows: board int32[cap][cells] (absolute colours), color[cap], nlegal[cap],
+ * moves_prob f32[cap][cells] dense by child index, reward f32[cap], game_uid[cap]. */
+int azx_play(azx_engine *e, int64_t min_positions, int64_t max_plies, int64_t cap,
+             int32_t *board, int32_t *color, int32_t *nlegal, float *moves_prob,
+             float *reward, int64_t *game_uid, azx_play_stats *stats);
+
+/* bench hook: run `plies` lock-step engine moves on all slots (device RNG, finished games
+ * restart in place), no row transfer; fills stats. */
+int azx_play_steps(azx_engine *e, int64_t plies, azx_play_stats *stats);
+
+/* float32 arithmetic self-test (tests): the tree kernels need IEEE-rounded sqrt and divide and
+ * no FMA contraction (mcts.py:132-135).  sq=sqrtf(a), dv=a/(1+b), mul=(0.75f*a)*b+a. */
+int azx_selftest_arith(int device, int n, const float *a, const float *b, float *sq, float *dv,
+                       float *mul);
+
+/* engine stream (hipStream_t) so callers can bracket work with HIP events */
+void *azx_stream(azx_engine *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZX_H */

@@ -1,0 +1,269 @@
+"""GPU parity of the HIP rules + tree kernels (through the C ABI) against the golden vectors
+generated from the reference and against the CPU oracle.  Bit-exact."""
+import glob
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from azalea_amd import engine
+    return engine
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def test_f32_arithmetic_is_ieee_and_uncontracted(eng):
+    """mcts.py:132-135 is evaluated op by op in float32 by numpy: the tree kernels need
+    correctly rounded sqrt/divide and no FMA contraction."""
+    rng = np.random.RandomState(0)
+    a = np.concatenate([rng.randint(0, 5000, 50000).astype(np.float32),
+                        rng.rand(50000).astype(np.float32) * 100]).astype(np.float32)
+    b = np.concatenate([rng.randint(0, 500, 50000).astype(np.float32),
+                        rng.rand(50000).astype(np.float32)]).astype(np.float32)
+    sq, dv, mul = eng.selftest_arith(a, b)
+    assert np.array_equal(bits(sq), bits(np.sqrt(a)))
+    assert np.array_equal(bits(dv), bits(a / (np.float32(1.0) + b)))
+    assert np.array_equal(bits(mul), bits((np.float32(0.75) * a) * b + a))
+
+
+@pytest.mark.parametrize("n", [3, 5, 11, 13])
+def test_g1_movegen_on_device(eng, n):
+    z = np.load(os.path.join(GOLDEN, "g1_movegen.npz"))
+    moves, res, nl = z["moves_%d" % n], z["result_%d" % n], z["nlegal_%d" % n]
+    crc, length, final = z["legalcrc_%d" % n], z["length_%d" % n], z["final_%d" % n]
+    r, k, em, fb = eng.hex_replay(n, moves.astype(np.int32), length.astype(np.int32))
+    for g in range(len(moves)):
+        L = int(length[g])
+        assert np.array_equal(r[g, :L], res[g, :L])
+        assert np.array_equal(k[g, :L], nl[g, :L])
+        for p in range(L):
+            cells = [c for c in range(n * n) if (int(em[g, p, c >> 6]) >> (c & 63)) & 1]
+            lm = np.array(cells, np.int32) + 1
+            assert len(lm) == nl[g, p]
+            assert zlib.crc32(lm.tobytes()) == crc[g, p]
+    assert np.array_equal(fb, final)
+
+
+G4 = sorted(glob.glob(os.path.join(GOLDEN, "g4_search_*.npz")))
+
+
+def _check_dump(d, z, pre):
+    assert d["num_nodes"] == int(z[pre + "num_nodes"])
+    assert d["root_id"] == int(z[pre + "root_id"])
+    for name in ("parent", "first_child", "num_children"):
+        assert np.array_equal(d[name], z[pre + name]), name
+    for name in ("num_visits", "total_value", "prior_prob"):
+        assert np.array_equal(bits(d[name]), bits(z[pre + name])), name
+
+
+class TapeFeeder:
+    """Replays the reference's recorded evaluate_batch outputs to the engine."""
+
+    def __init__(self, z, pre):
+        self.value, self.nch = z[pre + "tape_value"], z[pre + "tape_nch"]
+        self.prior, self.off = z[pre + "tape_prior"], z[pre + "tape_off"]
+        self.pos = 0
+
+    def __call__(self, boards, lm, slot, k):
+        n = len(k)
+        v = np.zeros(n, np.float32)
+        p = np.zeros((n, lm.shape[1]), np.float32)
+        for i in range(n):
+            while self.nch[self.pos] == 0:     # terminal rows never reach the evaluator
+                self.pos += 1
+            assert self.nch[self.pos] == k[i]
+            v[i] = self.value[self.pos]
+            p[i, :k[i]] = self.prior[self.off[self.pos]:self.off[self.pos + 1]]
+            self.pos += 1
+        return v, p
+
+
+@pytest.mark.parametrize("path", G4, ids=[os.path.basename(p)[10:-4] for p in G4])
+def test_g4_search_tape_external_evaluator(eng, path):
+    """The HIP select/expand/backup kernels, fed the exact (value, prior) stream the reference
+    produced, must rebuild the reference's tree bit for bit (six-array dump), including
+    across SearchTree.move follow-ups (reference never-free arena: AZX_FLAG_NO_COMPACT)."""
+    z = np.load(path)
+    n, follow = int(z["cfg_n"]), int(z["follow"])
+    E = eng.Engine(board_size=n, n_games=1, simulations=int(z["cfg_sims"]),
+                   search_batch_size=int(z["cfg_batch"]), exploration_coef=float(z["cfg_c"]),
+                   evaluator=eng.EVAL_EXTERNAL, nodes_per_game=1 << 17,
+                   flags=eng.FLAG_NO_COMPACT)
+    E.reset(moves=[list(z["prefix_moves"])])
+    eps = float(z["cfg_eps"])
+    for step in range(follow + 1):
+        pre = "s%d_" % step
+        gm = E.get_games()
+        assert np.array_equal(gm["board"][0], z[pre + "root_board"])
+        noise = None
+        if eps:
+            nz = z[pre + "noise"]
+            noise = nz[None, :, :]
+        E.search_external(TapeFeeder(z, pre), noise=noise, noise_scale=eps)
+        _check_dump(E.tree_dump(0), z, pre)
+        root = E.get_root()
+        k = int(root["k"][0])
+        assert np.array_equal(root["legal_moves"][0, :k], z[pre + "legal_moves"])
+        assert abs(float(root["search_value"][0]) - float(z[pre + "search_value"])) <= 1e-6
+        assert root["root_value"][0] / root["root_visits"][0] == z[pre + "value"]
+        if step < follow:
+            E.advance(np.array([int(z[pre + "move_id"])], np.int32))
+    E.close()
+
+
+@pytest.mark.parametrize("path", [p for p in G4 if "_u0" in p or "_uh" in p],
+                         ids=lambda p: os.path.basename(p)[10:-4])
+def test_g4_search_inline_uniform_evaluator(eng, path):
+    """Same trees from the single-launch inline evaluator (uniform priors by-k table + fnv1a
+    value hash computed on the device)."""
+    z = np.load(path)
+    n = int(z["cfg_n"])
+    table = np.zeros(n * n + 1, np.float32)
+    nch, off, pr = z["s0_tape_nch"], z["s0_tape_off"], z["s0_tape_prior"]
+    for i, k in enumerate(nch):
+        if k:
+            table[k] = pr[off[i]]
+    hashed = str(z["mode"]) == "uniformhash"
+    E = eng.Engine(board_size=n, n_games=1, simulations=int(z["cfg_sims"]),
+                   search_batch_size=int(z["cfg_batch"]), exploration_coef=float(z["cfg_c"]),
+                   evaluator=eng.EVAL_UNIFORM_HASH if hashed else eng.EVAL_UNIFORM,
+                   nodes_per_game=1 << 17)
+    E.set_prior_table(table)
+    E.reset(moves=[list(z["prefix_moves"])])
+    E.search()
+    _check_dump(E.tree_dump(0), z, "s0_")
+    E.close()
+
+
+def canonical(d):
+    """Relabel a six-array tree breadth-first from its root: compaction-invariant form."""
+    order, stack = [], [d["root_id"]]
+    i = 0
+    order.append(d["root_id"])
+    while i < len(order):
+        v = order[i]
+        i += 1
+        if d["num_children"][v] > 0:
+            fc = d["first_child"][v]
+            order.extend(range(fc, fc + d["num_children"][v]))
+    order = np.array(order)
+    nc = d["num_children"][order]
+    return (nc, bits(d["num_visits"][order]), bits(d["total_value"][order]),
+            bits(d["prior_prob"][order]))
+
+
+def test_many_games_vs_oracle_with_compaction(eng, orc):
+    """64 concurrent games from different positions, several searches + moves each: the
+    engine (arena compaction on) and the CPU oracle (reference never-free tree) must agree
+    bit-exactly on every game's kept subtree after every search."""
+    n, G, sims = 11, 64, 100
+    rng = np.random.RandomState(5)
+    table = (np.float32(1.0) / np.arange(0, n * n + 1).clip(1).astype(np.float32)).astype(np.float32)
+    prefixes = []
+    for g in range(G):
+        h = orc.Hex(n)
+        mv = []
+        for _ in range(int(rng.randint(0, 95))):
+            lm = h.legal_moves()
+            m = int(lm[rng.randint(len(lm))])
+            h2 = h.copy()
+            h2.step(m)
+            if h2.result:
+                break
+            h = h2
+            mv.append(m)
+        prefixes.append(mv)
+    E = eng.Engine(board_size=n, n_games=G, simulations=sims, search_batch_size=10,
+                   exploration_coef=0.5, evaluator=eng.EVAL_UNIFORM_HASH)
+    E.set_prior_table(table)
+    E.reset(moves=prefixes)
+    games, trees = [], []
+    for g in range(G):
+        h = orc.Hex(n)
+        for m in prefixes[g]:
+            h.step(m)
+        games.append(h)
+        trees.append(orc.Tree(1 << 17))
+    ev = orc.UniformEval(hash_value=True, prior_by_k=table)
+    alive = np.ones(G, bool)
+    for rnd in range(4):
+        E.search()
+        root = E.get_root()
+        move_ids = np.full(G, -1, np.int32)
+        for g in range(G):
+            if not alive[g]:
+                continue
+            st = orc.search(trees[g], games[g], ev, sims, 10, 0.5)
+            assert st.status == 0
+            a, b = canonical(E.tree_dump(g)), canonical(trees[g].dump())
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), (rnd, g)
+            nv = root["child_visits"][g, :root["k"][g]]
+            onv = trees[g].root_stats()[0]
+            assert np.array_equal(bits(nv), bits(onv))
+            mid = int(np.argmax(nv))
+            move_ids[g] = mid
+            lm = games[g].legal_moves()
+            trees[g].move(mid)
+            games[g].step(int(lm[mid]))
+            if games[g].result:
+                alive[g] = False
+        E.advance(move_ids)
+        gm = E.get_games()
+        for g in range(G):
+            assert np.array_equal(gm["board"][g], games[g].board)
+            assert gm["result"][g] == games[g].result
+    E.close()
+
+
+def test_tree_full_sets_status(eng):
+    E = eng.Engine(board_size=11, n_games=2, simulations=40, search_batch_size=10,
+                   evaluator=eng.EVAL_UNIFORM, nodes_per_game=500)
+    E.search()
+    root = E.get_root()
+    assert (root["num_nodes"] <= 500).all()
+    E.close()
+
+
+def test_play_mode_whole_games(eng):
+    """Player.read semantics: whole finished games, rewards alternate from the last mover,
+    rows are legal positions with normalised move distributions."""
+    n = 7
+    E = eng.Engine(board_size=n, n_games=32, simulations=30, search_batch_size=10,
+                   exploration_depth=6, evaluator=eng.EVAL_UNIFORM, seed=123)
+    rows, st = E.play(200)
+    P = len(rows["board"])
+    assert P >= 200 and st["games"] >= 1 and st["positions"] == P
+    uid = rows["game_uid"]
+    for u in np.unique(uid):
+        idx = np.flatnonzero(uid == u)
+        assert np.array_equal(idx, np.arange(idx[0], idx[0] + len(idx)))   # contiguous game
+        b = rows["board"][idx]
+        assert (b[0] == 0).all()
+        for i in range(len(idx)):
+            stones = int((b[i] > 0).sum())
+            assert stones == i and rows["color"][idx[i]] == i % 2
+            assert rows["nlegal"][idx[i]] == n * n - i
+            p = rows["moves_prob"][idx[i]]
+            assert abs(p[:n * n - i].sum() - 1.0) < 1e-5 and (p[n * n - i:] == 0).all()
+        rw = rows["reward"][idx]
+        assert abs(rw[-1]) == 1.0 and np.array_equal(rw[::-1][::2], np.full(len(rw[::-1][::2]), rw[-1]))
+        assert rw[-1] == 1.0     # the last mover made the winning move
+    assert st["selects"] > 0 and st["sum_k_leaf"] > 0
+    E.close()
