@@ -66,6 +66,7 @@ SYMBOLS = {
     "azx_search_step": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "azx_get_leaves": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p, _i32p, C.POINTER(C.c_int)]),
     "azx_put_evals": (C.c_int, [_vp, C.c_int, _f32p, _f32p]),
+    "azx_get_evals": (C.c_int, [_vp, C.c_int, _f32p, _f32p, C.POINTER(C.c_int)]),
     "azx_get_root": (C.c_int, [_vp, _i32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p, _f32p]),
     "azx_get_games": (C.c_int, [_vp, _i32p, _i32p, _i32p, _i32p]),
     "azx_advance": (C.c_int, [_vp, _i32p]),

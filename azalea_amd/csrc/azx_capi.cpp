@@ -348,7 +348,10 @@ extern "C" int azx_search_begin(azx_engine *e, const double *noise, int n_select
         return fail(AZX_ESTATE, "phase API needs AZX_EVAL_EXTERNAL (or RESNET)");
     TRY(upload_noise(e, noise, n_select, noise_stride, noise_scale));
     HIPCHECK(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), e->stream));
+    if (e->d.evaluator == AZX_EVAL_RESNET && !azx_net_ready(e->net))
+        return fail(AZX_ESTATE, "azx_set_weights has not been called");
     azx_launch_mcts(e->d, MODE_BEGIN, e->num_batches, e->stream);
+    if (e->d.evaluator == AZX_EVAL_RESNET) azx_net_eval(e->net, e->d, e->stream);
     HIPCHECK(hipGetLastError());
     e->ext_active = true;
     e->ext_batches_done = 0;
@@ -361,6 +364,7 @@ extern "C" int azx_search_step(azx_engine *e, int *n_pending, int *done) {
     HIPCHECK(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), e->stream));
     if (e->ext_batches_done < e->num_batches) {
         azx_launch_mcts(e->d, MODE_APPLY | MODE_SELECT, e->num_batches, e->stream);
+        if (e->d.evaluator == AZX_EVAL_RESNET) azx_net_eval(e->net, e->d, e->stream);
         e->ext_batches_done += 1;
         *done = 0;
     } else {
@@ -439,6 +443,30 @@ extern "C" int azx_put_evals(azx_engine *e, int n, const float *value, const flo
     HIPCHECK(hipMemcpyAsync(d.ev_value, hv.data(), sizeof(float) * n, hipMemcpyHostToDevice, e->stream));
     HIPCHECK(hipMemcpyAsync(d.ev_prior, hp.data(), sizeof(float) * hp.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHECK(hipStreamSynchronize(e->stream));
+    return AZX_OK;
+}
+
+extern "C" int azx_get_evals(azx_engine *e, int cap, float *value, float *prior, int *n_out) {
+    if (!e || !n_out) return fail(AZX_EINVAL, "null argument");
+    DevEngine &d = e->d;
+    const int n = (int)e->ext_order.size();
+    if (n > cap) return fail(AZX_EINVAL, "%d evaluations, caller capacity %d", n, cap);
+    *n_out = n;
+    if (n == 0) return AZX_OK;
+    std::vector<float> hv(n), hp((size_t)n * AZX_CELL_STRIDE);
+    HIPCHECK(hipMemcpyAsync(hv.data(), d.ev_value, sizeof(float) * n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipMemcpyAsync(hp.data(), d.ev_prior, sizeof(float) * hp.size(), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    for (int j = 0; j < n; ++j) {
+        const int ev = e->ext_order[j];
+        if (value) value[j] = hv[ev];
+        if (prior) {
+            const std::vector<int> &cells = e->ext_cells[j];
+            for (int c = 0; c < d.ncells; ++c) prior[(size_t)j * d.ncells + c] = 0.0f;
+            for (size_t i = 0; i < cells.size(); ++i)
+                prior[(size_t)j * d.ncells + i] = hp[(size_t)ev * AZX_CELL_STRIDE + cells[i]];
+        }
+    }
     return AZX_OK;
 }
 

@@ -1,12 +1,632 @@
-// placeholder -- replaced by the MFMA implementation
+// net_kernels.hip -- HexNetwork inference forward for gfx950 (MI355X), hand-written MFMA.
+//
+// Restates azalea/network.py:17-85 (Network/Resblock forward, eval-mode BatchNorm) and
+// :120-152 (HexNetwork: embedding, policy FC, legal-move gather + log_softmax).
+//
+// k_tower_mfma: the whole residual tower for a tile of boards in ONE launch.  Activations of
+// the tile stay in LDS ([pos][C] fp32, row stride C+4 floats so ds_read_b128 A-fragment reads
+// are bank-conflict free); each 3x3 convolution is an implicit GEMM (M = board positions padded
+// to 32-row tiles, N = C_out, K = 9 taps x C_in) on v_mfma_f32_32x32x2_f32 (exact fp32, the
+// 1e-4 logit tolerance rules out bf16); folded-BN bias, residual add and ReLU run in the MFMA
+// epilogue straight back into LDS.  Weights are pre-packed on the host into the B-fragment
+// order so every lane fetches its 4 k-steps with one coalesced 16-byte load from L2.
+// k_heads: value/policy heads + masked softmax, one block per board.
+// k_*_generic: plain VALU fallback for channel counts the MFMA tiling does not cover.
 #include "net.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
 #include <string>
-static std::string g_net_err;
-struct AzxNet { int dummy; };
-int azx_net_create(AzxNet **, int, int, int, int, hipStream_t) { g_net_err = "resnet evaluator not built yet"; return AZX_ESTATE; }
-void azx_net_destroy(AzxNet *) {}
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static thread_local std::string g_net_err;
 const char *azx_net_error() { return g_net_err.c_str(); }
-int azx_net_set_weights(AzxNet *, int, const char *const *, const void *const *, const int64_t *, int) { return AZX_ESTATE; }
-bool azx_net_ready(const AzxNet *) { return false; }
-void azx_net_eval(AzxNet *, const DevEngine &, hipStream_t) {}
-int azx_net_forward_host(AzxNet *, int, int, const int32_t *, const int32_t *, float *, float *, hipStream_t) { return AZX_ESTATE; }
+
+static int nfail(int code, const char *msg) {
+    g_net_err = msg;
+    return code;
+}
+
+struct NetDev {
+    int N, ncells, C, blocks, layers;     // layers = 2*blocks
+    // stem: embedding folded through conv1+bn1 (network.py:125,:141-142,:47-48,:73)
+    const float *stemT;    // [9][3][C]   table[tap][cell value][cout]
+    const float *stem_b;   // [C]
+    // tower (network.py:17-39, :50-52): BN folded into the conv weights
+    const float *Wp;       // MFMA pack [layers][9][C/8][C/32][64][4]
+    const float *Wg;       // generic   [layers][9][C][C]  (tap, cin, cout)
+    const float *bias;     // [layers][C]
+    // heads (network.py:54-60, :77-84, :127-128, :146)
+    const float *wv, *bv;  // [2][C], [2]
+    const float *wp, *bp;  // [4][C], [4]
+    const float *fc2T, *fc2b;   // [2*ncells][64], [64]
+    const float *fc3w, *fc3b;   // [64], [1]
+    const float *mfcT, *mfcb;   // [4*ncells][AZX_CELL_STRIDE], [AZX_CELL_STRIDE]
+};
+
+// ============================================================================================
+// fused residual tower on MFMA
+//   C      channels (multiple of 32)
+//   MT     32-row M tiles per board (ncells <= 32*MT)
+//   BPB    boards per 256-thread block;  waves per board = 4/BPB = MS*NS
+//   MS/NS  how a board's (MT x C/32) output tiles are split over its waves
+// ============================================================================================
+template <int C, int MT, int BPB, int MS, int NS>
+__global__ __launch_bounds__(256) void k_tower_mfma(NetDev P, const uint8_t *__restrict__ ev_board,
+                                                     const int32_t *__restrict__ n_eval_ptr,
+                                                     int n_eval_host, float *__restrict__ act_out) {
+    constexpr int NT = C / 32;
+    constexpr int MTW = MT / MS, NTW = NT / NS;
+    constexpr int LDW = C + 4;                      // LDS row stride in floats
+    static_assert(MS * NS * BPB == 4, "4 waves per block");
+    static_assert(MT % MS == 0 && NT % NS == 0, "tile split");
+    extern __shared__ __align__(16) float lds[];
+    const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
+    const int e0 = blockIdx.x * BPB;
+    if (e0 >= n_eval) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = P.N, ncells = P.ncells;
+    const int rows = ncells + 1;                    // + one all-zero row (padding / tile tail)
+    const int wb = wave / (MS * NS);                // board of this wave within the block
+    const int part = wave % (MS * NS);
+    const int ms = part / NS, ns = part % NS;
+    float *X = lds + (size_t)wb * 2 * rows * LDW;   // block input / residual / block output
+    float *Y = X + (size_t)rows * LDW;              // conv1 output
+
+    // ---- stem: table lookups (embedding o conv3x3 o BN) + ReLU into X ------------------------
+    for (int b = 0; b < BPB; ++b) {
+        float *Xb = lds + (size_t)b * 2 * rows * LDW;
+        const int e = e0 + b;
+        const uint8_t *bd = ev_board + (size_t)min(e, n_eval - 1) * AZX_CELL_STRIDE;
+        for (int idx = tid; idx < ncells * C; idx += 256) {
+            const int pos = idx / C, co = idx - pos * C;
+            const int y = pos / N, x = pos - y * N;
+            float acc = P.stem_b[co];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if (yy >= 0 && yy < N && xx >= 0 && xx < N)
+                    acc += P.stemT[(tap * 3 + bd[yy * N + xx]) * C + co];
+            }
+            Xb[pos * LDW + co] = fmaxf(acc, 0.0f);
+        }
+        for (int c = tid; c < LDW; c += 256) {      // zero rows
+            Xb[ncells * LDW + c] = 0.0f;
+            Xb[(size_t)rows * LDW + ncells * LDW + c] = 0.0f;
+        }
+    }
+    __syncthreads();
+
+    // per-lane geometry of the A fragment rows: lane (i = lane&31, h = lane>>5)
+    const int li = lane & 31, lh = lane >> 5;
+    int ry[MTW], rx[MTW];
+    bool rvalid[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        const int r = (ms * MTW + m) * 32 + li;
+        rvalid[m] = r < ncells;
+        ry[m] = r / N;
+        rx[m] = r - ry[m] * N;
+    }
+
+    for (int layer = 0; layer < P.layers; ++layer) {
+        const float *src = (layer & 1) ? Y : X;
+        float *dst = (layer & 1) ? X : Y;
+        f32x16 acc[MTW][NTW];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+        const float4 *wl = reinterpret_cast<const float4 *>(P.Wp) +
+                           (size_t)layer * 9 * (C / 8) * NT * 64;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            int aoff[MTW];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int yy = ry[m] + dy, xx = rx[m] + dx;
+                const bool ok = rvalid[m] && yy >= 0 && yy < N && xx >= 0 && xx < N;
+                aoff[m] = (ok ? (yy * N + xx) : ncells) * LDW + 4 * lh;
+            }
+            const float4 *wt = wl + (size_t)tap * (C / 8) * NT * 64;
+#pragma unroll 2
+            for (int q = 0; q < C / 8; ++q) {
+                float4 bfrag[NTW];
+#pragma unroll
+                for (int n = 0; n < NTW; ++n)
+                    bfrag[n] = wt[((size_t)q * NT + (ns * NTW + n)) * 64 + lane];
+                float4 afrag[MTW];
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+                    afrag[m] = *reinterpret_cast<const float4 *>(src + aoff[m] + 8 * q);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m].x, bfrag[n].x, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m].y, bfrag[n].y, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m].z, bfrag[n].z, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m].w, bfrag[n].w, acc[m][n], 0, 0, 0);
+                    }
+            }
+        }
+        // ---- epilogue: + folded-BN bias (+ residual) -> ReLU -> LDS -----------------------
+        // C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        const bool residual = (layer & 1) != 0;       // conv2 of a Resblock: y += x (network.py:37)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const int co = (ns * NTW + n) * 32 + li;
+            const float bb = P.bias[layer * C + co];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (ms * MTW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < ncells) {
+                        float v = acc[m][n][r] + bb;
+                        if (residual) v += dst[row * LDW + co];
+                        dst[row * LDW + co] = fmaxf(v, 0.0f);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- tower output -> HBM [e][ncells][C] (the heads kernel consumes it) -------------------
+    for (int b = 0; b < BPB; ++b) {
+        const int e = e0 + b;
+        if (e >= n_eval) break;
+        const float *Xb = lds + (size_t)b * 2 * rows * LDW;   // layers is even: result is in X
+        float4 *out = reinterpret_cast<float4 *>(act_out + (size_t)e * ncells * C);
+        for (int idx = tid; idx < ncells * (C / 4); idx += 256) {
+            const int pos = idx / (C / 4), c4 = idx - pos * (C / 4);
+            out[idx] = *reinterpret_cast<const float4 *>(Xb + pos * LDW + 4 * c4);
+        }
+    }
+}
+
+// ============================================================================================
+// generic VALU fallback (any channel count): one thread per output element, activations in HBM
+// ============================================================================================
+__global__ void k_stem_generic(NetDev P, const uint8_t *ev_board, const int32_t *n_eval_ptr,
+                               int n_eval_host, float *out) {
+    const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
+    const int C = P.C, N = P.N, ncells = P.ncells;
+    const size_t total = (size_t)n_eval * ncells * C;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int co = idx % C;
+        const int pos = (idx / C) % ncells;
+        const size_t e = idx / ((size_t)C * ncells);
+        const uint8_t *bd = ev_board + e * AZX_CELL_STRIDE;
+        const int y = pos / N, x = pos - y * N;
+        float acc = P.stem_b[co];
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy >= 0 && yy < N && xx >= 0 && xx < N)
+                acc += P.stemT[(tap * 3 + bd[yy * N + xx]) * C + co];
+        }
+        out[idx] = fmaxf(acc, 0.0f);
+    }
+}
+
+__global__ void k_conv_generic(NetDev P, int layer, const float *in, const float *residual,
+                               const int32_t *n_eval_ptr, int n_eval_host, float *out) {
+    const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
+    const int C = P.C, N = P.N, ncells = P.ncells;
+    const float *w = P.Wg + (size_t)layer * 9 * C * C;
+    const size_t total = (size_t)n_eval * ncells * C;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int co = idx % C;
+        const int pos = (idx / C) % ncells;
+        const size_t e = idx / ((size_t)C * ncells);
+        const int y = pos / N, x = pos - y * N;
+        float acc = 0.0f;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy < 0 || yy >= N || xx < 0 || xx >= N) continue;
+            const float *ip = in + (e * ncells + yy * N + xx) * C;
+            const float *wp = w + (size_t)tap * C * C + co;
+            for (int ci = 0; ci < C; ++ci) acc += ip[ci] * wp[(size_t)ci * C];
+        }
+        float v = acc + P.bias[layer * C + co];
+        if (residual) v += residual[idx];
+        out[idx] = fmaxf(v, 0.0f);
+    }
+}
+
+// ============================================================================================
+// heads: value (conv1x1 C->2, BN, ReLU, FC 2N^2->64, ReLU, FC 64->1, tanh) and policy
+// (conv1x1 C->4, BN, ReLU, FC 4N^2->N^2) -- network.py:77-84, :146; then, for the search, the
+// masked softmax over the legal (= empty) cells, written by ORIGINAL cell index.
+// One 192-thread block per board.
+// ============================================================================================
+__global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict__ act,
+                                               const uint8_t *__restrict__ ev_board,
+                                               const int32_t *__restrict__ ev_flip,
+                                               const int32_t *__restrict__ n_eval_ptr,
+                                               int n_eval_host, float *__restrict__ logit_out,
+                                               float *__restrict__ value_out,
+                                               float *__restrict__ prior_out) {
+    __shared__ float hv[2 * AZX_MAX_CELLS];
+    __shared__ float hp[4 * AZX_MAX_CELLS];
+    __shared__ float h2[64];
+    __shared__ float red[192];
+    const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
+    const int e = blockIdx.x;
+    if (e >= n_eval) return;
+    const int tid = threadIdx.x;
+    const int C = P.C, N = P.N, ncells = P.ncells;
+
+    if (tid < ncells) {
+        const float *a = act + ((size_t)e * ncells + tid) * C;
+        float v0 = 0.f, v1 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float x = a[c];
+            v0 += x * P.wv[c];
+            v1 += x * P.wv[C + c];
+            p0 += x * P.wp[c];
+            p1 += x * P.wp[C + c];
+            p2 += x * P.wp[2 * C + c];
+            p3 += x * P.wp[3 * C + c];
+        }
+        hv[tid] = fmaxf(v0 + P.bv[0], 0.f);
+        hv[ncells + tid] = fmaxf(v1 + P.bv[1], 0.f);
+        hp[tid] = fmaxf(p0 + P.bp[0], 0.f);
+        hp[ncells + tid] = fmaxf(p1 + P.bp[1], 0.f);
+        hp[2 * ncells + tid] = fmaxf(p2 + P.bp[2], 0.f);
+        hp[3 * ncells + tid] = fmaxf(p3 + P.bp[3], 0.f);
+    }
+    __syncthreads();
+    if (tid < 64) {                                   // value_fc2 + ReLU (network.py:79)
+        float acc = 0.f;
+        for (int i = 0; i < 2 * ncells; ++i) acc += hv[i] * P.fc2T[i * 64 + tid];
+        h2[tid] = fmaxf(acc + P.fc2b[tid], 0.f);
+    }
+    float logit = 0.f;
+    if (tid < ncells) {                               // move_fc (network.py:146)
+        float acc = 0.f;
+        for (int i = 0; i < 4 * ncells; ++i) acc += hp[i] * P.mfcT[(size_t)i * AZX_CELL_STRIDE + tid];
+        logit = acc + P.mfcb[tid];
+        logit_out[(size_t)e * AZX_CELL_STRIDE + tid] = logit;
+    }
+    __syncthreads();
+    if (tid == 0) {                                   // value_fc3 + tanh (network.py:80-81)
+        float acc = 0.f;
+        for (int i = 0; i < 64; ++i) acc += h2[i] * P.fc3w[i];
+        value_out[e] = tanhf(acc + P.fc3b[0]);
+    }
+    if (!prior_out) return;
+    // masked softmax over the legal cells of the network-frame board (network.py:147-151),
+    // prior = exp(log_softmax) (mcts.py:210)
+    const bool legal = tid < ncells && ev_board[(size_t)e * AZX_CELL_STRIDE + tid] == 0;
+    red[tid] = legal ? logit : -INFINITY;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s && tid + s < 192) red[tid] = fmaxf(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    const float mx = red[0];
+    __syncthreads();
+    const float ex = legal ? expf(logit - mx) : 0.f;
+    red[tid] = ex;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s && tid + s < 192) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const float lse = mx + logf(red[0]);
+    if (tid < ncells) {
+        int cell = tid;
+        if (ev_flip[e]) {                              // back to the mover's frame (hex.py:107-111)
+            const int i = tid / N, j = tid - i * N;
+            cell = (N - 1 - j) * N + (N - 1 - i);
+        }
+        prior_out[(size_t)e * AZX_CELL_STRIDE + cell] = legal ? expf(logit - lse) : 0.f;
+    }
+}
+
+// ============================================================================================
+// host side
+// ============================================================================================
+struct AzxNet {
+    NetDev d;
+    int max_evals = 0;
+    bool ready = false;
+    bool use_mfma = false;
+    hipStream_t stream = nullptr;
+    std::vector<void *> allocs;
+    float *act = nullptr, *act2 = nullptr, *act3 = nullptr;   // [E][ncells][C]
+    float *logit = nullptr;                                     // [E][AZX_CELL_STRIDE]
+    // host-forward staging
+    uint8_t *hb_board = nullptr;
+    int32_t *hb_flip = nullptr;
+    float *hb_value = nullptr;
+    size_t lds_bytes = 0;
+    int tower_variant = 0;
+};
+
+template <typename T>
+static T *nalloc(AzxNet *net, size_t count) {
+    void *p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)) != hipSuccess) return nullptr;
+    (void)hipMemset(p, 0, std::max<size_t>(count * sizeof(T), 16));
+    net->allocs.push_back(p);
+    return reinterpret_cast<T *>(p);
+}
+
+int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hipStream_t st) {
+    if (N < 2 || N > AZX_MAX_BOARD) return nfail(AZX_EINVAL, "net: board size out of range");
+    if (blocks < 0 || chans < 1) return nfail(AZX_EINVAL, "net: bad num_blocks/base_chans");
+    AzxNet *net = new AzxNet();
+    memset(&net->d, 0, sizeof net->d);
+    net->d.N = N;
+    net->d.ncells = N * N;
+    net->d.C = chans;
+    net->d.blocks = blocks;
+    net->d.layers = 2 * blocks;
+    net->max_evals = max_evals;
+    net->stream = st;
+    const int ncells = N * N;
+    // pick the fused MFMA tower when its tiling covers (C, N)
+    if (chans == 64 && ncells <= 128) net->tower_variant = 1;        // <64,4,2,1,2>
+    else if (chans == 64 && ncells <= 192) net->tower_variant = 2;   // <64,6,1,2,2>
+    else if (chans == 32 && ncells <= 192) net->tower_variant = 3;   // <32,6,2,2,1>
+    net->use_mfma = net->tower_variant != 0;
+    const size_t E = max_evals;
+    net->act = nalloc<float>(net, E * ncells * chans);
+    net->logit = nalloc<float>(net, E * AZX_CELL_STRIDE);
+    net->hb_board = nalloc<uint8_t>(net, E * AZX_CELL_STRIDE);
+    net->hb_flip = nalloc<int32_t>(net, E);
+    net->hb_value = nalloc<float>(net, E);
+    if (!net->use_mfma) {
+        net->act2 = nalloc<float>(net, E * ncells * chans);
+        net->act3 = nalloc<float>(net, E * ncells * chans);
+    }
+    if (!net->act || !net->logit || !net->hb_board || !net->hb_flip || !net->hb_value ||
+        (!net->use_mfma && (!net->act2 || !net->act3))) {
+        azx_net_destroy(net);
+        return nfail(AZX_ENOMEM, "net: hipMalloc failed");
+    }
+    const int bpb = net->tower_variant == 2 ? 1 : 2;
+    net->lds_bytes = (size_t)bpb * 2 * (ncells + 1) * (chans + 4) * sizeof(float);
+    *out = net;
+    return AZX_OK;
+}
+
+void azx_net_destroy(AzxNet *net) {
+    if (!net) return;
+    for (void *p : net->allocs) (void)hipFree(p);
+    delete net;
+}
+
+bool azx_net_ready(const AzxNet *net) { return net && net->ready; }
+
+static float *upload(AzxNet *net, const std::vector<float> &h) {
+    float *p = nalloc<float>(net, h.size());
+    if (p) (void)hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+    return p;
+}
+
+int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void *const *ptrs,
+                        const int64_t *counts, int on_device) {
+    std::map<std::string, std::vector<float>> T;
+    for (int i = 0; i < n; ++i) {
+        std::vector<float> h((size_t)counts[i]);
+        if (on_device) {
+            if (hipMemcpy(h.data(), ptrs[i], h.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+                return nfail(AZX_EHIP, "net: copying a weight tensor from the device failed");
+        } else {
+            memcpy(h.data(), ptrs[i], h.size() * sizeof(float));
+        }
+        T[names[i]] = std::move(h);
+    }
+    const int C = net->d.C, N = net->d.N, n2 = N * N, L = net->d.layers;
+    static std::string missing;
+    auto get = [&](const std::string &name, size_t want) -> const std::vector<float> * {
+        auto it = T.find(name);
+        if (it == T.end() || it->second.size() != want) {
+            missing = "net: tensor '" + name + "' missing or has the wrong size";
+            return nullptr;
+        }
+        return &it->second;
+    };
+    // eval-mode BatchNorm2d folded to scale/shift, eps 1e-5 (network.py:21,:48)
+    auto fold = [&](const std::string &pre, int c, std::vector<double> &scale, std::vector<double> &shift) -> bool {
+        auto w = get(pre + ".weight", c), b = get(pre + ".bias", c), m = get(pre + ".running_mean", c),
+             v = get(pre + ".running_var", c);
+        if (!w || !b || !m || !v) return false;
+        scale.resize(c);
+        shift.resize(c);
+        for (int i = 0; i < c; ++i) {
+            scale[i] = (double)(*w)[i] / std::sqrt((double)(*v)[i] + 1e-5);
+            shift[i] = (double)(*b)[i] - (double)(*m)[i] * scale[i];
+        }
+        return true;
+    };
+#define NEED(x) if (!(x)) return nfail(AZX_EINVAL, missing.c_str())
+    std::vector<double> sc, sh;
+    // stem table: T[tap][v][co] = scale[co] * sum_i emb[v][i] * w[co][i][tap]
+    auto emb = get("encoder.weight", 12);
+    auto w1 = get("conv1.weight", (size_t)C * 4 * 9);
+    NEED(emb && w1 && fold("bn1", C, sc, sh));
+    std::vector<float> stemT((size_t)9 * 3 * C), stem_b(C);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int v = 0; v < 3; ++v)
+            for (int co = 0; co < C; ++co) {
+                double s = 0;
+                for (int i = 0; i < 4; ++i) s += (double)(*emb)[v * 4 + i] * (double)(*w1)[(co * 4 + i) * 9 + tap];
+                stemT[(tap * 3 + v) * C + co] = (float)(s * sc[co]);
+            }
+    for (int co = 0; co < C; ++co) stem_b[co] = (float)sh[co];
+    // tower
+    std::vector<float> Wg((size_t)L * 9 * C * C), bias((size_t)L * C);
+    for (int l = 0; l < L; ++l) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "resblocks.%d.conv%d.weight", l / 2, l % 2 + 1);
+        auto w = get(nm, (size_t)C * C * 9);
+        snprintf(nm, sizeof nm, "resblocks.%d.bn%d", l / 2, l % 2 + 1);
+        NEED(w && fold(nm, C, sc, sh));
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ci = 0; ci < C; ++ci)
+                for (int co = 0; co < C; ++co)
+                    Wg[(((size_t)l * 9 + tap) * C + ci) * C + co] =
+                        (float)((double)(*w)[((size_t)co * C + ci) * 9 + tap] * sc[co]);
+        for (int co = 0; co < C; ++co) bias[(size_t)l * C + co] = (float)sh[co];
+    }
+    std::vector<float> Wp;
+    if (net->use_mfma) {
+        // B-fragment order: [layer][tap][q][ntile][lane(j + 32 h)][t] = W[tap][cin 8q+4h+t][cout 32 ntile + j]
+        const int NT = C / 32, Q = C / 8;
+        Wp.resize((size_t)L * 9 * Q * NT * 64 * 4);
+        for (int l = 0; l < L; ++l)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int q = 0; q < Q; ++q)
+                    for (int nt = 0; nt < NT; ++nt)
+                        for (int ln = 0; ln < 64; ++ln)
+                            for (int t = 0; t < 4; ++t) {
+                                const int j = ln & 31, h = ln >> 5;
+                                const int ci = 8 * q + 4 * h + t, co = 32 * nt + j;
+                                Wp[(((((size_t)l * 9 + tap) * Q + q) * NT + nt) * 64 + ln) * 4 + t] =
+                                    Wg[(((size_t)l * 9 + tap) * C + ci) * C + co];
+                            }
+    }
+    // heads
+    auto wvc = get("value_conv1.weight", (size_t)2 * C), wpc = get("move_conv1.weight", (size_t)4 * C);
+    std::vector<double> scv, shv, scp, shp;
+    NEED(wvc && wpc && fold("value_bn1", 2, scv, shv) && fold("move_bn1", 4, scp, shp));
+    std::vector<float> wv((size_t)2 * C), bv(2), wp((size_t)4 * C), bp(4);
+    for (int o = 0; o < 2; ++o) {
+        for (int c = 0; c < C; ++c) wv[(size_t)o * C + c] = (float)((double)(*wvc)[(size_t)o * C + c] * scv[o]);
+        bv[o] = (float)shv[o];
+    }
+    for (int o = 0; o < 4; ++o) {
+        for (int c = 0; c < C; ++c) wp[(size_t)o * C + c] = (float)((double)(*wpc)[(size_t)o * C + c] * scp[o]);
+        bp[o] = (float)shp[o];
+    }
+    auto fc2w = get("value_fc2.weight", (size_t)64 * 2 * n2), fc2b = get("value_fc2.bias", 64);
+    auto fc3w = get("value_fc3.weight", 64), fc3b = get("value_fc3.bias", 1);
+    auto mfw = get("move_fc.weight", (size_t)n2 * 4 * n2), mfb = get("move_fc.bias", n2);
+    NEED(fc2w && fc2b && fc3w && fc3b && mfw && mfb);
+    std::vector<float> fc2T((size_t)2 * n2 * 64), mfcT((size_t)4 * n2 * AZX_CELL_STRIDE, 0.f), mfcb(AZX_CELL_STRIDE, 0.f);
+    for (int o = 0; o < 64; ++o)
+        for (int i = 0; i < 2 * n2; ++i) fc2T[(size_t)i * 64 + o] = (*fc2w)[(size_t)o * 2 * n2 + i];
+    for (int t = 0; t < n2; ++t) {
+        for (int i = 0; i < 4 * n2; ++i) mfcT[(size_t)i * AZX_CELL_STRIDE + t] = (*mfw)[(size_t)t * 4 * n2 + i];
+        mfcb[t] = (*mfb)[t];
+    }
+#undef NEED
+    (void)hipStreamSynchronize(net->stream);
+    NetDev &d = net->d;
+    d.stemT = upload(net, stemT);
+    d.stem_b = upload(net, stem_b);
+    d.Wg = upload(net, Wg);
+    d.Wp = net->use_mfma ? upload(net, Wp) : nullptr;
+    d.bias = upload(net, bias);
+    d.wv = upload(net, wv); d.bv = upload(net, bv);
+    d.wp = upload(net, wp); d.bp = upload(net, bp);
+    d.fc2T = upload(net, fc2T); d.fc2b = upload(net, *fc2b);
+    d.fc3w = upload(net, *fc3w); d.fc3b = upload(net, *fc3b);
+    d.mfcT = upload(net, mfcT); d.mfcb = upload(net, mfcb);
+    if (!d.stemT || !d.stem_b || !d.Wg || !d.bias || !d.wv || !d.bv || !d.wp || !d.bp || !d.fc2T ||
+        !d.fc2b || !d.fc3w || !d.fc3b || !d.mfcT || !d.mfcb || (net->use_mfma && !d.Wp))
+        return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
+    (void)hipDeviceSynchronize();
+    net->ready = true;
+    return AZX_OK;
+}
+
+// tower + heads over boards[0 .. n) (n read from n_eval_ptr on the device when given)
+static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, const int32_t *n_eval_ptr,
+                    int n_host, int max_n, float *logit, float *value, float *prior, hipStream_t st) {
+    const NetDev &d = net->d;
+    if (max_n <= 0) return;
+    if (net->use_mfma) {
+        const size_t lds = net->lds_bytes;
+        if (net->tower_variant == 1) {
+            static bool attr1 = false;
+            if (!attr1) { (void)hipFuncSetAttribute((const void *)k_tower_mfma<64, 4, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
+            hipLaunchKernelGGL((k_tower_mfma<64, 4, 2, 1, 2>), dim3((max_n + 1) / 2), dim3(256), lds, st, d, boards, n_eval_ptr, n_host, net->act);
+        } else if (net->tower_variant == 2) {
+            static bool attr2 = false;
+            if (!attr2) { (void)hipFuncSetAttribute((const void *)k_tower_mfma<64, 6, 1, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
+            hipLaunchKernelGGL((k_tower_mfma<64, 6, 1, 2, 2>), dim3(max_n), dim3(256), lds, st, d, boards, n_eval_ptr, n_host, net->act);
+        } else {
+            static bool attr3 = false;
+            if (!attr3) { (void)hipFuncSetAttribute((const void *)k_tower_mfma<32, 6, 2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr3 = true; }
+            hipLaunchKernelGGL((k_tower_mfma<32, 6, 2, 2, 1>), dim3((max_n + 1) / 2), dim3(256), lds, st, d, boards, n_eval_ptr, n_host, net->act);
+        }
+    } else {
+        const int grid = 2048;
+        hipLaunchKernelGGL(k_stem_generic, dim3(grid), dim3(256), 0, st, d, boards, n_eval_ptr, n_host, net->act);
+        float *x = net->act, *y = net->act2, *z = net->act3;
+        for (int b = 0; b < d.blocks; ++b) {
+            hipLaunchKernelGGL(k_conv_generic, dim3(grid), dim3(256), 0, st, d, 2 * b, x, (const float *)nullptr, n_eval_ptr, n_host, y);
+            hipLaunchKernelGGL(k_conv_generic, dim3(grid), dim3(256), 0, st, d, 2 * b + 1, y, x, n_eval_ptr, n_host, z);
+            std::swap(x, z);
+        }
+        if (x != net->act)   // heads read net->act
+            (void)hipMemcpyAsync(net->act, x, (size_t)max_n * d.ncells * d.C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    }
+    hipLaunchKernelGGL(k_heads, dim3(max_n), dim3(192), 0, st, d, net->act, boards, flip, n_eval_ptr, n_host, logit, value, prior);
+}
+
+void azx_net_eval(AzxNet *net, const DevEngine &e, hipStream_t st) {
+    run_net(net, e.ev_board, e.ev_flip, e.n_eval, 0, net->max_evals, net->logit, e.ev_value, e.ev_prior, st);
+}
+
+int azx_net_forward_host(AzxNet *net, int B, int K, const int32_t *boards, const int32_t *legal_moves,
+                         float *value, float *logprob, hipStream_t st) {
+    if (!net->ready) return nfail(AZX_ESTATE, "net: azx_set_weights has not been called");
+    if (B < 0 || K < 0 || (B && (!boards || !legal_moves || !value || !logprob)))
+        return nfail(AZX_EINVAL, "net: bad forward arguments");
+    const NetDev &d = net->d;
+    const int ncells = d.ncells;
+    std::vector<uint8_t> hb((size_t)net->max_evals * AZX_CELL_STRIDE);
+    std::vector<float> hl((size_t)net->max_evals * AZX_CELL_STRIDE), hv(net->max_evals);
+    for (int b0 = 0; b0 < B; b0 += net->max_evals) {
+        const int nb = std::min(net->max_evals, B - b0);
+        std::fill(hb.begin(), hb.end(), 0);
+        for (int i = 0; i < nb; ++i)
+            for (int c = 0; c < ncells; ++c) {
+                const int32_t v = boards[(size_t)(b0 + i) * ncells + c];
+                if (v < 0 || v > 2) return nfail(AZX_EINVAL, "net: board values must be 0/1/2");
+                hb[(size_t)i * AZX_CELL_STRIDE + c] = (uint8_t)v;
+            }
+        if (hipMemcpyAsync(net->hb_board, hb.data(), (size_t)nb * AZX_CELL_STRIDE, hipMemcpyHostToDevice, st) != hipSuccess)
+            return nfail(AZX_EHIP, "net: H2D copy failed");
+        run_net(net, net->hb_board, net->hb_flip, nullptr, nb, nb, net->logit, net->hb_value, nullptr, st);
+        if (hipGetLastError() != hipSuccess) return nfail(AZX_EHIP, "net: kernel launch failed");
+        if (hipMemcpyAsync(hl.data(), net->logit, (size_t)nb * AZX_CELL_STRIDE * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(hv.data(), net->hb_value, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return nfail(AZX_EHIP, "net: D2H copy failed");
+        for (int i = 0; i < nb; ++i) {
+            value[b0 + i] = hv[i];
+            // gather + pad mask + log_softmax over the padded row (network.py:147-151)
+            const int32_t *lm = legal_moves + (size_t)(b0 + i) * K;
+            float *lp = logprob + (size_t)(b0 + i) * K;
+            float mx = -INFINITY;
+            for (int j = 0; j < K; ++j) {
+                if (lm[j] < 0 || lm[j] > ncells) return nfail(AZX_EINVAL, "net: legal move out of range");
+                const int tile = lm[j] > 0 ? lm[j] - 1 : 0;
+                lp[j] = lm[j] == 0 ? -99.0f : hl[(size_t)i * AZX_CELL_STRIDE + tile];
+                mx = std::max(mx, lp[j]);
+            }
+            double sum = 0.0;
+            for (int j = 0; j < K; ++j) sum += std::exp((double)lp[j] - (double)mx);
+            const float lse = (float)((double)mx + std::log(sum));
+            for (int j = 0; j < K; ++j) lp[j] = lp[j] - lse;
+        }
+    }
+    return AZX_OK;
+}

@@ -132,6 +132,31 @@ class Engine:
             p[:, :pr.shape[1]] = pr
         check(self.L.azx_put_evals(self.h, len(v), _p(v, C.c_float), _p(p, C.c_float)))
 
+    def get_evals(self):
+        """Device-network results for the pending leaves (EVAL_RESNET + phase API)."""
+        cap = self.G * self.bs
+        v = np.zeros(cap, np.float32)
+        p = np.zeros((cap, self.cells), np.float32)
+        n = C.c_int(0)
+        check(self.L.azx_get_evals(self.h, cap, _p(v, C.c_float), _p(p, C.c_float), C.byref(n)))
+        return v[:n.value], p[:n.value]
+
+    def search_recorded(self, noise=None, noise_scale=0.0):
+        """EVAL_RESNET search driven phase by phase, returning the evaluation tape
+        [(slot, k, value, prior[:k])] in mcts.evaluate_batch order."""
+        tape = []
+        n = self.search_begin(noise, noise_scale)
+        while True:
+            if n:
+                b, lm, slot, k = self.get_leaves()
+                v, p = self.get_evals()
+                for i in range(len(k)):
+                    tape.append((int(slot[i]), int(k[i]), np.float32(v[i]), p[i, :k[i]].copy()))
+            n, done = self.search_step()
+            if done:
+                break
+        return tape
+
     def search_external(self, evaluate, noise=None, noise_scale=0.0):
         """Drive one search with a host evaluator: evaluate(boards, legal_moves, slot, k) ->
         (value[n], prior[n, >=max k]).  Mirrors mcts.sample_paths' call order."""

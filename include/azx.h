@@ -120,6 +120,10 @@ int azx_get_leaves(azx_engine *e, int cap, int32_t *boards, int32_t *legal_moves
                    int32_t *slot, int32_t *k, int *n_out);
 /* value[n], prior[n][cells] (prior j = child j, first k entries) in the same order */
 int azx_put_evals(azx_engine *e, int n, const float *value, const float *prior);
+/* AZX_EVAL_RESNET driven through the phase API: the device network has already evaluated the
+ * pending positions; read its (value, prior) back in azx_get_leaves order (call that first).
+ * This is the "evaluation tape" parity tests replay through the CPU oracle. */
+int azx_get_evals(azx_engine *e, int cap, float *value, float *prior, int *n_out);
 
 /* ---- results ---------------------------------------------------------------------------- */
 

@@ -1,0 +1,181 @@
+"""GPU parity of the HIP resnet forward (MFMA tower + heads) against the reference's golden
+outputs (<= 1e-4 on value and legal-move log-probabilities, network.py:134-152) and of the
+resnet-driven search against the CPU oracle replaying the device's own evaluations."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-4
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from azalea_amd import engine
+    return engine
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.mark.parametrize("tag", ["5_1x8", "13_2x32", "11_6x64"])
+def test_g3_forward_golden(eng, orc, tag):
+    z = np.load(os.path.join(GOLDEN, "g3_forward_%s.npz" % tag))
+    n, blocks, chans = [int(x) for x in z["cfg"]]
+    state = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
+    E = eng.Engine(board_size=n, n_games=8, simulations=10, search_batch_size=10,
+                   evaluator=eng.EVAL_RESNET, num_blocks=blocks, base_chans=chans)
+    E.set_weights(state)
+    value, logprob = E.forward(z["board"], z["legal_moves"])
+    legal = z["legal_moves"] > 0
+    assert np.abs(value - z["value"]).max() <= TOL
+    assert np.abs(logprob - z["moves_logprob"])[legal].max() <= TOL
+    if (~legal).any():
+        assert np.abs(logprob - z["moves_logprob"])[~legal].max() <= 1e-3
+    ov, olp = orc.Net(n, blocks, chans, state).forward(z["board"], z["legal_moves"])
+    assert np.abs(value - ov).max() <= TOL and np.abs(logprob - olp)[legal].max() <= TOL
+    E.close()
+
+
+def _random_positions(orc, n, count, rng):
+    boards, moves = [], []
+    while len(boards) < count:
+        h = orc.Hex(n)
+        for _ in range(int(rng.randint(0, n * n - 2))):
+            lm = h.legal_moves()
+            h2 = h.copy()
+            h2.step(int(lm[rng.randint(len(lm))]))
+            if h2.result:
+                break
+            h = h2
+        b, lm = h.board, h.legal_moves()
+        if h.color == 1:
+            b, lm = orc.flip_board_moves(b, lm)
+        boards.append(b)
+        moves.append(lm)
+    K = max(len(m) for m in moves)
+    lm = np.zeros((count, K), np.int32)
+    for i, m in enumerate(moves):
+        lm[i, :len(m)] = m
+    return np.array(boards, np.int32), lm
+
+
+def test_forward_13x13_64ch_vs_oracle(eng, orc):
+    """BASELINE config 5's board with the 64-channel MFMA tiling (6 M-tiles, one board/block)."""
+    import torch
+    from azalea_amd.network import HexNetwork
+    torch.manual_seed(3)
+    net = HexNetwork(board_size=13, num_blocks=3, base_chans=64).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.3, 1.7)
+    state = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    rng = np.random.RandomState(4)
+    boards, lm = _random_positions(orc, 13, 24, rng)
+    E = eng.Engine(board_size=13, n_games=4, simulations=10, search_batch_size=10,
+                   evaluator=eng.EVAL_RESNET, num_blocks=3, base_chans=64)
+    E.set_weights(state)
+    value, logprob = E.forward(boards, lm)
+    ov, olp = orc.Net(13, 3, 64, state).forward(boards, lm)
+    legal = lm > 0
+    assert np.abs(value - ov).max() <= TOL and np.abs(logprob - olp)[legal].max() <= TOL
+    with torch.no_grad():
+        t = net(torch.tensor(boards), torch.tensor(lm))
+    assert np.abs(value - t["value"].numpy()).max() <= TOL
+    assert np.abs(logprob - t["moves_logprob"].numpy())[legal].max() <= TOL
+    E.close()
+
+
+def test_resnet_search_replayed_by_oracle(eng, orc):
+    """Search with the device network; feed the SAME (value, prior) stream to the CPU oracle:
+    trees must be identical bit for bit (visit counts, values, priors, topology), and the
+    stream itself must match the oracle's own fp32 forward within 1e-4."""
+    z = np.load(os.path.join(GOLDEN, "g3_forward_11_6x64.npz"))
+    state = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
+    n, G, sims = 11, 6, 60
+    rng = np.random.RandomState(11)
+    prefixes = []
+    for g in range(G):
+        h, mv = orc.Hex(n), []
+        for _ in range(int(rng.randint(0, 80))):
+            lm = h.legal_moves()
+            m = int(lm[rng.randint(len(lm))])
+            h2 = h.copy()
+            h2.step(m)
+            if h2.result:
+                break
+            h, mv = h2, mv + [m]
+        prefixes.append(mv)
+    E = eng.Engine(board_size=n, n_games=G, simulations=sims, search_batch_size=10,
+                   exploration_coef=0.5, evaluator=eng.EVAL_RESNET, num_blocks=6, base_chans=64,
+                   flags=eng.FLAG_NO_COMPACT, nodes_per_game=1 << 16)
+    E.set_weights(state)
+    E.reset(moves=prefixes)
+    onet = orc.Net(n, 6, 64, state)
+    games = []
+    for g in range(G):
+        h = orc.Hex(n)
+        for m in prefixes[g]:
+            h.step(m)
+        games.append(h)
+    trees = [orc.Tree(1 << 16) for _ in range(G)]
+    for rnd in range(2):
+        tape = E.search_recorded()
+        move_ids = np.full(G, -1, np.int32)
+        for g in range(G):
+            rows = [t for t in tape if t[0] == g]
+            off = np.zeros(len(rows) + 1, np.int64)
+            off[1:] = np.cumsum([r[1] for r in rows])
+            ev = orc.TapeEval([r[2] for r in rows], [r[1] for r in rows],
+                              np.concatenate([r[3] for r in rows]), off)
+            st = orc.search(trees[g], games[g], ev, sims, 10, 0.5)
+            assert st.status == 0 and not ev.mismatch and ev.consumed == len(rows)
+            d, o = E.tree_dump(g), trees[g].dump()
+            assert d["num_nodes"] == o["num_nodes"] and d["root_id"] == o["root_id"]
+            for name in ("parent", "first_child", "num_children"):
+                assert np.array_equal(d[name], o[name]), (g, name)
+            for name in ("num_visits", "total_value", "prior_prob"):
+                assert np.array_equal(bits(d[name]), bits(o[name])), (g, name)
+            # the device evaluations themselves vs the oracle network on the same positions
+            if rnd == 0:
+                t2 = orc.Tree(1 << 16)
+                st2 = orc.search(t2, games[g], onet, sims, 10, 0.5)
+                nv_dev = trees[g].root_stats()[0]
+                # not bit-exact (1e-4 logits can flip a near-tie) but the root priors must agree
+                assert np.abs(trees[g].root_stats()[2] - t2.root_stats()[2]).max() <= TOL
+                assert abs(nv_dev.sum() - t2.root_stats()[0].sum()) == 0
+            nv = trees[g].root_stats()[0]
+            mid = int(np.argmax(nv))
+            move_ids[g] = mid
+            lm = games[g].legal_moves()
+            trees[g].move(mid)
+            games[g].step(int(lm[mid]))
+        E.advance(move_ids)
+    E.close()
+
+
+def test_resnet_play_mode_runs(eng):
+    """Throughput path with the device network: azx_search (no phases) + device move draw."""
+    import torch
+    from azalea_amd.network import HexNetwork
+    torch.manual_seed(0)
+    net = HexNetwork(board_size=7, num_blocks=2, base_chans=64).eval()
+    state = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    E = eng.Engine(board_size=7, n_games=16, simulations=20, search_batch_size=10,
+                   exploration_depth=4, evaluator=eng.EVAL_RESNET, num_blocks=2, base_chans=64)
+    E.set_weights(state)
+    rows, st = E.play(64)
+    assert len(rows["board"]) >= 64 and st["games"] >= 1 and st["evals"] > 0
+    assert np.isfinite(rows["moves_prob"]).all()
+    E.close()
