@@ -68,6 +68,7 @@ SYMBOLS = {
     "azx_put_evals": (C.c_int, [_vp, C.c_int, _f32p, _f32p]),
     "azx_get_evals": (C.c_int, [_vp, C.c_int, _f32p, _f32p, C.POINTER(C.c_int)]),
     "azx_get_root": (C.c_int, [_vp, _i32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p, _f32p]),
+    "azx_get_status": (C.c_int, [_vp, _i32p]),
     "azx_get_games": (C.c_int, [_vp, _i32p, _i32p, _i32p, _i32p]),
     "azx_advance": (C.c_int, [_vp, _i32p]),
     "azx_tree_dump": (C.c_int, [_vp, C.c_int, C.c_int, _i32p, _i32p, _i32p, _f32p, _f32p, _f32p, _i32p, _i32p]),

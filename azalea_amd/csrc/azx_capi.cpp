@@ -502,6 +502,15 @@ extern "C" int azx_get_root(azx_engine *e, int32_t *k, int32_t *legal_moves, flo
     return AZX_OK;
 }
 
+extern "C" int azx_get_status(azx_engine *e, int32_t *status) {
+    if (!e || !status) return fail(AZX_EINVAL, "null argument");
+    std::vector<TreeHdr> th(e->d.G);
+    HIPCHECK(hipMemcpyAsync(th.data(), e->d.thdr, sizeof(TreeHdr) * th.size(), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    for (int g = 0; g < e->d.G; ++g) status[g] = th[g].status;
+    return AZX_OK;
+}
+
 extern "C" int azx_get_games(azx_engine *e, int32_t *board, int32_t *color, int32_t *result,
                              int32_t *ply) {
     if (!e) return fail(AZX_EINVAL, "null engine");

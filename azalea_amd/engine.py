@@ -187,6 +187,11 @@ class Engine:
             _p(out["search_value"], C.c_float)))
         return out
 
+    def get_status(self):
+        st = np.zeros(self.G, np.int32)
+        check(self.L.azx_get_status(self.h, _p(st, C.c_int32)))
+        return st
+
     def get_games(self):
         G = self.G
         board = np.zeros((G, self.n, self.n), np.int32)

@@ -1,0 +1,177 @@
+"""Player: endless stream of self-play games, read in whole games (azalea/parallel_player.py:17-76).
+
+The reference runs one game per worker process and ships pickled frames back through pipes.
+Here a Policy with the device network plays `n_games` games concurrently inside one engine
+(throughput mode: device RNG, device move draw); finished games are harvested in whole, buffered
+on the host and handed out by `read(size)` exactly as batch_examples does -- whole games until
+`len >= size`, metrics summed over the games returned.  With torch.distributed initialised each
+rank plays its share and the rows are all-gathered (azalea_amd/distributed.py).
+
+The `pool` argument is accepted for signature compatibility (policy_trainer.py:75) and unused:
+there are no worker processes.  Random movers and duck-typed networks go through the host
+play_game loop (one game at a time), like the reference's in-process pool (num_workers=0).
+"""
+import logging
+import os
+from collections import defaultdict, deque
+from typing import Dict, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import distributed as azdist
+from . import engine as _eng
+from .game.hex import HexGameState
+from .play_game import play_game
+from .policy import Policy, SearchTreeFull
+from .replay_buffer import ReplayDataFrame
+
+Metrics = Dict[str, float]
+
+
+def rows_to_frame(rows) -> ReplayDataFrame:
+    """Engine rows -> the reference's struct-of-lists frame (replay_buffer.py:11-38)."""
+    frame = ReplayDataFrame()
+    n = rows["board"].shape[-1]
+    for i in range(len(rows["reward"])):
+        board = rows["board"][i].astype(np.int32).reshape(n, n)
+        legal = (np.flatnonzero(board.ravel() == 0) + 1).astype(np.int32)
+        k = int(rows["nlegal"][i])
+        assert k == len(legal)
+        frame.state.append(HexGameState(int(rows["color"][i]), legal, 0, board))
+        frame.moves_prob.append(rows["moves_prob"][i, :k].astype(np.float32))
+        frame.reward.append(np.float32(rows["reward"][i]))
+    return frame
+
+
+class Player:
+    def __init__(self, pool, agents: Sequence, *, n_games: int = None, gather: bool = True):
+        self.agents = agents
+        self.running = True
+        self.gather = gather
+        self.n_games = n_games or int(os.environ.get("AZX_GAMES", "4096"))
+        self._games = deque()          # finished games waiting to be read: (rows dict, metrics)
+        self._engine = None
+        self._engine_key = None
+        self._seed_base = None
+
+    # ---- reference surface -------------------------------------------------------------------
+    def read(self, size) -> Tuple[ReplayDataFrame, Metrics]:
+        """Whole games until at least `size` positions (parallel_player.py:41-52)."""
+        quota = azdist.shard_quota(size) if (self.gather and azdist.is_distributed()) else size
+        rows_list, metrics = [], defaultdict(float)
+        have = 0
+        while have < quota:
+            if not self._games:
+                self._produce(quota - have)
+            rows, gm = self._games.popleft()
+            rows_list.append(rows)
+            have += len(rows["reward"])
+            for name, v in gm.items():
+                metrics[name] += v
+        rows = {k: np.concatenate([r[k] for r in rows_list]) for k in rows_list[0]}
+        if self.gather and azdist.is_distributed():
+            rows = azdist.all_gather_rows(rows, rows["board"].shape[-1])
+            metrics = azdist.all_reduce_metrics(dict(metrics))
+        return rows_to_frame(rows), dict(metrics)
+
+    def stop(self) -> None:
+        self.running = False
+        self._games.clear()
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+    # ---- production --------------------------------------------------------------------------
+    def _device_policy(self):
+        pol = getattr(self.agents[0], "policy", None)
+        return pol if isinstance(pol, Policy) and pol._uses_device_net() and len(self.agents) == 1 else None
+
+    def _produce(self, want: int) -> None:
+        pol = self._device_policy()
+        if pol is None:
+            self._produce_on_host()
+        else:
+            self._produce_on_device(pol, want)
+
+    def _produce_on_host(self) -> None:
+        """One game through the generic loop (random mover / duck-typed nets / two agents)."""
+        for a in self.agents:
+            net = getattr(getattr(a, "policy", None), "_net", None)
+            if hasattr(net, "eval"):
+                net.eval()
+        try:
+            _, frame, gm = play_game(self.agents, collect_data=True)
+        except SearchTreeFull:
+            logging.warning("game failed because of SearchTreeFull (skipped)")
+            return
+        n = self.agents[0].game.board_size
+        P = len(frame)
+        rows = dict(board=np.stack([s.board for s in frame.state]).astype(np.int32),
+                    color=np.array([s.color for s in frame.state], np.int32),
+                    nlegal=np.array([len(s.legal_moves) for s in frame.state], np.int32),
+                    moves_prob=np.zeros((P, n * n), np.float32),
+                    reward=np.array(frame.reward, np.float32),
+                    game_uid=np.full(P, -1, np.int64))
+        for i, p in enumerate(frame.moves_prob):
+            rows["moves_prob"][i, :len(p)] = p
+        self._games.append((rows, dict(gm)))
+
+    def _get_engine(self, pol: Policy):
+        n = self.agents[0].game.board_size
+        rank = torch.distributed.get_rank() if azdist.is_distributed() else 0
+        key = (n, pol.simulations, pol.search_batch_size, float(pol.exploration_coef),
+               pol.exploration_depth, pol.exploration_noise_alpha, pol.exploration_noise_scale,
+               pol.exploration_temperature, pol.num_blocks, pol.base_chans,
+               bool(pol.settings.get("move_sampling")), bool(pol.settings.get("move_exploration")))
+        if self._engine is None or key != self._engine_key:
+            if self._engine is not None:
+                self._engine.close()
+            sampling = pol.settings.get("move_sampling", False)
+            explore = sampling and pol.settings.get("move_exploration", False)
+            if self._seed_base is None:
+                # each game draws from its own stream: seed base + global game index
+                self._seed_base = int(pol.rng.randint(0, 2 ** 31 - 1)) + (rank << 40)
+            device = pol.net.device.index or 0 if pol.net.device.type == "cuda" else 0
+            self._engine = _eng.Engine(
+                board_size=n, n_games=self.n_games, simulations=pol.simulations,
+                search_batch_size=pol.search_batch_size, exploration_coef=pol.exploration_coef,
+                exploration_depth=pol.exploration_depth if sampling else 0,
+                noise_alpha=pol.exploration_noise_alpha,
+                noise_scale=pol.exploration_noise_scale if explore else 0.0,
+                temperature=pol.exploration_temperature if sampling else 0.0,
+                evaluator=_eng.EVAL_RESNET, num_blocks=pol.num_blocks, base_chans=pol.base_chans,
+                device=device, seed=self._seed_base)
+            self._engine_key = key
+        return self._engine
+
+    def _produce_on_device(self, pol: Policy, want: int) -> None:
+        eng = self._get_engine(pol)
+        self._push_weights(eng, pol)
+        rows, st = eng.play(max(1, int(want)))
+        uid = rows["game_uid"]
+        if len(uid) == 0:
+            return
+        plies = max(1, st["plies"])
+        per_ply = {"search_value": st["sum_search_value"] / plies,
+                   "search_root_width": st["sum_root_width"] / plies,
+                   "action_logprob": st["sum_action_logprob"] / plies}
+        starts = np.flatnonzero(np.r_[True, uid[1:] != uid[:-1]])
+        ends = np.r_[starts[1:], len(uid)]
+        errs = st["game_errors"]
+        for s, e in zip(starts, ends):
+            game = {k: v[s:e] for k, v in rows.items()}
+            gm = dict(games=1, reward=float(game["reward"][-1]), moves_per_game=int(e - s),
+                      seconds_per_game=st["seconds"] / max(1, st["games"]), game_error=errs,
+                      **per_ply)
+            errs = 0
+            self._games.append((game, gm))
+
+    @staticmethod
+    def _push_weights(eng, pol: Policy) -> None:
+        net = pol.net
+        sd = {k: v for k, v in net.state_dict().items() if v.dtype == torch.float32}
+        if net.device.type == "cuda":
+            eng.set_weights({k: (v.contiguous().data_ptr(), v.numel()) for k, v in sd.items()}, on_device=True)
+        else:
+            eng.set_weights({k: v.detach().cpu().numpy() for k, v in sd.items()})

@@ -132,6 +132,9 @@ int azx_get_evals(azx_engine *e, int cap, float *value, float *prior, int *n_out
 int azx_get_root(azx_engine *e, int32_t *k, int32_t *legal_moves, float *child_visits,
                  float *child_value, float *child_prior, float *root_visits,
                  float *root_value, int32_t *num_nodes, float *search_value);
+/* per slot: 0 ok, 1 = the arena overflowed during the last search (SearchTreeFull,
+ * search_tree.py:258-259): the caller skips the game as parallel_player.py:73-76 does */
+int azx_get_status(azx_engine *e, int32_t *status);
 
 /* game state per slot: HexGame.state (hex.py:55-60): board [n_games][cells] int32,
  * color (0/1), result (0/1/3), ply. */
