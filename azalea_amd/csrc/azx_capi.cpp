@@ -147,7 +147,7 @@ extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
     if (!rc) rc = dev_alloc(e, &d.arena[0], G * (size_t)cap, false);
     if (cfg->flags & AZX_FLAG_NO_COMPACT) d.arena[1] = d.arena[0];
     else if (!rc) rc = dev_alloc(e, &d.arena[1], G * (size_t)cap, false);
-    A(d.leaf_node, E); A(d.leaf_len, E); A(d.leaf_eval, E); A(d.leaf_link, E);
+    A(d.leaf_node, E); A(d.leaf_len, E); A(d.leaf_eval, E); A(d.leaf_link, E); A(d.leaf_cells, E);
     A(d.leaf_mask, E * 4); A(d.path, E * pstride);
     A(d.ev_board, E * AZX_CELL_STRIDE); A(d.ev_src, E); A(d.ev_flip, E);
     A(d.ev_value, E); A(d.ev_prior, E * AZX_CELL_STRIDE); A(d.n_eval, 4);

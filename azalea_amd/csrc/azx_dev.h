@@ -74,6 +74,7 @@ struct DevEngine {
     int32_t *leaf_len;      // [G][bs] path length (nodes below the root)
     int32_t *leaf_eval;     // [G][bs] index into ev_* or -1 (terminal)
     int32_t *leaf_link;     // [G][bs] the leaf's link when it was selected (-1 or terminal code)
+    int32_t *leaf_cells;    // [G][bs] first cell of the path | last cell << 16
     uint64_t *leaf_mask;    // [G][bs][4] empties bitmask at the leaf (original frame)
     int32_t *path;          // [G][bs][ncells]
     // evaluation requests / results (packed by atomic counter)
@@ -111,20 +112,39 @@ struct DevEngine {
     double *stat_sums;      // [8] search_value, root_width, action_logprob, reward_last
 };
 
+// ---- wave64 reductions on DPP (no LDS crossbar round trips) ---------------------------------
+// row_shr 1/2/4/8 build an inclusive scan inside each 16-lane row, row_bcast15 / row_bcast31
+// fold the rows; the total lands in lane 63 and is broadcast with v_readlane.
+#define AZX_DPP(old, v, ctrl, rmask) \
+    __builtin_amdgcn_update_dpp((old), (v), (ctrl), (rmask), 0xf, false)
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += __int_as_float(AZX_DPP(0, __float_as_int(v), 0x111, 0xf));
+    v += __int_as_float(AZX_DPP(0, __float_as_int(v), 0x112, 0xf));
+    v += __int_as_float(AZX_DPP(0, __float_as_int(v), 0x114, 0xf));
+    v += __int_as_float(AZX_DPP(0, __float_as_int(v), 0x118, 0xf));
+    v += __int_as_float(AZX_DPP(0, __float_as_int(v), 0x142, 0xa));
+    v += __int_as_float(AZX_DPP(0, __float_as_int(v), 0x143, 0xc));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += AZX_DPP(0, v, 0x111, 0xf);
+    v += AZX_DPP(0, v, 0x112, 0xf);
+    v += AZX_DPP(0, v, 0x114, 0xf);
+    v += AZX_DPP(0, v, 0x118, 0xf);
+    v += AZX_DPP(0, v, 0x142, 0xa);
+    v += AZX_DPP(0, v, 0x143, 0xc);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    const int ninf = 0xff800000;   // -inf: identity of max
+    v = fmaxf(v, __int_as_float(AZX_DPP(ninf, __float_as_int(v), 0x111, 0xf)));
+    v = fmaxf(v, __int_as_float(AZX_DPP(ninf, __float_as_int(v), 0x112, 0xf)));
+    v = fmaxf(v, __int_as_float(AZX_DPP(ninf, __float_as_int(v), 0x114, 0xf)));
+    v = fmaxf(v, __int_as_float(AZX_DPP(ninf, __float_as_int(v), 0x118, 0xf)));
+    v = fmaxf(v, __int_as_float(AZX_DPP(ninf, __float_as_int(v), 0x142, 0xa)));
+    v = fmaxf(v, __int_as_float(AZX_DPP(ninf, __float_as_int(v), 0x143, 0xc)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // ---- Hex rules on one wavefront: azalea/game/hex.py:137-231 ------------------------------

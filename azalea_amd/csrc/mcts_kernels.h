@@ -11,7 +11,7 @@
 #define MODE_SELECT 4   // select the next batch and emit evaluation requests
 #define MODE_INLINE 8   // evaluator is inline (uniform priors): loop all batches in one launch
 
-size_t azx_mcts_lds_bytes(int ncells);
+size_t azx_mcts_lds_bytes(int ncells, int bs);
 void azx_launch_mcts(const DevEngine &E, int mode, int num_batches, hipStream_t st);
 void azx_launch_reset(const DevEngine &E, const int32_t *slots, int n_slots, const int32_t *moves,
                       const int32_t *n_moves, int stride, int assign_uid, hipStream_t st);

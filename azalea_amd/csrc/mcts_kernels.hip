@@ -59,22 +59,44 @@ __device__ __forceinline__ Philox game_rng(const DevEngine &E, int64_t uid) {
     return ph;
 }
 
-// log of a Gamma(alpha) variate, alpha < 1 (Marsaglia-Tsang on alpha+1, boosted by U^(1/alpha))
-__device__ inline float log_gamma_variate(const Philox &ph, uint32_t c0, uint32_t c1, uint32_t c2,
-                                          float alpha) {
-    const float d = alpha + 1.0f - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
+// 32-bit mixer (two multiplies per word instead of Philox's forty per four): the Dirichlet
+// noise only needs decorrelated uniforms, it is re-drawn 410 times per move per cell
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+// log of a Gamma(alpha) variate, alpha < 1 (Marsaglia-Tsang on alpha+1, boosted by U^(1/alpha)).
+// `stream` is unique per (game, ply, select_leaf call); the cell index decorrelates lanes.
+// Native-rate transcendentals on purpose: this is noise, not part of the bit-exact score path.
+struct GammaConst { float d, c, inv_alpha; };
+__device__ __forceinline__ GammaConst gamma_const(float alpha) {
+    GammaConst g;
+    g.d = alpha + 1.0f - 1.0f / 3.0f;
+    g.c = __builtin_amdgcn_rsqf(9.0f * g.d);
+    g.inv_alpha = __builtin_amdgcn_rcpf(alpha);
+    return g;
+}
+__device__ __forceinline__ float fast_ln(float x) { return __builtin_amdgcn_logf(x) * 0.69314718f; }
+__device__ inline float log_gamma_variate(uint32_t stream, uint32_t cell, const GammaConst &gc) {
     float lg = 0.0f;
-    for (uint32_t t = 0; t < 64; ++t) {
-        uint32_t r[4];
-        ph.gen(c0, c1, c2, t, r);
-        const float u1 = u01(r[0]), u2 = u01(r[1]);
-        const float x = sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
-        float v = 1.0f + c * x;
+    uint32_t x = mix32(stream ^ (cell * 0x9E3779B9u));
+    for (uint32_t t = 0; t < 32; ++t) {
+        const uint32_t r0 = mix32(x + 0x68bc21ebu), r1 = mix32(x + 0x02e5be93u);
+        const uint32_t r2 = mix32(x + 0x967a889bu);
+        x = r2 ^ r0;
+        const float u1 = u01(r0), u2 = u01(r1);
+        // Box-Muller; v_cos_f32 takes revolutions
+        const float nrm = __builtin_amdgcn_sqrtf(-2.0f * fast_ln(u1)) * __builtin_amdgcn_cosf(u2);
+        float v = __builtin_fmaf(gc.c, nrm, 1.0f);
         if (v <= 0.0f) continue;
         v = v * v * v;
-        const float u = u01(r[2]);
-        if (__logf(u) < 0.5f * x * x + d - d * v + d * __logf(v)) {
-            lg = __logf(d * v) + __logf(u01(r[3])) / alpha;
+        const float u = u01(r2 >> 8 | r1 << 24);
+        const float lv = fast_ln(v);
+        if (fast_ln(u) < __builtin_fmaf(0.5f * nrm, nrm, gc.d) - gc.d * v + gc.d * lv) {
+            lg = fast_ln(gc.d) + lv + fast_ln(u01(mix32(x))) * gc.inv_alpha;
             break;
         }
     }
@@ -104,29 +126,6 @@ __device__ __forceinline__ Masks<SLOTS> make_masks(const HexWave<SLOTS> &h, int 
 
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
-// read-modify-write of (num_visits, total_value) along a recorded path: lane d handles path
-// element d.  `with_root` prepends the root (backup only, mcts.py:253).  The value added at
-// the LEAF is leaf_amount; with `alternate` its sign flips at every step towards the root
-// (mcts.py:252).  Visits get +dv everywhere.
-__device__ __forceinline__ void path_rmw(Node *arena, const int32_t *path_s, int len, int root_id,
-                                         bool with_root, float leaf_amount, bool alternate,
-                                         float dv, int lane) {
-    const int total = len + (with_root ? 1 : 0);
-    for (int b0 = 0; b0 < total; b0 += 64) {
-        const int d = b0 + lane;
-        if (d < total) {
-            const int id = with_root ? (d == 0 ? root_id : path_s[d - 1]) : path_s[d];
-            const int dist = total - 1 - d;              // 0 at the leaf
-            const float a = (alternate && (dist & 1)) ? -leaf_amount : leaf_amount;
-            float2 *p = reinterpret_cast<float2 *>(arena + id);
-            float2 x = *p;
-            x.x += dv;
-            x.y += a;
-            *p = x;
-        }
-    }
-}
-
 __device__ __forceinline__ void wave_mem_sync() {
     // global stores of this wave must be visible to later loads issued by OTHER lanes of it
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -146,38 +145,54 @@ __device__ __forceinline__ int flip_src(int o, int N) {
 }
 
 struct Lds {
-    int32_t *path;        // [AZX_MAX_BATCH][ncells]
-    uint64_t *mask;       // [AZX_MAX_BATCH][4]
-    unsigned char *colors;// [AZX_MAX_BATCH][AZX_CELL_STRIDE] absolute colours at the leaf
-    int32_t *node, *len, *link, *term, *mover, *uidx;   // [AZX_MAX_BATCH]
+    int32_t *path;        // [bs][pstride] node ids along each selected path (index d = depth d+1)
+    uint64_t *mask;       // [bs][4] empties bitmask at the leaf
+    unsigned char *colors;// [bs][AZX_CELL_STRIDE] absolute colours at the leaf
+    int32_t *node, *len, *link, *term, *mover, *uidx, *cells;   // [AZX_MAX_BATCH]
     float *value;         // [AZX_MAX_BATCH]
 };
 
-size_t azx_mcts_lds_bytes(int ncells) {
-    size_t b = (size_t)AZX_MAX_BATCH * (ncells + (ncells & 1)) * 4;   // path
-    b += AZX_MAX_BATCH * 4 * 8;                                        // mask
-    b += AZX_MAX_BATCH * AZX_CELL_STRIDE;                              // colors
-    b += AZX_MAX_BATCH * 4 * 7;                                        // small arrays
+size_t azx_mcts_lds_bytes(int ncells, int bs) {
+    size_t b = (size_t)bs * (ncells + (ncells & 1)) * 4;   // path
+    b += (size_t)bs * 4 * 8;                               // mask
+    b += (size_t)bs * AZX_CELL_STRIDE;                     // colors
+    b += AZX_MAX_BATCH * 4 * 8;                            // small arrays
     return b + 64;
 }
 
-__device__ __forceinline__ Lds carve_lds(unsigned char *raw, int ncells) {
+__device__ __forceinline__ Lds carve_lds(unsigned char *raw, int ncells, int bs) {
     Lds L;
     L.path = reinterpret_cast<int32_t *>(raw);
-    L.mask = reinterpret_cast<uint64_t *>(L.path + AZX_MAX_BATCH * (ncells + (ncells & 1)));
-    L.colors = reinterpret_cast<unsigned char *>(L.mask + AZX_MAX_BATCH * 4);
-    L.node = reinterpret_cast<int32_t *>(L.colors + AZX_MAX_BATCH * AZX_CELL_STRIDE);
+    L.mask = reinterpret_cast<uint64_t *>(L.path + bs * (ncells + (ncells & 1)));
+    L.colors = reinterpret_cast<unsigned char *>(L.mask + bs * 4);
+    L.node = reinterpret_cast<int32_t *>(L.colors + bs * AZX_CELL_STRIDE);
     L.len = L.node + AZX_MAX_BATCH;
     L.link = L.len + AZX_MAX_BATCH;
     L.term = L.link + AZX_MAX_BATCH;
     L.mover = L.term + AZX_MAX_BATCH;
     L.uidx = L.mover + AZX_MAX_BATCH;
-    L.value = reinterpret_cast<float *>(L.uidx + AZX_MAX_BATCH);
+    L.cells = L.uidx + AZX_MAX_BATCH;
+    L.value = reinterpret_cast<float *>(L.cells + AZX_MAX_BATCH);
     return L;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
 // ============================================================================================
 // The search kernel.  mode = MODE_* bits (mcts_kernels.h).
+//
+// On-chip tree state (what makes the kernel one HBM round trip per simulation instead of six):
+//  * the root's children (stats + link) live in registers, lane = board cell, for the whole
+//    launch: every descent's first level, and every virtual-loss / backup update of a depth-1
+//    node, is pure ALU;
+//  * deeper nodes touched by a path sit in a 64-entry write-back cache (lane j = entry j:
+//    id, num_visits, total_value).  They enter it with the values just loaded on the way down,
+//    virtual loss / undo / backup update the entry, child-block loads are patched from it, and
+//    it is written back when full and at the end of the launch.
+// Every update is still the same sequence of float32 additions per node as mcts.py:79-92 /
+// :242-255, so results are bit-identical to the sequential reference.
 // ============================================================================================
 template <int SLOTS>
 __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batches) {
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
     GameHdr *gh = E.ghdr + g;
     if (!gh->active) return;
     TreeHdr *th = E.thdr + g;
-    const Lds L = carve_lds(smem_raw, ncells);
+    const Lds L = carve_lds(smem_raw, ncells, bs);
 
     int num_nodes = th->num_nodes;
     const int root_id = th->root_id;
@@ -213,6 +228,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
     const float c32 = E.c_puct;
     const float keep32 = (float)(1.0 - E.noise_scale);   // python float -> f32 (weak scalar)
     const Philox ph = game_rng(E, gh->uid);
+    const GammaConst gconst = gamma_const(E.noise_alpha);
 
     if (mode & MODE_BEGIN) {
         batches_left = num_batches;
@@ -222,8 +238,74 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
         pending_root = 0;
     }
 
-    // ---- create_child_nodes (search_tree.py:254-274) for one leaf; returns false when full
-    auto expand = [&](int node, int lnk, bool terminal, const uint64_t *lm,
+    // ---- on-chip tree state ----------------------------------------------------------------
+    float4 rst[SLOTS];                 // root children: {num_visits, total_value, prior, link}
+    int rrk[SLOTS];                    // child rank of this lane's cells at the root
+    bool rempty[SLOTS];
+    float root_nv, root_tv;
+    int root_link;
+    {
+        const Node rn = arena[root_id];
+        root_nv = rn.nv;
+        root_tv = rn.tv;
+        root_link = rn.link;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            rempty[s] = ((rootmk.m[s] >> lane) & 1ull) && rootmk.k > 0;
+            rrk[s] = rootmk.base[s] + popc64(rootmk.m[s] & lanemask_lt(lane));
+            rst[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (root_link >= 0 && rempty[s])
+                rst[s] = *reinterpret_cast<const float4 *>(arena + root_link + rrk[s]);
+        }
+    }
+    int c_id = -1, n_c = 0;            // node cache: entry j lives in lane j
+    float c_nv = 0.0f, c_tv = 0.0f;
+
+    auto cache_flush = [&]() {
+        if (lane < n_c) *reinterpret_cast<float2 *>(arena + c_id) = make_float2(c_nv, c_tv);
+        n_c = 0;
+        wave_mem_sync();
+    };
+    // entry index of node `id`; on a miss it is inserted with (nv0, tv0) when `known`
+    // (values just read on the way down) or with the values in HBM
+    auto cache_find = [&](int id, bool known, float nv0, float tv0) -> int {
+        const uint64_t hit = __ballot(lane < n_c && c_id == id);
+        if (hit) return (int)__ffsll((long long)hit) - 1;
+        if (n_c == 64) cache_flush();
+        if (!known) {
+            const float2 x = *reinterpret_cast<const float2 *>(arena + id);
+            nv0 = x.x;
+            tv0 = x.y;
+        }
+        if (lane == n_c) { c_id = id; c_nv = nv0; c_tv = tv0; }
+        return n_c++;
+    };
+    auto root_child_add = [&](int cell, float dv, float dt) {
+        const int ln = cell & 63, sl = cell >> 6;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (s == sl && lane == ln) { rst[s].x += dv; rst[s].y += dt; }
+    };
+    // (num_visits += dv, total_value += +-amount) along one recorded path.  pth[d] is the node at
+    // depth d+1; the value added at the LEAF is `amount`, with `alternate` its sign flips at
+    // every step towards the root (mcts.py:252); `with_root` includes the root (mcts.py:253).
+    auto path_apply = [&](const int32_t *pth, int len, int cell0, float dv, float amount,
+                          bool alternate, bool with_root) {
+        if (with_root) {
+            root_nv += dv;
+            root_tv += (alternate && (len & 1)) ? -amount : amount;
+        }
+        if (len >= 1) root_child_add(cell0, dv, (alternate && ((len - 1) & 1)) ? -amount : amount);
+        for (int d = 1; d < len; ++d) {
+            const float a = (alternate && ((len - 1 - d) & 1)) ? -amount : amount;
+            const int slot = cache_find(pth[d], false, 0.f, 0.f);
+            if (lane == slot) { c_nv += dv; c_tv += a; }
+        }
+    };
+
+    // ---- create_child_nodes (search_tree.py:254-274) for one leaf; returns false when full.
+    // `cells` = first cell of the path | last cell << 16 (owner lanes of the link word).
+    auto expand = [&](int node, int len, int cells, int lnk, bool terminal, const uint64_t *lm,
                       const float *prior_row, float prior_const) -> bool {
         if (lnk != AZX_LINK_UNEVAL) return true;          // re-selected terminal: mcts.py:237
         int k = 0;
@@ -246,11 +328,25 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                     nd.pp = prior_row ? prior_row[cell] : prior_const;
                     nd.link = AZX_LINK_UNEVAL;
                     arena[fc + rk] = nd;
+                    if (len == 0) rst[s] = make_float4(0.f, 0.f, nd.pp, __int_as_float(AZX_LINK_UNEVAL));
                 }
             }
             c_kleaf += (unsigned long long)k;
         }
-        if (lane == 0) arena[node].link = (k > 0) ? fc : AZX_LINK_TERM(fc);
+        const int newlink = (k > 0) ? fc : AZX_LINK_TERM(fc);
+        if (len == 0) {                                   // the root itself
+            root_link = newlink;
+            if (lane == 0) arena[root_id].link = newlink;
+        } else if (len == 1) {                            // a root child: its link is in registers
+            const int c0 = cells & 0xffff, ln = c0 & 63, sl = c0 >> 6;
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+                if (s == sl && lane == ln) rst[s].w = __int_as_float(newlink);
+        } else {
+            // stored by the lane that will load this node as a child (same-lane program order)
+            const int cl = (cells >> 16) & 0xffff;
+            if (lane == (cl & 63)) arena[node].link = newlink;
+        }
         return true;
     };
 
@@ -292,38 +388,35 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
     };
 
     // =================================== BEGIN: root evaluation (mcts.py:272-273) ========
-    if ((mode & MODE_BEGIN) && status == 0) {
-        const int root_link = arena[root_id].link;
-        if (root_link == AZX_LINK_UNEVAL) {
+    if ((mode & MODE_BEGIN) && status == 0 && root_link == AZX_LINK_UNEVAL) {
 #pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const int cell = s * 64 + lane;
-                if (cell < ncells) L.colors[cell] = (unsigned char)(root.c[s] & 3u);
-            }
-            lds_sync();
-            if (inline_eval) {
-                expand(root_id, AZX_LINK_UNEVAL, root.winner != 0, rootmk.m, nullptr,
-                       rootmk.k ? inline_prior(rootmk.k) : 0.0f);
-                c_evals += 1;
-                wave_mem_sync();
-            } else {
-                int e = 0;
-                if (lane == 0) e = atomicAdd(E.n_eval, 1);
-                e = __builtin_amdgcn_readfirstlane(e);
-                emit_request(e, g * bs + 0, L.colors, root.color);
-                if (lane == 0) {
-                    const size_t lb = (size_t)g * bs;
-                    E.leaf_node[lb] = root_id;
-                    E.leaf_len[lb] = 0;
-                    E.leaf_eval[lb] = e;
-                    E.leaf_link[lb] = AZX_LINK_UNEVAL;
+        for (int s = 0; s < SLOTS; ++s) {
+            const int cell = s * 64 + lane;
+            if (cell < ncells) L.colors[cell] = (unsigned char)(root.c[s] & 3u);
+        }
+        lds_sync();
+        if (inline_eval) {
+            expand(root_id, 0, 0, AZX_LINK_UNEVAL, root.winner != 0, rootmk.m, nullptr,
+                   rootmk.k ? inline_prior(rootmk.k) : 0.0f);
+            c_evals += 1;
+        } else {
+            int e = 0;
+            if (lane == 0) e = atomicAdd(E.n_eval, 1);
+            e = __builtin_amdgcn_readfirstlane(e);
+            emit_request(e, g * bs + 0, L.colors, root.color);
+            if (lane == 0) {
+                const size_t lb = (size_t)g * bs;
+                E.leaf_node[lb] = root_id;
+                E.leaf_len[lb] = 0;
+                E.leaf_eval[lb] = e;
+                E.leaf_link[lb] = AZX_LINK_UNEVAL;
+                E.leaf_cells[lb] = 0;
 #pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) E.leaf_mask[lb * 4 + s] = rootmk.m[s];
-                }
-                pending = 1;
-                pending_root = 1;
-                c_evals += 1;
+                for (int s = 0; s < SLOTS; ++s) E.leaf_mask[lb * 4 + s] = rootmk.m[s];
             }
+            pending = 1;
+            pending_root = 1;
+            c_evals += 1;
         }
     }
 
@@ -335,6 +428,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
             const int len = E.leaf_len[lb + i];
             const int ev = E.leaf_eval[lb + i];
             const int lnk = E.leaf_link[lb + i];
+            const int cells = E.leaf_cells[lb + i];
             uint64_t lm[SLOTS];
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) lm[s] = E.leaf_mask[(lb + i) * 4 + s];
@@ -344,14 +438,13 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
             const bool terminal = ev < 0;
             float v = -1.0f;                                   // mcts.py:194-195
             if (!terminal) v = E.ev_value[ev];
-            if (!expand(node, lnk, terminal, lm,
+            if (!expand(node, len, cells, lnk, terminal, lm,
                         terminal ? nullptr : E.ev_prior + (size_t)ev * AZX_CELL_STRIDE, 0.0f))
                 break;
             if (!pending_root) {
-                path_rmw(arena, L.path, len, root_id, true, v, true, 1.0f, lane);   // mcts.py:247-255
+                path_apply(L.path, len, cells & 0xffff, 1.0f, v, true, true);   // mcts.py:247-255
                 if (lane == 0) L.value[i] = v;
             }
-            wave_mem_sync();
             lds_sync();
         }
         if (!pending_root && status == 0) {
@@ -365,115 +458,154 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
     // =================================== SELECT (+ inline evaluate/expand/backup) =========
     const bool do_select = (mode & (MODE_SELECT | MODE_INLINE)) != 0;
     while (do_select && batches_left > 0 && status == 0 && pending == 0) {
-        const int root_link = arena[root_id].link;
         if (root_link < 0) break;   // unevaluated or terminal root: nothing to search
 
         // ---- select_batch: bs sequential descents with virtual loss (mcts.py:62-70) ----
         for (int i = 0; i < bs; ++i) {
             HexWave<SLOTS> cur = root;                        // snapshot/restore, search_tree.py:150-154
             int link = root_link;
-            int depth = 0, node = root_id, child_link = 0;
+            int depth = 0, node = root_id, child_link = 0, cell0 = 0, cellL = 0;
+            float cur_nv = 0.0f;               // num_visits (incl. virtual) of the node being scored
             bool at_root = true;
             for (;;) {
-                const Masks<SLOTS> mk = make_masks<SLOTS>(cur, lane, ncells);
-                // ---- children statistics: one 16-byte load per legal move --------------
-                float4 st[SLOTS];
-                int rk[SLOTS];
-                float sumn = 0.0f;
+                Masks<SLOTS> mk = rootmk;
+                if (!at_root) mk = make_masks<SLOTS>(cur, lane, ncells);
+                int best_cell = 0x7fffffff, child_rank = 0;
+                float cnv = 0.f, ctv = 0.f;
+                if (!at_root && cur_nv == 1.0f) {
+                    // A node visited once (its own expansion) has only unvisited children
+                    // (sum of their visits == its visits - 1 == 0): every score is -0 + 0, so
+                    // np.argmax takes child 0, an unevaluated leaf.  No load, no scoring.
 #pragma unroll
-                for (int s = 0; s < SLOTS; ++s) {
-                    const bool empty = (mk.m[s] >> lane) & 1ull;
-                    rk[s] = mk.base[s] + popc64(mk.m[s] & lanemask_lt(lane));
-                    st[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (empty) {
-                        st[s] = *reinterpret_cast<const float4 *>(arena + link + rk[s]);
-                        sumn += st[s].x;
-                    }
-                }
-                sumn = wave_sum(sumn);                         // exact: visit counts are integers
-                const float sq = sqrtf(sumn);                  // mcts.py:132
-                // ---- Dirichlet noise at the root only (mcts.py:126-131, :114) ----------
-                float nz[SLOTS];
-                const bool noisy = at_root && E.noise_scale != 0.0;
-                if (noisy && E.device_noise) {
-                    float lg[SLOTS];
-                    float mx = -3.0e38f;
+                    for (int s = SLOTS - 1; s >= 0; --s)
+                        if (mk.m[s]) best_cell = s * 64 + (int)__ffsll((long long)mk.m[s]) - 1;
+                    child_link = AZX_LINK_UNEVAL;
+                } else {
+                    // ---- children statistics ------------------------------------------------
+                    float4 st[SLOTS];
+                    int rk[SLOTS];
+                    float sumn = 0.0f;
+                    if (at_root) {
 #pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) {
-                        lg[s] = -3.0e38f;
-                        if ((mk.m[s] >> lane) & 1ull) {
-                            lg[s] = log_gamma_variate(ph, (uint32_t)(s * 64 + lane),
-                                                      (uint32_t)select_count, (uint32_t)ply,
-                                                      E.noise_alpha);
-                            mx = fmaxf(mx, lg[s]);
+                        for (int s = 0; s < SLOTS; ++s) { st[s] = rst[s]; rk[s] = rrk[s]; }
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < SLOTS; ++s) {
+                            const bool empty = (mk.m[s] >> lane) & 1ull;
+                            rk[s] = mk.base[s] + popc64(mk.m[s] & lanemask_lt(lane));
+                            st[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (empty) st[s] = *reinterpret_cast<const float4 *>(arena + link + rk[s]);
+                        }
+                        // newer (num_visits, total_value) of cached children override HBM
+                        uint64_t pm = __ballot(lane < n_c && c_id >= link && c_id < link + mk.k);
+                        while (pm) {
+                            const int j = (int)__ffsll((long long)pm) - 1;
+                            pm &= pm - 1;
+                            const int r = __builtin_amdgcn_readlane(c_id, j) - link;
+                            const float pnv = readlane_f(c_nv, j), ptv = readlane_f(c_tv, j);
+#pragma unroll
+                            for (int s = 0; s < SLOTS; ++s)
+                                if (((mk.m[s] >> lane) & 1ull) && rk[s] == r) { st[s].x = pnv; st[s].y = ptv; }
                         }
                     }
-                    mx = wave_max(mx);
-                    float sw = 0.0f;
 #pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) {
-                        nz[s] = ((mk.m[s] >> lane) & 1ull) ? __expf(lg[s] - mx) : 0.0f;
-                        sw += nz[s];
-                    }
-                    sw = wave_sum(sw);
+                    for (int s = 0; s < SLOTS; ++s)
+                        if ((mk.m[s] >> lane) & 1ull) sumn += st[s].x;
+                    sumn = wave_sum(sumn);                         // exact: visit counts are integers
+                    const float sq = sqrtf(sumn);                  // mcts.py:132
+                    // ---- Dirichlet noise at the root only (mcts.py:126-131, :114) ----------
+                    float nz[SLOTS];
+                    const bool noisy = at_root && E.noise_scale != 0.0;
+                    if (noisy && E.device_noise) {
+                        const uint32_t noise_stream =
+                            mix32(ph.k0 ^ mix32(ph.k1 + (uint32_t)ply * 0x632be5abu + (uint32_t)select_count));
+                        float lg[SLOTS];
+                        float mx = -3.0e38f;
 #pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) nz[s] = nz[s] / sw;
-                }
-                // ---- score_actions (mcts.py:119-136), op by op in float32 --------------
-                float best = -INFINITY;
-                int best_cell = 0x7fffffff;
-#pragma unroll
-                for (int s = 0; s < SLOTS; ++s) {
-                    if ((mk.m[s] >> lane) & 1ull) {
-                        float P = st[s].z;
-                        if (noisy) {
-                            const float kept = keep32 * P;
-                            if (E.device_noise) {
-                                P = kept + (float)E.noise_scale * nz[s];
-                            } else {
-                                const double *row = E.noise +
-                                    ((size_t)g * E.n_select + select_count) * E.noise_stride;
-                                P = (float)((double)kept + E.noise_scale * row[rk[s]]);
+                        for (int s = 0; s < SLOTS; ++s) {
+                            lg[s] = -3.0e38f;
+                            if ((mk.m[s] >> lane) & 1ull) {
+                                lg[s] = log_gamma_variate(noise_stream, (uint32_t)(s * 64 + lane), gconst);
+                                mx = fmaxf(mx, lg[s]);
                             }
                         }
-                        const float nvj = st[s].x;
-                        const float gap = sq / (1.0f + nvj);              // mcts.py:132
-                        const float U = (c32 * P) * gap;                  // mcts.py:133
-                        const float W = -st[s].y;                         // search_tree.py:203
-                        const float Q = W / fmaxf(nvj, 1.0f);             // mcts.py:134
-                        const float score = Q + U;                        // mcts.py:135
-                        const int cell = s * 64 + lane;
-                        if (score > best || (score == best && cell < best_cell)) {
-                            best = score;
-                            best_cell = cell;
+                        mx = wave_max(mx);
+                        float sw = 0.0f;
+#pragma unroll
+                        for (int s = 0; s < SLOTS; ++s) {
+                            nz[s] = ((mk.m[s] >> lane) & 1ull) ? __builtin_amdgcn_exp2f((lg[s] - mx) * 1.44269504f) : 0.0f;
+                            sw += nz[s];
+                        }
+                        sw = (float)E.noise_scale * __builtin_amdgcn_rcpf(wave_sum(sw));   // eps / sum
+#pragma unroll
+                        for (int s = 0; s < SLOTS; ++s) nz[s] = nz[s] * sw;
+                    }
+                    // ---- score_actions (mcts.py:119-136), op by op in float32 --------------
+                    float slot_score[SLOTS];
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) {
+                        slot_score[s] = -INFINITY;
+                        if ((mk.m[s] >> lane) & 1ull) {
+                            float P = st[s].z;
+                            if (noisy) {
+                                const float kept = keep32 * P;
+                                if (E.device_noise) {
+                                    P = kept + nz[s];
+                                } else {
+                                    const double *row = E.noise +
+                                        ((size_t)g * E.n_select + select_count) * E.noise_stride;
+                                    P = (float)((double)kept + E.noise_scale * row[rk[s]]);
+                                }
+                            }
+                            const float nvj = st[s].x;
+                            const float gap = sq / (1.0f + nvj);              // mcts.py:132
+                            const float U = (c32 * P) * gap;                  // mcts.py:133
+                            const float W = -st[s].y;                         // search_tree.py:203
+                            const float Q = W / fmaxf(nvj, 1.0f);             // mcts.py:134
+                            const float score = Q + U;                        // mcts.py:135
+                            slot_score[s] = score;
                         }
                     }
-                }
-                // np.argmax: highest score, lowest index on ties (mcts.py:112)
+                    // np.argmax: highest score, lowest index on ties (mcts.py:112): wave max, then
+                    // the lowest cell whose score equals it (-0.0 == +0.0, as in numpy)
+                    {
+                        float sc[SLOTS];
+                        float lmax = -INFINITY;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ob = __shfl_xor(best, o, 64);
-                    const int oc = __shfl_xor(best_cell, o, 64);
-                    if (ob > best || (ob == best && oc < best_cell)) { best = ob; best_cell = oc; }
-                }
-                best_cell = __builtin_amdgcn_readfirstlane(best_cell);
-                const int bl = best_cell & 63, bsl = best_cell >> 6;
-                int child_rank = 0;
+                        for (int s = 0; s < SLOTS; ++s) {
+                            sc[s] = slot_score[s];
+                            lmax = fmaxf(lmax, sc[s]);
+                        }
+                        const float wmax = wave_max(lmax);
+                        best_cell = 0x7fffffff;
 #pragma unroll
-                for (int s = 0; s < SLOTS; ++s) {
-                    const int r_ = __builtin_amdgcn_readlane(rk[s], bl);
-                    const int l_ = __builtin_amdgcn_readlane(__float_as_int(st[s].w), bl);
-                    if (s == bsl) { child_rank = r_; child_link = l_; }
+                        for (int s = SLOTS - 1; s >= 0; --s) {
+                            const uint64_t eq = __ballot(((mk.m[s] >> lane) & 1ull) && sc[s] == wmax);
+                            if (eq) best_cell = s * 64 + (int)__ffsll((long long)eq) - 1;
+                        }
+                    }
+                    const int bl = best_cell & 63, bsl = best_cell >> 6;
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) {
+                        const int r_ = __builtin_amdgcn_readlane(rk[s], bl);
+                        const int l_ = __builtin_amdgcn_readlane(__float_as_int(st[s].w), bl);
+                        const float n_ = readlane_f(st[s].x, bl), t_ = readlane_f(st[s].y, bl);
+                        if (s == bsl) { child_rank = r_; child_link = l_; cnv = n_; ctv = t_; }
+                    }
                 }
                 c_depth += 1;
                 c_kint += (unsigned long long)mk.k;
                 node = link + child_rank;
+                if (at_root) cell0 = best_cell;
+                else (void)cache_find(node, true, cnv, ctv);   // deeper path nodes enter the cache
+                cellL = best_cell;
                 if (lane == 0) L.path[i * pstride + depth] = node;
                 cur.step(best_cell, N, lane);                  // search_tree.py:306-308
                 depth += 1;
                 at_root = false;
                 if (child_link < 0) break;                     // leaf: unevaluated or terminal
                 link = child_link;
+                cur_nv = cnv;
             }
             select_count += 1;
             c_selects += 1;
@@ -490,19 +622,17 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                 L.link[i] = child_link;
                 L.term[i] = cur.winner != 0;
                 L.mover[i] = cur.color;
+                L.cells[i] = cell0 | (cellL << 16);
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s) L.mask[i * 4 + s] = lmk.m[s];
             }
             lds_sync();
             // ... and apply the virtual loss to its path (mcts.py:68, :79-92)
-            path_rmw(arena, L.path + i * pstride, depth, root_id, false, 1.0f, false, 1.0f, lane);
-            wave_mem_sync();
+            path_apply(L.path + i * pstride, depth, cell0, 1.0f, 1.0f, false, false);
         }
         // undo the virtual losses in list order (mcts.py:72)
-        for (int i = 0; i < bs; ++i) {
-            path_rmw(arena, L.path + i * pstride, L.len[i], root_id, false, -1.0f, false, -1.0f, lane);
-            wave_mem_sync();
-        }
+        for (int i = 0; i < bs; ++i)
+            path_apply(L.path + i * pstride, L.len[i], L.cells[i] & 0xffff, -1.0f, -1.0f, false, false);
         // deduplicate_leaves: keep first occurrence by node id (mcts.py:139-152)
         int nu = 0;
         for (int i = 0; i < bs; ++i) {
@@ -533,12 +663,11 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                 } else {
                     c_term += 1;
                 }
-                if (!expand(L.node[i], L.link[i], terminal, lm, nullptr,
+                if (!expand(L.node[i], L.len[i], L.cells[i], L.link[i], terminal, lm, nullptr,
                             (!terminal && k) ? inline_prior(k) : 0.0f))
                     break;
-                path_rmw(arena, L.path + i * pstride, L.len[i], root_id, true, v, true, 1.0f, lane);
+                path_apply(L.path + i * pstride, L.len[i], L.cells[i] & 0xffff, 1.0f, v, true, true);
                 if (lane == 0) L.value[u] = v;
-                wave_mem_sync();
             }
             lds_sync();
             if (status == 0) search_value += np_sum_f32(L.value, nu);   // mcts.py:287
@@ -561,6 +690,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                     E.leaf_node[lb + u] = L.node[i];
                     E.leaf_len[lb + u] = len;
                     E.leaf_link[lb + u] = L.link[i];
+                    E.leaf_cells[lb + u] = L.cells[i];
                     E.leaf_eval[lb + u] = terminal ? -1 : e;
 #pragma unroll
                     for (int s = 0; s < SLOTS; ++s) E.leaf_mask[(lb + u) * 4 + s] = L.mask[i * 4 + s];
@@ -577,8 +707,15 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
         }
     }
 
-    // =================================== epilogue ========================================
+    // =================================== epilogue: write the on-chip state back ===========
+    cache_flush();
+    if (root_link >= 0) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (rempty[s]) *reinterpret_cast<float4 *>(arena + root_link + rrk[s]) = rst[s];
+    }
     if (lane == 0) {
+        *reinterpret_cast<float2 *>(arena + root_id) = make_float2(root_nv, root_tv);
         th->num_nodes = num_nodes;
         th->status = status;
         th->batches_left = batches_left;
@@ -1018,7 +1155,7 @@ __global__ void k_arith(const float *a, const float *b, float *sq, float *dv, fl
     } while (0)
 
 void azx_launch_mcts(const DevEngine &E, int mode, int num_batches, hipStream_t st) {
-    const size_t lds = azx_mcts_lds_bytes(E.ncells);
+    const size_t lds = azx_mcts_lds_bytes(E.ncells, E.bs);
 #define CALL(S) hipLaunchKernelGGL((k_mcts<S>), dim3(E.G), dim3(64), lds, st, E, mode, num_batches)
     DISPATCH_SLOTS(E.slots, CALL);
 #undef CALL

@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=6)
     ap.add_argument("--chans", type=int, default=64)
     ap.add_argument("--seed", type=int, default=0xBAD5EED5)
+    ap.add_argument("--noise-scale", type=float, default=0.25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.steps is None:
@@ -101,7 +102,7 @@ def main():
     # per-game seeds come from the global game index: rank r owns uids r*2^40 + ...
     E = eng.Engine(board_size=args.board, n_games=args.games, simulations=args.sims,
                    search_batch_size=args.batch, exploration_coef=0.5, exploration_depth=15,
-                   noise_alpha=0.03, noise_scale=0.25, temperature=1.0, evaluator=evaluator,
+                   noise_alpha=0.03, noise_scale=args.noise_scale, temperature=1.0, evaluator=evaluator,
                    num_blocks=args.blocks, base_chans=args.chans, device=local_rank,
                    seed=args.seed + (rank << 40))
     net_state = None
