@@ -171,54 +171,56 @@ struct HexWave {
         color = 1;
         winner = 0;
     }
-    // wave-uniform read of one cell
-    __device__ __forceinline__ uint32_t read_cell(int cell) const {
-        const int s = cell >> 6, ln = cell & 63;
-        uint32_t v = 0;
+    // row / column of this lane's cells (set once per kernel by geom())
+    int gr[SLOTS], gc[SLOTS];
+    __device__ __forceinline__ void geom(int N, int lane) {
 #pragma unroll
-        for (int i = 0; i < SLOTS; ++i) {
-            uint32_t t = __builtin_amdgcn_readlane(c[i], ln);
-            if (s == i) v = t;
+        for (int s = 0; s < SLOTS; ++s) {
+            const int cell = s * 64 + lane;
+            gr[s] = cell / N;
+            gc[s] = cell - gr[s] * N;
         }
-        return v;
     }
     // empties bitmask, slot s (hex.py:151-159: legal moves are the empty cells while winner==0)
     __device__ __forceinline__ uint64_t empties(int s, int lane, int ncells) const {
         return __ballot(((c[s] & 3u) == 0u) && (s * 64 + lane < ncells));
     }
     // hex.py:172-179 step + :204-231 check_win.  `cell` must be wave-uniform, empty, winner==0.
+    // Every lane tests whether its cells touch the new stone (hex.py:190-195 neighbourhood:
+    // |dr|<=1, |dc|<=1, |dr+dc|<=1, not the cell itself); the same-colour neighbours' group
+    // flags are OR-ed by ballot and their groups relabelled, one pass per neighbouring stone.
     __device__ __forceinline__ void step(int cell, int N, int lane) {
         const int col = color;
-        const int r = cell / N, q = cell - r * N;
-        const int e = (col == 1) ? r : q;            // colour 1 tracks rows, 2 columns
+        const int r0 = cell / N, q0 = cell - r0 * N;
+        const int e = (col == 1) ? r0 : q0;          // colour 1 tracks rows, 2 columns
         uint32_t flags = (e == 0 ? 1u : 0u) | (e == N - 1 ? 2u : 0u);
-        uint32_t labs[6];
-        const int dr[6] = {-1, -1, 0, 0, 1, 1};      // hex.py:190-195 neighbour order
-        const int dc[6] = {0, 1, -1, 1, -1, 0};
+        uint64_t nb[SLOTS];
 #pragma unroll
-        for (int d = 0; d < 6; ++d) {
-            const int nr = r + dr[d], nc = q + dc[d];
-            uint32_t lab = AZX_LABEL_NONE;
-            if (nr >= 0 && nr < N && nc >= 0 && nc < N) {
-                const uint32_t v = read_cell(nr * N + nc);
-                if ((int)(v & 3u) == col) {
-                    flags |= (v >> 2) & 3u;
-                    lab = v >> 8;
-                }
-            }
-            labs[d] = lab;
+        for (int s = 0; s < SLOTS; ++s) {
+            const int dr = gr[s] - r0, dc = gc[s] - q0;
+            const bool adj = (unsigned)(dr + 1) <= 2u && (unsigned)(dc + 1) <= 2u &&
+                             (unsigned)(dr + dc + 1) <= 2u && (dr | dc) != 0;
+            const bool isn = adj && (int)(c[s] & 3u) == col;
+            nb[s] = __ballot(isn);
+            if (__ballot(isn && (c[s] & 4u))) flags |= 1u;
+            if (__ballot(isn && (c[s] & 8u))) flags |= 2u;
         }
         const uint32_t nv = (uint32_t)col | (flags << 2) | ((uint32_t)cell << 8);
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const uint32_t v = c[s];
-            const uint32_t lb = v >> 8;
-            const bool same = (int)(v & 3u) == col;
-            const bool hit = same && (lb == labs[0] || lb == labs[1] || lb == labs[2] ||
-                                      lb == labs[3] || lb == labs[4] || lb == labs[5]);
-            const bool mine = (s * 64 + lane) == cell;
-            c[s] = (mine || hit) ? nv : v;
+            uint64_t m = nb[s];
+            while (m) {
+                const int j = (int)__ffsll((long long)m) - 1;
+                m &= m - 1;
+                const uint32_t lab = (uint32_t)__builtin_amdgcn_readlane((int)c[s], j) >> 8;
+#pragma unroll
+                for (int t = 0; t < SLOTS; ++t)
+                    if ((int)(c[t] & 3u) == col && (c[t] >> 8) == lab) c[t] = nv;
+            }
         }
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (s * 64 + lane == cell) c[s] = nv;
         winner = (flags == 3u) ? col : 0;
         color = 3 - col;
     }

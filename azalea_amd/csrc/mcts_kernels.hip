@@ -218,6 +218,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
 
     HexWave<SLOTS> root;
     root.load(E.cells + (size_t)g * SLOTS * 64, lane);
+    root.geom(N, lane);
     root.color = gh->color;
     root.winner = gh->winner;
     const int ply = gh->ply;
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
 
     unsigned long long c_selects = 0, c_depth = 0, c_kint = 0, c_kleaf = 0, c_evals = 0, c_term = 0;
     const bool inline_eval = (mode & MODE_INLINE) != 0;
+    const bool need_colors = !inline_eval || E.evaluator == AZX_EVAL_UNIFORM_HASH;   // leaf boards leave the wave
     const float c32 = E.c_puct;
     const float keep32 = (float)(1.0 - E.noise_scale);   // python float -> f32 (weak scalar)
     const Philox ph = game_rng(E, gh->uid);
@@ -260,6 +262,41 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
     }
     int c_id = -1, n_c = 0;            // node cache: entry j lives in lane j
     float c_nv = 0.0f, c_tv = 0.0f;
+    // per-leaf metadata of the batch in flight: leaf i lives in lane i (v_readlane to fetch)
+    int m_node = -1, m_len = 0, m_link = 0, m_tm = 0, m_cells = 0, m_uidx = 0;
+    float m_val = 0.0f;
+    uint64_t m_mask[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) m_mask[s] = 0ull;
+    auto rl = [&](int v, int i) -> int { return __builtin_amdgcn_readlane(v, i); };
+    auto rl64 = [&](uint64_t v, int i) -> uint64_t {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), i) << 32) |
+               (uint32_t)__builtin_amdgcn_readlane((int)v, i);
+    };
+    // numpy's pairwise float32 sum over the first n lanes' m_val (mcts.py:287)
+    auto np_sum_vals = [&](int n) -> float {
+        float a[AZX_MAX_BATCH];
+#pragma unroll
+        for (int i = 0; i < AZX_MAX_BATCH; ++i) a[i] = readlane_f(m_val, i);
+        if (n < 8) {
+            float r = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) if (i < n) r += a[i];
+            return r;
+        }
+        float r8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r8[j] = a[j];
+        if (n >= 16) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r8[j] += a[8 + j];
+        }
+        float res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+        const int done = n >= 16 ? 16 : 8;
+#pragma unroll
+        for (int i = 8; i < AZX_MAX_BATCH; ++i) if (i >= done && i < n) res += a[i];
+        return res;
+    };
 
     auto cache_flush = [&]() {
         if (lane < n_c) *reinterpret_cast<float2 *>(arena + c_id) = make_float2(c_nv, c_tv);
@@ -443,14 +480,11 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                 break;
             if (!pending_root) {
                 path_apply(L.path, len, cells & 0xffff, 1.0f, v, true, true);   // mcts.py:247-255
-                if (lane == 0) L.value[i] = v;
+                if (lane == i) m_val = v;
             }
             lds_sync();
         }
-        if (!pending_root && status == 0) {
-            lds_sync();
-            search_value += np_sum_f32(L.value, pending);       // mcts.py:287
-        }
+        if (!pending_root && status == 0) search_value += np_sum_vals(pending);   // mcts.py:287
         pending = 0;
         pending_root = 0;
     }
@@ -611,20 +645,21 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
             c_selects += 1;
             // record the leaf (mcts.py:69-70) ...
             const Masks<SLOTS> lmk = make_masks<SLOTS>(cur, lane, ncells);
+            if (need_colors) {
 #pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const int cell = s * 64 + lane;
-                if (cell < ncells) L.colors[i * AZX_CELL_STRIDE + cell] = (unsigned char)(cur.c[s] & 3u);
+                for (int s = 0; s < SLOTS; ++s) {
+                    const int cell = s * 64 + lane;
+                    if (cell < ncells) L.colors[i * AZX_CELL_STRIDE + cell] = (unsigned char)(cur.c[s] & 3u);
+                }
             }
-            if (lane == 0) {
-                L.node[i] = node;
-                L.len[i] = depth;
-                L.link[i] = child_link;
-                L.term[i] = cur.winner != 0;
-                L.mover[i] = cur.color;
-                L.cells[i] = cell0 | (cellL << 16);
+            if (lane == i) {
+                m_node = node;
+                m_len = depth;
+                m_link = child_link;
+                m_tm = (cur.winner != 0 ? 1 : 0) | (cur.color << 1);
+                m_cells = cell0 | (cellL << 16);
 #pragma unroll
-                for (int s = 0; s < SLOTS; ++s) L.mask[i * 4 + s] = lmk.m[s];
+                for (int s = 0; s < SLOTS; ++s) m_mask[s] = lmk.m[s];
             }
             lds_sync();
             // ... and apply the virtual loss to its path (mcts.py:68, :79-92)
@@ -632,71 +667,72 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
         }
         // undo the virtual losses in list order (mcts.py:72)
         for (int i = 0; i < bs; ++i)
-            path_apply(L.path + i * pstride, L.len[i], L.cells[i] & 0xffff, -1.0f, -1.0f, false, false);
+            path_apply(L.path + i * pstride, rl(m_len, i), rl(m_cells, i) & 0xffff, -1.0f, -1.0f, false, false);
         // deduplicate_leaves: keep first occurrence by node id (mcts.py:139-152)
         int nu = 0;
         for (int i = 0; i < bs; ++i) {
-            bool dup = false;
-            for (int j = 0; j < i; ++j) dup = dup || (L.node[j] == L.node[i]);
+            const int id = rl(m_node, i);
+            const bool dup = __ballot(lane < i && m_node == id) != 0ull;
             if (!dup) {
-                if (lane == 0) L.uidx[nu] = i;
+                if (lane == nu) m_uidx = i;
                 nu += 1;
             }
         }
-        lds_sync();
         batches_left -= 1;
 
         if (inline_eval) {
             // evaluate_batch + expand_batch + backup_batch for the inline (uniform) evaluator
             for (int u = 0; u < nu; ++u) {
-                const int i = L.uidx[u];
-                const bool terminal = L.term[i] != 0;
+                const int i = rl(m_uidx, u);
+                const int tm = rl(m_tm, i);
+                const bool terminal = (tm & 1) != 0;
                 uint64_t lm[SLOTS];
                 int k = 0;
 #pragma unroll
-                for (int s = 0; s < SLOTS; ++s) { lm[s] = L.mask[i * 4 + s]; k += popc64(lm[s]); }
+                for (int s = 0; s < SLOTS; ++s) { lm[s] = rl64(m_mask[s], i); k += popc64(lm[s]); }
                 float v = -1.0f;
                 if (!terminal) {
                     v = (E.evaluator == AZX_EVAL_UNIFORM_HASH)
-                            ? hash_value(L.colors + i * AZX_CELL_STRIDE, L.mover[i]) : 0.0f;
+                            ? hash_value(L.colors + i * AZX_CELL_STRIDE, tm >> 1) : 0.0f;
                     c_evals += 1;
                 } else {
                     c_term += 1;
                 }
-                if (!expand(L.node[i], L.len[i], L.cells[i], L.link[i], terminal, lm, nullptr,
+                const int lf_len = rl(m_len, i), lf_cells = rl(m_cells, i);
+                if (!expand(rl(m_node, i), lf_len, lf_cells, rl(m_link, i), terminal, lm, nullptr,
                             (!terminal && k) ? inline_prior(k) : 0.0f))
                     break;
-                path_apply(L.path + i * pstride, L.len[i], L.cells[i] & 0xffff, 1.0f, v, true, true);
-                if (lane == 0) L.value[u] = v;
+                path_apply(L.path + i * pstride, lf_len, lf_cells & 0xffff, 1.0f, v, true, true);
+                if (lane == u) m_val = v;
             }
-            lds_sync();
-            if (status == 0) search_value += np_sum_f32(L.value, nu);   // mcts.py:287
+            if (status == 0) search_value += np_sum_vals(nu);   // mcts.py:287
         } else {
             // hand the unique leaves to the evaluator: scratch + packed requests
             int n_nt = 0;
-            for (int u = 0; u < nu; ++u) n_nt += L.term[L.uidx[u]] ? 0 : 1;
+            for (int u = 0; u < nu; ++u) n_nt += (rl(m_tm, rl(m_uidx, u)) & 1) ? 0 : 1;
             int e0 = 0;
             if (lane == 0 && n_nt) e0 = atomicAdd(E.n_eval, n_nt);
             e0 = __builtin_amdgcn_readfirstlane(e0);
             const size_t lb = (size_t)g * bs;
             int e = e0;
             for (int u = 0; u < nu; ++u) {
-                const int i = L.uidx[u];
-                const bool terminal = L.term[i] != 0;
-                const int len = L.len[i];
+                const int i = rl(m_uidx, u);
+                const int tm = rl(m_tm, i);
+                const bool terminal = (tm & 1) != 0;
+                const int len = rl(m_len, i);
                 int32_t *pth = E.path + (lb + u) * (size_t)pstride;
                 for (int d = lane; d < len; d += 64) pth[d] = L.path[i * pstride + d];
                 if (lane == 0) {
-                    E.leaf_node[lb + u] = L.node[i];
+                    E.leaf_node[lb + u] = rl(m_node, i);
                     E.leaf_len[lb + u] = len;
-                    E.leaf_link[lb + u] = L.link[i];
-                    E.leaf_cells[lb + u] = L.cells[i];
+                    E.leaf_link[lb + u] = rl(m_link, i);
+                    E.leaf_cells[lb + u] = rl(m_cells, i);
                     E.leaf_eval[lb + u] = terminal ? -1 : e;
 #pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) E.leaf_mask[(lb + u) * 4 + s] = L.mask[i * 4 + s];
+                    for (int s = 0; s < SLOTS; ++s) E.leaf_mask[(lb + u) * 4 + s] = rl64(m_mask[s], i);
                 }
                 if (!terminal) {
-                    emit_request(e, g * bs + u, L.colors + i * AZX_CELL_STRIDE, L.mover[i]);
+                    emit_request(e, g * bs + u, L.colors + i * AZX_CELL_STRIDE, tm >> 1);
                     e += 1;
                     c_evals += 1;
                 } else {
@@ -766,6 +802,7 @@ __global__ __launch_bounds__(64) void k_reset(DevEngine E, const int32_t *slots,
     const int g = slots ? slots[idx] : idx;
     HexWave<SLOTS> h;
     h.clear();
+    h.geom(E.N, lane);
     int ply = 0;
     if (moves) {
         const int nm = n_moves[idx];
@@ -811,6 +848,7 @@ __global__ __launch_bounds__(64) void k_advance(DevEngine E, const int32_t *move
 
     HexWave<SLOTS> h;
     h.load(E.cells + (size_t)g * SLOTS * 64, lane);
+    h.geom(E.N, lane);
     h.color = gh->color;
     h.winner = gh->winner;
     int ply = gh->ply;
@@ -1116,6 +1154,7 @@ __global__ __launch_bounds__(64) void k_hex_replay(int N, int n_games, const int
     const int ncells = N * N;
     HexWave<SLOTS> h;
     h.clear();
+    h.geom(N, lane);
     const int len = length[g];
     for (int p = 0; p < len; ++p) {
         const Masks<SLOTS> mk = make_masks<SLOTS>(h, lane, ncells);
