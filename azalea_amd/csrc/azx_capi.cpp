@@ -810,3 +810,18 @@ extern "C" int azx_selftest_arith(int device, int n, const float *a, const float
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(ds); (void)hipFree(dd); (void)hipFree(dm);
     return AZX_OK;
 }
+
+// ---- device Dirichlet self-test hook (tests): n_rows draws of Dirichlet(alpha * 1_k) -------------
+extern "C" int azx_selftest_dirichlet(int device, double alpha, int k, int n_rows, uint32_t seed, float *out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(AZX_ENODEV, "no HIP device visible");
+    if (k < 1 || k > 128 || n_rows < 1 || !out) return fail(AZX_EINVAL, "bad argument");
+    HIPCHECK(hipSetDevice(device));
+    float *d = nullptr;
+    HIPCHECK(hipMalloc(&d, sizeof(float) * (size_t)k * n_rows));
+    azx_launch_noise_test((float)alpha, k, n_rows, seed, d, nullptr);
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(out, d, sizeof(float) * (size_t)k * n_rows, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return AZX_OK;
+}

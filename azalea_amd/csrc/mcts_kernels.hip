@@ -68,39 +68,67 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     return x;
 }
 
-// log of a Gamma(alpha) variate, alpha < 1 (Marsaglia-Tsang on alpha+1, boosted by U^(1/alpha)).
+// log of a Gamma(alpha) variate for 0 < alpha < 1: Ahrens-Dieter GS rejection sampler, kept in
+// log space (for alpha = 0.03 x = p^(1/alpha) underflows float32 all the time; only the ratios
+// matter to the Dirichlet).  With b = 1 + alpha/e:  p = b*U1;  p <= 1: x = p^(1/alpha), accept
+// if U2 <= exp(-x);  else x = -ln((b-p)/alpha), accept if U2 <= x^(alpha-1).
 // `stream` is unique per (game, ply, select_leaf call); the cell index decorrelates lanes.
 // Native-rate transcendentals on purpose: this is noise, not part of the bit-exact score path.
-struct GammaConst { float d, c, inv_alpha; };
+struct GammaConst { float alpha, inv_alpha, b; };
 __device__ __forceinline__ GammaConst gamma_const(float alpha) {
     GammaConst g;
-    g.d = alpha + 1.0f - 1.0f / 3.0f;
-    g.c = __builtin_amdgcn_rsqf(9.0f * g.d);
+    g.alpha = alpha;
     g.inv_alpha = __builtin_amdgcn_rcpf(alpha);
+    g.b = 1.0f + alpha * 0.36787944f;
     return g;
 }
 __device__ __forceinline__ float fast_ln(float x) { return __builtin_amdgcn_logf(x) * 0.69314718f; }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504f); }
 __device__ inline float log_gamma_variate(uint32_t stream, uint32_t cell, const GammaConst &gc) {
-    float lg = 0.0f;
+    float lx = 0.0f;
     uint32_t x = mix32(stream ^ (cell * 0x9E3779B9u));
     for (uint32_t t = 0; t < 32; ++t) {
         const uint32_t r0 = mix32(x + 0x68bc21ebu), r1 = mix32(x + 0x02e5be93u);
-        const uint32_t r2 = mix32(x + 0x967a889bu);
-        x = r2 ^ r0;
-        const float u1 = u01(r0), u2 = u01(r1);
-        // Box-Muller; v_cos_f32 takes revolutions
-        const float nrm = __builtin_amdgcn_sqrtf(-2.0f * fast_ln(u1)) * __builtin_amdgcn_cosf(u2);
-        float v = __builtin_fmaf(gc.c, nrm, 1.0f);
-        if (v <= 0.0f) continue;
-        v = v * v * v;
-        const float u = u01(r2 >> 8 | r1 << 24);
-        const float lv = fast_ln(v);
-        if (fast_ln(u) < __builtin_fmaf(0.5f * nrm, nrm, gc.d) - gc.d * v + gc.d * lv) {
-            lg = fast_ln(gc.d) + lv + fast_ln(u01(mix32(x))) * gc.inv_alpha;
-            break;
+        x = r1 ^ (r0 >> 3);
+        const float p = gc.b * u01(r0), u2 = u01(r1);
+        if (p <= 1.0f) {
+            lx = fast_ln(p) * gc.inv_alpha;
+            if (u2 <= fast_exp(-fast_exp(lx))) break;
+        } else {
+            const float xv = -fast_ln((gc.b - p) * gc.inv_alpha);
+            lx = fast_ln(xv);
+            if (u2 <= fast_exp((gc.alpha - 1.0f) * lx)) break;
         }
     }
-    return lg;
+    return lx;
+}
+
+// scale * Dirichlet(alpha * 1_k) over the cells set in m[] (one value per lane-slot), the device
+// counterpart of rng.dirichlet(np.full(k, alpha)) at mcts.py:128: independent Gamma(alpha)
+// variates normalised by their sum, computed from log-variates with the maximum subtracted.
+template <int SLOTS>
+__device__ __forceinline__ void dirichlet_noise(const uint64_t *m, int lane, uint32_t stream,
+                                                const GammaConst &gc, float scale, float *nz) {
+    float lg[SLOTS];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        lg[s] = -3.0e38f;
+        if ((m[s] >> lane) & 1ull) {
+            lg[s] = log_gamma_variate(stream, (uint32_t)(s * 64 + lane), gc);
+            mx = fmaxf(mx, lg[s]);
+        }
+    }
+    mx = wave_max(mx);
+    float sw = 0.0f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        nz[s] = ((m[s] >> lane) & 1ull) ? fast_exp(lg[s] - mx) : 0.0f;
+        sw += nz[s];
+    }
+    sw = scale * __builtin_amdgcn_rcpf(wave_sum(sw));
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) nz[s] = nz[s] * sw;
 }
 
 template <int SLOTS>
@@ -553,26 +581,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                     if (noisy && E.device_noise) {
                         const uint32_t noise_stream =
                             mix32(ph.k0 ^ mix32(ph.k1 + (uint32_t)ply * 0x632be5abu + (uint32_t)select_count));
-                        float lg[SLOTS];
-                        float mx = -3.0e38f;
-#pragma unroll
-                        for (int s = 0; s < SLOTS; ++s) {
-                            lg[s] = -3.0e38f;
-                            if ((mk.m[s] >> lane) & 1ull) {
-                                lg[s] = log_gamma_variate(noise_stream, (uint32_t)(s * 64 + lane), gconst);
-                                mx = fmaxf(mx, lg[s]);
-                            }
-                        }
-                        mx = wave_max(mx);
-                        float sw = 0.0f;
-#pragma unroll
-                        for (int s = 0; s < SLOTS; ++s) {
-                            nz[s] = ((mk.m[s] >> lane) & 1ull) ? __builtin_amdgcn_exp2f((lg[s] - mx) * 1.44269504f) : 0.0f;
-                            sw += nz[s];
-                        }
-                        sw = (float)E.noise_scale * __builtin_amdgcn_rcpf(wave_sum(sw));   // eps / sum
-#pragma unroll
-                        for (int s = 0; s < SLOTS; ++s) nz[s] = nz[s] * sw;
+                        dirichlet_noise<SLOTS>(mk.m, lane, noise_stream, gconst, (float)E.noise_scale, nz);
                     }
                     // ---- score_actions (mcts.py:119-136), op by op in float32 --------------
                     float slot_score[SLOTS];
@@ -1182,6 +1191,24 @@ __global__ void k_arith(const float *a, const float *b, float *sq, float *dv, fl
         dv[i] = a[i] / (1.0f + b[i]);
         mul[i] = (0.75f * a[i]) * b[i] + a[i];
     }
+}
+
+// ---- device Dirichlet self-test: rows of k-cell noise exactly as k_mcts draws it ---------------
+__global__ __launch_bounds__(64) void k_noise_test(float alpha, int k, int n_rows, uint32_t seed, float *out) {
+    const int lane = threadIdx.x, row = blockIdx.x;
+    if (row >= n_rows) return;
+    uint64_t m[2];
+    m[0] = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+    m[1] = k > 64 ? ((1ull << (k - 64)) - 1ull) : 0ull;
+    const GammaConst gc = gamma_const(alpha);
+    float nz[2];
+    dirichlet_noise<2>(m, lane, mix32(seed ^ mix32((uint32_t)row + 0x632be5abu)), gc, 1.0f, nz);
+    if (lane < k) out[(size_t)row * k + lane] = nz[0];
+    if (64 + lane < k) out[(size_t)row * k + 64 + lane] = nz[1];
+}
+
+void azx_launch_noise_test(float alpha, int k, int n_rows, uint32_t seed, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_noise_test, dim3(n_rows), dim3(64), 0, st, alpha, k, n_rows, seed, out);
 }
 
 // ============================================================================================

@@ -277,3 +277,9 @@ def selftest_arith(a, b, device=0):
     check(_lib.lib().azx_selftest_arith(device, a.size, _p(a, C.c_float), _p(b, C.c_float),
                                         _p(sq, C.c_float), _p(dv, C.c_float), _p(mul, C.c_float)))
     return sq, dv, mul
+
+
+def selftest_dirichlet(alpha, k, n_rows, seed=1, device=0):
+    out = np.zeros((n_rows, k), np.float32)
+    check(_lib.lib().azx_selftest_dirichlet(device, float(alpha), k, n_rows, seed, _p(out, C.c_float)))
+    return out

@@ -194,6 +194,11 @@ int azx_play_steps(azx_engine *e, int64_t plies, azx_play_stats *stats);
 int azx_selftest_arith(int device, int n, const float *a, const float *b, float *sq, float *dv,
                        float *mul);
 
+/* throughput mode draws its Dirichlet noise on the device (mcts.py:128 uses numpy): n_rows
+ * draws of Dirichlet(alpha * 1_k), k <= 128, exactly as the search kernel generates them, for
+ * distribution tests. */
+int azx_selftest_dirichlet(int device, double alpha, int k, int n_rows, uint32_t seed, float *out);
+
 /* engine stream (hipStream_t) so callers can bracket work with HIP events */
 void *azx_stream(azx_engine *e);
 

@@ -42,6 +42,30 @@ def test_f32_arithmetic_is_ieee_and_uncontracted(eng):
     assert np.array_equal(bits(mul), bits((np.float32(0.75) * a) * b + a))
 
 
+@pytest.mark.parametrize("alpha,k", [(0.03, 121), (0.03, 7), (0.3, 64), (0.9, 30)])
+def test_device_dirichlet_noise_distribution(eng, alpha, k):
+    """Throughput mode replaces rng.dirichlet (mcts.py:128) by a device sampler: rows must sum to
+    one and every coordinate must follow Beta(alpha, (k-1) alpha) (KS test on 20k draws)."""
+    from scipy import stats
+    x = eng.selftest_dirichlet(alpha, k, 20000, seed=7)
+    assert np.isfinite(x).all() and (x >= 0).all()
+    assert np.abs(x.sum(1) - 1.0).max() < 1e-4
+    assert abs(x.mean() - 1.0 / k) < 1e-6 + 1e-4
+    for col in (0, k // 2, k - 1):
+        v = x[:, col].astype(np.float64)
+        # compare in log space above the float32 underflow floor (alpha=0.03 puts most mass at ~0)
+        floor = 1e-30
+        emp = np.mean(v <= floor)
+        assert abs(emp - stats.beta.cdf(floor, alpha, (k - 1) * alpha)) < 0.02
+        sel = v[v > floor]
+        d, _ = stats.kstest(sel, lambda t: (stats.beta.cdf(t, alpha, (k - 1) * alpha) -
+                                            stats.beta.cdf(floor, alpha, (k - 1) * alpha)) /
+                                           (1 - stats.beta.cdf(floor, alpha, (k - 1) * alpha)))
+        assert d < 0.03, (col, d)
+    # coordinates are exchangeable: per-column means agree
+    assert np.abs(x.mean(0) - 1.0 / k).max() < 6.0 * np.sqrt((1.0 / k) / (k * alpha + 1) / 20000) + 1e-3
+
+
 @pytest.mark.parametrize("n", [3, 5, 11, 13])
 def test_g1_movegen_on_device(eng, n):
     z = np.load(os.path.join(GOLDEN, "g1_movegen.npz"))
