@@ -78,6 +78,7 @@ SYMBOLS = {
     "azx_play_steps": (C.c_int, [_vp, C.c_int64, C.POINTER(PlayStats)]),
     "azx_selftest_arith": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p]),
     "azx_selftest_dirichlet": (C.c_int, [C.c_int, C.c_double, C.c_int, C.c_int, C.c_uint32, _f32p]),
+    "azx_debug_counters": (C.c_int, [_vp, _u64p]),
     "azx_stream": (_vp, [_vp]),
 }
 

@@ -151,7 +151,7 @@ extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
     A(d.leaf_mask, E * 4); A(d.path, E * pstride);
     A(d.ev_board, E * AZX_CELL_STRIDE); A(d.ev_src, E); A(d.ev_flip, E);
     A(d.ev_value, E); A(d.ev_prior, E * AZX_CELL_STRIDE); A(d.n_eval, 4);
-    A(d.counters, CTR_COUNT); A(d.q_count, 2); A(d.next_uid, 2); A(d.stat_sums, 8);
+    A(d.counters, G * CTR_COUNT); A(d.q_count, 2); A(d.next_uid, 2); A(d.stat_sums, G * 8);
     A(e->g_k, G); A(e->g_legal, G * d.ncells); A(e->g_nn, G);
     A(e->g_cv, G * d.ncells); A(e->g_cw, G * d.ncells); A(e->g_cp, G * d.ncells);
     A(e->g_rv, G); A(e->g_rw, G); A(e->g_sv, G);
@@ -163,6 +163,12 @@ extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
         if (rc) { g_err = azx_net_error(); azx_destroy(e); return rc; }
     }
     *out = e;
+    {   // default uniform prior table: float32 1/k, the same bits as the IEEE division on device
+        std::vector<float> tab(d.ncells + 1, 0.0f);
+        for (int k = 1; k <= d.ncells; ++k) tab[k] = 1.0f / (float)k;
+        rc = azx_set_prior_table(e, tab.data(), d.ncells + 1);
+        if (rc) { azx_destroy(e); *out = nullptr; return rc; }
+    }
     // all slots start as fresh games with uids 0..G-1
     azx_launch_reset(d, nullptr, d.G, nullptr, nullptr, 0, 1, e->stream);
     HIPCHECK(hipStreamSynchronize(e->stream));
@@ -678,9 +684,17 @@ struct CounterSnap {
 };
 
 static int snap_counters(azx_engine *e, CounterSnap *s) {
-    HIPCHECK(hipMemcpyAsync(s->c, e->d.counters, sizeof s->c, hipMemcpyDeviceToHost, e->stream));
-    HIPCHECK(hipMemcpyAsync(s->s, e->d.stat_sums, sizeof s->s, hipMemcpyDeviceToHost, e->stream));
+    const size_t G = e->d.G;
+    std::vector<unsigned long long> hc(G * CTR_COUNT);
+    std::vector<double> hs(G * 8);
+    HIPCHECK(hipMemcpyAsync(hc.data(), e->d.counters, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipMemcpyAsync(hs.data(), e->d.stat_sums, hs.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCHECK(hipStreamSynchronize(e->stream));
+    memset(s, 0, sizeof *s);
+    for (size_t g = 0; g < G; ++g) {   // per-game accumulators (no device atomics): sum here
+        for (int j = 0; j < CTR_COUNT; ++j) s->c[j] += hc[g * CTR_COUNT + j];
+        for (int j = 0; j < 8; ++j) s->s[j] += hs[g * 8 + j];
+    }
     return AZX_OK;
 }
 
@@ -823,5 +837,13 @@ extern "C" int azx_selftest_dirichlet(int device, double alpha, int k, int n_row
     HIPCHECK(hipDeviceSynchronize());
     HIPCHECK(hipMemcpy(out, d, sizeof(float) * (size_t)k * n_rows, hipMemcpyDeviceToHost));
     (void)hipFree(d);
+    return AZX_OK;
+}
+
+extern "C" int azx_debug_counters(azx_engine *e, uint64_t *out16) {
+    if (!e || !out16) return fail(AZX_EINVAL, "null argument");
+    CounterSnap snap;
+    TRY(snap_counters(e, &snap));
+    for (int j = 0; j < CTR_COUNT; ++j) out16[j] = snap.c[j];
     return AZX_OK;
 }

@@ -92,7 +92,7 @@ struct DevEngine {
     int32_t device_noise;
     uint64_t seed;
     const float *prior_by_k;   // [ncells+1] or null
-    unsigned long long *counters;
+    unsigned long long *counters;   // [G][CTR_COUNT] per-game (no atomics); the host sums over games
     // throughput mode (azx_play): per-slot replay rows of the game in progress ...
     int32_t exploration_depth;
     float temperature;
@@ -109,7 +109,7 @@ struct DevEngine {
     int64_t *q_uid;         // [Q]
     unsigned long long *q_count;   // [1] rows appended
     unsigned long long *next_uid;  // [1]
-    double *stat_sums;      // [8] search_value, root_width, action_logprob, reward_last
+    double *stat_sums;      // [G][8] per game: search_value, root_width, action_logprob, reward_last
 };
 
 // ---- wave64 reductions on DPP (no LDS crossbar round trips) ---------------------------------
@@ -191,7 +191,16 @@ struct HexWave {
     // flags are OR-ed by ballot and their groups relabelled, one pass per neighbouring stone.
     __device__ __forceinline__ void step(int cell, int N, int lane) {
         const int col = color;
-        const int r0 = cell / N, q0 = cell - r0 * N;
+        int r0 = 0, q0 = 0;                          // row / column of the new stone, read from
+        {                                            // its owner lane (no integer division)
+            const int ln = cell & 63, sl = cell >> 6;
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int rr = __builtin_amdgcn_readlane(gr[s], ln);
+                const int cc = __builtin_amdgcn_readlane(gc[s], ln);
+                if (s == sl) { r0 = rr; q0 = cc; }
+            }
+        }
         const int e = (col == 1) ? r0 : q0;          // colour 1 tracks rows, 2 columns
         uint32_t flags = (e == 0 ? 1u : 0u) | (e == N - 1 ? 2u : 0u);
         uint64_t nb[SLOTS];

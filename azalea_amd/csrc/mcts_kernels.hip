@@ -14,6 +14,18 @@
 #include "azx_dev.h"
 #include "mcts_kernels.h"
 
+// Diagnostic build only (-DAZX_STAMP): per-region s_memtime sums in counters[10..15].  The
+// shipped kernel executes no stamp.
+#ifdef AZX_STAMP
+#define T_DECL unsigned long long t_last = __builtin_amdgcn_s_memtime(), t_acc[6] = {0, 0, 0, 0, 0, 0};
+#define T_MARK(r) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[r] += t_now - t_last; t_last = t_now; }
+#define T_FLUSH if (lane == 0) { for (int r_ = 0; r_ < 6; ++r_) E.counters[(size_t)g * CTR_COUNT + 10 + r_] += t_acc[r_]; }
+#else
+#define T_DECL
+#define T_MARK(r)
+#define T_FLUSH
+#endif
+
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 
 // numpy's float32 pairwise add-reduce for n < 128 (np.sum over the batch values, mcts.py:287)
@@ -449,7 +461,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
     };
 
     auto inline_prior = [&](int k) -> float {
-        return E.prior_by_k ? E.prior_by_k[k] : 1.0f / (float)k;
+        return E.prior_by_k[k];   // host table; defaults to float32 1/k (azx_create)
     };
 
     // =================================== BEGIN: root evaluation (mcts.py:272-273) ========
@@ -519,6 +531,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
 
     // =================================== SELECT (+ inline evaluate/expand/backup) =========
     const bool do_select = (mode & (MODE_SELECT | MODE_INLINE)) != 0;
+    T_DECL
     while (do_select && batches_left > 0 && status == 0 && pending == 0) {
         if (root_link < 0) break;   // unevaluated or terminal root: nothing to search
 
@@ -636,6 +649,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                         if (s == bsl) { child_rank = r_; child_link = l_; cnv = n_; ctv = t_; }
                     }
                 }
+                T_MARK(depth == 0 ? 0 : 1)
                 c_depth += 1;
                 c_kint += (unsigned long long)mk.k;
                 node = link + child_rank;
@@ -644,6 +658,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                 cellL = best_cell;
                 if (lane == 0) L.path[i * pstride + depth] = node;
                 cur.step(best_cell, N, lane);                  // search_tree.py:306-308
+                T_MARK(2)
                 depth += 1;
                 at_root = false;
                 if (child_link < 0) break;                     // leaf: unevaluated or terminal
@@ -673,6 +688,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
             lds_sync();
             // ... and apply the virtual loss to its path (mcts.py:68, :79-92)
             path_apply(L.path + i * pstride, depth, cell0, 1.0f, 1.0f, false, false);
+            T_MARK(3)
         }
         // undo the virtual losses in list order (mcts.py:72)
         for (int i = 0; i < bs; ++i)
@@ -688,6 +704,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
             }
         }
         batches_left -= 1;
+        T_MARK(4)
 
         if (inline_eval) {
             // evaluate_batch + expand_batch + backup_batch for the inline (uniform) evaluator
@@ -715,6 +732,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                 if (lane == u) m_val = v;
             }
             if (status == 0) search_value += np_sum_vals(nu);   // mcts.py:287
+            T_MARK(5)
         } else {
             // hand the unique leaves to the evaluator: scratch + packed requests
             int n_nt = 0;
@@ -753,6 +771,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
     }
 
     // =================================== epilogue: write the on-chip state back ===========
+    T_FLUSH
     cache_flush();
     if (root_link >= 0) {
 #pragma unroll
@@ -768,12 +787,12 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
         th->pending_root = pending_root;
         th->select_count = select_count;
         th->search_value = search_value;
-        if (c_selects) atomicAdd(E.counters + CTR_SELECTS, c_selects);
-        if (c_depth) atomicAdd(E.counters + CTR_SUM_DEPTH, c_depth);
-        if (c_kint) atomicAdd(E.counters + CTR_SUM_K_INT, c_kint);
-        if (c_kleaf) atomicAdd(E.counters + CTR_SUM_K_LEAF, c_kleaf);
-        if (c_evals) atomicAdd(E.counters + CTR_EVALS, c_evals);
-        if (c_term) atomicAdd(E.counters + CTR_TERM_EVALS, c_term);
+        if (c_selects) E.counters[(size_t)g * CTR_COUNT + CTR_SELECTS] += c_selects;
+        if (c_depth) E.counters[(size_t)g * CTR_COUNT + CTR_SUM_DEPTH] += c_depth;
+        if (c_kint) E.counters[(size_t)g * CTR_COUNT + CTR_SUM_K_INT] += c_kint;
+        if (c_kleaf) E.counters[(size_t)g * CTR_COUNT + CTR_SUM_K_LEAF] += c_kleaf;
+        if (c_evals) E.counters[(size_t)g * CTR_COUNT + CTR_EVALS] += c_evals;
+        if (c_term) E.counters[(size_t)g * CTR_COUNT + CTR_TERM_EVALS] += c_term;
     }
 }
 
@@ -937,7 +956,7 @@ __global__ __launch_bounds__(64) void k_advance(DevEngine E, const int32_t *move
             gh->winner = h.winner;
             gh->ply = ply;
             gh->move_id = -1;
-            atomicAdd(E.counters + CTR_PLIES, 1ull);
+            E.counters[(size_t)g * CTR_COUNT + CTR_PLIES] += 1ull;
         }
     }
 
@@ -975,15 +994,15 @@ __global__ __launch_bounds__(64) void k_advance(DevEngine E, const int32_t *move
                 }
             }
             if (lane == 0) {
-                atomicAdd(E.counters + CTR_GAMES, 1ull);
-                atomicAdd(E.counters + CTR_ROWS, (unsigned long long)rows);
+                E.counters[(size_t)g * CTR_COUNT + CTR_GAMES] += 1ull;
+                E.counters[(size_t)g * CTR_COUNT + CTR_ROWS] += (unsigned long long)rows;
                 float last = (float)(result - 2);
                 if ((rows - 1) & 1) last = -last;
-                atomicAdd(E.stat_sums + 3, (double)last);       // metrics['reward']
+                E.stat_sums[(size_t)g * 8 + 3] += (double)last;       // metrics['reward']
             }
         }
     } else {
-        if (lane == 0) atomicAdd(E.counters + CTR_ERRORS, 1ull);   // parallel_player.py:73-76
+        if (lane == 0) E.counters[(size_t)g * CTR_COUNT + CTR_ERRORS] += 1ull;   // parallel_player.py:73-76
     }
     if (restart) {
         HexWave<SLOTS> z;
@@ -1143,9 +1162,9 @@ __global__ __launch_bounds__(64) void k_choose(DevEngine E) {
         E.row_k[(size_t)g * E.ncells + row] = mk.k;
         gh->n_rows = row + 1;
         gh->move_id = chosen;
-        atomicAdd(E.stat_sums + 0, (double)(th->search_value));
-        atomicAdd(E.stat_sums + 1, (double)width);
-        atomicAdd(E.stat_sums + 2, (double)__logf(chosen_w / tot));
+        E.stat_sums[(size_t)g * 8 + 0] += (double)(th->search_value);
+        E.stat_sums[(size_t)g * 8 + 1] += (double)width;
+        E.stat_sums[(size_t)g * 8 + 2] += (double)__logf(chosen_w / tot);
     }
 }
 

@@ -249,6 +249,11 @@ class Engine:
         return dict(board=board[:n], color=color[:n], nlegal=nlegal[:n], moves_prob=prob[:n],
                     reward=reward[:n], game_uid=uid[:n]), st.as_dict()
 
+    def debug_counters(self):
+        out = np.zeros(16, np.uint64)
+        check(self.L.azx_debug_counters(self.h, _p(out, C.c_uint64)))
+        return out
+
     def play_steps(self, plies):
         st = PlayStats()
         check(self.L.azx_play_steps(self.h, int(plies), C.byref(st)))

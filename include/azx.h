@@ -199,6 +199,10 @@ int azx_selftest_arith(int device, int n, const float *a, const float *b, float 
  * distribution tests. */
 int azx_selftest_dirichlet(int device, double alpha, int k, int n_rows, uint32_t seed, float *out);
 
+/* raw device counters (16 x u64) since engine creation: selects, sum_depth, sum_k_interior,
+ * sum_k_leaf, evals, terminal evals, games, errors, plies, rows, then diagnostic slots */
+int azx_debug_counters(azx_engine *e, uint64_t *out16);
+
 /* engine stream (hipStream_t) so callers can bracket work with HIP events */
 void *azx_stream(azx_engine *e);
 
