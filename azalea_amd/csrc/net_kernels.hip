@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -38,6 +39,7 @@ struct NetDev {
     const float *stem_b;   // [C]
     // tower (network.py:17-39, :50-52): BN folded into the conv weights
     const float *Wp;       // MFMA pack [layers][9][C/8][C/32][64][4]
+    const unsigned short *Wh;  // f16x3 pack [layers*18 stages][2 kk][2 ntile][hi,lo][64 lanes][8] f16 bits
     const float *Wg;       // generic   [layers][9][C][C]  (tap, cin, cout)
     const float *bias;     // [layers][C]
     // heads (network.py:54-60, :77-84, :127-128, :146)
@@ -190,6 +192,198 @@ __global__ __launch_bounds__(256) void k_tower_mfma(NetDev P, const uint8_t *__r
             const int pos = idx / (C / 4), c4 = idx - pos * (C / 4);
             out[idx] = *reinterpret_cast<const float4 *>(Xb + pos * LDW + 4 * c4);
         }
+    }
+}
+
+
+// ============================================================================================
+// fused residual tower on f16 MFMA with a 2-term split ("f16x3"): every fp32 operand x is carried
+// as hi = f16(x), lo = f16(x - hi) (22 significant bits) and a product sum is accumulated in
+// fp32 as  hi*hi + hi*lo + lo*hi  -- three v_mfma_f32_32x32x16_f16 at 16x the fp32-MFMA rate,
+// i.e. ~5x the exact-fp32 kernel above at fp32-class accuracy (the dropped lo*lo term is 2^-22
+// relative).  C = 64, N <= 11.
+//   * two waves own one board (32 output channels each): the layer's whole output lives in their
+//     accumulators (4 tiles of 32x32 each), so a layer overwrites its input in place and the
+//     block input (residual) is simply kept in registers -- one LDS activation buffer per board;
+//   * 4 boards per 512-thread block (2 waves per SIMD); LDS: 4 x 121 rows x 272 B (128 B hi | 128 B lo | 16 B pad:
+//     ds_read_b128 A fragments conflict-free) + one shared zero row + 3 x 8 KB weight stages;
+//   * weights stream global -> registers -> LDS in 8 KB stages (tap x 32 input channels), triple
+//     buffered (published two stages ahead), one barrier per stage; fragments of the next k-step
+//     (also across the stage boundary) are in flight while the current 12 MFMAs issue.
+// ============================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+__global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t *__restrict__ ev_board,
+                                                         const int32_t *__restrict__ n_eval_ptr,
+                                                         int n_eval_host, float *__restrict__ act_out) {
+    constexpr int C = 64, MT = 4, ROWB = 272;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
+    const int e0 = blockIdx.x * 4;
+    if (e0 >= n_eval) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wb = wave >> 1, nt = wave & 1;             // board within the block, output n-tile
+    const int N = P.N, ncells = P.ncells;
+    const int e = e0 + wb;
+    const bool live = e < n_eval;
+    const int board_b = ncells * ROWB;
+    const int x_off = wb * board_b;
+    unsigned char *X = smem + x_off;                     // this wave pair's board
+    const int zero_off = 4 * board_b;                    // shared all-zero row
+
+    // ---- stem (table lookups) -> split f16 rows; lane = output channel, waves split positions --
+    {
+        const uint8_t *bd = ev_board + (size_t)(live ? e : n_eval - 1) * AZX_CELL_STRIDE;
+        const float sb = P.stem_b[lane];
+        for (int pos = nt; pos < ncells; pos += 2) {
+            const int y = pos / N, x = pos - y * N;
+            float acc = sb;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if (yy >= 0 && yy < N && xx >= 0 && xx < N)
+                    acc += P.stemT[(tap * 3 + bd[yy * N + xx]) * C + lane];
+            }
+            _Float16 hi, lo;
+            split_f16(fmaxf(acc, 0.0f), hi, lo);
+            *reinterpret_cast<_Float16 *>(X + pos * ROWB + lane * 2) = hi;
+            *reinterpret_cast<_Float16 *>(X + pos * ROWB + 128 + lane * 2) = lo;
+        }
+        if (tid < ROWB / 4) reinterpret_cast<uint32_t *>(smem + zero_off)[tid] = 0u;
+    }
+
+    __syncthreads();
+
+    // per-lane geometry of the A fragment rows: lane (i = lane&31, h = lane>>5)
+    const int li = lane & 31, lh = lane >> 5;
+    int ry[MT], rx[MT];
+    bool rvalid[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int r = m * 32 + li;
+        rvalid[m] = r < ncells;
+        ry[m] = r / N;
+        rx[m] = r - ry[m] * N;
+    }
+    const int co = nt * 32 + li;                         // this lane's output channel
+
+    // residual (block input) in accumulator layout: row = m*32 + (r&3) + 8*(r>>2) + 4*lh
+    f32x16 res[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = min(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, ncells);   // ncells = zero row
+            const unsigned char *pr = (row < ncells ? X + row * ROWB : smem + zero_off) + co * 2;
+            res[m][r] = (float)*reinterpret_cast<const _Float16 *>(pr) +
+                        (float)*reinterpret_cast<const _Float16 *>(pr + 128);
+        }
+
+    // A-fragment byte offsets of one tap (zero row for padding taps and the tile tail)
+    auto tap_offsets = [&](int tap, int *aoff) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int yy = ry[m] + dy, xx = rx[m] + dx;
+            const bool ok = rvalid[m] && yy >= 0 && yy < N && xx >= 0 && xx < N;
+            aoff[m] = (ok ? x_off + (yy * N + xx) * ROWB : zero_off) + 16 * lh;
+        }
+    };
+    // fragments of one k-step: A (hi, lo) for the 4 row tiles, B (hi, lo) for this wave's n-tile
+    struct Frags { f16x8 ah[MT], al[MT], bh, bl; };
+    // B fragments come straight from L2/L1 (packed in fragment order: one coalesced 16-byte load
+    // per lane and part); A fragments from this board's LDS rows
+    const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.Wh);     // 512 uint4 per stage
+    auto load_frags = [&](Frags &f, const int *aoff, int half, int kk, int stage) {
+        // weights: [stage][kk][ntile][part][lane][8 f16]
+        const uint4 *pb = wsrc + (size_t)stage * 512 + ((kk * 2 + nt) * 2) * 64 + lane;
+        const uint4 qh = pb[0], ql = pb[64];
+        f.bh = *reinterpret_cast<const f16x8 *>(&qh);
+        f.bl = *reinterpret_cast<const f16x8 *>(&ql);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const unsigned char *pa = smem + aoff[m] + (half * 32 + kk * 16) * 2;
+            f.ah[m] = *reinterpret_cast<const f16x8 *>(pa);
+            f.al[m] = *reinterpret_cast<const f16x8 *>(pa + 128);
+        }
+    };
+
+    int stage = 0;
+    for (int layer = 0; layer < P.layers; ++layer) {
+        f32x16 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+        auto mfma_step = [&](const Frags &f) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[m], f.bh, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[m], f.bl, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[m], f.bh, acc[m], 0, 0, 0);
+            }
+        };
+
+        int aoff[MT];
+        tap_offsets(0, aoff);
+        Frags f0, f1;                                    // ping-pong fragment sets (no copies)
+        load_frags(f0, aoff, 0, 0, stage);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                // k-step 0 of the stage computes while k-step 1's fragments are in flight
+                load_frags(f1, aoff, half, 1, stage);
+                mfma_step(f0);
+                // k-step 1 computes while the next stage's first fragments are in flight
+                if (!(tap == 8 && half == 1)) {
+                    if (half == 1) tap_offsets(tap + 1, aoff);
+                    load_frags(f0, aoff, half ^ 1, 0, stage + 1);
+                }
+                mfma_step(f1);
+                ++stage;
+            }
+        }
+        __syncthreads();   // both waves of the board finished reading it
+        // ---- epilogue: + folded-BN bias (+ residual) -> ReLU -> split f16 back into the board -----
+        // (the last stage's barrier guarantees both waves of the board finished reading it)
+        const bool residual = (layer & 1) != 0;       // conv2 of a Resblock: y += x (network.py:37)
+        const float bb = P.bias[layer * C + co];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[m][r] + bb;
+                if (residual) v += res[m][r];
+                v = fmaxf(v, 0.0f);
+                if (residual) res[m][r] = v;          // block output = next block's input
+                if (row < ncells) {
+                    _Float16 hi, lo;
+                    split_f16(v, hi, lo);
+                    *reinterpret_cast<_Float16 *>(X + row * ROWB + co * 2) = hi;
+                    *reinterpret_cast<_Float16 *>(X + row * ROWB + 128 + co * 2) = lo;
+                }
+            }
+        }
+        __syncthreads();   // the partner wave wrote the other 32 channels of these rows
+    }
+
+    // ---- tower output (fp32, from registers) -> HBM [e][ncells][C] -----------------------------
+    if (live) {
+        float *out = act_out + (size_t)e * ncells * C;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < ncells) out[row * C + co] = res[m][r];
+            }
     }
 }
 
@@ -378,7 +572,10 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     net->stream = st;
     const int ncells = N * N;
     // pick the fused MFMA tower when its tiling covers (C, N)
-    if (chans == 64 && ncells <= 128) net->tower_variant = 1;        // <64,4,2,1,2>
+    const char *force = getenv("AZX_TOWER");
+    const bool want_fp32 = force && !strcmp(force, "fp32");
+    if (chans == 64 && ncells <= 121 && blocks >= 1 && !want_fp32) net->tower_variant = 4;   // k_tower_f16x3
+    else if (chans == 64 && ncells <= 128) net->tower_variant = 1;   // <64,4,2,1,2>
     else if (chans == 64 && ncells <= 192) net->tower_variant = 2;   // <64,6,1,2,2>
     else if (chans == 32 && ncells <= 192) net->tower_variant = 3;   // <32,6,2,2,1>
     net->use_mfma = net->tower_variant != 0;
@@ -399,6 +596,7 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     }
     const int bpb = net->tower_variant == 2 ? 1 : 2;
     net->lds_bytes = (size_t)bpb * 2 * (ncells + 1) * (chans + 4) * sizeof(float);
+    if (net->tower_variant == 4) net->lds_bytes = (size_t)4 * ncells * 272 + 272;
     *out = net;
     return AZX_OK;
 }
@@ -484,7 +682,7 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
         for (int co = 0; co < C; ++co) bias[(size_t)l * C + co] = (float)sh[co];
     }
     std::vector<float> Wp;
-    if (net->use_mfma) {
+    if (net->use_mfma && net->tower_variant != 4) {
         // B-fragment order: [layer][tap][q][ntile][lane(j + 32 h)][t] = W[tap][cin 8q+4h+t][cout 32 ntile + j]
         const int NT = C / 32, Q = C / 8;
         Wp.resize((size_t)L * 9 * Q * NT * 64 * 4);
@@ -499,6 +697,31 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
                                 Wp[(((((size_t)l * 9 + tap) * Q + q) * NT + nt) * 64 + ln) * 4 + t] =
                                     Wg[(((size_t)l * 9 + tap) * C + ci) * C + co];
                             }
+    }
+    std::vector<unsigned short> Wh;
+    if (net->tower_variant == 4) {
+        // f16x3 pack: [stage = (layer*9 + tap)*2 + half][kk][ntile][part hi/lo][lane j + 32 h][t]
+        //   = split(W[tap][cin 32 half + 16 kk + 8 h + t][cout 32 ntile + j])
+        Wh.resize((size_t)L * 18 * 2 * 2 * 2 * 64 * 8);
+        size_t o = 0;
+        for (int l = 0; l < L; ++l)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int half = 0; half < 2; ++half)
+                    for (int kk = 0; kk < 2; ++kk)
+                        for (int nt = 0; nt < 2; ++nt)
+                            for (int part = 0; part < 2; ++part)
+                                for (int ln = 0; ln < 64; ++ln)
+                                    for (int t = 0; t < 8; ++t) {
+                                        const int j = ln & 31, h = ln >> 5;
+                                        const int ci = 32 * half + 16 * kk + 8 * h + t, co = 32 * nt + j;
+                                        const float w = Wg[(((size_t)l * 9 + tap) * C + ci) * C + co];
+                                        const _Float16 hi = (_Float16)w;
+                                        const _Float16 lo = (_Float16)(w - (float)hi);
+                                        const _Float16 v = part ? lo : hi;
+                                        unsigned short bits;
+                                        memcpy(&bits, &v, 2);
+                                        Wh[o++] = bits;
+                                    }
     }
     // heads
     auto wvc = get("value_conv1.weight", (size_t)2 * C), wpc = get("move_conv1.weight", (size_t)4 * C);
@@ -530,7 +753,14 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
     d.stemT = upload(net, stemT);
     d.stem_b = upload(net, stem_b);
     d.Wg = upload(net, Wg);
-    d.Wp = net->use_mfma ? upload(net, Wp) : nullptr;
+    d.Wp = (net->use_mfma && net->tower_variant != 4) ? upload(net, Wp) : nullptr;
+    d.Wh = nullptr;
+    if (net->tower_variant == 4) {
+        unsigned short *wh = nalloc<unsigned short>(net, Wh.size());
+        if (!wh) return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
+        (void)hipMemcpy(wh, Wh.data(), Wh.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+        d.Wh = wh;
+    }
     d.bias = upload(net, bias);
     d.wv = upload(net, wv); d.bv = upload(net, bv);
     d.wp = upload(net, wp); d.bp = upload(net, bp);
@@ -538,7 +768,7 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
     d.fc3w = upload(net, *fc3w); d.fc3b = upload(net, *fc3b);
     d.mfcT = upload(net, mfcT); d.mfcb = upload(net, mfcb);
     if (!d.stemT || !d.stem_b || !d.Wg || !d.bias || !d.wv || !d.bv || !d.wp || !d.bp || !d.fc2T ||
-        !d.fc2b || !d.fc3w || !d.fc3b || !d.mfcT || !d.mfcb || (net->use_mfma && !d.Wp))
+        !d.fc2b || !d.fc3w || !d.fc3b || !d.mfcT || !d.mfcb || (net->use_mfma && net->tower_variant != 4 && !d.Wp))
         return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
     (void)hipDeviceSynchronize();
     net->ready = true;
@@ -552,7 +782,11 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
     if (max_n <= 0) return;
     if (net->use_mfma) {
         const size_t lds = net->lds_bytes;
-        if (net->tower_variant == 1) {
+        if (net->tower_variant == 4) {
+            static bool attr4 = false;
+            if (!attr4) { (void)hipFuncSetAttribute((const void *)k_tower_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr4 = true; }
+            hipLaunchKernelGGL(k_tower_f16x3, dim3((max_n + 3) / 4), dim3(512), lds, st, d, boards, n_eval_ptr, n_host, net->act);
+        } else if (net->tower_variant == 1) {
             static bool attr1 = false;
             if (!attr1) { (void)hipFuncSetAttribute((const void *)k_tower_mfma<64, 4, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
             hipLaunchKernelGGL((k_tower_mfma<64, 4, 2, 1, 2>), dim3((max_n + 1) / 2), dim3(256), lds, st, d, boards, n_eval_ptr, n_host, net->act);
