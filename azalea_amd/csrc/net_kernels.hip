@@ -20,6 +20,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t 
     const int N = P.N, ncells = P.ncells;
     const int e = e0 + wb;
     const bool live = e < n_eval;
-    const int board_b = ncells * ROWB;
+    const int board_b = 128 * ROWB;                      // 128 rows: the tile tail is scratch, never read
     const int x_off = wb * board_b;
     unsigned char *X = smem + x_off;                     // this wave pair's board
     const int zero_off = 4 * board_b;                    // shared all-zero row
@@ -274,12 +275,12 @@ __global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t 
 
     // residual (block input) in accumulator layout: row = m*32 + (r&3) + 8*(r>>2) + 4*lh
     f32x16 res[MT];
+    const unsigned char *xrow = X + (4 * lh) * ROWB + co * 2;   // element (m, r): + (m*32 + (r&3) + 8*(r>>2)) rows
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = min(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, ncells);   // ncells = zero row
-            const unsigned char *pr = (row < ncells ? X + row * ROWB : smem + zero_off) + co * 2;
+            const unsigned char *pr = xrow + (m * 32 + (r & 3) + 8 * (r >> 2)) * ROWB;
             res[m][r] = (float)*reinterpret_cast<const _Float16 *>(pr) +
                         (float)*reinterpret_cast<const _Float16 *>(pr + 128);
         }
@@ -314,7 +315,8 @@ __global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t 
     };
 
     int stage = 0;
-    for (int layer = 0; layer < P.layers; ++layer) {
+    auto conv_layer = [&](int layer, auto residual_tag) {
+        constexpr bool residual = decltype(residual_tag)::value;   // conv2 of a Resblock: y += x (network.py:37)
         f32x16 acc[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -351,27 +353,29 @@ __global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t 
         }
         __syncthreads();   // both waves of the board finished reading it
         // ---- epilogue: + folded-BN bias (+ residual) -> ReLU -> split f16 back into the board -----
-        // (the last stage's barrier guarantees both waves of the board finished reading it)
-        const bool residual = (layer & 1) != 0;       // conv2 of a Resblock: y += x (network.py:37)
+        // (the barrier above guarantees both waves of the board finished reading it)
         const float bb = P.bias[layer * C + co];
+        unsigned char *wrow = X + (4 * lh) * ROWB + co * 2;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 float v = acc[m][r] + bb;
                 if (residual) v += res[m][r];
                 v = fmaxf(v, 0.0f);
                 if (residual) res[m][r] = v;          // block output = next block's input
-                if (row < ncells) {
-                    _Float16 hi, lo;
-                    split_f16(v, hi, lo);
-                    *reinterpret_cast<_Float16 *>(X + row * ROWB + co * 2) = hi;
-                    *reinterpret_cast<_Float16 *>(X + row * ROWB + 128 + co * 2) = lo;
-                }
+                _Float16 hi, lo;
+                split_f16(v, hi, lo);
+                unsigned char *pw = wrow + (m * 32 + (r & 3) + 8 * (r >> 2)) * ROWB;
+                *reinterpret_cast<_Float16 *>(pw) = hi;
+                *reinterpret_cast<_Float16 *>(pw + 128) = lo;
             }
         }
         __syncthreads();   // the partner wave wrote the other 32 channels of these rows
+    };
+    for (int blk = 0; blk < P.blocks; ++blk) {
+        conv_layer(2 * blk, std::false_type{});
+        conv_layer(2 * blk + 1, std::true_type{});
     }
 
     // ---- tower output (fp32, from registers) -> HBM [e][ncells][C] -----------------------------
@@ -596,7 +600,7 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     }
     const int bpb = net->tower_variant == 2 ? 1 : 2;
     net->lds_bytes = (size_t)bpb * 2 * (ncells + 1) * (chans + 4) * sizeof(float);
-    if (net->tower_variant == 4) net->lds_bytes = (size_t)4 * ncells * 272 + 272;
+    if (net->tower_variant == 4) net->lds_bytes = (size_t)4 * 128 * 272 + 272;
     *out = net;
     return AZX_OK;
 }
