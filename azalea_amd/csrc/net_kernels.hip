@@ -239,8 +239,18 @@ __global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t 
 
     // ---- stem (table lookups) -> split f16 rows; lane = output channel, waves split positions --
     {
+        // stage the board's cells in the (not yet used) tail rows 121..127 of its LDS region
+        unsigned char *cells = X + 121 * ROWB;           // 7 * 272 B >= 128 B
         const uint8_t *bd = ev_board + (size_t)(live ? e : n_eval - 1) * AZX_CELL_STRIDE;
+        if (nt == 0) {
+            cells[lane] = bd[lane];
+            cells[64 + lane] = bd[64 + lane];
+        }
+        if (tid < ROWB / 4) reinterpret_cast<uint32_t *>(smem + zero_off)[tid] = 0u;
+        __syncthreads();
         const float sb = P.stem_b[lane];
+        const float *T = P.stemT + lane;
+#pragma unroll 2
         for (int pos = nt; pos < ncells; pos += 2) {
             const int y = pos / N, x = pos - y * N;
             float acc = sb;
@@ -248,16 +258,14 @@ __global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t 
             for (int tap = 0; tap < 9; ++tap) {
                 const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
                 if (yy >= 0 && yy < N && xx >= 0 && xx < N)
-                    acc += P.stemT[(tap * 3 + bd[yy * N + xx]) * C + lane];
+                    acc += T[(tap * 3 + cells[yy * N + xx]) * C];
             }
             _Float16 hi, lo;
             split_f16(fmaxf(acc, 0.0f), hi, lo);
             *reinterpret_cast<_Float16 *>(X + pos * ROWB + lane * 2) = hi;
             *reinterpret_cast<_Float16 *>(X + pos * ROWB + 128 + lane * 2) = lo;
         }
-        if (tid < ROWB / 4) reinterpret_cast<uint32_t *>(smem + zero_off)[tid] = 0u;
     }
-
     __syncthreads();
 
     // per-lane geometry of the A fragment rows: lane (i = lane&31, h = lane>>5)
