@@ -279,18 +279,24 @@ __global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t 
         ry[m] = r / N;
         rx[m] = r - ry[m] * N;
     }
-    const int co = nt * 32 + li;                         // this lane's output channel
+    // The product is computed transposed (weights as the MFMA A operand, activations as B), so in
+    // the 32x32 result a LANE is a board position (row m*32 + li) and the 16 registers are output
+    // channels cb + (r&3) + 8*(r>>2): four consecutive channels per register quad -> the epilogue
+    // writes 8-byte packed f16 quads instead of single halves.
+    const int cb = nt * 32 + 4 * lh;                     // channel of register 0
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-    // residual (block input) in accumulator layout: row = m*32 + (r&3) + 8*(r>>2) + 4*lh
+    // residual (block input) in accumulator layout
     f32x16 res[MT];
-    const unsigned char *xrow = X + (4 * lh) * ROWB + co * 2;   // element (m, r): + (m*32 + (r&3) + 8*(r>>2)) rows
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned char *pr = xrow + (m * 32 + (r & 3) + 8 * (r >> 2)) * ROWB;
-            res[m][r] = (float)*reinterpret_cast<const _Float16 *>(pr) +
-                        (float)*reinterpret_cast<const _Float16 *>(pr + 128);
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const unsigned char *pr = X + (m * 32 + li) * ROWB + (cb + 8 * g4) * 2;
+            const f16x4 h4 = *reinterpret_cast<const f16x4 *>(pr);
+            const f16x4 l4 = *reinterpret_cast<const f16x4 *>(pr + 128);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) res[m][4 * g4 + j] = (float)h4[j] + (float)l4[j];
         }
 
     // A-fragment byte offsets of one tap (zero row for padding taps and the tile tail)
@@ -333,9 +339,9 @@ __global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t 
         auto mfma_step = [&](const Frags &f) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[m], f.bh, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[m], f.bl, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[m], f.bh, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh, f.ah[m], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl, f.ah[m], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh, f.al[m], acc[m], 0, 0, 0);
             }
         };
 
@@ -362,21 +368,32 @@ __global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t 
         __syncthreads();   // both waves of the board finished reading it
         // ---- epilogue: + folded-BN bias (+ residual) -> ReLU -> split f16 back into the board -----
         // (the barrier above guarantees both waves of the board finished reading it)
-        const float bb = P.bias[layer * C + co];
-        unsigned char *wrow = X + (4 * lh) * ROWB + co * 2;
+        float bv[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(P.bias + layer * C + cb + 8 * g4);
+            bv[4 * g4] = b4.x; bv[4 * g4 + 1] = b4.y; bv[4 * g4 + 2] = b4.z; bv[4 * g4 + 3] = b4.w;
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[m][r] + bb;
-                if (residual) v += res[m][r];
-                v = fmaxf(v, 0.0f);
-                if (residual) res[m][r] = v;          // block output = next block's input
-                _Float16 hi, lo;
-                split_f16(v, hi, lo);
-                unsigned char *pw = wrow + (m * 32 + (r & 3) + 8 * (r >> 2)) * ROWB;
-                *reinterpret_cast<_Float16 *>(pw) = hi;
-                *reinterpret_cast<_Float16 *>(pw + 128) = lo;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f16x4 h4, l4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g4 + j;
+                    float v = acc[m][r] + bv[r];
+                    if (residual) v += res[m][r];
+                    v = fmaxf(v, 0.0f);
+                    if (residual) res[m][r] = v;      // block output = next block's input
+                    _Float16 hi, lo;
+                    split_f16(v, hi, lo);
+                    h4[j] = hi;
+                    l4[j] = lo;
+                }
+                unsigned char *pw = X + (m * 32 + li) * ROWB + (cb + 8 * g4) * 2;
+                *reinterpret_cast<f16x4 *>(pw) = h4;
+                *reinterpret_cast<f16x4 *>(pw + 128) = l4;
             }
         }
         __syncthreads();   // the partner wave wrote the other 32 channels of these rows
@@ -390,12 +407,15 @@ __global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t 
     if (live) {
         float *out = act_out + (size_t)e * ncells * C;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+            const int row = m * 32 + li;
+            if (row < ncells) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < ncells) out[row * C + co] = res[m][r];
+                for (int g4 = 0; g4 < 4; ++g4)
+                    *reinterpret_cast<float4 *>(out + row * C + cb + 8 * g4) =
+                        make_float4(res[m][4 * g4], res[m][4 * g4 + 1], res[m][4 * g4 + 2], res[m][4 * g4 + 3]);
             }
+        }
     }
 }
 
