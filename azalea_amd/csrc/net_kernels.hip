@@ -14,6 +14,12 @@
 // k_*_generic: plain VALU fallback for channel counts the MFMA tiling does not cover.
 #include "net.h"
 
+// Diagnostic builds only (-DAZX_NET_ABLATE=bits): time the f16x3 tower without its A-fragment LDS
+// reads (1), MFMAs (2) or weight loads (4).  Outputs are garbage; the shipped build uses 0.
+#ifndef AZX_NET_ABLATE
+#define AZX_NET_ABLATE 0
+#endif
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -317,15 +323,25 @@ __global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t 
     auto load_frags = [&](Frags &f, const int *aoff, int half, int kk, int stage) {
         // weights: [stage][kk][ntile][part][lane][8 f16]
         const uint4 *pb = wsrc + (size_t)stage * 512 + ((kk * 2 + nt) * 2) * 64 + lane;
+#if AZX_NET_ABLATE & 4
+        const uint4 qh = make_uint4(stage, kk, 1, 2), ql = qh; (void)pb;
+#else
         const uint4 qh = pb[0], ql = pb[64];
+#endif
         f.bh = *reinterpret_cast<const f16x8 *>(&qh);
         f.bl = *reinterpret_cast<const f16x8 *>(&ql);
+#if AZX_NET_ABLATE & 1
+        (void)aoff; (void)half;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { f.ah[m] = f.bh; f.al[m] = f.bl; }
+#else
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const unsigned char *pa = smem + aoff[m] + (half * 32 + kk * 16) * 2;
             f.ah[m] = *reinterpret_cast<const f16x8 *>(pa);
             f.al[m] = *reinterpret_cast<const f16x8 *>(pa + 128);
         }
+#endif
     };
 
     int stage = 0;
@@ -337,12 +353,17 @@ __global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
         auto mfma_step = [&](const Frags &f) {
+#if AZX_NET_ABLATE & 2
+#pragma unroll
+            for (int m = 0; m < MT; ++m) asm volatile("" :: "v"(f.ah[m]), "v"(f.al[m]), "v"(f.bh), "v"(f.bl));
+#else
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh, f.ah[m], acc[m], 0, 0, 0);
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl, f.ah[m], acc[m], 0, 0, 0);
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh, f.al[m], acc[m], 0, 0, 0);
             }
+#endif
         };
 
         int aoff[MT];
@@ -355,13 +376,17 @@ __global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t 
             for (int half = 0; half < 2; ++half) {
                 // k-step 0 of the stage computes while k-step 1's fragments are in flight
                 load_frags(f1, aoff, half, 1, stage);
+                __builtin_amdgcn_sched_barrier(0);       // keep the prefetch a whole k-step ahead
                 mfma_step(f0);
+                __builtin_amdgcn_sched_barrier(0);
                 // k-step 1 computes while the next stage's first fragments are in flight
                 if (!(tap == 8 && half == 1)) {
                     if (half == 1) tap_offsets(tap + 1, aoff);
                     load_frags(f0, aoff, half ^ 1, 0, stage + 1);
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 mfma_step(f1);
+                __builtin_amdgcn_sched_barrier(0);
                 ++stage;
             }
         }
