@@ -501,6 +501,7 @@ __global__ void k_conv_generic(NetDev P, int layer, const float *in, const float
 // masked softmax over the legal (= empty) cells, written by ORIGINAL cell index.
 // One 192-thread block per board.
 // ============================================================================================
+#define HEADS_BPB 8
 __global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict__ act,
                                                const uint8_t *__restrict__ ev_board,
                                                const int32_t *__restrict__ ev_flip,
@@ -508,81 +509,126 @@ __global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict
                                                int n_eval_host, float *__restrict__ logit_out,
                                                float *__restrict__ value_out,
                                                float *__restrict__ prior_out) {
-    __shared__ float hv[2 * AZX_MAX_CELLS];
-    __shared__ float hp[4 * AZX_MAX_CELLS];
-    __shared__ float h2[64];
-    __shared__ float red[192];
+    // 8 boards per block share every FC weight load (the policy FC matrix alone is 234 KB)
+    __shared__ __align__(16) float hv[2 * AZX_MAX_CELLS][HEADS_BPB];   // [feature][board]
+    __shared__ __align__(16) float hp[4 * AZX_MAX_CELLS][HEADS_BPB];
+    __shared__ float h2[64][HEADS_BPB];
+    __shared__ float lg[HEADS_BPB][AZX_CELL_STRIDE];
     const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
-    const int e = blockIdx.x;
-    if (e >= n_eval) return;
+    const int e0 = blockIdx.x * HEADS_BPB;
+    if (e0 >= n_eval) return;
+    const int nb = min(HEADS_BPB, n_eval - e0);
     const int tid = threadIdx.x;
     const int C = P.C, N = P.N, ncells = P.ncells;
 
+    // ---- 1x1 convs + folded BN + ReLU (network.py:77, :83); flatten order (c, h, w) -----------
     if (tid < ncells) {
-        const float *a = act + ((size_t)e * ncells + tid) * C;
-        float v0 = 0.f, v1 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-        for (int c = 0; c < C; ++c) {
-            const float x = a[c];
-            v0 += x * P.wv[c];
-            v1 += x * P.wv[C + c];
-            p0 += x * P.wp[c];
-            p1 += x * P.wp[C + c];
-            p2 += x * P.wp[2 * C + c];
-            p3 += x * P.wp[3 * C + c];
+        for (int b = 0; b < HEADS_BPB; ++b) {
+            float v0 = 0.f, v1 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+            if (b < nb) {
+                const float4 *a = reinterpret_cast<const float4 *>(act + ((size_t)(e0 + b) * ncells + tid) * C);
+                for (int c4 = 0; c4 < C / 4; ++c4) {
+                    const float4 x = a[c4];
+                    const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = 4 * c4 + j;
+                        v0 += xs[j] * P.wv[c];
+                        v1 += xs[j] * P.wv[C + c];
+                        p0 += xs[j] * P.wp[c];
+                        p1 += xs[j] * P.wp[C + c];
+                        p2 += xs[j] * P.wp[2 * C + c];
+                        p3 += xs[j] * P.wp[3 * C + c];
+                    }
+                }
+                for (int c = (C / 4) * 4; c < C; ++c) {      // channel counts not divisible by 4
+                    const float x = act[((size_t)(e0 + b) * ncells + tid) * C + c];
+                    v0 += x * P.wv[c]; v1 += x * P.wv[C + c];
+                    p0 += x * P.wp[c]; p1 += x * P.wp[C + c]; p2 += x * P.wp[2 * C + c]; p3 += x * P.wp[3 * C + c];
+                }
+            }
+            hv[tid][b] = fmaxf(v0 + P.bv[0], 0.f);
+            hv[ncells + tid][b] = fmaxf(v1 + P.bv[1], 0.f);
+            hp[tid][b] = fmaxf(p0 + P.bp[0], 0.f);
+            hp[ncells + tid][b] = fmaxf(p1 + P.bp[1], 0.f);
+            hp[2 * ncells + tid][b] = fmaxf(p2 + P.bp[2], 0.f);
+            hp[3 * ncells + tid][b] = fmaxf(p3 + P.bp[3], 0.f);
         }
-        hv[tid] = fmaxf(v0 + P.bv[0], 0.f);
-        hv[ncells + tid] = fmaxf(v1 + P.bv[1], 0.f);
-        hp[tid] = fmaxf(p0 + P.bp[0], 0.f);
-        hp[ncells + tid] = fmaxf(p1 + P.bp[1], 0.f);
-        hp[2 * ncells + tid] = fmaxf(p2 + P.bp[2], 0.f);
-        hp[3 * ncells + tid] = fmaxf(p3 + P.bp[3], 0.f);
     }
     __syncthreads();
     if (tid < 64) {                                   // value_fc2 + ReLU (network.py:79)
-        float acc = 0.f;
-        for (int i = 0; i < 2 * ncells; ++i) acc += hv[i] * P.fc2T[i * 64 + tid];
-        h2[tid] = fmaxf(acc + P.fc2b[tid], 0.f);
+        float acc[HEADS_BPB];
+#pragma unroll
+        for (int b = 0; b < HEADS_BPB; ++b) acc[b] = 0.f;
+        for (int i = 0; i < 2 * ncells; ++i) {
+            const float w = P.fc2T[i * 64 + tid];
+            const float4 x0 = *reinterpret_cast<const float4 *>(&hv[i][0]);
+            const float4 x1 = *reinterpret_cast<const float4 *>(&hv[i][4]);
+            acc[0] += x0.x * w; acc[1] += x0.y * w; acc[2] += x0.z * w; acc[3] += x0.w * w;
+            acc[4] += x1.x * w; acc[5] += x1.y * w; acc[6] += x1.z * w; acc[7] += x1.w * w;
+        }
+#pragma unroll
+        for (int b = 0; b < HEADS_BPB; ++b) h2[tid][b] = fmaxf(acc[b] + P.fc2b[tid], 0.f);
     }
-    float logit = 0.f;
     if (tid < ncells) {                               // move_fc (network.py:146)
-        float acc = 0.f;
-        for (int i = 0; i < 4 * ncells; ++i) acc += hp[i] * P.mfcT[(size_t)i * AZX_CELL_STRIDE + tid];
-        logit = acc + P.mfcb[tid];
-        logit_out[(size_t)e * AZX_CELL_STRIDE + tid] = logit;
+        float acc[HEADS_BPB];
+#pragma unroll
+        for (int b = 0; b < HEADS_BPB; ++b) acc[b] = 0.f;
+        for (int i = 0; i < 4 * ncells; ++i) {
+            const float w = P.mfcT[(size_t)i * AZX_CELL_STRIDE + tid];
+            const float4 x0 = *reinterpret_cast<const float4 *>(&hp[i][0]);
+            const float4 x1 = *reinterpret_cast<const float4 *>(&hp[i][4]);
+            acc[0] += x0.x * w; acc[1] += x0.y * w; acc[2] += x0.z * w; acc[3] += x0.w * w;
+            acc[4] += x1.x * w; acc[5] += x1.y * w; acc[6] += x1.z * w; acc[7] += x1.w * w;
+        }
+        const float bias = P.mfcb[tid];
+#pragma unroll
+        for (int b = 0; b < HEADS_BPB; ++b) {
+            const float logit = acc[b] + bias;
+            lg[b][tid] = logit;
+            if (b < nb) logit_out[(size_t)(e0 + b) * AZX_CELL_STRIDE + tid] = logit;
+        }
     }
     __syncthreads();
-    if (tid == 0) {                                   // value_fc3 + tanh (network.py:80-81)
+    if (tid < nb) {                                   // value_fc3 + tanh (network.py:80-81)
         float acc = 0.f;
-        for (int i = 0; i < 64; ++i) acc += h2[i] * P.fc3w[i];
-        value_out[e] = tanhf(acc + P.fc3b[0]);
+        for (int i = 0; i < 64; ++i) acc += h2[i][tid] * P.fc3w[i];
+        value_out[e0 + tid] = tanhf(acc + P.fc3b[0]);
     }
     if (!prior_out) return;
     // masked softmax over the legal cells of the network-frame board (network.py:147-151),
-    // prior = exp(log_softmax) (mcts.py:210)
-    const bool legal = tid < ncells && ev_board[(size_t)e * AZX_CELL_STRIDE + tid] == 0;
-    red[tid] = legal ? logit : -INFINITY;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s && tid + s < 192) red[tid] = fmaxf(red[tid], red[tid + s]);
-        __syncthreads();
-    }
-    const float mx = red[0];
-    __syncthreads();
-    const float ex = legal ? expf(logit - mx) : 0.f;
-    red[tid] = ex;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s && tid + s < 192) red[tid] += red[tid + s];
-        __syncthreads();
-    }
-    const float lse = mx + logf(red[0]);
-    if (tid < ncells) {
-        int cell = tid;
-        if (ev_flip[e]) {                              // back to the mover's frame (hex.py:107-111)
-            const int i = tid / N, j = tid - i * N;
-            cell = (N - 1 - j) * N + (N - 1 - i);
+    // prior = exp(log_softmax) (mcts.py:210); one wavefront per board, cells lane, lane+64, lane+128
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int b = wave; b < nb; b += 3) {
+        const int e = e0 + b;
+        float x[3];
+        bool legal[3];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int cell = s * 64 + lane;
+            legal[s] = cell < ncells && ev_board[(size_t)e * AZX_CELL_STRIDE + cell] == 0;
+            x[s] = legal[s] ? lg[b][cell] : -INFINITY;
+            mx = fmaxf(mx, x[s]);
         }
-        prior_out[(size_t)e * AZX_CELL_STRIDE + cell] = legal ? expf(logit - lse) : 0.f;
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) sum += legal[s] ? expf(x[s] - mx) : 0.f;
+        const float lse = mx + logf(wave_sum(sum));
+        const int flip = ev_flip[e];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int cell = s * 64 + lane;
+            if (cell < ncells) {
+                int oc = cell;
+                if (flip) {                            // back to the mover's frame (hex.py:107-111)
+                    const int i = cell / N, j = cell - i * N;
+                    oc = (N - 1 - j) * N + (N - 1 - i);
+                }
+                prior_out[(size_t)e * AZX_CELL_STRIDE + oc] = legal[s] ? expf(x[s] - lse) : 0.f;
+            }
+        }
     }
 }
 
@@ -868,7 +914,7 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
         if (x != net->act)   // heads read net->act
             (void)hipMemcpyAsync(net->act, x, (size_t)max_n * d.ncells * d.C * sizeof(float), hipMemcpyDeviceToDevice, st);
     }
-    hipLaunchKernelGGL(k_heads, dim3(max_n), dim3(192), 0, st, d, net->act, boards, flip, n_eval_ptr, n_host, logit, value, prior);
+    hipLaunchKernelGGL(k_heads, dim3((max_n + HEADS_BPB - 1) / HEADS_BPB), dim3(192), 0, st, d, net->act, boards, flip, n_eval_ptr, n_host, logit, value, prior);
 }
 
 void azx_net_eval(AzxNet *net, const DevEngine &e, hipStream_t st) {
