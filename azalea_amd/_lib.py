@@ -39,7 +39,8 @@ class PlayStats(C.Structure):
                 ("sum_k_leaf", C.c_int64), ("sum_search_value", C.c_double),
                 ("sum_root_width", C.c_double), ("sum_action_logprob", C.c_double),
                 ("sum_reward_last", C.c_double), ("seconds", C.c_double),
-                ("mcts_seconds", C.c_double), ("mcts_launches", C.c_int64)]
+                ("mcts_seconds", C.c_double), ("mcts_launches", C.c_int64),
+                ("net_seconds", C.c_double), ("net_launches", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -65,6 +65,7 @@ struct azx_engine {
     std::vector<void *> q_allocs;
     // timing
     std::vector<hipEvent_t> ev_pool;
+    std::vector<char> ev_tag;           // 0 = tree kernel, 1 = network (tower + heads)
     size_t ev_used = 0;
     AzxNet *net = nullptr;
 };
@@ -248,7 +249,7 @@ extern "C" int azx_reset(azx_engine *e, const int32_t *slots, int n_slots, const
 }
 
 // ---- timing of the tree kernels (roofline: algorithmic bytes / measured launch time) --------
-static void time_begin(azx_engine *e) {
+static void time_begin(azx_engine *e, char tag = 0) {
     if (e->ev_used + 2 > e->ev_pool.size()) {
         if (e->ev_pool.size() >= 1 << 16) return;
         hipEvent_t a, b;
@@ -256,6 +257,8 @@ static void time_begin(azx_engine *e) {
         e->ev_pool.push_back(a);
         e->ev_pool.push_back(b);
     }
+    if (e->ev_tag.size() < e->ev_pool.size() / 2) e->ev_tag.resize(e->ev_pool.size() / 2, 0);
+    e->ev_tag[e->ev_used / 2] = tag;
     (void)hipEventRecord(e->ev_pool[e->ev_used], e->stream);
 }
 static void time_end(azx_engine *e) {
@@ -263,12 +266,12 @@ static void time_end(azx_engine *e) {
     (void)hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream);
     e->ev_used += 2;
 }
-static void time_collect(azx_engine *e, double *seconds, int64_t *launches) {
+static void time_collect(azx_engine *e, azx_play_stats *st) {
     for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e->ev_pool[i], e->ev_pool[i + 1]) == hipSuccess) {
-            *seconds += ms * 1e-3;
-            *launches += 1;
+            if (e->ev_tag[i / 2]) { st->net_seconds += ms * 1e-3; st->net_launches += 1; }
+            else { st->mcts_seconds += ms * 1e-3; st->mcts_launches += 1; }
         }
     }
     e->ev_used = 0;
@@ -311,13 +314,17 @@ static int enqueue_search(azx_engine *e, bool timed) {
         if (timed) time_begin(e);
         azx_launch_mcts(d, MODE_BEGIN, e->num_batches, e->stream);
         if (timed) time_end(e);
+        if (timed) time_begin(e, 1);
         azx_net_eval(e->net, d, e->stream);
+        if (timed) time_end(e);
         for (int b = 0; b < e->num_batches; ++b) {
             HIPCHECK(hipMemsetAsync(d.n_eval, 0, sizeof(int32_t), e->stream));
             if (timed) time_begin(e);
             azx_launch_mcts(d, MODE_APPLY | MODE_SELECT, e->num_batches, e->stream);
             if (timed) time_end(e);
+            if (timed) time_begin(e, 1);
             azx_net_eval(e->net, d, e->stream);
+            if (timed) time_end(e);
         }
         if (timed) time_begin(e);
         azx_launch_mcts(d, MODE_APPLY, e->num_batches, e->stream);
@@ -744,7 +751,7 @@ extern "C" int azx_play_steps(azx_engine *e, int64_t plies, azx_play_stats *stat
     fill_stats(a, b, stats);
     stats->positions = (int64_t)(b.c[CTR_ROWS] - a.c[CTR_ROWS]);
     stats->seconds = ms * 1e-3;
-    time_collect(e, &stats->mcts_seconds, &stats->mcts_launches);
+    time_collect(e, stats);
     return AZX_OK;
 }
 
@@ -783,7 +790,7 @@ extern "C" int azx_play(azx_engine *e, int64_t min_positions, int64_t max_plies,
     fill_stats(a, b, stats);
     stats->positions = (int64_t)rows;
     stats->seconds = ms * 1e-3;
-    time_collect(e, &stats->mcts_seconds, &stats->mcts_launches);
+    time_collect(e, stats);
     if (rows == 0) return AZX_OK;
     const size_t n = (size_t)rows;
     std::vector<uint8_t> hb(n * AZX_CELL_STRIDE);

@@ -175,6 +175,8 @@ typedef struct {
     double  seconds;          /* device time of the call (hipEvents on the engine stream) */
     double  mcts_seconds;     /* device time in the tree kernels */
     int64_t mcts_launches;
+    double  net_seconds;      /* device time in the network kernels (tower + heads), per batch */
+    int64_t net_launches;
 } azx_play_stats;
 
 /* Self-play until >= min_positions rows from FINISHED games are available (whole games
