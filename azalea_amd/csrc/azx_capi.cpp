@@ -112,6 +112,7 @@ extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
     if (cfg->device < 0 || cfg->device >= ndev)
         return fail(AZX_EINVAL, "device %d not in [0, %d)", cfg->device, ndev);
     HIPCHECK(hipSetDevice(cfg->device));
+    if (azx_init_geometry(cfg->device)) return fail(AZX_EHIP, "uploading the board geometry tables failed");
 
     azx_engine *e = new azx_engine();
     e->cfg = *cfg;
@@ -169,6 +170,7 @@ extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
         for (int k = 1; k <= d.ncells; ++k) tab[k] = 1.0f / (float)k;
         rc = azx_set_prior_table(e, tab.data(), d.ncells + 1);
         if (rc) { azx_destroy(e); *out = nullptr; return rc; }
+        e->d.prior_default = 1;
     }
     // all slots start as fresh games with uids 0..G-1
     azx_launch_reset(d, nullptr, d.G, nullptr, nullptr, 0, 1, e->stream);
@@ -206,6 +208,7 @@ extern "C" int azx_set_prior_table(azx_engine *e, const float *prior_by_k, int c
                             hipMemcpyHostToDevice, e->stream));
     HIPCHECK(hipStreamSynchronize(e->stream));
     e->d.prior_by_k = e->prior_table_dev;
+    e->d.prior_default = 0;
     return AZX_OK;
 }
 
@@ -616,6 +619,7 @@ extern "C" int azx_hex_replay(int device, int board_size, int n_games, const int
     if (board_size < 2 || board_size > AZX_MAX_BOARD) return fail(AZX_EINVAL, "bad board_size");
     if (n_games < 1 || stride < 1 || !moves || !length) return fail(AZX_EINVAL, "bad argument");
     HIPCHECK(hipSetDevice(device));
+    if (azx_init_geometry(device)) return fail(AZX_EHIP, "uploading the board geometry tables failed");
     const int ncells = board_size * board_size;
     for (int g = 0; g < n_games; ++g) {
         if (length[g] < 0 || length[g] > stride) return fail(AZX_EINVAL, "length[%d] out of range", g);

@@ -91,7 +91,8 @@ struct DevEngine {
     float noise_alpha;
     int32_t device_noise;
     uint64_t seed;
-    const float *prior_by_k;   // [ncells+1] or null
+    const float *prior_by_k;   // [ncells+1]
+    int32_t prior_default;     // 1: prior_by_k is the default float32 1/k table
     unsigned long long *counters;   // [G][CTR_COUNT] per-game (no atomics); the host sums over games
     // throughput mode (azx_play): per-slot replay rows of the game in progress ...
     int32_t exploration_depth;
@@ -151,15 +152,33 @@ __device__ __forceinline__ float wave_max(float v) {
 // The reference flood-fills the last mover's group (hex.py:204-231); here every cell carries
 // its group's label and edge flags, so placing a stone is one O(1) wave-parallel relabel
 // (a union of <= 6 neighbouring groups) and the win test is "merged flags == both edges".
+// Board geometry in constant memory (scalar loads): for every board size N = 2..13 and every cell
+// four u64: the neighbour bitmask (hex.py:190-195 neighbourhood) over cell slots 0..2, and the
+// cell's own edge bits (bit0/1: row 0 / row N-1 for colour 1, bit2/3: column 0 / N-1 for colour 2).
+#define AZX_GEO_CELLS 820            // sum of N^2 for N = 2..13 is 818
+extern __constant__ uint64_t c_geo[AZX_GEO_CELLS * 4];
+__host__ __device__ inline int azx_geo_base(int N) {   // cells of all smaller boards
+    int b = 0;
+    for (int n = 2; n < N; ++n) b += n * n;
+    return b;
+}
+
 template <int SLOTS>
 struct HexWave {
-    uint32_t c[SLOTS];
-    int color;    // 1 = X to move, 2 = O (hex.py:148)
-    int winner;   // hex.py:149
+    uint32_t c[SLOTS];        // per-lane cells: colour | group flags << 2 | group label << 8
+    uint64_t occ[2][SLOTS];   // wave-uniform bitboards of the X / O stones
+    int color;                // 1 = X to move, 2 = O (hex.py:148)
+    int winner;               // hex.py:149
+    int gbase;                // this board size's offset into c_geo
 
+    __device__ __forceinline__ void geom(int N, int lane) { (void)lane; gbase = azx_geo_base(N); }
     __device__ __forceinline__ void load(const uint32_t *p, int lane) {
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) c[s] = p[s * 64 + lane];
+        for (int s = 0; s < SLOTS; ++s) {
+            c[s] = p[s * 64 + lane];
+            occ[0][s] = __ballot((c[s] & 3u) == 1u);
+            occ[1][s] = __ballot((c[s] & 3u) == 2u);
+        }
     }
     __device__ __forceinline__ void store(uint32_t *p, int lane) const {
 #pragma unroll
@@ -167,52 +186,37 @@ struct HexWave {
     }
     __device__ __forceinline__ void clear() {
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) c[s] = 0;
+        for (int s = 0; s < SLOTS; ++s) { c[s] = 0; occ[0][s] = 0ull; occ[1][s] = 0ull; }
         color = 1;
         winner = 0;
     }
-    // row / column of this lane's cells (set once per kernel by geom())
-    int gr[SLOTS], gc[SLOTS];
-    __device__ __forceinline__ void geom(int N, int lane) {
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int cell = s * 64 + lane;
-            gr[s] = cell / N;
-            gc[s] = cell - gr[s] * N;
-        }
-    }
-    // empties bitmask, slot s (hex.py:151-159: legal moves are the empty cells while winner==0)
+    // empties bitmask, slot s (hex.py:151-159: legal moves are the empty cells while winner==0):
+    // pure scalar arithmetic on the stone bitboards
     __device__ __forceinline__ uint64_t empties(int s, int lane, int ncells) const {
-        return __ballot(((c[s] & 3u) == 0u) && (s * 64 + lane < ncells));
+        (void)lane;
+        const int nv = ncells - 64 * s;
+        const uint64_t valid = nv >= 64 ? ~0ull : (nv <= 0 ? 0ull : ((1ull << nv) - 1ull));
+        return ~(occ[0][s] | occ[1][s]) & valid;
     }
     // hex.py:172-179 step + :204-231 check_win.  `cell` must be wave-uniform, empty, winner==0.
-    // Every lane tests whether its cells touch the new stone (hex.py:190-195 neighbourhood:
-    // |dr|<=1, |dc|<=1, |dr+dc|<=1, not the cell itself); the same-colour neighbours' group
-    // flags are OR-ed by ballot and their groups relabelled, one pass per neighbouring stone.
+    // The same-colour neighbours are the AND of the cell's neighbour mask (constant memory) with
+    // the mover's bitboard -- scalar work; their groups' edge flags are OR-ed and their groups
+    // relabelled with one vector compare per neighbouring stone.
     __device__ __forceinline__ void step(int cell, int N, int lane) {
+        (void)N;
         const int col = color;
-        int r0 = 0, q0 = 0;                          // row / column of the new stone, read from
-        {                                            // its owner lane (no integer division)
-            const int ln = cell & 63, sl = cell >> 6;
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const int rr = __builtin_amdgcn_readlane(gr[s], ln);
-                const int cc = __builtin_amdgcn_readlane(gc[s], ln);
-                if (s == sl) { r0 = rr; q0 = cc; }
-            }
-        }
-        const int e = (col == 1) ? r0 : q0;          // colour 1 tracks rows, 2 columns
-        uint32_t flags = (e == 0 ? 1u : 0u) | (e == N - 1 ? 2u : 0u);
+        const uint64_t *g = c_geo + (size_t)(gbase + cell) * 4;
+        uint32_t flags = (uint32_t)(g[3] >> (2 * (col - 1))) & 3u;
         uint64_t nb[SLOTS];
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const int dr = gr[s] - r0, dc = gc[s] - q0;
-            const bool adj = (unsigned)(dr + 1) <= 2u && (unsigned)(dc + 1) <= 2u &&
-                             (unsigned)(dr + dc + 1) <= 2u && (dr | dc) != 0;
-            const bool isn = adj && (int)(c[s] & 3u) == col;
-            nb[s] = __ballot(isn);
-            if (__ballot(isn && (c[s] & 4u))) flags |= 1u;
-            if (__ballot(isn && (c[s] & 8u))) flags |= 2u;
+            nb[s] = g[s] & (col == 1 ? occ[0][s] : occ[1][s]);
+            uint64_t m = nb[s];
+            while (m) {
+                const int j = (int)__ffsll((long long)m) - 1;
+                m &= m - 1;
+                flags |= ((uint32_t)__builtin_amdgcn_readlane((int)c[s], j) >> 2) & 3u;
+            }
         }
         const uint32_t nv = (uint32_t)col | (flags << 2) | ((uint32_t)cell << 8);
 #pragma unroll
@@ -227,10 +231,16 @@ struct HexWave {
                     if ((int)(c[t] & 3u) == col && (c[t] >> 8) == lab) c[t] = nv;
             }
         }
+        const uint64_t bit = 1ull << (cell & 63);
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s)
+        for (int s = 0; s < SLOTS; ++s) {
             if (s * 64 + lane == cell) c[s] = nv;
+            if (s == (cell >> 6)) {
+                if (col == 1) occ[0][s] |= bit; else occ[1][s] |= bit;
+            }
+        }
         winner = (flags == 3u) ? col : 0;
         color = 3 - col;
     }
 };
+

@@ -11,8 +11,40 @@
 //   :226-239 expand_batch, :242-255 backup_batch, :258-293 sample_paths;
 //   azalea/search_tree.py:59-71 reset, :115-132 move, :254-274 create_child_nodes;
 //   azalea/game/hex.py:137-231 rules, :72-122 perspective flip.
+#include <cstring>
+
 #include "azx_dev.h"
 #include "mcts_kernels.h"
+
+__constant__ uint64_t c_geo[AZX_GEO_CELLS * 4];
+
+// fill c_geo for every supported board size (once per device)
+int azx_init_geometry(int device) {
+    static bool done[64] = {false};
+    if (device >= 0 && device < 64 && done[device]) return 0;
+    static uint64_t tab[AZX_GEO_CELLS * 4];
+    memset(tab, 0, sizeof tab);
+    for (int N = 2; N <= AZX_MAX_BOARD; ++N) {
+        const int base = azx_geo_base(N);
+        const int dr[6] = {-1, -1, 0, 0, 1, 1}, dc[6] = {0, 1, -1, 1, -1, 0};   // hex.py:190-195
+        for (int r = 0; r < N; ++r)
+            for (int c = 0; c < N; ++c) {
+                uint64_t *g = tab + (size_t)(base + r * N + c) * 4;
+                for (int d = 0; d < 6; ++d) {
+                    const int rr = r + dr[d], cc = c + dc[d];
+                    if (rr >= 0 && rr < N && cc >= 0 && cc < N) {
+                        const int cell = rr * N + cc;
+                        g[cell >> 6] |= 1ull << (cell & 63);
+                    }
+                }
+                g[3] = (r == 0 ? 1ull : 0ull) | (r == N - 1 ? 2ull : 0ull) |
+                       (c == 0 ? 4ull : 0ull) | (c == N - 1 ? 8ull : 0ull);
+            }
+    }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_geo), tab, sizeof tab) != hipSuccess) return -1;
+    if (device >= 0 && device < 64) done[device] = true;
+    return 0;
+}
 
 // Diagnostic build only (-DAZX_STAMP): per-region s_memtime sums in counters[10..15].  The
 // shipped kernel executes no stamp.
@@ -28,24 +60,7 @@
 
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 
-// numpy's float32 pairwise add-reduce for n < 128 (np.sum over the batch values, mcts.py:287)
-__device__ inline float np_sum_f32(const float *a, int n) {
-    if (n < 8) {
-        float r = 0.0f;
-        for (int i = 0; i < n; ++i) r += a[i];
-        return r;
-    }
-    float r[8];
-    int i;
-    for (i = 0; i < 8; ++i) r[i] = a[i];
-    for (i = 8; i < n - (n % 8); i += 8)
-        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
-    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; ++i) res += a[i];
-    return res;
-}
-
-// ---- Philox4x32-10 counter RNG (device noise + move sampling in throughput mode) ----------
+// ---- Philox4x32-10 counter RNG (per-game stream key; the device move draw in k_choose) -------
 struct Philox {
     uint32_t k0, k1;
     __device__ __forceinline__ void gen(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -185,34 +200,18 @@ __device__ __forceinline__ int flip_src(int o, int N) {
 }
 
 struct Lds {
-    int32_t *path;        // [bs][pstride] node ids along each selected path (index d = depth d+1)
-    uint64_t *mask;       // [bs][4] empties bitmask at the leaf
-    unsigned char *colors;// [bs][AZX_CELL_STRIDE] absolute colours at the leaf
-    int32_t *node, *len, *link, *term, *mover, *uidx, *cells;   // [AZX_MAX_BATCH]
-    float *value;         // [AZX_MAX_BATCH]
+    int32_t *path;         // [bs][pstride] node ids along each selected path (index d = depth d+1)
+    unsigned char *colors; // [bs][AZX_CELL_STRIDE] absolute colours at the leaf (only when leaf boards leave the wave)
 };
 
 size_t azx_mcts_lds_bytes(int ncells, int bs) {
-    size_t b = (size_t)bs * (ncells + (ncells & 1)) * 4;   // path
-    b += (size_t)bs * 4 * 8;                               // mask
-    b += (size_t)bs * AZX_CELL_STRIDE;                     // colors
-    b += AZX_MAX_BATCH * 4 * 8;                            // small arrays
-    return b + 64;
+    return (size_t)bs * (ncells + (ncells & 1)) * 4 + (size_t)bs * AZX_CELL_STRIDE + 64;
 }
 
 __device__ __forceinline__ Lds carve_lds(unsigned char *raw, int ncells, int bs) {
     Lds L;
     L.path = reinterpret_cast<int32_t *>(raw);
-    L.mask = reinterpret_cast<uint64_t *>(L.path + bs * (ncells + (ncells & 1)));
-    L.colors = reinterpret_cast<unsigned char *>(L.mask + bs * 4);
-    L.node = reinterpret_cast<int32_t *>(L.colors + bs * AZX_CELL_STRIDE);
-    L.len = L.node + AZX_MAX_BATCH;
-    L.link = L.len + AZX_MAX_BATCH;
-    L.term = L.link + AZX_MAX_BATCH;
-    L.mover = L.term + AZX_MAX_BATCH;
-    L.uidx = L.mover + AZX_MAX_BATCH;
-    L.cells = L.uidx + AZX_MAX_BATCH;
-    L.value = reinterpret_cast<float *>(L.cells + AZX_MAX_BATCH);
+    L.colors = reinterpret_cast<unsigned char *>(L.path + bs * (ncells + (ncells & 1)));
     return L;
 }
 
@@ -461,7 +460,8 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
     };
 
     auto inline_prior = [&](int k) -> float {
-        return E.prior_by_k[k];   // host table; defaults to float32 1/k (azx_create)
+        // the default table is float32 1/k: the IEEE divide gives the same bits without a load
+        return E.prior_default ? 1.0f / (float)k : E.prior_by_k[k];
     };
 
     // =================================== BEGIN: root evaluation (mcts.py:272-273) ========
