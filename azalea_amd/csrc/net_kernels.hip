@@ -225,13 +225,14 @@ __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
     lo = (_Float16)(v - (float)hi);
 }
 
-__global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t *__restrict__ ev_board,
+#define F16X3_BPB 2   // boards per block: 2 -> 70 KB LDS, two blocks per CU overlap each other's prologue/epilogue
+__global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, const uint8_t *__restrict__ ev_board,
                                                          const int32_t *__restrict__ n_eval_ptr,
                                                          int n_eval_host, float *__restrict__ act_out) {
     constexpr int C = 64, MT = 4, ROWB = 272;
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
-    const int e0 = blockIdx.x * 4;
+    const int e0 = blockIdx.x * F16X3_BPB;
     if (e0 >= n_eval) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wb = wave >> 1, nt = wave & 1;             // board within the block, output n-tile
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t 
     const int board_b = 128 * ROWB;                      // 128 rows: the tile tail is scratch, never read
     const int x_off = wb * board_b;
     unsigned char *X = smem + x_off;                     // this wave pair's board
-    const int zero_off = 4 * board_b;                    // shared all-zero row
+    const int zero_off = F16X3_BPB * board_b;            // shared all-zero row
 
     // ---- stem (table lookups) -> split f16 rows; lane = output channel, waves split positions --
     {
@@ -305,15 +306,26 @@ __global__ __launch_bounds__(512, 2) void k_tower_f16x3(NetDev P, const uint8_t 
             for (int j = 0; j < 4; ++j) res[m][4 * g4 + j] = (float)h4[j] + (float)l4[j];
         }
 
-    // A-fragment byte offsets of one tap (zero row for padding taps and the tile tail)
-    auto tap_offsets = [&](int tap, int *aoff) {
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    // A-fragment byte offsets of one tap: row offset + the tap's (wave-uniform) displacement when
+    // the neighbour is on the board, else the shared zero row.  Validity of the 9 taps x 4 row
+    // tiles is one precomputed bit each, so a tap costs three VALU ops per row tile.
+    unsigned long long tapok = 0ull;                     // bit tap*4 + m
+    int rbase[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int yy = ry[m] + dy, xx = rx[m] + dx;
-            const bool ok = rvalid[m] && yy >= 0 && yy < N && xx >= 0 && xx < N;
-            aoff[m] = (ok ? x_off + (yy * N + xx) * ROWB : zero_off) + 16 * lh;
+    for (int m = 0; m < MT; ++m) {
+        rbase[m] = x_off + (m * 32 + li) * ROWB + 16 * lh;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = ry[m] + tap / 3 - 1, xx = rx[m] + tap % 3 - 1;
+            if (rvalid[m] && yy >= 0 && yy < N && xx >= 0 && xx < N) tapok |= 1ull << (tap * 4 + m);
         }
+    }
+    const int zbase = zero_off + 16 * lh;
+    auto tap_offsets = [&](int tap, int *aoff) {
+        const int delta = ((tap / 3 - 1) * N + (tap % 3 - 1)) * ROWB;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            aoff[m] = ((tapok >> (tap * 4 + m)) & 1ull) ? rbase[m] + delta : zbase;
     };
     // fragments of one k-step: A (hi, lo) for the 4 row tiles, B (hi, lo) for this wave's n-tile
     struct Frags { f16x8 ah[MT], al[MT], bh, bl; };
@@ -699,7 +711,7 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     }
     const int bpb = net->tower_variant == 2 ? 1 : 2;
     net->lds_bytes = (size_t)bpb * 2 * (ncells + 1) * (chans + 4) * sizeof(float);
-    if (net->tower_variant == 4) net->lds_bytes = (size_t)4 * 128 * 272 + 272;
+    if (net->tower_variant == 4) net->lds_bytes = (size_t)F16X3_BPB * 128 * 272 + 272;
     *out = net;
     return AZX_OK;
 }
@@ -888,7 +900,7 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
         if (net->tower_variant == 4) {
             static bool attr4 = false;
             if (!attr4) { (void)hipFuncSetAttribute((const void *)k_tower_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr4 = true; }
-            hipLaunchKernelGGL(k_tower_f16x3, dim3((max_n + 3) / 4), dim3(512), lds, st, d, boards, n_eval_ptr, n_host, net->act);
+            hipLaunchKernelGGL(k_tower_f16x3, dim3((max_n + F16X3_BPB - 1) / F16X3_BPB), dim3(F16X3_BPB * 128), lds, st, d, boards, n_eval_ptr, n_host, net->act);
         } else if (net->tower_variant == 1) {
             static bool attr1 = false;
             if (!attr1) { (void)hipFuncSetAttribute((const void *)k_tower_mfma<64, 4, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
