@@ -89,12 +89,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     import torch
+    ndev = torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one rank per GPU over RCCL; AZX_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a
+        # box with fewer GPUs than ranks (ranks then share devices: a functional check, not a benchmark)
+        backend = os.environ.get("AZX_BENCH_BACKEND", "nccl")
+        if backend == "nccl" and ndev < world:
+            raise SystemExit("bench.py --gpus %d needs %d GPUs (found %d)" % (world, world, ndev))
+        local_rank = local_rank % max(1, ndev)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine is HIP-only (no CPU fallback)")
 
@@ -133,10 +143,11 @@ def main():
 
     sums = [float(st[k]) for k in ("selects", "games", "plies", "evals", "positions")]
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        cdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        s = torch.tensor(sums, device="cuda", dtype=torch.float64)
+        s = torch.tensor(sums, device=cdev, dtype=torch.float64)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         sums = [float(x) for x in s.tolist()]
     selects, games, plies, evals, positions = sums
