@@ -59,6 +59,12 @@ int azx_init_geometry(int device) {
 #endif
 
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
+// bit `lane` of a wave-uniform mask as a lane predicate (v_cndmask on the SGPR pair) and the
+// number of set bits below this lane (v_mbcnt): no 64-bit vector shifts
+__device__ __forceinline__ bool lane_bit(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+__device__ __forceinline__ int rank_below(uint64_t m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 
 // ---- Philox4x32-10 counter RNG (per-game stream key; the device move draw in k_choose) -------
 struct Philox {
@@ -141,7 +147,7 @@ __device__ __forceinline__ void dirichlet_noise(const uint64_t *m, int lane, uin
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         lg[s] = -3.0e38f;
-        if ((m[s] >> lane) & 1ull) {
+        if (lane_bit(m[s])) {
             lg[s] = log_gamma_variate(stream, (uint32_t)(s * 64 + lane), gc);
             mx = fmaxf(mx, lg[s]);
         }
@@ -150,7 +156,7 @@ __device__ __forceinline__ void dirichlet_noise(const uint64_t *m, int lane, uin
     float sw = 0.0f;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        nz[s] = ((m[s] >> lane) & 1ull) ? fast_exp(lg[s] - mx) : 0.0f;
+        nz[s] = lane_bit(m[s]) ? fast_exp(lg[s] - mx) : 0.0f;
         sw += nz[s];
     }
     sw = scale * __builtin_amdgcn_rcpf(wave_sum(sw));
@@ -292,8 +298,8 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
         root_link = rn.link;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            rempty[s] = ((rootmk.m[s] >> lane) & 1ull) && rootmk.k > 0;
-            rrk[s] = rootmk.base[s] + popc64(rootmk.m[s] & lanemask_lt(lane));
+            rempty[s] = lane_bit(rootmk.m[s]) && rootmk.k > 0;
+            rrk[s] = rootmk.base[s] + rank_below(rootmk.m[s]);
             rst[s] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (root_link >= 0 && rempty[s])
                 rst[s] = *reinterpret_cast<const float4 *>(arena + root_link + rrk[s]);
@@ -395,9 +401,9 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
         if (k > 0) {
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
-                if ((lm[s] >> lane) & 1ull) {
+                if (lane_bit(lm[s])) {
                     const int cell = s * 64 + lane;
-                    const int rk = base[s] + popc64(lm[s] & lanemask_lt(lane));
+                    const int rk = base[s] + rank_below(lm[s]);
                     Node nd;
                     nd.nv = 0.0f;
                     nd.tv = 0.0f;
@@ -566,8 +572,8 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                     } else {
 #pragma unroll
                         for (int s = 0; s < SLOTS; ++s) {
-                            const bool empty = (mk.m[s] >> lane) & 1ull;
-                            rk[s] = mk.base[s] + popc64(mk.m[s] & lanemask_lt(lane));
+                            const bool empty = lane_bit(mk.m[s]);
+                            rk[s] = mk.base[s] + rank_below(mk.m[s]);
                             st[s] = make_float4(0.f, 0.f, 0.f, 0.f);
                             if (empty) st[s] = *reinterpret_cast<const float4 *>(arena + link + rk[s]);
                         }
@@ -580,12 +586,12 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                             const float pnv = readlane_f(c_nv, j), ptv = readlane_f(c_tv, j);
 #pragma unroll
                             for (int s = 0; s < SLOTS; ++s)
-                                if (((mk.m[s] >> lane) & 1ull) && rk[s] == r) { st[s].x = pnv; st[s].y = ptv; }
+                                if (lane_bit(mk.m[s]) && rk[s] == r) { st[s].x = pnv; st[s].y = ptv; }
                         }
                     }
 #pragma unroll
                     for (int s = 0; s < SLOTS; ++s)
-                        if ((mk.m[s] >> lane) & 1ull) sumn += st[s].x;
+                        if (lane_bit(mk.m[s])) sumn += st[s].x;
                     sumn = wave_sum(sumn);                         // exact: visit counts are integers
                     const float sq = sqrtf(sumn);                  // mcts.py:132
                     // ---- Dirichlet noise at the root only (mcts.py:126-131, :114) ----------
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
 #pragma unroll
                     for (int s = 0; s < SLOTS; ++s) {
                         slot_score[s] = -INFINITY;
-                        if ((mk.m[s] >> lane) & 1ull) {
+                        if (lane_bit(mk.m[s])) {
                             float P = st[s].z;
                             if (noisy) {
                                 const float kept = keep32 * P;
@@ -636,7 +642,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                         best_cell = 0x7fffffff;
 #pragma unroll
                         for (int s = SLOTS - 1; s >= 0; --s) {
-                            const uint64_t eq = __ballot(((mk.m[s] >> lane) & 1ull) && sc[s] == wmax);
+                            const uint64_t eq = __ballot(lane_bit(mk.m[s]) && sc[s] == wmax);
                             if (eq) best_cell = s * 64 + (int)__ffsll((long long)eq) - 1;
                         }
                     }
@@ -888,8 +894,8 @@ __global__ __launch_bounds__(64) void k_advance(DevEngine E, const int32_t *move
         int cell = -1;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const bool empty = (mk.m[s] >> lane) & 1ull;
-            const int rk = mk.base[s] + popc64(mk.m[s] & lanemask_lt(lane));
+            const bool empty = lane_bit(mk.m[s]);
+            const int rk = mk.base[s] + rank_below(mk.m[s]);
             const uint64_t hit = __ballot(empty && rk == mid);
             if (hit) cell = s * 64 + (int)__ffsll((long long)hit) - 1;
         }
@@ -926,7 +932,7 @@ __global__ __launch_bounds__(64) void k_advance(DevEngine E, const int32_t *move
                     if (i < lvl_end) oldfc = dst[i].link;
                     const bool has = oldfc >= 0;
                     const uint64_t hm = __ballot(has);
-                    const int newfc = n_new + kL * popc64(hm & lanemask_lt(lane));
+                    const int newfc = n_new + kL * rank_below(hm);
                     if (has) dst[i].link = newfc;
                     uint64_t rem = hm;
                     while (rem) {
@@ -1042,8 +1048,8 @@ __global__ __launch_bounds__(64) void k_gather_root(DevEngine E, int32_t *k_out,
     const size_t ob = (size_t)g * E.ncells;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        if (((mk.m[s] >> lane) & 1ull) && mk.k > 0) {
-            const int rk = mk.base[s] + popc64(mk.m[s] & lanemask_lt(lane));
+        if (lane_bit(mk.m[s]) && mk.k > 0) {
+            const int rk = mk.base[s] + rank_below(mk.m[s]);
             if (legal) legal[ob + rk] = s * 64 + lane + 1;
             if (rootn.link >= 0) {
                 const Node c = arena[rootn.link + rk];
@@ -1091,8 +1097,8 @@ __global__ __launch_bounds__(64) void k_choose(DevEngine E) {
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         nv[s] = 0.0f;
-        rk[s] = mk.base[s] + popc64(mk.m[s] & lanemask_lt(lane));
-        if ((mk.m[s] >> lane) & 1ull) nv[s] = arena[rootn.link + rk[s]].nv;
+        rk[s] = mk.base[s] + rank_below(mk.m[s]);
+        if (lane_bit(mk.m[s])) nv[s] = arena[rootn.link + rk[s]].nv;
         mx = fmaxf(mx, nv[s]);
     }
     mx = wave_max(mx);
@@ -1100,7 +1106,7 @@ __global__ __launch_bounds__(64) void k_choose(DevEngine E) {
     int width = 0;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        const bool empty = (mk.m[s] >> lane) & 1ull;
+        const bool empty = lane_bit(mk.m[s]);
         float x = 0.0f;
         if (empty) {
             if (T > 0.0f) x = (nv[s] > 0.0f) ? (T == 1.0f ? nv[s] : __powf(nv[s], 1.0f / T)) : 0.0f;
@@ -1128,7 +1134,7 @@ __global__ __launch_bounds__(64) void k_choose(DevEngine E) {
             if (lane >= o) inc += t;
         }
         const float cum = run + inc;
-        const bool cand = ((mk.m[s] >> lane) & 1ull) && w[s] > 0.0f && cum > target;
+        const bool cand = lane_bit(mk.m[s]) && w[s] > 0.0f && cum > target;
         const uint64_t cm = __ballot(cand);
         if (cm && chosen < 0) {
             const int l = (int)__ffsll((long long)cm) - 1;
@@ -1140,7 +1146,7 @@ __global__ __launch_bounds__(64) void k_choose(DevEngine E) {
     if (chosen < 0) {   // rounding left the target at the very top: take the last positive child
 #pragma unroll
         for (int s = SLOTS - 1; s >= 0; --s) {
-            const uint64_t cm = __ballot(((mk.m[s] >> lane) & 1ull) && w[s] > 0.0f);
+            const uint64_t cm = __ballot(lane_bit(mk.m[s]) && w[s] > 0.0f);
             if (cm && chosen < 0) {
                 const int l = 63 - __clzll((long long)cm);
                 chosen = __builtin_amdgcn_readlane(rk[s], l);
@@ -1155,7 +1161,7 @@ __global__ __launch_bounds__(64) void k_choose(DevEngine E) {
     for (int s = 0; s < SLOTS; ++s) {
         const int cell = s * 64 + lane;
         if (cell < AZX_CELL_STRIDE) E.row_board[rb + cell] = (unsigned char)(h.c[s] & 3u);
-        if ((mk.m[s] >> lane) & 1ull) E.row_prob[rb + rk[s]] = w[s] / tot;
+        if (lane_bit(mk.m[s])) E.row_prob[rb + rk[s]] = w[s] / tot;
     }
     for (int o = mk.k + lane; o < AZX_CELL_STRIDE; o += 64) E.row_prob[rb + o] = 0.0f;
     if (lane == 0) {

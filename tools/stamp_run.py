@@ -6,7 +6,8 @@ from azalea_amd import _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libazx_stamp.so")
 from azalea_amd import engine as eng
 ns = float(sys.argv[1]) if len(sys.argv) > 1 else 0.25
-E = eng.Engine(board_size=11, n_games=4096, simulations=400, search_batch_size=10, evaluator=eng.EVAL_UNIFORM, noise_scale=ns)
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+E = eng.Engine(board_size=11, n_games=G, simulations=400, search_batch_size=10, evaluator=eng.EVAL_UNIFORM, noise_scale=ns)
 E.play_steps(20)
 a = E.debug_counters().astype(np.float64)
 st = E.play_steps(40)
