@@ -137,6 +137,19 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     v += AZX_DPP(0, v, 0x143, 0xc);
     return __builtin_amdgcn_readlane(v, 63);
 }
+// unsigned max: 0 is the identity, so bound_ctrl DPP reads need no 'old' operand
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define AZX_DPPZ(v, ctrl, rmask) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xf, true)
+    uint32_t t;
+    t = AZX_DPPZ(v, 0x111, 0xf); v = t > v ? t : v;
+    t = AZX_DPPZ(v, 0x112, 0xf); v = t > v ? t : v;
+    t = AZX_DPPZ(v, 0x114, 0xf); v = t > v ? t : v;
+    t = AZX_DPPZ(v, 0x118, 0xf); v = t > v ? t : v;
+    t = AZX_DPPZ(v, 0x142, 0xa); v = t > v ? t : v;
+    t = AZX_DPPZ(v, 0x143, 0xc); v = t > v ? t : v;
+#undef AZX_DPPZ
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ float wave_max(float v) {
     const int ninf = 0xff800000;   // -inf: identity of max
     v = fmaxf(v, __int_as_float(AZX_DPP(ninf, __float_as_int(v), 0x111, 0xf)));

@@ -603,46 +603,47 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                         dirichlet_noise<SLOTS>(mk.m, lane, noise_stream, gconst, (float)E.noise_scale, nz);
                     }
                     // ---- score_actions (mcts.py:119-136), op by op in float32 --------------
-                    float slot_score[SLOTS];
+                    // branch-free: every lane computes, non-legal lanes are masked at the end
+                    float Pn[SLOTS];
 #pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) {
-                        slot_score[s] = -INFINITY;
-                        if (lane_bit(mk.m[s])) {
-                            float P = st[s].z;
-                            if (noisy) {
-                                const float kept = keep32 * P;
-                                if (E.device_noise) {
-                                    P = kept + nz[s];
-                                } else {
-                                    const double *row = E.noise +
-                                        ((size_t)g * E.n_select + select_count) * E.noise_stride;
-                                    P = (float)((double)kept + E.noise_scale * row[rk[s]]);
-                                }
-                            }
-                            const float nvj = st[s].x;
-                            const float gap = sq / (1.0f + nvj);              // mcts.py:132
-                            const float U = (c32 * P) * gap;                  // mcts.py:133
-                            const float W = -st[s].y;                         // search_tree.py:203
-                            const float Q = W / fmaxf(nvj, 1.0f);             // mcts.py:134
-                            const float score = Q + U;                        // mcts.py:135
-                            slot_score[s] = score;
+                    for (int s = 0; s < SLOTS; ++s) Pn[s] = st[s].z;
+                    if (noisy) {
+                        if (E.device_noise) {
+#pragma unroll
+                            for (int s = 0; s < SLOTS; ++s) Pn[s] = keep32 * Pn[s] + nz[s];
+                        } else {
+                            const double *row = E.noise +
+                                ((size_t)g * E.n_select + select_count) * E.noise_stride;
+#pragma unroll
+                            for (int s = 0; s < SLOTS; ++s)
+                                if (lane_bit(mk.m[s]))
+                                    Pn[s] = (float)((double)(keep32 * Pn[s]) + E.noise_scale * row[rk[s]]);
                         }
                     }
-                    // np.argmax: highest score, lowest index on ties (mcts.py:112): wave max, then
-                    // the lowest cell whose score equals it (-0.0 == +0.0, as in numpy)
-                    {
-                        float sc[SLOTS];
-                        float lmax = -INFINITY;
+                    uint32_t key[SLOTS], lkey = 0u;
 #pragma unroll
-                        for (int s = 0; s < SLOTS; ++s) {
-                            sc[s] = slot_score[s];
-                            lmax = fmaxf(lmax, sc[s]);
-                        }
-                        const float wmax = wave_max(lmax);
+                    for (int s = 0; s < SLOTS; ++s) {
+                        const float nvj = st[s].x;
+                        const float gap = sq / (1.0f + nvj);              // mcts.py:132
+                        const float U = (c32 * Pn[s]) * gap;              // mcts.py:133
+                        const float W = -st[s].y;                         // search_tree.py:203
+                        const float Q = W / (nvj < 1.0f ? 1.0f : nvj);    // mcts.py:134 (clip(min=1))
+                        const float score = (Q + U) + 0.0f;               // mcts.py:135; -0.0 -> +0.0
+                        // order-preserving map float -> u32 (np.argmax compares values; equal
+                        // floats <=> equal keys once -0.0 is folded into +0.0)
+                        const uint32_t bts = (uint32_t)__float_as_int(score);
+                        const uint32_t k32 = bts ^ ((uint32_t)((int32_t)bts >> 31) | 0x80000000u);
+                        key[s] = lane_bit(mk.m[s]) ? k32 : 0u;
+                        lkey = key[s] > lkey ? key[s] : lkey;
+                    }
+                    // np.argmax: highest score, lowest index on ties (mcts.py:112): wave max of the
+                    // keys, then the lowest cell holding it
+                    {
+                        const uint32_t wmax = wave_max_u32(lkey);
                         best_cell = 0x7fffffff;
 #pragma unroll
                         for (int s = SLOTS - 1; s >= 0; --s) {
-                            const uint64_t eq = __ballot(lane_bit(mk.m[s]) && sc[s] == wmax);
+                            const uint64_t eq = __ballot(key[s] == wmax) & mk.m[s];
                             if (eq) best_cell = s * 64 + (int)__ffsll((long long)eq) - 1;
                         }
                     }

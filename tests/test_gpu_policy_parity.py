@@ -124,3 +124,47 @@ def test_device_net_policy_is_deterministic_and_player_reads_whole_games():
     frame2, _ = player.read(10)
     assert len(frame2) >= 10
     player.stop()
+
+
+def test_trainer_style_loop_consumes_the_engine():
+    """What azalea/policy_trainer.py:45-90 does with these classes: seed a ReplayBuffer from the
+    random mover, DataLoader + torch_batch_replays collate, SGD step on the live network,
+    replaybuf.consume(...) pulling fresh self-play (device network, throughput mode) from Player."""
+    from torch import optim
+    from torch.utils.data import DataLoader
+    from azalea_amd import AzaleaAgent, HexGame, Player, Policy, ReplayBuffer
+    from azalea_amd.prep import torch_batch_replays
+    cfg = dict(device="cuda", network="HexNetwork", board_size=5, num_blocks=1, base_chans=64,
+               simulations=20, search_batch_size=10, exploration_coef=0.5, exploration_depth=3,
+               exploration_noise_alpha=0.03, exploration_noise_scale=0.25,
+               exploration_temperature=1.0, seed=5)
+    torch.manual_seed(1)
+    policy = Policy()
+    policy.initialize(cfg)
+    game_factory = lambda: HexGame(5)   # noqa: E731
+    seed_player = Player(None, [AzaleaAgent(game_factory)])
+    examples, metrics = seed_player.read(200)
+    seed_player.stop()
+    assert metrics["games"] >= 1
+    buf = ReplayBuffer(examples)
+    size0 = len(buf)
+    loader = DataLoader(buf, batch_size=32, shuffle=True, collate_fn=torch_batch_replays)
+    opt = optim.SGD(policy.net.parameters(), lr=0.01, momentum=0.9)
+    policy.net.train()
+    policy.settings.update(move_sampling=True, move_exploration=True)
+    player = Player(None, [AzaleaAgent(game_factory, policy=policy, device="cuda")], n_games=32)
+    steps, fresh_games = 0, 0
+    for batch in loader:
+        batch = {k: v.to("cuda") for k, v in batch.items()}
+        opt.zero_grad()
+        out, loss = policy.net.run(batch, compute_loss=True)
+        loss.backward()
+        opt.step()
+        m = buf.consume(32 / 4, player)            # oversampling 4, policy_trainer.py:90
+        fresh_games += m.get("games", 0)
+        assert np.isfinite(loss.item())
+        steps += 1
+        if steps == 6:
+            break
+    player.stop()
+    assert fresh_games >= 1 and len(buf) == size0   # FIFO keeps its size; new rows overwrote old
