@@ -226,16 +226,22 @@ __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
 }
 
 #define F16X3_BPB 2   // boards per block: 2 -> 70 KB LDS, two blocks per CU overlap each other's prologue/epilogue
+// SPLIT_M: how the two waves of a board divide its 4 x 2 output tiles (32 positions x 32 channels):
+//   false: each wave takes all 4 position tiles of one channel tile  (8 LDS + 2 L2 fragment loads / k-step)
+//   true : each wave takes 2 position tiles of both channel tiles    (4 LDS + 4 L2 fragment loads / k-step)
+template <bool SPLIT_M>
 __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, const uint8_t *__restrict__ ev_board,
                                                          const int32_t *__restrict__ n_eval_ptr,
                                                          int n_eval_host, float *__restrict__ act_out) {
-    constexpr int C = 64, MT = 4, ROWB = 272;
+    constexpr int C = 64, ROWB = 272;
+    constexpr int MW = SPLIT_M ? 2 : 4, NW = SPLIT_M ? 2 : 1;
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
     const int e0 = blockIdx.x * F16X3_BPB;
     if (e0 >= n_eval) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wb = wave >> 1, nt = wave & 1;             // board within the block, output n-tile
+    const int wb = wave >> 1, wh = wave & 1;             // board within the block, which half of its tiles
+    const int mbase = SPLIT_M ? 2 * wh : 0, nbase = SPLIT_M ? 0 : wh;
     const int N = P.N, ncells = P.ncells;
     const int e = e0 + wb;
     const bool live = e < n_eval;
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
         // stage the board's cells in the (not yet used) tail rows 121..127 of its LDS region
         unsigned char *cells = X + 121 * ROWB;           // 7 * 272 B >= 128 B
         const uint8_t *bd = ev_board + (size_t)(live ? e : n_eval - 1) * AZX_CELL_STRIDE;
-        if (nt == 0) {
+        if (wh == 0) {
             cells[lane] = bd[lane];
             cells[64 + lane] = bd[64 + lane];
         }
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
         const float sb = P.stem_b[lane];
         const float *T = P.stemT + lane;
 #pragma unroll 2
-        for (int pos = nt; pos < ncells; pos += 2) {
+        for (int pos = wh; pos < ncells; pos += 2) {
             const int y = pos / N, x = pos - y * N;
             float acc = sb;
 #pragma unroll
@@ -275,80 +281,75 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
     }
     __syncthreads();
 
-    // per-lane geometry of the A fragment rows: lane (i = lane&31, h = lane>>5)
+    // lane (i = lane&31, h = lane>>5).  The product is computed transposed (weights as the MFMA A
+    // operand, activations as B), so in a 32x32 result tile a LANE is a board position (row
+    // (mbase+m)*32 + li) and the 16 registers are output channels cb + (r&3) + 8*(r>>2): four
+    // consecutive channels per register quad -> 8-byte packed f16 epilogue writes.
     const int li = lane & 31, lh = lane >> 5;
-    int ry[MT], rx[MT];
-    bool rvalid[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int r = m * 32 + li;
-        rvalid[m] = r < ncells;
-        ry[m] = r / N;
-        rx[m] = r - ry[m] * N;
-    }
-    // The product is computed transposed (weights as the MFMA A operand, activations as B), so in
-    // the 32x32 result a LANE is a board position (row m*32 + li) and the 16 registers are output
-    // channels cb + (r&3) + 8*(r>>2): four consecutive channels per register quad -> the epilogue
-    // writes 8-byte packed f16 quads instead of single halves.
-    const int cb = nt * 32 + 4 * lh;                     // channel of register 0
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-    // residual (block input) in accumulator layout
-    f32x16 res[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const unsigned char *pr = X + (m * 32 + li) * ROWB + (cb + 8 * g4) * 2;
-            const f16x4 h4 = *reinterpret_cast<const f16x4 *>(pr);
-            const f16x4 l4 = *reinterpret_cast<const f16x4 *>(pr + 128);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) res[m][4 * g4 + j] = (float)h4[j] + (float)l4[j];
-        }
-
     // A-fragment byte offsets of one tap: row offset + the tap's (wave-uniform) displacement when
-    // the neighbour is on the board, else the shared zero row.  Validity of the 9 taps x 4 row
-    // tiles is one precomputed bit each, so a tap costs three VALU ops per row tile.
+    // the neighbour is on the board, else the shared zero row; validity is one precomputed bit
     unsigned long long tapok = 0ull;                     // bit tap*4 + m
-    int rbase[MT];
+    int rbase[MW];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        rbase[m] = x_off + (m * 32 + li) * ROWB + 16 * lh;
+    for (int m = 0; m < MW; ++m) {
+        const int r = (mbase + m) * 32 + li;
+        const int ry = r / N, rx = r - ry * N;
+        rbase[m] = x_off + r * ROWB + 16 * lh;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int yy = ry[m] + tap / 3 - 1, xx = rx[m] + tap % 3 - 1;
-            if (rvalid[m] && yy >= 0 && yy < N && xx >= 0 && xx < N) tapok |= 1ull << (tap * 4 + m);
+            const int yy = ry + tap / 3 - 1, xx = rx + tap % 3 - 1;
+            if (r < ncells && yy >= 0 && yy < N && xx >= 0 && xx < N) tapok |= 1ull << (tap * 4 + m);
         }
     }
     const int zbase = zero_off + 16 * lh;
     auto tap_offsets = [&](int tap, int *aoff) {
         const int delta = ((tap / 3 - 1) * N + (tap % 3 - 1)) * ROWB;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MW; ++m)
             aoff[m] = ((tapok >> (tap * 4 + m)) & 1ull) ? rbase[m] + delta : zbase;
     };
-    // fragments of one k-step: A (hi, lo) for the 4 row tiles, B (hi, lo) for this wave's n-tile
-    struct Frags { f16x8 ah[MT], al[MT], bh, bl; };
-    // B fragments come straight from L2/L1 (packed in fragment order: one coalesced 16-byte load
-    // per lane and part); A fragments from this board's LDS rows
+
+    // residual (block input) in accumulator layout
+    f32x16 res[MW][NW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const unsigned char *pr = X + ((mbase + m) * 32 + li) * ROWB + ((nbase + n) * 32 + 4 * lh + 8 * g4) * 2;
+                const f16x4 h4 = *reinterpret_cast<const f16x4 *>(pr);
+                const f16x4 l4 = *reinterpret_cast<const f16x4 *>(pr + 128);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) res[m][n][4 * g4 + j] = (float)h4[j] + (float)l4[j];
+            }
+
+    // fragments of one k-step: activations (hi, lo) for this wave's row tiles from LDS, weights
+    // (hi, lo) for its channel tiles straight from L2/L1 (packed in fragment order)
+    struct Frags { f16x8 ah[MW], al[MW], bh[NW], bl[NW]; };
     const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.Wh);     // 512 uint4 per stage
     auto load_frags = [&](Frags &f, const int *aoff, int half, int kk, int stage) {
-        // weights: [stage][kk][ntile][part][lane][8 f16]
-        const uint4 *pb = wsrc + (size_t)stage * 512 + ((kk * 2 + nt) * 2) * 64 + lane;
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            // weights: [stage][kk][ntile][part][lane][8 f16]
+            const uint4 *pb = wsrc + (size_t)stage * 512 + ((kk * 2 + nbase + n) * 2) * 64 + lane;
 #if AZX_NET_ABLATE & 4
-        const uint4 qh = make_uint4(stage, kk, 1, 2), ql = qh; (void)pb;
+            const uint4 qh = make_uint4(stage, kk, 1, 2), ql = qh; (void)pb;
 #else
-        const uint4 qh = pb[0], ql = pb[64];
+            const uint4 qh = pb[0], ql = pb[64];
 #endif
-        f.bh = *reinterpret_cast<const f16x8 *>(&qh);
-        f.bl = *reinterpret_cast<const f16x8 *>(&ql);
+            f.bh[n] = *reinterpret_cast<const f16x8 *>(&qh);
+            f.bl[n] = *reinterpret_cast<const f16x8 *>(&ql);
+        }
 #if AZX_NET_ABLATE & 1
         (void)aoff; (void)half;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { f.ah[m] = f.bh; f.al[m] = f.bl; }
+        for (int m = 0; m < MW; ++m) { f.ah[m] = f.bh[0]; f.al[m] = f.bl[0]; }
 #else
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int m = 0; m < MW; ++m) {
             const unsigned char *pa = smem + aoff[m] + (half * 32 + kk * 16) * 2;
             f.ah[m] = *reinterpret_cast<const f16x8 *>(pa);
             f.al[m] = *reinterpret_cast<const f16x8 *>(pa + 128);
@@ -359,26 +360,30 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
     int stage = 0;
     auto conv_layer = [&](int layer, auto residual_tag) {
         constexpr bool residual = decltype(residual_tag)::value;   // conv2 of a Resblock: y += x (network.py:37)
-        f32x16 acc[MT];
+        f32x16 acc[MW][NW];
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MW; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+            for (int n = 0; n < NW; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
         auto mfma_step = [&](const Frags &f) {
 #if AZX_NET_ABLATE & 2
 #pragma unroll
-            for (int m = 0; m < MT; ++m) asm volatile("" :: "v"(f.ah[m]), "v"(f.al[m]), "v"(f.bh), "v"(f.bl));
+            for (int m = 0; m < MW; ++m) asm volatile("" :: "v"(f.ah[m]), "v"(f.al[m]), "v"(f.bh[0]), "v"(f.bl[0]));
 #else
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh, f.ah[m], acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl, f.ah[m], acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh, f.al[m], acc[m], 0, 0, 0);
-            }
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int n = 0; n < NW; ++n) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[n], f.ah[m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[n], f.ah[m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[n], f.al[m], acc[m][n], 0, 0, 0);
+                }
 #endif
         };
 
-        int aoff[MT];
+        int aoff[MW];
         tap_offsets(0, aoff);
         Frags f0, f1;                                    // ping-pong fragment sets (no copies)
         load_frags(f0, aoff, 0, 0, stage);
@@ -404,36 +409,39 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
         }
         __syncthreads();   // both waves of the board finished reading it
         // ---- epilogue: + folded-BN bias (+ residual) -> ReLU -> split f16 back into the board -----
-        // (the barrier above guarantees both waves of the board finished reading it)
-        float bv[16];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 b4 = *reinterpret_cast<const float4 *>(P.bias + layer * C + cb + 8 * g4);
-            bv[4 * g4] = b4.x; bv[4 * g4 + 1] = b4.y; bv[4 * g4 + 2] = b4.z; bv[4 * g4 + 3] = b4.w;
-        }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int n = 0; n < NW; ++n) {
+            const int cb = (nbase + n) * 32 + 4 * lh;    // channel of register 0
+            float bv[16];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                f16x4 h4, l4;
+                const float4 b4 = *reinterpret_cast<const float4 *>(P.bias + layer * C + cb + 8 * g4);
+                bv[4 * g4] = b4.x; bv[4 * g4 + 1] = b4.y; bv[4 * g4 + 2] = b4.z; bv[4 * g4 + 3] = b4.w;
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * g4 + j;
-                    float v = acc[m][r] + bv[r];
-                    if (residual) v += res[m][r];
-                    v = fmaxf(v, 0.0f);
-                    if (residual) res[m][r] = v;      // block output = next block's input
-                    _Float16 hi, lo;
-                    split_f16(v, hi, lo);
-                    h4[j] = hi;
-                    l4[j] = lo;
+            for (int m = 0; m < MW; ++m) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f16x4 h4, l4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * g4 + j;
+                        float v = acc[m][n][r] + bv[r];
+                        if (residual) v += res[m][n][r];
+                        v = fmaxf(v, 0.0f);
+                        if (residual) res[m][n][r] = v;  // block output = next block's input
+                        _Float16 hi, lo;
+                        split_f16(v, hi, lo);
+                        h4[j] = hi;
+                        l4[j] = lo;
+                    }
+                    unsigned char *pw = X + ((mbase + m) * 32 + li) * ROWB + (cb + 8 * g4) * 2;
+                    *reinterpret_cast<f16x4 *>(pw) = h4;
+                    *reinterpret_cast<f16x4 *>(pw + 128) = l4;
                 }
-                unsigned char *pw = X + (m * 32 + li) * ROWB + (cb + 8 * g4) * 2;
-                *reinterpret_cast<f16x4 *>(pw) = h4;
-                *reinterpret_cast<f16x4 *>(pw + 128) = l4;
             }
         }
-        __syncthreads();   // the partner wave wrote the other 32 channels of these rows
+        __syncthreads();   // the partner wave wrote the other tiles of this board
     };
     for (int blk = 0; blk < P.blocks; ++blk) {
         conv_layer(2 * blk, std::false_type{});
@@ -444,13 +452,16 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
     if (live) {
         float *out = act_out + (size_t)e * ncells * C;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int row = m * 32 + li;
+        for (int m = 0; m < MW; ++m) {
+            const int row = (mbase + m) * 32 + li;
             if (row < ncells) {
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
-                    *reinterpret_cast<float4 *>(out + row * C + cb + 8 * g4) =
-                        make_float4(res[m][4 * g4], res[m][4 * g4 + 1], res[m][4 * g4 + 2], res[m][4 * g4 + 3]);
+                for (int n = 0; n < NW; ++n)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        *reinterpret_cast<float4 *>(out + row * C + (nbase + n) * 32 + 4 * lh + 8 * g4) =
+                            make_float4(res[m][n][4 * g4], res[m][n][4 * g4 + 1], res[m][n][4 * g4 + 2],
+                                        res[m][n][4 * g4 + 3]);
             }
         }
     }
@@ -898,9 +909,16 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
     if (net->use_mfma) {
         const size_t lds = net->lds_bytes;
         if (net->tower_variant == 4) {
+            static const bool split_m = getenv("AZX_TOWER_SPLIT") ? atoi(getenv("AZX_TOWER_SPLIT")) != 0 : true;
             static bool attr4 = false;
-            if (!attr4) { (void)hipFuncSetAttribute((const void *)k_tower_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr4 = true; }
-            hipLaunchKernelGGL(k_tower_f16x3, dim3((max_n + F16X3_BPB - 1) / F16X3_BPB), dim3(F16X3_BPB * 128), lds, st, d, boards, n_eval_ptr, n_host, net->act);
+            if (!attr4) {
+                (void)hipFuncSetAttribute((const void *)k_tower_f16x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute((const void *)k_tower_f16x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr4 = true;
+            }
+            const dim3 grid((max_n + F16X3_BPB - 1) / F16X3_BPB), block(F16X3_BPB * 128);
+            if (split_m) hipLaunchKernelGGL(k_tower_f16x3<true>, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act);
+            else hipLaunchKernelGGL(k_tower_f16x3<false>, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act);
         } else if (net->tower_variant == 1) {
             static bool attr1 = false;
             if (!attr1) { (void)hipFuncSetAttribute((const void *)k_tower_mfma<64, 4, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
