@@ -134,9 +134,10 @@ extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
     d.temperature = (float)cfg->temperature;
     e->num_batches = cfg->simulations / cfg->search_batch_size + 1;   // mcts.py:268
     e->selects_per_search = e->num_batches * cfg->search_batch_size;
-    // arena capacity: enough for one move's growth on top of a carried subtree by default
     int cap = cfg->nodes_per_game;
-    if (cap <= 0) cap = 2 * (e->selects_per_search + 1) * d.ncells + 1024;
+    // default: six moves' worth of expansions -- a sharply peaked network carries most of its tree
+    // from move to move (the reference allows 10M nodes per game, search_tree.py:18)
+    if (cap <= 0) cap = 6 * (e->selects_per_search + 1) * d.ncells + 1024;
     d.cap = cap;
 
     const size_t G = d.G, bs = d.bs, E = G * bs;

@@ -179,3 +179,27 @@ def test_resnet_play_mode_runs(eng):
     assert len(rows["board"]) >= 64 and st["games"] >= 1 and st["evals"] > 0
     assert np.isfinite(rows["moves_prob"]).all()
     E.close()
+
+
+def test_forward_config5_shape_13x13_256ch_vs_oracle(eng, orc):
+    """BASELINE config 5's network shape (13x13, 256 channels; 2 of its 19 blocks to keep the CPU
+    oracle quick): the forward must hold the same 1e-4 bound on the wide-channel path."""
+    import torch
+    from azalea_amd.network import HexNetwork
+    torch.manual_seed(5)
+    net = HexNetwork(board_size=13, num_blocks=2, base_chans=256).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    state = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    rng = np.random.RandomState(6)
+    boards, lm = _random_positions(orc, 13, 6, rng)
+    E = eng.Engine(board_size=13, n_games=2, simulations=10, search_batch_size=10,
+                   evaluator=eng.EVAL_RESNET, num_blocks=2, base_chans=256)
+    E.set_weights(state)
+    value, logprob = E.forward(boards, lm)
+    ov, olp = orc.Net(13, 2, 256, state).forward(boards, lm)
+    legal = lm > 0
+    assert np.abs(value - ov).max() <= TOL and np.abs(logprob - olp)[legal].max() <= TOL
+    E.close()
