@@ -40,7 +40,8 @@ struct alignas(64) TreeHdr {
     int32_t pending_root;  // the pending leaf is the root evaluation (no backup)
     int32_t select_count;  // select_leaf calls so far in this search (noise row index)
     float   search_value;  // mcts.py:287 accumulator (float32)
-    int32_t pad[5];
+    int32_t slow_div;      // a backed-up value was outside the range the unscaled divide is exact for
+    int32_t pad[4];
 };
 
 struct alignas(64) GameHdr {
@@ -170,6 +171,10 @@ __device__ __forceinline__ float wave_max(float v) {
 // cell's own edge bits (bit0/1: row 0 / row N-1 for colour 1, bit2/3: column 0 / N-1 for colour 2).
 #define AZX_GEO_CELLS 820            // sum of N^2 for N = 2..13 is 818
 extern __constant__ uint64_t c_geo[AZX_GEO_CELLS * 4];
+// float32 sqrt of the integers 0..AZX_SQRT_TAB-1 (correctly rounded, filled by the host): the
+// sum of child visit counts under the square root of mcts.py:132 is always a small integer
+#define AZX_SQRT_TAB 4096
+extern __constant__ float c_sqrt[AZX_SQRT_TAB];
 __host__ __device__ inline int azx_geo_base(int N) {   // cells of all smaller boards
     int b = 0;
     for (int n = 2; n < N; ++n) b += n * n;

@@ -11,12 +11,15 @@
 //   :226-239 expand_batch, :242-255 backup_batch, :258-293 sample_paths;
 //   azalea/search_tree.py:59-71 reset, :115-132 move, :254-274 create_child_nodes;
 //   azalea/game/hex.py:137-231 rules, :72-122 perspective flip.
+#include <cmath>
 #include <cstring>
+#include <type_traits>
 
 #include "azx_dev.h"
 #include "mcts_kernels.h"
 
 __constant__ uint64_t c_geo[AZX_GEO_CELLS * 4];
+__constant__ float c_sqrt[AZX_SQRT_TAB];
 
 // fill c_geo for every supported board size (once per device)
 int azx_init_geometry(int device) {
@@ -42,6 +45,9 @@ int azx_init_geometry(int device) {
             }
     }
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_geo), tab, sizeof tab) != hipSuccess) return -1;
+    static float rt[AZX_SQRT_TAB];
+    for (int i = 0; i < AZX_SQRT_TAB; ++i) rt[i] = sqrtf((float)i);   // IEEE: same bits as np.sqrt(float32)
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_sqrt), rt, sizeof rt) != hipSuccess) return -1;
     if (device >= 0 && device < 64) done[device] = true;
     return 0;
 }
@@ -101,36 +107,53 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     return x;
 }
 
-// log of a Gamma(alpha) variate for 0 < alpha < 1: Ahrens-Dieter GS rejection sampler, kept in
+// order-preserving float32 <-> uint32 map (total order of the non-NaN floats): wave maxima of
+// floats become one v_max_u32 per DPP step, and the inverse runs on the scalar unit
+__device__ __forceinline__ uint32_t f32_key(float x) {
+    const uint32_t b = (uint32_t)__float_as_int(x);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(uint32_t k) {
+    return __int_as_float((int)((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k));
+}
+
+// log2 of a Gamma(alpha) variate for 0 < alpha < 1: Ahrens-Dieter GS rejection sampler, kept in
 // log space (for alpha = 0.03 x = p^(1/alpha) underflows float32 all the time; only the ratios
 // matter to the Dirichlet).  With b = 1 + alpha/e:  p = b*U1;  p <= 1: x = p^(1/alpha), accept
 // if U2 <= exp(-x);  else x = -ln((b-p)/alpha), accept if U2 <= x^(alpha-1).
-// `stream` is unique per (game, ply, select_leaf call); the cell index decorrelates lanes.
+// `seed` is unique per (game, ply, select_leaf call, cell).  U1 is a mixed 32-bit hash of the
+// seed, U2 its multiplicative scramble (the pairs form a 2^32-point lattice over the unit
+// square, plenty for an accept test that passes ~98 % of the time).
 // Native-rate transcendentals on purpose: this is noise, not part of the bit-exact score path.
-struct GammaConst { float alpha, inv_alpha, b; };
+struct GammaConst { float alpha, inv_alpha, b, bs24, bs25, am1; };
 __device__ __forceinline__ GammaConst gamma_const(float alpha) {
     GammaConst g;
     g.alpha = alpha;
     g.inv_alpha = __builtin_amdgcn_rcpf(alpha);
     g.b = 1.0f + alpha * 0.36787944f;
+    g.bs24 = g.b * (1.0f / 16777216.0f);
+    g.bs25 = g.b * (0.5f / 16777216.0f);
+    g.am1 = alpha - 1.0f;
     return g;
 }
-__device__ __forceinline__ float fast_ln(float x) { return __builtin_amdgcn_logf(x) * 0.69314718f; }
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504f); }
-__device__ inline float log_gamma_variate(uint32_t stream, uint32_t cell, const GammaConst &gc) {
+__device__ inline float log2_gamma_variate(uint32_t seed, const GammaConst &gc) {
     float lx = 0.0f;
-    uint32_t x = mix32(stream ^ (cell * 0x9E3779B9u));
+    uint32_t x = seed;
     for (uint32_t t = 0; t < 32; ++t) {
-        const uint32_t r0 = mix32(x + 0x68bc21ebu), r1 = mix32(x + 0x02e5be93u);
-        x = r1 ^ (r0 >> 3);
-        const float p = gc.b * u01(r0), u2 = u01(r1);
+        const uint32_t r0 = mix32(x);
+        uint32_t r1 = r0 * 0x9E3779B9u;
+        r1 ^= r1 >> 15;
+        x = r1 + 0x68bc21ebu;
+        // p = b * (r0>>8 + 0.5) / 2^24,  u2 = (r1>>8 + 0.5) / 2^24
+        const float p = __builtin_fmaf((float)(r0 >> 8), gc.bs24, gc.bs25);
+        const float u2 = __builtin_fmaf((float)(r1 >> 8), 1.0f / 16777216.0f, 0.5f / 16777216.0f);
         if (p <= 1.0f) {
-            lx = fast_ln(p) * gc.inv_alpha;
-            if (u2 <= fast_exp(-fast_exp(lx))) break;
+            lx = __builtin_amdgcn_logf(p) * gc.inv_alpha;                      // log2 x
+            if (u2 <= __builtin_amdgcn_exp2f(__builtin_amdgcn_exp2f(lx) * -1.44269504f)) break;
         } else {
-            const float xv = -fast_ln((gc.b - p) * gc.inv_alpha);
-            lx = fast_ln(xv);
-            if (u2 <= fast_exp((gc.alpha - 1.0f) * lx)) break;
+            const float xv = __builtin_amdgcn_logf((gc.b - p) * gc.inv_alpha) * -0.69314718f;
+            lx = __builtin_amdgcn_logf(xv);
+            if (u2 <= __builtin_amdgcn_exp2f(gc.am1 * lx)) break;
         }
     }
     return lx;
@@ -138,25 +161,26 @@ __device__ inline float log_gamma_variate(uint32_t stream, uint32_t cell, const 
 
 // scale * Dirichlet(alpha * 1_k) over the cells set in m[] (one value per lane-slot), the device
 // counterpart of rng.dirichlet(np.full(k, alpha)) at mcts.py:128: independent Gamma(alpha)
-// variates normalised by their sum, computed from log-variates with the maximum subtracted.
+// variates normalised by their sum, computed from log2-variates with the maximum subtracted.
 template <int SLOTS>
 __device__ __forceinline__ void dirichlet_noise(const uint64_t *m, int lane, uint32_t stream,
                                                 const GammaConst &gc, float scale, float *nz) {
     float lg[SLOTS];
-    float mx = -3.0e38f;
+    uint32_t kmax = 0u;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        lg[s] = -3.0e38f;
+        lg[s] = 0.0f;
         if (lane_bit(m[s])) {
-            lg[s] = log_gamma_variate(stream, (uint32_t)(s * 64 + lane), gc);
-            mx = fmaxf(mx, lg[s]);
+            lg[s] = log2_gamma_variate(stream ^ ((uint32_t)(s * 64 + lane) * 0x9E3779B9u), gc);
+            const uint32_t k = f32_key(lg[s]);
+            kmax = k > kmax ? k : kmax;
         }
     }
-    mx = wave_max(mx);
+    const float mx = key_f32(wave_max_u32(kmax));   // >= one cell is set whenever this is called
     float sw = 0.0f;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        nz[s] = lane_bit(m[s]) ? fast_exp(lg[s] - mx) : 0.0f;
+        nz[s] = lane_bit(m[s]) ? __builtin_amdgcn_exp2f(lg[s] - mx) : 0.0f;
         sw += nz[s];
     }
     sw = scale * __builtin_amdgcn_rcpf(wave_sum(sw));
@@ -225,6 +249,46 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+// ---- score arithmetic, two board slots per instruction (v_pk_mul/add/fma_f32) -----------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+// Correctly rounded float32 n/d: the reciprocal-refine-correct FMA chain the compiler emits for
+// an IEEE '/', without its v_div_scale / v_div_fixup range handling.  Exact (same bits as '/')
+// whenever d is normal in [1, 2^24] and n is 0 or 2^-100 <= |n| <= 2^100: no intermediate
+// underflows, so scaling would be the identity.  (A -0 numerator gives +0; the score adds 0.0
+// afterwards, mcts.py:135, so the sign of a zero never reaches the argmax.)
+__device__ __forceinline__ f2 div2_unscaled(f2 n, f2 d) {
+    f2 r;
+    r.x = __builtin_amdgcn_rcpf(d.x);
+    r.y = __builtin_amdgcn_rcpf(d.y);
+    const f2 one = {1.0f, 1.0f};
+    f2 e = fma2(-d, r, one);
+    r = fma2(e, r, r);
+    f2 q = n * r;
+    e = fma2(-d, q, n);
+    q = fma2(e, r, q);
+    e = fma2(-d, q, n);
+    return fma2(e, r, q);
+}
+__device__ __forceinline__ f2 div2_ieee(f2 n, f2 d) {
+    f2 q;
+    q.x = n.x / d.x;
+    q.y = n.y / d.y;
+    return q;
+}
+// values whose backup keeps every total_value either 0 or >= 2^-83 in magnitude (sums of
+// multiples of 2^-83 stay multiples of it): 0 or 2^-60 <= |v|
+__device__ __forceinline__ bool value_in_fast_range(float v) {
+    const float a = __builtin_fabsf(v);
+    return v == 0.0f || (a >= 8.67361738e-19f && a <= 1.0e30f);
+}
+// wave-uniform float load on the scalar unit (lgkmcnt): keeps vmcnt free of read-after-store waits
+__device__ __forceinline__ float sload_f32(const float *p) {
+    float v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
 // ============================================================================================
 // The search kernel.  mode = MODE_* bits (mcts_kernels.h).
 //
@@ -259,6 +323,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
     int pending_root = th->pending_root;
     int select_count = th->select_count;
     float search_value = th->search_value;
+    bool slow_div = th->slow_div != 0;
     Node *arena = E.arena[th->arena] + (size_t)g * E.cap;
 
     HexWave<SLOTS> root;
@@ -304,6 +369,22 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
             if (root_link >= 0 && rempty[s])
                 rst[s] = *reinterpret_cast<const float4 *>(arena + root_link + rrk[s]);
         }
+    }
+    // sum of the root children's visit counts (the integer under the square root of mcts.py:132),
+    // kept as a scalar: every change of a root child's count goes through root_child_add
+    int root_sumn = 0;
+    {
+        int t = 0;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) t += (int)rst[s].x;
+        root_sumn = wave_sum_i(t);
+    }
+    uint64_t rootall[SLOTS];           // cells that are not empty at the root: stones + off-board bits
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int nvalid = ncells - 64 * s;
+        const uint64_t valid = nvalid >= 64 ? ~0ull : (nvalid <= 0 ? 0ull : ((1ull << nvalid) - 1ull));
+        rootall[s] = root.occ[0][s] | root.occ[1][s] | ~valid;
     }
     int c_id = -1, n_c = 0;            // node cache: entry j lives in lane j
     float c_nv = 0.0f, c_tv = 0.0f;
@@ -356,6 +437,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
         if (n_c == 64) cache_flush();
         if (!known) {
             const float2 x = *reinterpret_cast<const float2 *>(arena + id);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) here, so the (usual) hit path never waits
             nv0 = x.x;
             tv0 = x.y;
         }
@@ -364,6 +446,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
     };
     auto root_child_add = [&](int cell, float dv, float dt) {
         const int ln = cell & 63, sl = cell >> 6;
+        root_sumn += (int)dv;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s)
             if (s == sl && lane == ln) { rst[s].x += dv; rst[s].y += dt; }
@@ -380,7 +463,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
         if (len >= 1) root_child_add(cell0, dv, (alternate && ((len - 1) & 1)) ? -amount : amount);
         for (int d = 1; d < len; ++d) {
             const float a = (alternate && ((len - 1 - d) & 1)) ? -amount : amount;
-            const int slot = cache_find(pth[d], false, 0.f, 0.f);
+            const int slot = cache_find(pth[d] & 0xffffff, false, 0.f, 0.f);
             if (lane == slot) { c_nv += dv; c_tv += a; }
         }
     };
@@ -418,6 +501,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
         const int newlink = (k > 0) ? fc : AZX_LINK_TERM(fc);
         if (len == 0) {                                   // the root itself
             root_link = newlink;
+            root_sumn = 0;
             if (lane == 0) arena[root_id].link = newlink;
         } else if (len == 1) {                            // a root child: its link is in registers
             const int c0 = cells & 0xffff, ln = c0 & 63, sl = c0 >> 6;
@@ -467,7 +551,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
 
     auto inline_prior = [&](int k) -> float {
         // the default table is float32 1/k: the IEEE divide gives the same bits without a load
-        return E.prior_default ? 1.0f / (float)k : E.prior_by_k[k];
+        return E.prior_default ? 1.0f / (float)k : sload_f32(E.prior_by_k + k);
     };
 
     // =================================== BEGIN: root evaluation (mcts.py:272-273) ========
@@ -521,6 +605,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
             const bool terminal = ev < 0;
             float v = -1.0f;                                   // mcts.py:194-195
             if (!terminal) v = E.ev_value[ev];
+            if (!value_in_fast_range(v)) slow_div = true;
             if (!expand(node, len, cells, lnk, terminal, lm,
                         terminal ? nullptr : E.ev_prior + (size_t)ev * AZX_CELL_STRIDE, 0.0f))
                 break;
@@ -543,14 +628,29 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
 
         // ---- select_batch: bs sequential descents with virtual loss (mcts.py:62-70) ----
         for (int i = 0; i < bs; ++i) {
-            HexWave<SLOTS> cur = root;                        // snapshot/restore, search_tree.py:150-154
+            // snapshot/restore (search_tree.py:150-154): the descent only tracks which cells are
+            // occupied (`all`), scalar bit-ors; the win test runs once, at a new leaf (interior
+            // nodes are not won)
+            uint64_t all[SLOTS];
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) all[s] = rootall[s];
+            int mover = root.color;                           // colour placing the next stone
             int link = root_link;
             int depth = 0, node = root_id, child_link = 0, cell0 = 0, cellL = 0;
             float cur_nv = 0.0f;               // num_visits (incl. virtual) of the node being scored
             bool at_root = true;
             for (;;) {
-                Masks<SLOTS> mk = rootmk;
-                if (!at_root) mk = make_masks<SLOTS>(cur, lane, ncells);
+                Masks<SLOTS> mk;
+                {
+                    int k = 0;
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) {
+                        mk.m[s] = ~all[s];
+                        mk.base[s] = k;
+                        k += popc64(mk.m[s]);
+                    }
+                    mk.k = k;
+                }
                 int best_cell = 0x7fffffff, child_rank = 0;
                 float cnv = 0.f, ctv = 0.f;
                 if (!at_root && cur_nv == 1.0f) {
@@ -565,7 +665,6 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                     // ---- children statistics ------------------------------------------------
                     float4 st[SLOTS];
                     int rk[SLOTS];
-                    float sumn = 0.0f;
                     if (at_root) {
 #pragma unroll
                         for (int s = 0; s < SLOTS; ++s) { st[s] = rst[s]; rk[s] = rrk[s]; }
@@ -589,11 +688,12 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                                 if (lane_bit(mk.m[s]) && rk[s] == r) { st[s].x = pnv; st[s].y = ptv; }
                         }
                     }
-#pragma unroll
-                    for (int s = 0; s < SLOTS; ++s)
-                        if (lane_bit(mk.m[s])) sumn += st[s].x;
-                    sumn = wave_sum(sumn);                         // exact: visit counts are integers
-                    const float sq = sqrtf(sumn);                  // mcts.py:132
+                    // sqrt(sum of the children's visits), mcts.py:132.  The sum is an integer known
+                    // without adding anything up: root_sumn at the root, and below it every
+                    // evaluated node has been visited once more than its children together (its
+                    // own expansion), virtual losses included since they mark node and child alike.
+                    const int sumn = at_root ? root_sumn : (int)cur_nv - 1;
+                    const float sq = sumn < AZX_SQRT_TAB ? c_sqrt[sumn] : sqrtf((float)sumn);
                     // ---- Dirichlet noise at the root only (mcts.py:126-131, :114) ----------
                     float nz[SLOTS];
                     const bool noisy = at_root && E.noise_scale != 0.0;
@@ -621,21 +721,36 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                         }
                     }
                     uint32_t key[SLOTS], lkey = 0u;
+                    auto score_slots = [&](auto exact_tag) {
+                        constexpr bool kIeee = decltype(exact_tag)::value;
 #pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) {
-                        const float nvj = st[s].x;
-                        const float gap = sq / (1.0f + nvj);              // mcts.py:132
-                        const float U = (c32 * Pn[s]) * gap;              // mcts.py:133
-                        const float W = -st[s].y;                         // search_tree.py:203
-                        const float Q = W / (nvj < 1.0f ? 1.0f : nvj);    // mcts.py:134 (clip(min=1))
-                        const float score = (Q + U) + 0.0f;               // mcts.py:135; -0.0 -> +0.0
-                        // order-preserving map float -> u32 (np.argmax compares values; equal
-                        // floats <=> equal keys once -0.0 is folded into +0.0)
-                        const uint32_t bts = (uint32_t)__float_as_int(score);
-                        const uint32_t k32 = bts ^ ((uint32_t)((int32_t)bts >> 31) | 0x80000000u);
-                        key[s] = lane_bit(mk.m[s]) ? k32 : 0u;
-                        lkey = key[s] > lkey ? key[s] : lkey;
-                    }
+                        for (int s = 0; s < SLOTS; s += 2) {
+                            const int s1 = s + 1 < SLOTS ? s + 1 : s;
+                            const f2 nvj = {st[s].x, st[s1].x};
+                            const f2 tvj = {st[s].y, st[s1].y};
+                            const f2 P = {Pn[s], Pn[s1]};
+                            const f2 sq2 = {sq, sq}, one = {1.0f, 1.0f}, zero = {0.0f, 0.0f}, c2 = {c32, c32};
+                            const f2 dg = one + nvj;
+                            const f2 gap = kIeee ? div2_ieee(sq2, dg) : div2_unscaled(sq2, dg);   // mcts.py:132
+                            const f2 U = (c2 * P) * gap;                                       // mcts.py:133
+                            f2 dq;                                                             // clip(min=1)
+                            dq.x = __builtin_amdgcn_fmed3f(nvj.x, 1.0f, 3.0e38f);
+                            dq.y = __builtin_amdgcn_fmed3f(nvj.y, 1.0f, 3.0e38f);
+                            const f2 W = -tvj;                                                 // search_tree.py:203
+                            const f2 Q = kIeee ? div2_ieee(W, dq) : div2_unscaled(W, dq);     // mcts.py:134
+                            const f2 score = (Q + U) + zero;                    // mcts.py:135; -0.0 -> +0.0
+                            // order-preserving map float -> u32 (np.argmax compares values; equal
+                            // floats <=> equal keys once -0.0 is folded into +0.0)
+                            key[s] = lane_bit(mk.m[s]) ? f32_key(score.x) : 0u;
+                            lkey = key[s] > lkey ? key[s] : lkey;
+                            if (s1 != s) {
+                                key[s1] = lane_bit(mk.m[s1]) ? f32_key(score.y) : 0u;
+                                lkey = key[s1] > lkey ? key[s1] : lkey;
+                            }
+                        }
+                    };
+                    if (slow_div) score_slots(std::true_type{});
+                    else score_slots(std::false_type{});
                     // np.argmax: highest score, lowest index on ties (mcts.py:112): wave max of the
                     // keys, then the lowest cell holding it
                     {
@@ -663,8 +778,14 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                 if (at_root) cell0 = best_cell;
                 else (void)cache_find(node, true, cnv, ctv);   // deeper path nodes enter the cache
                 cellL = best_cell;
-                if (lane == 0) L.path[i * pstride + depth] = node;
-                cur.step(best_cell, N, lane);                  // search_tree.py:306-308
+                if (lane == 0) L.path[i * pstride + depth] = node | (best_cell << 24);
+                {                                              // search_tree.py:306-308, stones only
+                    const uint64_t bit = 1ull << (best_cell & 63);
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s)
+                        if (s == (best_cell >> 6)) all[s] |= bit;
+                    mover = 3 - mover;
+                }
                 T_MARK(2)
                 depth += 1;
                 at_root = false;
@@ -674,23 +795,66 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
             }
             select_count += 1;
             c_selects += 1;
-            // record the leaf (mcts.py:69-70) ...
-            const Masks<SLOTS> lmk = make_masks<SLOTS>(cur, lane, ncells);
+            // ---- the leaf position: winner (hex.py:204-231) and legal moves ---------------------
+            const int last = 3 - mover;                       // colour of the stone just placed
+            int winner = last;                                // a terminal link: the last mover won
+            if (child_link == AZX_LINK_UNEVAL) {
+                if (depth <= 2) {
+                    // `last` has one stone on the path: OR the edge flags of the root groups around it
+                    const uint64_t *gp = c_geo + (size_t)(root.gbase + cellL) * 4;
+                    uint32_t flags = (uint32_t)(gp[3] >> (2 * (last - 1))) & 3u;
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) {
+                        uint64_t m = gp[s] & (last == 1 ? root.occ[0][s] : root.occ[1][s]);
+                        while (m) {
+                            const int j = (int)__ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            flags |= ((uint32_t)__builtin_amdgcn_readlane((int)root.c[s], j) >> 2) & 3u;
+                        }
+                    }
+                    winner = flags == 3u ? last : 0;
+                } else {
+                    // several stones of `last`: replay them on a copy of the root groups
+                    lds_sync();
+                    HexWave<SLOTS> tmp = root;
+                    for (int d = (depth - 1) & 1; d < depth; d += 2) {
+                        const int cell = (L.path[i * pstride + d] >> 24) & 0xff;
+                        tmp.color = last;
+                        tmp.step(cell, N, lane);
+                    }
+                    winner = tmp.winner;
+                }
+            }
+            uint64_t lmask[SLOTS];
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) lmask[s] = ~all[s];
             if (need_colors) {
+                // the leaf board: root colours plus the path's stones, alternating from the root mover
+                lds_sync();
+                uint32_t v[SLOTS];
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) v[s] = root.c[s] & 3u;
+                for (int d = 0; d < depth; ++d) {
+                    const int cell = (L.path[i * pstride + d] >> 24) & 0xff;
+                    const uint32_t colour = (uint32_t)((d & 1) ? 3 - root.color : root.color);
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s)
+                        if (s * 64 + lane == cell) v[s] = colour;
+                }
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s) {
                     const int cell = s * 64 + lane;
-                    if (cell < ncells) L.colors[i * AZX_CELL_STRIDE + cell] = (unsigned char)(cur.c[s] & 3u);
+                    if (cell < ncells) L.colors[i * AZX_CELL_STRIDE + cell] = (unsigned char)v[s];
                 }
             }
             if (lane == i) {
                 m_node = node;
                 m_len = depth;
                 m_link = child_link;
-                m_tm = (cur.winner != 0 ? 1 : 0) | (cur.color << 1);
+                m_tm = (winner != 0 ? 1 : 0) | (mover << 1);
                 m_cells = cell0 | (cellL << 16);
 #pragma unroll
-                for (int s = 0; s < SLOTS; ++s) m_mask[s] = lmk.m[s];
+                for (int s = 0; s < SLOTS; ++s) m_mask[s] = lmask[s];
             }
             lds_sync();
             // ... and apply the virtual loss to its path (mcts.py:68, :79-92)
@@ -728,6 +892,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                     v = (E.evaluator == AZX_EVAL_UNIFORM_HASH)
                             ? hash_value(L.colors + i * AZX_CELL_STRIDE, tm >> 1) : 0.0f;
                     c_evals += 1;
+                    if (!value_in_fast_range(v)) slow_div = true;
                 } else {
                     c_term += 1;
                 }
@@ -794,6 +959,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
         th->pending_root = pending_root;
         th->select_count = select_count;
         th->search_value = search_value;
+        th->slow_div = slow_div ? 1 : 0;
         if (c_selects) E.counters[(size_t)g * CTR_COUNT + CTR_SELECTS] += c_selects;
         if (c_depth) E.counters[(size_t)g * CTR_COUNT + CTR_SUM_DEPTH] += c_depth;
         if (c_kint) E.counters[(size_t)g * CTR_COUNT + CTR_SUM_K_INT] += c_kint;
@@ -824,6 +990,7 @@ __device__ __forceinline__ void tree_reset(const DevEngine &E, int g, TreeHdr *t
         th->pending_root = 0;
         th->select_count = 0;
         th->search_value = 0.0f;
+        th->slow_div = 0;
     }
 }
 
