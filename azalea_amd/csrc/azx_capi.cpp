@@ -852,6 +852,15 @@ extern "C" int azx_selftest_dirichlet(int device, double alpha, int k, int n_row
     return AZX_OK;
 }
 
+extern "C" int azx_debug_counters_raw(azx_engine *e, uint64_t *out, int64_t n_games) {
+    if (!e || !out) return fail(AZX_EINVAL, "null argument");
+    if (n_games != e->d.G) return fail(AZX_EINVAL, "n_games must equal the engine's game count");
+    HIPCHECK(hipMemcpyAsync(out, e->d.counters, (size_t)n_games * CTR_COUNT * sizeof(unsigned long long),
+                            hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    return AZX_OK;
+}
+
 extern "C" int azx_debug_counters(azx_engine *e, uint64_t *out16) {
     if (!e || !out16) return fail(AZX_EINVAL, "null argument");
     CounterSnap snap;

@@ -254,6 +254,11 @@ class Engine:
         check(self.L.azx_debug_counters(self.h, _p(out, C.c_uint64)))
         return out
 
+    def debug_counters_raw(self):
+        out = np.zeros((self.G, 16), np.uint64)
+        check(self.L.azx_debug_counters_raw(self.h, _p(out, C.c_uint64), self.G))
+        return out
+
     def play_steps(self, plies):
         st = PlayStats()
         check(self.L.azx_play_steps(self.h, int(plies), C.byref(st)))

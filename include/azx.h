@@ -204,6 +204,8 @@ int azx_selftest_dirichlet(int device, double alpha, int k, int n_rows, uint32_t
 /* raw device counters (16 x u64) since engine creation: selects, sum_depth, sum_k_interior,
  * sum_k_leaf, evals, terminal evals, games, errors, plies, rows, then diagnostic slots */
 int azx_debug_counters(azx_engine *e, uint64_t *out16);
+/* the same counters per game slot, not summed: out[n_games][16] (diagnostics: load balance) */
+int azx_debug_counters_raw(azx_engine *e, uint64_t *out, int64_t n_games);
 
 /* engine stream (hipStream_t) so callers can bracket work with HIP events */
 void *azx_stream(azx_engine *e);
