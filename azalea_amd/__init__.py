@@ -12,6 +12,7 @@ _LAZY = {
     "ReplayBuffer": ("replay_buffer", "ReplayBuffer"),
     "ReplayDataFrame": ("replay_buffer", "ReplayDataFrame"),
     "ReplayRecord": ("replay_buffer", "ReplayRecord"),
+    "DeviceReplayBuffer": ("device_replay", "DeviceReplayBuffer"),
     "HexGame": ("game.hex", "HexGame"),
     "HexNetwork": ("network", "HexNetwork"),
     "SearchTreeFull": ("policy", "SearchTreeFull"),

@@ -77,6 +77,12 @@ SYMBOLS = {
     "azx_hex_replay": (C.c_int, [C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _i32p, _i32p, _u64p, _i32p]),
     "azx_play": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _i32p, _i32p, _i32p, _f32p, _f32p, _i64p, C.POINTER(PlayStats)]),
     "azx_play_steps": (C.c_int, [_vp, C.c_int64, C.POINTER(PlayStats)]),
+    "azx_replay_create": (C.c_int, [_vp, C.c_int64]),
+    "azx_replay_state": (C.c_int, [_vp, _i64p, _i64p, _i64p]),
+    "azx_replay_set_state": (C.c_int, [_vp, C.c_int64, C.c_int64]),
+    "azx_replay_put": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, _i32p, _f32p, _f32p]),
+    "azx_replay_fill": (C.c_int, [_vp, C.c_int64, C.c_int64, _i64p, C.POINTER(PlayStats)]),
+    "azx_replay_collate": (C.c_int, [_vp, C.c_int64, _i64p, _vp, _vp, _vp, _vp, _vp, _vp, _i32p]),
     "azx_selftest_arith": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p]),
     "azx_selftest_dirichlet": (C.c_int, [C.c_int, C.c_double, C.c_int, C.c_int, C.c_uint32, _f32p]),
     "azx_debug_counters": (C.c_int, [_vp, _u64p]),

@@ -16,6 +16,7 @@
 #include "azx_dev.h"
 #include "mcts_kernels.h"
 #include "net.h"
+#include "replay_kernels.h"
 
 static thread_local std::string g_err;
 
@@ -63,6 +64,13 @@ struct azx_engine {
     bool play_ready = false;
     int64_t q_alloc = 0;
     std::vector<void *> q_allocs;
+    // device-resident replay ring (azx_replay_*)
+    ReplayRows ring = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t ring_cap = 0, ring_size = 0, ring_write = 0;
+    long long *ring_idx = nullptr;      // sampled row indices of the collate in flight
+    int64_t ring_idx_cap = 0;
+    int32_t *ring_maxk = nullptr;
+    std::vector<void *> ring_allocs;
     // timing
     std::vector<hipEvent_t> ev_pool;
     std::vector<char> ev_tag;           // 0 = tree kernel, 1 = network (tower + heads)
@@ -185,6 +193,7 @@ extern "C" void azx_destroy(azx_engine *e) {
     if (e->net) azx_net_destroy(e->net);
     for (void *p : e->allocs) (void)hipFree(p);
     for (void *p : e->q_allocs) (void)hipFree(p);
+    for (void *p : e->ring_allocs) (void)hipFree(p);
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -760,17 +769,12 @@ extern "C" int azx_play_steps(azx_engine *e, int64_t plies, azx_play_stats *stat
     return AZX_OK;
 }
 
-extern "C" int azx_play(azx_engine *e, int64_t min_positions, int64_t max_plies, int64_t cap,
-                        int32_t *board, int32_t *color, int32_t *nlegal, float *moves_prob,
-                        float *reward, int64_t *game_uid, azx_play_stats *stats) {
-    if (!e || !stats) return fail(AZX_EINVAL, "null argument");
-    if (e->d.evaluator == AZX_EVAL_EXTERNAL) return fail(AZX_ESTATE, "play mode needs a device evaluator");
+// play whole games into the harvest queue until it holds >= min_positions rows
+static int play_until(azx_engine *e, int64_t min_positions, int64_t max_plies, azx_play_stats *stats,
+                      unsigned long long *rows_out) {
     DevEngine &d = e->d;
     memset(stats, 0, sizeof *stats);
     const int64_t worst = min_positions + (int64_t)d.G * d.ncells;
-    if (cap < worst)
-        return fail(AZX_EINVAL, "cap %lld < min_positions + n_games*cells = %lld (whole games only)",
-                    (long long)cap, (long long)worst);
     TRY(play_setup(e, worst, 0));
     TRY(upload_noise(e, nullptr, 0, 0, e->cfg.noise_scale));
     CounterSnap a, b;
@@ -796,6 +800,22 @@ extern "C" int azx_play(azx_engine *e, int64_t min_positions, int64_t max_plies,
     stats->positions = (int64_t)rows;
     stats->seconds = ms * 1e-3;
     time_collect(e, stats);
+    *rows_out = rows;
+    return AZX_OK;
+}
+
+extern "C" int azx_play(azx_engine *e, int64_t min_positions, int64_t max_plies, int64_t cap,
+                        int32_t *board, int32_t *color, int32_t *nlegal, float *moves_prob,
+                        float *reward, int64_t *game_uid, azx_play_stats *stats) {
+    if (!e || !stats) return fail(AZX_EINVAL, "null argument");
+    if (e->d.evaluator == AZX_EVAL_EXTERNAL) return fail(AZX_ESTATE, "play mode needs a device evaluator");
+    DevEngine &d = e->d;
+    const int64_t worst = min_positions + (int64_t)d.G * d.ncells;
+    if (cap < worst)
+        return fail(AZX_EINVAL, "cap %lld < min_positions + n_games*cells = %lld (whole games only)",
+                    (long long)cap, (long long)worst);
+    unsigned long long rows = 0;
+    TRY(play_until(e, min_positions, max_plies, stats, &rows));
     if (rows == 0) return AZX_OK;
     const size_t n = (size_t)rows;
     std::vector<uint8_t> hb(n * AZX_CELL_STRIDE);
@@ -813,6 +833,137 @@ extern "C" int azx_play(azx_engine *e, int64_t min_positions, int64_t max_plies,
         if (moves_prob)
             for (int c = 0; c < d.ncells; ++c) moves_prob[r * d.ncells + c] = hp[r * AZX_CELL_STRIDE + c];
     }
+    return AZX_OK;
+}
+
+// ---- device-resident replay ring: ReplayBuffer.put FIFO (replay_buffer.py:134-149) and the
+// prep.batch_replays collate (prep.py:24-39) without leaving HBM ---------------------------------
+extern "C" int azx_replay_create(azx_engine *e, int64_t capacity) {
+    if (!e) return fail(AZX_EINVAL, "null engine");
+    if (capacity < 1) return fail(AZX_EINVAL, "capacity must be >= 1");
+    (void)hipStreamSynchronize(e->stream);
+    for (void *p : e->ring_allocs) (void)hipFree(p);
+    e->ring_allocs.clear();
+    e->ring_cap = e->ring_size = e->ring_write = 0;
+    e->ring_idx = nullptr;
+    e->ring_idx_cap = 0;
+    auto ra = [&](void **p, size_t bytes) -> int {
+        hipError_t err = hipMalloc(p, bytes);
+        if (err != hipSuccess) return fail(AZX_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+        e->ring_allocs.push_back(*p);
+        return AZX_OK;
+    };
+    TRY(ra((void **)&e->ring.board, (size_t)capacity * AZX_CELL_STRIDE));
+    TRY(ra((void **)&e->ring.prob, (size_t)capacity * AZX_CELL_STRIDE * sizeof(float)));
+    TRY(ra((void **)&e->ring.color, (size_t)capacity * sizeof(int32_t)));
+    TRY(ra((void **)&e->ring.k, (size_t)capacity * sizeof(int32_t)));
+    TRY(ra((void **)&e->ring.reward, (size_t)capacity * sizeof(float)));
+    TRY(ra((void **)&e->ring_maxk, sizeof(int32_t)));
+    e->ring_cap = capacity;
+    return AZX_OK;
+}
+
+extern "C" int azx_replay_state(azx_engine *e, int64_t *capacity, int64_t *size, int64_t *write_idx) {
+    if (!e) return fail(AZX_EINVAL, "null engine");
+    if (capacity) *capacity = e->ring_cap;
+    if (size) *size = e->ring_size;
+    if (write_idx) *write_idx = e->ring_write;
+    return AZX_OK;
+}
+
+extern "C" int azx_replay_set_state(azx_engine *e, int64_t size, int64_t write_idx) {
+    if (!e) return fail(AZX_EINVAL, "null engine");
+    if (e->ring_cap == 0) return fail(AZX_ESTATE, "no replay ring: call azx_replay_create first");
+    if (size < 0 || size > e->ring_cap || write_idx < 0 || write_idx >= e->ring_cap)
+        return fail(AZX_EINVAL, "size/write_idx outside the ring");
+    e->ring_size = size;
+    e->ring_write = write_idx;
+    return AZX_OK;
+}
+
+// rows [0, n) of `src` enter the ring in order, oldest rows overwritten first
+static int ring_put(azx_engine *e, const ReplayRows &src, int64_t n) {
+    azx_launch_replay_put(src, e->ring, n, e->ring_cap, e->ring_write, e->stream);
+    HIPCHECK(hipGetLastError());
+    e->ring_write = (e->ring_write + n) % e->ring_cap;
+    e->ring_size = std::min<int64_t>(e->ring_cap, e->ring_size + n);
+    return AZX_OK;
+}
+
+extern "C" int azx_replay_put(azx_engine *e, int64_t n, const int32_t *board, const int32_t *color,
+                              const int32_t *nlegal, const float *moves_prob, const float *reward) {
+    if (!e || !board || !color || !nlegal || !moves_prob || !reward) return fail(AZX_EINVAL, "null argument");
+    if (e->ring_cap == 0) return fail(AZX_ESTATE, "no replay ring: call azx_replay_create first");
+    if (n < 0) return fail(AZX_EINVAL, "n must be >= 0");
+    if (n == 0) return AZX_OK;
+    DevEngine &d = e->d;
+    // stage through the harvest queue buffers (same row format)
+    TRY(play_setup(e, n, 0));
+    std::vector<uint8_t> hb((size_t)n * AZX_CELL_STRIDE, 0);
+    std::vector<float> hp((size_t)n * AZX_CELL_STRIDE, 0.0f);
+    for (int64_t r = 0; r < n; ++r) {
+        if (nlegal[r] < 0 || nlegal[r] > d.ncells) return fail(AZX_EINVAL, "row %lld: nlegal out of range", (long long)r);
+        for (int c = 0; c < d.ncells; ++c) {
+            const int32_t v = board[r * d.ncells + c];
+            if (v < 0 || v > 2) return fail(AZX_EINVAL, "row %lld: cell value %d", (long long)r, v);
+            hb[r * AZX_CELL_STRIDE + c] = (uint8_t)v;
+        }
+        for (int c = 0; c < nlegal[r]; ++c) hp[r * AZX_CELL_STRIDE + c] = moves_prob[r * d.ncells + c];
+    }
+    HIPCHECK(hipMemcpyAsync(d.q_board, hb.data(), hb.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(hipMemcpyAsync(d.q_prob, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(hipMemcpyAsync(d.q_color, color, n * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(hipMemcpyAsync(d.q_k, nlegal, n * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(hipMemcpyAsync(d.q_reward, reward, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    const ReplayRows src = {d.q_board, d.q_prob, d.q_color, d.q_k, d.q_reward};
+    TRY(ring_put(e, src, n));
+    HIPCHECK(hipStreamSynchronize(e->stream));   // the host staging vectors die here
+    return AZX_OK;
+}
+
+extern "C" int azx_replay_fill(azx_engine *e, int64_t min_positions, int64_t max_plies,
+                               int64_t *rows_out, azx_play_stats *stats) {
+    if (!e || !stats) return fail(AZX_EINVAL, "null argument");
+    if (e->ring_cap == 0) return fail(AZX_ESTATE, "no replay ring: call azx_replay_create first");
+    if (e->d.evaluator == AZX_EVAL_EXTERNAL) return fail(AZX_ESTATE, "play mode needs a device evaluator");
+    unsigned long long rows = 0;
+    TRY(play_until(e, min_positions, max_plies, stats, &rows));
+    DevEngine &d = e->d;
+    const ReplayRows src = {d.q_board, d.q_prob, d.q_color, d.q_k, d.q_reward};
+    if (rows) TRY(ring_put(e, src, (int64_t)rows));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    if (rows_out) *rows_out = (int64_t)rows;
+    return AZX_OK;
+}
+
+extern "C" int azx_replay_collate(azx_engine *e, int64_t batch, const int64_t *indices, int64_t *color_dev,
+                                  int32_t *legal_moves_dev, int64_t *result_dev, int32_t *board_dev,
+                                  float *moves_prob_dev, float *reward_dev, int32_t *max_k_out) {
+    if (!e || !indices || !color_dev || !legal_moves_dev || !result_dev || !board_dev || !moves_prob_dev ||
+        !reward_dev || !max_k_out)
+        return fail(AZX_EINVAL, "null argument");
+    if (e->ring_cap == 0) return fail(AZX_ESTATE, "no replay ring: call azx_replay_create first");
+    if (batch < 1 || batch > (1 << 24)) return fail(AZX_EINVAL, "batch outside [1, 2^24]");
+    for (int64_t b = 0; b < batch; ++b)
+        if (indices[b] < 0 || indices[b] >= e->ring_size)
+            return fail(AZX_EINVAL, "index %lld outside the %lld rows held", (long long)indices[b], (long long)e->ring_size);
+    if (batch > e->ring_idx_cap) {
+        void *p = nullptr;
+        hipError_t err = hipMalloc(&p, (size_t)batch * sizeof(long long));
+        if (err != hipSuccess) return fail(AZX_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(err));
+        e->ring_allocs.push_back(p);       // the old (smaller) one is freed with the ring
+        e->ring_idx = (long long *)p;
+        e->ring_idx_cap = batch;
+    }
+    static_assert(sizeof(long long) == sizeof(int64_t), "index width");
+    HIPCHECK(hipMemcpyAsync(e->ring_idx, indices, (size_t)batch * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(hipMemsetAsync(e->ring_maxk, 0, sizeof(int32_t), e->stream));
+    azx_launch_replay_collate(e->ring, e->ring_idx, (int)batch, e->d.ncells, (long long *)color_dev,
+                              legal_moves_dev, (long long *)result_dev, board_dev, moves_prob_dev, reward_dev,
+                              e->ring_maxk, e->stream);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(max_k_out, e->ring_maxk, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
     return AZX_OK;
 }
 

@@ -1,0 +1,136 @@
+"""Replay buffer that stays in HBM.
+
+Same contract as ReplayBuffer (azalea/replay_buffer.py:107-149) for the trainer loop of
+azalea/policy_trainer.py:51-90 -- `len`, `put`, `consume(num_examples, player)`, `write_idx`,
+`fresh_counter`, `state_dict` -- but the rows live in the engine's device ring and minibatches are
+collated on the GPU (azx_replay_collate) instead of by DataLoader workers running
+prep.torch_batch_replays.  `loader(batch_size)` yields the batches a
+`DataLoader(buffer, batch_size, shuffle=True, collate_fn=torch_batch_replays)` would: the same
+random permutation (RandomSampler seeds a private generator from the global torch RNG), the same
+keys, dtypes and zero padding to the batch's widest row, as device tensors.
+"""
+from typing import Dict, Iterator
+
+import numpy as np
+import torch
+
+from .replay_buffer import ReplayDataFrame
+
+_KEYS = ("color", "legal_moves", "result", "board", "moves_prob", "reward")
+
+
+class DeviceReplayBuffer:
+    def __init__(self, engine, capacity: int, contents: ReplayDataFrame = None):
+        """`engine`: azalea_amd.engine.Engine whose self-play feeds the buffer (Player._get_engine).
+        `contents`: initial rows, like ReplayBuffer(contents)."""
+        self.engine = engine
+        self.capacity = int(capacity)
+        engine.replay_create(self.capacity)
+        self.fresh_counter = 0
+        self.device = torch.device("cuda", engine.cfg.device)
+        if contents is not None and len(contents):
+            self.put(contents)
+            self.fresh_counter = 0          # ReplayBuffer.__init__ starts with nothing fresh
+
+    # ---- ReplayBuffer surface -----------------------------------------------------------------
+    def __len__(self) -> int:
+        return self.engine.replay_state()["size"]
+
+    @property
+    def write_idx(self) -> int:
+        return self.engine.replay_state()["write_idx"]
+
+    def put(self, new_data: ReplayDataFrame) -> None:
+        """Host rows into the ring in FIFO order (replay_buffer.py:134-149)."""
+        P = len(new_data)
+        if P == 0:
+            return
+        n = self.engine.n
+        board = np.stack([np.asarray(s.board, np.int32).reshape(n * n) for s in new_data.state])
+        color = np.array([s.color for s in new_data.state], np.int32)
+        nlegal = np.array([len(p) for p in new_data.moves_prob], np.int32)
+        prob = np.zeros((P, n * n), np.float32)
+        for i, p in enumerate(new_data.moves_prob):
+            prob[i, :len(p)] = p
+        self.engine.replay_put(board, color, nlegal, prob, np.asarray(new_data.reward, np.float32))
+        self.fresh_counter += P
+
+    def consume(self, num_examples, player=None) -> Dict[str, float]:
+        """replay_buffer.py:121-132; the refill is played and stored on the device."""
+        self.fresh_counter -= num_examples
+        refill = max(0, num_examples - self.fresh_counter)
+        if not refill:
+            return {}
+        if player is not None and hasattr(player, "prepare_device_engine"):
+            player.prepare_device_engine(self.engine)     # push the trainer's current weights
+        rows, st = self.engine.replay_fill(int(np.ceil(refill)))
+        self.fresh_counter += rows
+        games = max(1, st["games"])
+        plies = max(1, st["plies"])
+        return {"games": float(st["games"]), "reward": st["sum_reward_last"],
+                "moves_per_game": float(rows), "seconds_per_game": st["seconds"],
+                "game_error": float(st["game_errors"]),
+                "search_value": games * st["sum_search_value"] / plies,
+                "search_root_width": games * st["sum_root_width"] / plies,
+                "action_logprob": games * st["sum_action_logprob"] / plies}
+
+    # ---- minibatches --------------------------------------------------------------------------
+    def sample(self, indices) -> Dict[str, torch.Tensor]:
+        """prep.torch_batch_replays([self[i] for i in indices]) as device tensors."""
+        idx = np.asarray(indices, np.int64).reshape(-1)
+        B, cells = len(idx), self.engine.n * self.engine.n
+        dev = self.device
+        out = dict(color=torch.empty(B, dtype=torch.int64, device=dev),
+                   legal_moves=torch.empty((B, cells), dtype=torch.int32, device=dev),
+                   result=torch.empty(B, dtype=torch.int64, device=dev),
+                   board=torch.empty((B, cells), dtype=torch.int32, device=dev),
+                   moves_prob=torch.empty((B, cells), dtype=torch.float32, device=dev),
+                   reward=torch.empty(B, dtype=torch.float32, device=dev))
+        torch.cuda.synchronize(dev)      # the allocator may hand back memory torch kernels still use
+        k = self.engine.replay_collate(idx, {name: t.data_ptr() for name, t in out.items()})
+        n = self.engine.n
+        out["legal_moves"] = out["legal_moves"][:, :k].contiguous()
+        out["moves_prob"] = out["moves_prob"][:, :k].contiguous()
+        out["board"] = out["board"].view(B, n, n)
+        return out
+
+    def epoch_indices(self) -> np.ndarray:
+        """The order a fresh `iter(DataLoader(..., shuffle=True))` visits the rows in: the loader
+        draws its worker base seed from the global RNG first, then RandomSampler seeds a private
+        generator from it and takes one randperm."""
+        torch.empty((), dtype=torch.int64).random_()
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        gen = torch.Generator()
+        gen.manual_seed(seed)
+        return torch.randperm(len(self), generator=gen).numpy()
+
+    def loader(self, batch_size: int, drop_last: bool = False) -> Iterator[Dict[str, torch.Tensor]]:
+        """One epoch of shuffled minibatches (policy_trainer.py:51-56, :82)."""
+        order = self.epoch_indices()
+        for s in range(0, len(order), batch_size):
+            chunk = order[s:s + batch_size]
+            if drop_last and len(chunk) < batch_size:
+                return
+            yield self.sample(chunk)
+
+    # ---- checkpointing (replay_buffer.py:151-165) ---------------------------------------------
+    def rows(self, indices=None) -> Dict[str, np.ndarray]:
+        """Host copy of ring rows (all rows held by default) in collated form."""
+        idx = np.arange(len(self)) if indices is None else np.asarray(indices, np.int64)
+        return {k: v.cpu().numpy() for k, v in self.sample(idx).items()} if len(idx) else {}
+
+    def state_dict(self) -> Dict:
+        return {"rows": self.rows(), "write_idx": self.write_idx, "fresh_counter": self.fresh_counter}
+
+    def load_state_dict(self, state: Dict) -> None:
+        rows = state["rows"]
+        self.engine.replay_create(self.capacity)
+        if rows:
+            nlegal = (rows["legal_moves"] > 0).sum(1).astype(np.int32)
+            P, n = len(nlegal), self.engine.n
+            prob = np.zeros((P, n * n), np.float32)
+            prob[:, :rows["moves_prob"].shape[1]] = rows["moves_prob"]
+            self.engine.replay_put(rows["board"].reshape(P, n * n), rows["color"].astype(np.int32), nlegal,
+                                   prob, rows["reward"])
+            self.engine.replay_set_state(P, int(state["write_idx"]) % self.capacity)
+        self.fresh_counter = state["fresh_counter"]

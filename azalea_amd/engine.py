@@ -254,6 +254,48 @@ class Engine:
         check(self.L.azx_debug_counters(self.h, _p(out, C.c_uint64)))
         return out
 
+    # ---- device-resident replay ring (azx_replay_*) -------------------------------------------
+    def replay_create(self, capacity):
+        check(self.L.azx_replay_create(self.h, int(capacity)))
+
+    def replay_state(self):
+        v = [C.c_int64(0) for _ in range(3)]
+        check(self.L.azx_replay_state(self.h, *(C.byref(x) for x in v)))
+        return dict(capacity=v[0].value, size=v[1].value, write_idx=v[2].value)
+
+    def replay_set_state(self, size, write_idx):
+        check(self.L.azx_replay_set_state(self.h, int(size), int(write_idx)))
+
+    def replay_put(self, board, color, nlegal, moves_prob, reward):
+        """Host rows (azx_play layout: board i32[P,cells], moves_prob f32[P,cells] dense by child
+        index) into the ring, FIFO."""
+        P = len(reward)
+        cells = self.n * self.n
+        board = np.ascontiguousarray(board, np.int32).reshape(P, cells)
+        prob = np.ascontiguousarray(moves_prob, np.float32).reshape(P, cells)
+        color = np.ascontiguousarray(color, np.int32)
+        nlegal = np.ascontiguousarray(nlegal, np.int32)
+        reward = np.ascontiguousarray(reward, np.float32)
+        check(self.L.azx_replay_put(self.h, P, _p(board, C.c_int32), _p(color, C.c_int32),
+                                    _p(nlegal, C.c_int32), _p(prob, C.c_float), _p(reward, C.c_float)))
+
+    def replay_fill(self, min_positions, max_plies=0):
+        st = PlayStats()
+        rows = C.c_int64(0)
+        check(self.L.azx_replay_fill(self.h, int(min_positions), int(max_plies), C.byref(rows), C.byref(st)))
+        return rows.value, st.as_dict()
+
+    def replay_collate(self, indices, out):
+        """indices: int64 host array; out: dict of device pointers (ints) color, legal_moves,
+        result, board, moves_prob, reward.  Returns the batch's largest legal-move count."""
+        idx = np.ascontiguousarray(indices, np.int64)
+        mk = C.c_int32(0)
+        check(self.L.azx_replay_collate(self.h, len(idx), _p(idx, C.c_int64),
+                                        *(C.c_void_p(int(out[k])) for k in
+                                          ("color", "legal_moves", "result", "board", "moves_prob", "reward")),
+                                        C.byref(mk)))
+        return mk.value
+
     def debug_counters_raw(self):
         out = np.zeros((self.G, 16), np.uint64)
         check(self.L.azx_debug_counters_raw(self.h, _p(out, C.c_uint64), self.G))

@@ -82,6 +82,20 @@ class Player:
             self._engine.close()
             self._engine = None
 
+    # ---- device-resident replay (azalea_amd/device_replay.py) ---------------------------------
+    def device_engine(self):
+        """The engine self-play runs in (created on first use); DeviceReplayBuffer keeps its ring there."""
+        pol = self._device_policy()
+        if pol is None:
+            raise RuntimeError("device-resident replay needs a single agent whose Policy holds a HexNetwork")
+        return self._get_engine(pol)
+
+    def prepare_device_engine(self, engine) -> None:
+        """Refresh the engine's packed weights from the trainer's live module (SURVEY 8(b) ownership)."""
+        pol = self._device_policy()
+        if pol is not None and engine is self._engine:
+            self._push_weights(engine, pol)
+
     # ---- production --------------------------------------------------------------------------
     def _device_policy(self):
         pol = getattr(self.agents[0], "policy", None)

@@ -191,6 +191,39 @@ int azx_play(azx_engine *e, int64_t min_positions, int64_t max_plies, int64_t ca
  * restart in place), no row transfer; fills stats. */
 int azx_play_steps(azx_engine *e, int64_t plies, azx_play_stats *stats);
 
+/* ---- device-resident replay buffer ------------------------------------------
+ * Replaces, for a trainer that keeps its minibatches on the GPU: ReplayBuffer.put's wrap-around
+ * FIFO (azalea/replay_buffer.py:134-149), Player.read feeding it (parallel_player.py:41-52,
+ * replay_buffer.py:121-132) and the DataLoader + prep.torch_batch_replays collate
+ * (policy_trainer.py:51-56, prep.py:24-39).  Rows live in a fixed-capacity ring in HBM.
+ * The fresh-example accounting of ReplayBuffer.consume (a float counter) stays with the caller. */
+
+/* allocate (or replace) the ring: `capacity` rows, empty */
+int azx_replay_create(azx_engine *e, int64_t capacity);
+/* capacity, rows held (<= capacity) and the next write position */
+int azx_replay_state(azx_engine *e, int64_t *capacity, int64_t *size, int64_t *write_idx);
+/* restore size/write position (ReplayBuffer.load_state_dict, replay_buffer.py:160-165) */
+int azx_replay_set_state(azx_engine *e, int64_t size, int64_t write_idx);
+/* ReplayBuffer.put of n host rows (same row layout as azx_play's outputs): written at the write
+ * position in order, wrapping; when n > capacity only the last `capacity` rows survive, as with
+ * the reference's recursive put. */
+int azx_replay_put(azx_engine *e, int64_t n, const int32_t *board, const int32_t *color,
+                   const int32_t *nlegal, const float *moves_prob, const float *reward);
+/* Player.read(min_positions) + ReplayBuffer.put without a host round trip: plays whole games
+ * (throughput mode, like azx_play) until >= min_positions rows were harvested and moves them
+ * into the ring.  *rows_out = rows added. */
+int azx_replay_fill(azx_engine *e, int64_t min_positions, int64_t max_plies, int64_t *rows_out,
+                    azx_play_stats *stats);
+/* prep.batch_replays of the rows `indices[0..batch)` (host array; each < rows held) into DEVICE
+ * buffers with row stride board_size^2: color i64[batch], legal_moves i32[batch][cells] (ascending
+ * tile+1, zero padded), result i64[batch] (always 0), board i32[batch][cells],
+ * moves_prob f32[batch][cells] (zero padded), reward f32[batch].  *max_k_out (host) = the batch's
+ * largest legal-move count: the reference's collate pads legal_moves/moves_prob to exactly that
+ * width, so callers slice [:, :max_k].  Blocking. */
+int azx_replay_collate(azx_engine *e, int64_t batch, const int64_t *indices, int64_t *color_dev,
+                       int32_t *legal_moves_dev, int64_t *result_dev, int32_t *board_dev,
+                       float *moves_prob_dev, float *reward_dev, int32_t *max_k_out);
+
 /* float32 arithmetic self-test (tests): the tree kernels need IEEE-rounded sqrt and divide and
  * no FMA contraction (mcts.py:132-135).  sq=sqrtf(a), dv=a/(1+b), mul=(0.75f*a)*b+a. */
 int azx_selftest_arith(int device, int n, const float *a, const float *b, float *sq, float *dv,

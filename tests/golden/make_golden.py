@@ -16,6 +16,7 @@ Fixtures:
   g4_search_*.npz  SearchTree.search with stub networks: evaluation tape + tree dump
   g5_game_*.npz    play_game([AzaleaAgent(Policy(stub))]) full self-play traces
   g6_collate.npz   prep.torch_batch_replays on a small ReplayDataFrame
+  g7_replay.npz    ReplayBuffer put/consume FIFO states and one shuffled DataLoader epoch
 """
 import os
 import sys
@@ -415,6 +416,79 @@ def make_g5_g6():
     save("g6_collate.npz", idx=np.array(idx, np.int32),
          **{"out_" + k: v.numpy() for k, v in tb.items()},
          **{"dtype_" + k: np.array(str(v.numpy().dtype)) for k, v in tb.items()})
+    make_g7(frames["b_11_s40"])
+
+
+# --------------------------------------------------------------------------- G7
+def collate_padded(recs, cells):
+    """torch_batch_replays of recs, legal_moves / moves_prob widened to `cells` columns + the width"""
+    tb = {k: v.numpy() for k, v in ref_prep.torch_batch_replays(recs).items()}
+    k = tb["legal_moves"].shape[1]
+    for name in ("legal_moves", "moves_prob"):
+        wide = np.zeros((len(recs), cells), tb[name].dtype)
+        wide[:, :k] = tb[name]
+        tb[name] = wide
+    return tb, k
+
+
+def make_g7(frame):
+    """ReplayBuffer (replay_buffer.py:107-149) driven through puts that append, wrap and exceed the
+    capacity; consume() against a stub player; one epoch of the trainer's shuffled DataLoader
+    (policy_trainer.py:51-56).  `frame` is the recorded 11x11 game of G5 case b."""
+    from azalea.replay_buffer import ReplayBuffer, ReplayDataFrame
+    from torch.utils.data import DataLoader
+    cells = 121
+    cap = 12
+    assert len(frame) >= cap + 7 + 8 + 30, len(frame)
+    out = {}
+    # every row of the source frame, collated once: tests rebuild frames from it
+    src, _ = collate_padded([frame[i] for i in range(len(frame))], cells)
+    for k, v in src.items():
+        out["src_" + k] = v
+    buf = ReplayBuffer(frame[:cap])
+    cuts = [(cap, cap + 7), (cap + 7, cap + 15), (cap + 15, cap + 45)]
+    out["cap"] = np.int32(cap)
+    out["cuts"] = np.array(cuts, np.int32)
+    for j, (a, b) in enumerate(cuts):
+        buf.put(frame[a:b])
+        tb, _ = collate_padded([buf[i] for i in range(len(buf))], cells)
+        for k, v in tb.items():
+            out["put%d_%s" % (j, k)] = v
+        out["put%d_write_idx" % j] = np.int64(buf.write_idx)
+        out["put%d_fresh" % j] = np.float64(buf.fresh_counter)
+
+    class StubPlayer:            # hands out the next rows of the frame, at least `size` of them
+        def __init__(self):
+            self.pos = 0
+            self.asked = []
+        def read(self, size):
+            n = int(np.ceil(size)) + 1
+            self.asked.append(float(size))
+            rows = frame[self.pos:self.pos + n]
+            self.pos += n
+            return rows, {"games": 1.0}
+    buf2 = ReplayBuffer(frame[:cap])
+    pl = StubPlayer()
+    log = []
+    for step in range(12):
+        buf2.consume(5 / 2, pl)          # batch_size / oversampling, policy_trainer.py:90
+        log.append((buf2.write_idx, buf2.fresh_counter, pl.pos))
+    out["consume_log"] = np.array(log, np.float64)
+    out["consume_asked"] = np.array(pl.asked, np.float64)
+    tb, _ = collate_padded([buf2[i] for i in range(len(buf2))], cells)
+    for k, v in tb.items():
+        out["consume_final_" + k] = v
+
+    torch.manual_seed(1234)
+    loader = DataLoader(buf, batch_size=5, shuffle=True, num_workers=0,
+                        collate_fn=ref_prep.torch_batch_replays)
+    widths = []
+    for j, batch in enumerate(loader):
+        widths.append(batch["legal_moves"].shape[1])
+        for k, v in batch.items():
+            out["epoch_b%d_%s" % (j, k)] = v.numpy()
+    out["epoch_widths"] = np.array(widths, np.int32)
+    save("g7_replay.npz", **out)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,119 @@
+"""Device-resident replay ring (azx_replay_*, azalea_amd/device_replay.py) against the reference's
+recorded ReplayBuffer states and shuffled DataLoader epoch (golden G7), and against the host
+mirror on rows the engine itself played."""
+import numpy as np
+import pytest
+import torch
+
+from replay_golden import KEYS, assert_batch_equal, load_g7, source_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def make_engine(n=11, games=8, sims=20):
+    from azalea_amd import engine as eng
+    return eng.Engine(board_size=n, n_games=games, simulations=sims, search_batch_size=10,
+                      evaluator=eng.EVAL_UNIFORM, noise_scale=0.25, temperature=1.0,
+                      exploration_depth=15, seed=99)
+
+
+def host(batch):
+    return {k: v.cpu().numpy() for k, v in batch.items()}
+
+
+def flat(batch):
+    out = dict(batch)
+    out["board"] = np.asarray(batch["board"])
+    return out
+
+
+def test_put_append_wrap_and_overflow_match_reference():
+    from azalea_amd.device_replay import DeviceReplayBuffer
+    z = load_g7()
+    frame = source_frame(z)
+    cap = int(z["cap"])
+    E = make_engine()
+    buf = DeviceReplayBuffer(E, cap, frame[:cap])
+    assert len(buf) == cap and buf.write_idx == 0 and buf.fresh_counter == 0
+    for j, (a, b) in enumerate(z["cuts"]):
+        buf.put(frame[int(a):int(b)])
+        assert buf.write_idx == int(z["put%d_write_idx" % j])
+        assert buf.fresh_counter == float(z["put%d_fresh" % j])
+        assert_batch_equal(host(buf.sample(np.arange(cap))), z, "put%d_" % j)
+    E.close()
+
+
+def test_shuffled_epoch_matches_reference_dataloader():
+    from azalea_amd.device_replay import DeviceReplayBuffer
+    z = load_g7()
+    frame = source_frame(z)
+    cap = int(z["cap"])
+    E = make_engine()
+    buf = DeviceReplayBuffer(E, cap, frame[:cap])
+    for a, b in z["cuts"]:
+        buf.put(frame[int(a):int(b)])
+    torch.manual_seed(1234)
+    n = 0
+    for j, batch in enumerate(buf.loader(5)):
+        assert list(batch.keys()) == list(KEYS)
+        assert all(v.is_cuda for v in batch.values())
+        assert_batch_equal(host(batch), z, "epoch_b%d_" % j, exact_width=int(z["epoch_widths"][j]))
+        n += 1
+    assert n == len(z["epoch_widths"])
+    E.close()
+
+
+def test_state_dict_round_trip():
+    from azalea_amd.device_replay import DeviceReplayBuffer
+    z = load_g7()
+    frame = source_frame(z)
+    E = make_engine()
+    buf = DeviceReplayBuffer(E, 12, frame[:12])
+    buf.put(frame[12:19])
+    sd = buf.state_dict()
+    before = host(buf.sample(np.arange(12)))
+    E2 = make_engine()
+    buf2 = DeviceReplayBuffer(E2, 12)
+    buf2.load_state_dict(sd)
+    assert buf2.write_idx == buf.write_idx and buf2.fresh_counter == buf.fresh_counter and len(buf2) == 12
+    after = host(buf2.sample(np.arange(12)))
+    for k in KEYS:
+        assert np.array_equal(before[k], after[k]), k
+    E.close(); E2.close()
+
+
+def test_consume_refills_on_device_with_whole_valid_games():
+    """ReplayBuffer.consume accounting (replay_buffer.py:121-132) with the refill played and stored
+    on the GPU; the stored rows are legal Hex positions with normalised visit distributions and
+    collate exactly like the same rows taken through the host path."""
+    from azalea_amd.device_replay import DeviceReplayBuffer
+    from azalea_amd.parallel_player import rows_to_frame
+    from azalea_amd.prep import torch_batch_replays
+    E = make_engine(n=7, games=16, sims=20)
+    cap = 4096
+    buf = DeviceReplayBuffer(E, cap)
+    assert len(buf) == 0
+    m = buf.consume(100)                       # nothing fresh: refill = 100 - (-100) = 200 rows at least
+    rows = len(buf)
+    assert rows >= 200 and buf.fresh_counter == rows - 100 and m["games"] >= 1
+    assert buf.consume(50) == {} or buf.fresh_counter >= 50
+    got = host(buf.sample(np.arange(rows)))
+    board = got["board"].reshape(rows, 49)
+    k = (got["legal_moves"] > 0).sum(1)
+    assert np.array_equal(k, (board == 0).sum(1))
+    for i in range(rows):
+        assert np.array_equal(got["legal_moves"][i, :k[i]], np.flatnonzero(board[i] == 0) + 1)
+        assert abs(got["moves_prob"][i, :k[i]].sum() - 1.0) < 1e-5 and np.all(got["moves_prob"][i, k[i]:] == 0)
+    assert set(np.unique(got["reward"])) <= {-1.0, 1.0} and np.all(got["result"] == 0)
+    # stones alternate: X (colour 0) moves on even plies
+    assert np.array_equal(got["color"], ((board > 0).sum(1) & 1))
+    # the same rows through the host mirror collate to the same tensors
+    frame = rows_to_frame(dict(board=board.reshape(rows, 7, 7), color=got["color"], nlegal=k,
+                               moves_prob=np.pad(got["moves_prob"], ((0, 0), (0, 49 - got["moves_prob"].shape[1]))),
+                               reward=got["reward"]))
+    idx = np.array([3, 0, rows - 1, rows // 2, 7])
+    want = {kk: v.numpy() for kk, v in torch_batch_replays([frame[int(i)] for i in idx]).items()}
+    have = host(buf.sample(idx))
+    for kk in KEYS:
+        assert have[kk].dtype == want[kk].dtype and np.array_equal(have[kk], want[kk]), kk
+    E.close()

@@ -7,5 +7,5 @@ F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fhip-fp32-corre
 for v in 1 2; do
   hipcc $F -DAZX_STAMP=$v -c mcts_kernels.hip -o build/mcts_stamp$v.o
   out=../libazx_stamp.so; [ $v = 2 ] && out=../libazx_stamp2.so
-  hipcc --offload-arch=gfx950 -shared -fPIC build/mcts_stamp$v.o build/net_kernels.o build/azx_capi.o -o $out
+  hipcc --offload-arch=gfx950 -shared -fPIC build/mcts_stamp$v.o build/net_kernels.o build/replay_kernels.o build/azx_capi.o -o $out
 done
