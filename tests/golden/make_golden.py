@@ -17,6 +17,8 @@ Fixtures:
   g5_game_*.npz    play_game([AzaleaAgent(Policy(stub))]) full self-play traces
   g6_collate.npz   prep.torch_batch_replays on a small ReplayDataFrame
   g7_replay.npz    ReplayBuffer put/consume FIFO states and one shuffled DataLoader epoch
+  g8_checkpoint.npz  Policy.load of the shipped models/hex11-20180712-3362.policy.pth: schema,
+                   per-tensor digests, forward outputs on 48 positions
 """
 import os
 import sys
@@ -491,8 +493,46 @@ def make_g7(frame):
     save("g7_replay.npz", **out)
 
 
+# --------------------------------------------------------------------------- G8
+def make_g8():
+    """The reference's own checkpoint through the reference's Policy.load (policy.py:181-208):
+    what a compatible loader must recover."""
+    import hashlib
+    path = os.path.join(os.path.dirname(os.path.dirname(azalea.__file__)), "models",
+                        "hex11-20180712-3362.policy.pth")
+    real_load = torch.load
+    torch.load = lambda *a, **k: real_load(*a, **{**k, "weights_only": False})   # torch >= 2.6 default
+    try:
+        policy = Policy.load(path, device="cpu")
+    finally:
+        torch.load = real_load
+    net = policy.net
+    net.eval()
+    net.encoder.register_forward_hook(
+        lambda mod, inp, out: out.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1))
+    rng = np.random.RandomState(88)
+    board, lm, color = positions_from_playouts(policy.board_size, 48, rng)
+    with torch.no_grad():
+        o = net.run({"board": torch.tensor(board), "legal_moves": torch.tensor(lm)})
+    sd = net.state_dict()
+    names = sorted(sd)
+    digests = [hashlib.sha256(np.ascontiguousarray(sd[k].numpy()).tobytes()).hexdigest() for k in names]
+    hyper = ["network_type", "board_size", "num_blocks", "base_chans", "simulations", "search_batch_size",
+             "exploration_coef", "exploration_depth", "exploration_noise_alpha", "exploration_noise_scale",
+             "exploration_temperature"]
+    save("g8_checkpoint.npz", file_bytes=np.int64(os.path.getsize(path)),
+         file_sha256=np.array(hashlib.sha256(open(path, "rb").read()).hexdigest()),
+         tensor_names=np.array(names), tensor_sha256=np.array(digests),
+         tensor_shapes=np.array([str(tuple(sd[k].shape)) for k in names]),
+         hyper_names=np.array(hyper), hyper_values=np.array([str(getattr(policy, k)) for k in hyper]),
+         board=board, legal_moves=lm, color=color,
+         value=o["value"].numpy(), moves_logprob=o["moves_logprob"].numpy(),
+         cfg=np.array([policy.board_size, policy.num_blocks, policy.base_chans], np.int32),
+         **{"w:" + k: sd[k].numpy() for k in names})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g8"]
     if "g1" in which:
         make_g1()
     if "g2" in which:
@@ -503,3 +543,5 @@ if __name__ == "__main__":
         make_g4()
     if "g5" in which:
         make_g5_g6()
+    if "g8" in which:
+        make_g8()

@@ -47,6 +47,22 @@ def test_g3_forward_golden(eng, orc, tag):
     E.close()
 
 
+def test_shipped_checkpoint_weights_forward(eng):
+    """The reference's trained 6x64 network (golden G8: tensors and outputs recorded through the
+    reference's Policy.load) on the MFMA path: saturated values, peaked policies."""
+    z = np.load(os.path.join(GOLDEN, "g8_checkpoint.npz"))
+    n, blocks, chans = [int(x) for x in z["cfg"]]
+    state = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
+    E = eng.Engine(board_size=n, n_games=8, simulations=10, search_batch_size=10,
+                   evaluator=eng.EVAL_RESNET, num_blocks=blocks, base_chans=chans)
+    E.set_weights(state)
+    value, logprob = E.forward(z["board"], z["legal_moves"])
+    legal = z["legal_moves"] > 0
+    assert np.abs(value - z["value"]).max() <= TOL
+    assert np.abs(logprob - z["moves_logprob"])[legal].max() <= TOL
+    E.close()
+
+
 def _random_positions(orc, n, count, rng):
     boards, moves = [], []
     while len(boards) < count:
