@@ -42,8 +42,9 @@ static int nfail(int code, const char *msg) {
 struct NetDev {
     int N, ncells, C, blocks, layers;     // layers = 2*blocks
     // stem: embedding folded through conv1+bn1 (network.py:125,:141-142,:47-48,:73)
-    const float *stemT;    // [9][3][C]   table[tap][cell value][cout]
+    const float *stemT;    // [9][3][C]   table[tap][cell value][cout], then one all-zero row
     const float *stem_b;   // [C]
+    const unsigned short *Ws;  // f16x3 pack of stemT as an MFMA A operand: [2 kk][2 ntile][hi,lo][64 lanes][8] f16 bits
     // tower (network.py:17-39, :50-52): BN folded into the conv weights
     const float *Wp;       // MFMA pack [layers][9][C/8][C/32][64][4]
     const unsigned short *Wh;  // f16x3 pack [layers*18 stages][2 kk][2 ntile][hi,lo][64 lanes][8] f16 bits
@@ -225,6 +226,19 @@ __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
     lo = (_Float16)(v - (float)hi);
 }
 
+// Diagnostic build only (-DAZX_NET_STAMP): per-region s_memtime sums of k_tower_f16x3 (wave 0 of
+// every block), printed by azx_net_destroy.  The shipped kernel executes no stamp.
+#ifdef AZX_NET_STAMP
+__device__ unsigned long long g_tower_stamp[8];
+#define NT_DECL unsigned long long nt_last = __builtin_amdgcn_s_memtime(), nt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define NT_MARK(r) { const unsigned long long nt_now = __builtin_amdgcn_s_memtime(); nt_acc[r] += nt_now - nt_last; nt_last = nt_now; }
+#define NT_FLUSH if (tid == 0) { for (int r_ = 0; r_ < 7; ++r_) atomicAdd(&g_tower_stamp[r_], nt_acc[r_]); atomicAdd(&g_tower_stamp[7], 1ull); }
+#else
+#define NT_DECL
+#define NT_MARK(r)
+#define NT_FLUSH
+#endif
+
 #define F16X3_BPB 2   // boards per block: 2 -> 70 KB LDS, two blocks per CU overlap each other's prologue/epilogue
 // SPLIT_M: how the two waves of a board divide its 4 x 2 output tiles (32 positions x 32 channels):
 //   false: each wave takes all 4 position tiles of one channel tile  (8 LDS + 2 L2 fragment loads / k-step)
@@ -250,37 +264,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
     unsigned char *X = smem + x_off;                     // this wave pair's board
     const int zero_off = F16X3_BPB * board_b;            // shared all-zero row
 
-    // ---- stem (table lookups) -> split f16 rows; lane = output channel, waves split positions --
-    {
-        // stage the board's cells in the (not yet used) tail rows 121..127 of its LDS region
-        unsigned char *cells = X + 121 * ROWB;           // 7 * 272 B >= 128 B
-        const uint8_t *bd = ev_board + (size_t)(live ? e : n_eval - 1) * AZX_CELL_STRIDE;
-        if (wh == 0) {
-            cells[lane] = bd[lane];
-            cells[64 + lane] = bd[64 + lane];
-        }
-        if (tid < ROWB / 4) reinterpret_cast<uint32_t *>(smem + zero_off)[tid] = 0u;
-        __syncthreads();
-        const float sb = P.stem_b[lane];
-        const float *T = P.stemT + lane;
-#pragma unroll 2
-        for (int pos = wh; pos < ncells; pos += 2) {
-            const int y = pos / N, x = pos - y * N;
-            float acc = sb;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-                if (yy >= 0 && yy < N && xx >= 0 && xx < N)
-                    acc += T[(tap * 3 + cells[yy * N + xx]) * C];
-            }
-            _Float16 hi, lo;
-            split_f16(fmaxf(acc, 0.0f), hi, lo);
-            *reinterpret_cast<_Float16 *>(X + pos * ROWB + lane * 2) = hi;
-            *reinterpret_cast<_Float16 *>(X + pos * ROWB + 128 + lane * 2) = lo;
-        }
-    }
-    __syncthreads();
-
+    NT_DECL
     // lane (i = lane&31, h = lane>>5).  The product is computed transposed (weights as the MFMA A
     // operand, activations as B), so in a 32x32 result tile a LANE is a board position (row
     // (mbase+m)*32 + li) and the 16 registers are output channels cb + (r&3) + 8*(r>>2): four
@@ -291,11 +275,13 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
     // A-fragment byte offsets of one tap: row offset + the tap's (wave-uniform) displacement when
     // the neighbour is on the board, else the shared zero row; validity is one precomputed bit
     unsigned long long tapok = 0ull;                     // bit tap*4 + m
-    int rbase[MW];
+    int rbase[MW], ry_[MW], rx_[MW];
 #pragma unroll
     for (int m = 0; m < MW; ++m) {
         const int r = (mbase + m) * 32 + li;
         const int ry = r / N, rx = r - ry * N;
+        ry_[m] = ry;
+        rx_[m] = rx;
         rbase[m] = x_off + r * ROWB + 16 * lh;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -311,26 +297,124 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
             aoff[m] = ((tapok >> (tap * 4 + m)) & 1ull) ? rbase[m] + delta : zbase;
     };
 
-    // residual (block input) in accumulator layout
+    // ---- epilogue of a layer: + bias (+ residual) -> ReLU -> split f16 rows of the board in LDS.
+    // kind 0: conv1 of a Resblock; 1: conv2, y += x (network.py:37), the sum is the next block's
+    // input; 2: stem, its output is the first block's input.  The block input stays in registers.
     f32x16 res[MW][NW];
+    auto epilogue = [&](f32x16 (&acc)[MW][NW], const float *bias, auto kind_tag) {
+        constexpr int kind = decltype(kind_tag)::value;
 #pragma unroll
-    for (int m = 0; m < MW; ++m)
-#pragma unroll
-        for (int n = 0; n < NW; ++n)
+        for (int n = 0; n < NW; ++n) {
+            const int cb = (nbase + n) * 32 + 4 * lh;    // channel of register 0
+            float bv[16];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const unsigned char *pr = X + ((mbase + m) * 32 + li) * ROWB + ((nbase + n) * 32 + 4 * lh + 8 * g4) * 2;
-                const f16x4 h4 = *reinterpret_cast<const f16x4 *>(pr);
-                const f16x4 l4 = *reinterpret_cast<const f16x4 *>(pr + 128);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) res[m][n][4 * g4 + j] = (float)h4[j] + (float)l4[j];
+                const float4 b4 = *reinterpret_cast<const float4 *>(bias + cb + 8 * g4);
+                bv[4 * g4] = b4.x; bv[4 * g4 + 1] = b4.y; bv[4 * g4 + 2] = b4.z; bv[4 * g4 + 3] = b4.w;
             }
+#pragma unroll
+            for (int m = 0; m < MW; ++m) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f16x4 h4, l4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * g4 + j;
+                        float v = acc[m][n][r] + bv[r];
+                        if (kind == 1) v += res[m][n][r];
+                        v = fmaxf(v, 0.0f);
+                        if (kind != 0) res[m][n][r] = v;
+                        _Float16 hi, lo;
+                        split_f16(v, hi, lo);
+                        h4[j] = hi;
+                        l4[j] = lo;
+                    }
+                    unsigned char *pw = X + ((mbase + m) * 32 + li) * ROWB + (cb + 8 * g4) * 2;
+                    *reinterpret_cast<f16x4 *>(pw) = h4;
+                    *reinterpret_cast<f16x4 *>(pw + 128) = l4;
+                }
+            }
+        }
+    };
 
-    // fragments of one k-step: activations (hi, lo) for this wave's row tiles from LDS, weights
-    // (hi, lo) for its channel tiles straight from L2/L1 (packed in fragment order)
-    struct Frags { f16x8 ah[MW], al[MW], bh[NW], bl[NW]; };
+    // ---- stem on the matrix cores: embedding -> conv1 -> bn1 (network.py:125,:141-142,:47-48,:73)
+    // folded to a 27-row table (tap x colour) is a K=27 product with ONE-HOT activations:
+    // out[co][pos] = sum_k Ws[co][k] * (cell(pos + tap(k)) == colour(k)).  One-hot is exact in f16,
+    // so only the weights are split (hi, lo): 2 MFMAs per tile and 16-wide k-step, two k-steps.
+    {
+        // the board with a one-cell "off board" (3) border, in the not yet used tail rows 121..127
+        const int NH = N + 2;
+        unsigned char *cells = X + 121 * ROWB;           // 7 * 272 B = 1904 B >= 15 * 15
+        const uint8_t *bd = ev_board + (size_t)(live ? e : n_eval - 1) * AZX_CELL_STRIDE;
+        if (wh == 0) {
+            for (int i = lane; i < NH * NH; i += 64) {
+                const int y = i / NH - 1, x = i - (y + 1) * NH - 1;
+                cells[i] = (y >= 0 && y < N && x >= 0 && x < N) ? bd[y * N + x] : (uint8_t)3;
+            }
+        }
+        if (tid < ROWB / 4) reinterpret_cast<uint32_t *>(smem + zero_off)[tid] = 0u;
+        __syncthreads();
+        uint32_t onehot[MW];                             // bit k = 3*tap + colour of that neighbour
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            onehot[m] = 0u;
+            const unsigned char *c0 = cells + ry_[m] * NH + rx_[m];   // halo coordinates of tap (0, 0)
+            if ((mbase + m) * 32 + li < ncells) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const uint32_t v = c0[(tap / 3) * NH + tap % 3];
+                    onehot[m] |= (v < 3u ? 1u : 0u) << (3 * tap + v);
+                }
+            }
+        }
+        f32x16 acc[MW][NW];
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int n = 0; n < NW; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+        const uint4 *ws = reinterpret_cast<const uint4 *>(P.Ws);   // [kk][ntile][hi,lo][lane]
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 bfr[MW];
+#pragma unroll
+            for (int m = 0; m < MW; ++m) {
+                const uint32_t byte = (onehot[m] >> (16 * kk + 8 * lh)) & 0xffu;
+                uint4 q;                                 // f16 1.0 = 0x3C00 per set bit
+                q.x = ((byte >> 0) & 1u) * 0x3C00u | ((byte >> 1) & 1u) * 0x3C000000u;
+                q.y = ((byte >> 2) & 1u) * 0x3C00u | ((byte >> 3) & 1u) * 0x3C000000u;
+                q.z = ((byte >> 4) & 1u) * 0x3C00u | ((byte >> 5) & 1u) * 0x3C000000u;
+                q.w = ((byte >> 6) & 1u) * 0x3C00u | ((byte >> 7) & 1u) * 0x3C000000u;
+                bfr[m] = *reinterpret_cast<const f16x8 *>(&q);
+            }
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                const uint4 *pa = ws + ((kk * 2 + nbase + n) * 2) * 64 + lane;
+                const uint4 qh = pa[0], ql = pa[64];
+                const f16x8 wh8 = *reinterpret_cast<const f16x8 *>(&qh);
+                const f16x8 wl8 = *reinterpret_cast<const f16x8 *>(&ql);
+#pragma unroll
+                for (int m = 0; m < MW; ++m) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh8, bfr[m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl8, bfr[m], acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();   // every wave has read the staged cells: the tail rows are free again
+        epilogue(acc, P.stem_b, std::integral_constant<int, 2>{});
+    }
+    __syncthreads();
+    NT_MARK(0)
+
+    // fragments of one k-step (16 input channels of one tap): activations (hi, lo) for this wave's
+    // row tiles from LDS, weights (hi, lo) for its channel tiles straight from L2 (packed in
+    // fragment order).  LDS answers in ~100 cycles, L2 in several hundred: activations are
+    // fetched one k-step ahead, weights two (three rotating register sets).
+    struct FragA { f16x8 ah[MW], al[MW]; };
+    struct FragB { f16x8 bh[NW], bl[NW]; };
     const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.Wh);     // 512 uint4 per stage
-    auto load_frags = [&](Frags &f, const int *aoff, int half, int kk, int stage) {
+    auto load_b = [&](FragB &f, int kk, int stage) {
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             // weights: [stage][kk][ntile][part][lane][8 f16]
@@ -343,21 +427,18 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
             f.bh[n] = *reinterpret_cast<const f16x8 *>(&qh);
             f.bl[n] = *reinterpret_cast<const f16x8 *>(&ql);
         }
-#if AZX_NET_ABLATE & 1
-        (void)aoff; (void)half;
-#pragma unroll
-        for (int m = 0; m < MW; ++m) { f.ah[m] = f.bh[0]; f.al[m] = f.bl[0]; }
-#else
+    };
+    auto load_a = [&](FragA &f, const int *aoff, int half, int kk) {
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
             const unsigned char *pa = smem + aoff[m] + (half * 32 + kk * 16) * 2;
             f.ah[m] = *reinterpret_cast<const f16x8 *>(pa);
             f.al[m] = *reinterpret_cast<const f16x8 *>(pa + 128);
         }
-#endif
     };
 
-    int stage = 0;
+    NT_MARK(1)
+    int stage = 0;                                       // weight stage = (layer, tap, half of the input channels)
     auto conv_layer = [&](int layer, auto residual_tag) {
         constexpr bool residual = decltype(residual_tag)::value;   // conv2 of a Resblock: y += x (network.py:37)
         f32x16 acc[MW][NW];
@@ -367,81 +448,49 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
             for (int n = 0; n < NW; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-        auto mfma_step = [&](const Frags &f) {
+        auto mfma_step = [&](const FragA &fa, const FragB &fb) {
 #if AZX_NET_ABLATE & 2
 #pragma unroll
-            for (int m = 0; m < MW; ++m) asm volatile("" :: "v"(f.ah[m]), "v"(f.al[m]), "v"(f.bh[0]), "v"(f.bl[0]));
+            for (int m = 0; m < MW; ++m) asm volatile("" :: "v"(fa.ah[m]), "v"(fa.al[m]), "v"(fb.bh[0]), "v"(fb.bl[0]));
 #else
 #pragma unroll
             for (int m = 0; m < MW; ++m)
 #pragma unroll
                 for (int n = 0; n < NW; ++n) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[n], f.ah[m], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[n], f.ah[m], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[n], f.al[m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.bh[n], fa.ah[m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.bl[n], fa.ah[m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.bh[n], fa.al[m], acc[m][n], 0, 0, 0);
                 }
 #endif
         };
 
+        // k-step t = 0..35: stage t/2 (tap t/4, channel half (t/2)%2), 16-channel slice t%2
         int aoff[MW];
         tap_offsets(0, aoff);
-        Frags f0, f1;                                    // ping-pong fragment sets (no copies)
-        load_frags(f0, aoff, 0, 0, stage);
+        FragA fa[2];
+        FragB fb[3];
+        load_b(fb[0], 0, stage);
+        load_b(fb[1], 1, stage);
+        load_a(fa[0], aoff, 0, 0);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                // k-step 0 of the stage computes while k-step 1's fragments are in flight
-                load_frags(f1, aoff, half, 1, stage);
-                __builtin_amdgcn_sched_barrier(0);       // keep the prefetch a whole k-step ahead
-                mfma_step(f0);
-                __builtin_amdgcn_sched_barrier(0);
-                // k-step 1 computes while the next stage's first fragments are in flight
-                if (!(tap == 8 && half == 1)) {
-                    if (half == 1) tap_offsets(tap + 1, aoff);
-                    load_frags(f0, aoff, half ^ 1, 0, stage + 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_step(f1);
-                __builtin_amdgcn_sched_barrier(0);
-                ++stage;
+        for (int t = 0; t < 36; ++t) {
+            if (t + 2 < 36) load_b(fb[(t + 2) % 3], (t + 2) & 1, stage + (t + 2) / 2);
+            if (t + 1 < 36) {
+                if (((t + 1) & 3) == 0) tap_offsets((t + 1) / 4, aoff);
+                load_a(fa[(t + 1) & 1], aoff, ((t + 1) >> 1) & 1, (t + 1) & 1);
             }
+            __builtin_amdgcn_sched_barrier(0);           // keep the prefetches ahead of this k-step's MFMAs
+            mfma_step(fa[t & 1], fb[t % 3]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        stage += 18;
+        NT_MARK(2)
         __syncthreads();   // both waves of the board finished reading it
-        // ---- epilogue: + folded-BN bias (+ residual) -> ReLU -> split f16 back into the board -----
-#pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            const int cb = (nbase + n) * 32 + 4 * lh;    // channel of register 0
-            float bv[16];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const float4 b4 = *reinterpret_cast<const float4 *>(P.bias + layer * C + cb + 8 * g4);
-                bv[4 * g4] = b4.x; bv[4 * g4 + 1] = b4.y; bv[4 * g4 + 2] = b4.z; bv[4 * g4 + 3] = b4.w;
-            }
-#pragma unroll
-            for (int m = 0; m < MW; ++m) {
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    f16x4 h4, l4;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r = 4 * g4 + j;
-                        float v = acc[m][n][r] + bv[r];
-                        if (residual) v += res[m][n][r];
-                        v = fmaxf(v, 0.0f);
-                        if (residual) res[m][n][r] = v;  // block output = next block's input
-                        _Float16 hi, lo;
-                        split_f16(v, hi, lo);
-                        h4[j] = hi;
-                        l4[j] = lo;
-                    }
-                    unsigned char *pw = X + ((mbase + m) * 32 + li) * ROWB + (cb + 8 * g4) * 2;
-                    *reinterpret_cast<f16x4 *>(pw) = h4;
-                    *reinterpret_cast<f16x4 *>(pw + 128) = l4;
-                }
-            }
-        }
+        NT_MARK(3)
+        epilogue(acc, P.bias + layer * C, std::integral_constant<int, residual ? 1 : 0>{});
+        NT_MARK(4)
         __syncthreads();   // the partner wave wrote the other tiles of this board
+        NT_MARK(5)
     };
     for (int blk = 0; blk < P.blocks; ++blk) {
         conv_layer(2 * blk, std::false_type{});
@@ -465,6 +514,8 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
             }
         }
     }
+    NT_MARK(6)
+    NT_FLUSH
 }
 
 // ============================================================================================
@@ -665,6 +716,7 @@ struct AzxNet {
     bool use_mfma = false;
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
+    size_t persistent_allocs = 0;    // allocs[0..persistent) live as long as the net; the rest are the current weights
     float *act = nullptr, *act2 = nullptr, *act3 = nullptr;   // [E][ncells][C]
     float *logit = nullptr;                                     // [E][AZX_CELL_STRIDE]
     // host-forward staging
@@ -723,11 +775,26 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     const int bpb = net->tower_variant == 2 ? 1 : 2;
     net->lds_bytes = (size_t)bpb * 2 * (ncells + 1) * (chans + 4) * sizeof(float);
     if (net->tower_variant == 4) net->lds_bytes = (size_t)F16X3_BPB * 128 * 272 + 272;
+    net->persistent_allocs = net->allocs.size();
     *out = net;
     return AZX_OK;
 }
 
 void azx_net_destroy(AzxNet *net) {
+#ifdef AZX_NET_STAMP
+    {
+        unsigned long long h[8] = {0};
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tower_stamp), sizeof h) == hipSuccess && h[7]) {
+            static const char *nm[7] = {"stem", "residual load/setup", "k-loop (MFMA)", "barrier after k-loop",
+                                        "epilogue", "barrier after epilogue", "output store"};
+            unsigned long long tot = 0;
+            for (int r = 0; r < 7; ++r) tot += h[r];
+            fprintf(stderr, "k_tower_f16x3 stamps over %llu blocks: %.0f cycles/block\n", h[7], (double)tot / h[7]);
+            for (int r = 0; r < 7; ++r)
+                fprintf(stderr, "  %-24s %6.1f%%  %9.0f cycles/block\n", nm[r], 100.0 * h[r] / tot, (double)h[r] / h[7]);
+        }
+    }
+#endif
     if (!net) return;
     for (void *p : net->allocs) (void)hipFree(p);
     delete net;
@@ -783,7 +850,7 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
     auto emb = get("encoder.weight", 12);
     auto w1 = get("conv1.weight", (size_t)C * 4 * 9);
     NEED(emb && w1 && fold("bn1", C, sc, sh));
-    std::vector<float> stemT((size_t)9 * 3 * C), stem_b(C);
+    std::vector<float> stemT((size_t)(9 * 3 + 1) * C, 0.0f), stem_b(C);   // row 27: zeros (off-board taps)
     for (int tap = 0; tap < 9; ++tap)
         for (int v = 0; v < 3; ++v)
             for (int co = 0; co < C; ++co) {
@@ -824,8 +891,27 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
                                     Wg[(((size_t)l * 9 + tap) * C + ci) * C + co];
                             }
     }
-    std::vector<unsigned short> Wh;
+    std::vector<unsigned short> Wh, Ws;
     if (net->tower_variant == 4) {
+        // stem table as K = 27 (tap*3 + colour, padded to 32) x C weights:
+        // [kk][ntile][part hi/lo][lane j + 32 h][t] = split(stemT[k = 16 kk + 8 h + t][cout 32 ntile + j])
+        Ws.resize((size_t)2 * 2 * 2 * 64 * 8);
+        size_t os = 0;
+        for (int kk = 0; kk < 2; ++kk)
+            for (int nt = 0; nt < 2; ++nt)
+                for (int part = 0; part < 2; ++part)
+                    for (int ln = 0; ln < 64; ++ln)
+                        for (int t = 0; t < 8; ++t) {
+                            const int j = ln & 31, h = ln >> 5;
+                            const int k = 16 * kk + 8 * h + t, co = 32 * nt + j;
+                            const float w = k < 27 ? stemT[(size_t)k * C + co] : 0.0f;
+                            const _Float16 hi = (_Float16)w;
+                            const _Float16 lo = (_Float16)(w - (float)hi);
+                            const _Float16 v = part ? lo : hi;
+                            unsigned short bits;
+                            memcpy(&bits, &v, 2);
+                            Ws[os++] = bits;
+                        }
         // f16x3 pack: [stage = (layer*9 + tap)*2 + half][kk][ntile][part hi/lo][lane j + 32 h][t]
         //   = split(W[tap][cin 32 half + 16 kk + 8 h + t][cout 32 ntile + j])
         Wh.resize((size_t)L * 18 * 2 * 2 * 2 * 64 * 8);
@@ -875,13 +961,22 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
     }
 #undef NEED
     (void)hipStreamSynchronize(net->stream);
+    // the previous weight set is no longer referenced by any queued kernel: release it (the
+    // trainer refreshes the weights on every Player.read)
+    for (size_t i = net->persistent_allocs; i < net->allocs.size(); ++i) (void)hipFree(net->allocs[i]);
+    net->allocs.resize(net->persistent_allocs);
     NetDev &d = net->d;
     d.stemT = upload(net, stemT);
     d.stem_b = upload(net, stem_b);
     d.Wg = upload(net, Wg);
     d.Wp = (net->use_mfma && net->tower_variant != 4) ? upload(net, Wp) : nullptr;
     d.Wh = nullptr;
+    d.Ws = nullptr;
     if (net->tower_variant == 4) {
+        unsigned short *wsd = nalloc<unsigned short>(net, Ws.size());
+        if (!wsd) return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
+        (void)hipMemcpy(wsd, Ws.data(), Ws.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+        d.Ws = wsd;
         unsigned short *wh = nalloc<unsigned short>(net, Wh.size());
         if (!wh) return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
         (void)hipMemcpy(wh, Wh.data(), Wh.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
