@@ -229,17 +229,23 @@ __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
 // Diagnostic build only (-DAZX_NET_STAMP): per-region s_memtime sums of k_tower_f16x3 (wave 0 of
 // every block), printed by azx_net_destroy.  The shipped kernel executes no stamp.
 #ifdef AZX_NET_STAMP
-__device__ unsigned long long g_tower_stamp[8];
-#define NT_DECL unsigned long long nt_last = __builtin_amdgcn_s_memtime(), nt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+__device__ unsigned long long g_tower_stamp[10];   // 7 regions, block count, s_memrealtime ticks (100 MHz)
+#define NT_DECL unsigned long long nt_last = __builtin_amdgcn_s_memtime(), nt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long nt_rt0 = __builtin_amdgcn_s_memrealtime();
+__device__ unsigned long long g_tower_trace[3 * 32768];   // per block of the last launch: cu key, start, end (100 MHz)
 #define NT_MARK(r) { const unsigned long long nt_now = __builtin_amdgcn_s_memtime(); nt_acc[r] += nt_now - nt_last; nt_last = nt_now; }
-#define NT_FLUSH if (tid == 0) { for (int r_ = 0; r_ < 7; ++r_) atomicAdd(&g_tower_stamp[r_], nt_acc[r_]); atomicAdd(&g_tower_stamp[7], 1ull); }
+#define NT_FLUSH if (tid == 0) { for (int r_ = 0; r_ < 7; ++r_) atomicAdd(&g_tower_stamp[r_], nt_acc[r_]); atomicAdd(&g_tower_stamp[7], 1ull); atomicAdd(&g_tower_stamp[8], __builtin_amdgcn_s_memrealtime() - nt_rt0); \
+    if (blockIdx.x < 32768) { const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xc = __builtin_amdgcn_s_getreg((31 << 11) | 20); \
+        g_tower_trace[3 * blockIdx.x] = ((unsigned long long)(xc & 0xf) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf); \
+        g_tower_trace[3 * blockIdx.x + 1] = nt_rt0; g_tower_trace[3 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime(); } }
 #else
 #define NT_DECL
 #define NT_MARK(r)
 #define NT_FLUSH
 #endif
 
+#ifndef F16X3_BPB
 #define F16X3_BPB 2   // boards per block: 2 -> 70 KB LDS, two blocks per CU overlap each other's prologue/epilogue
+#endif
 // SPLIT_M: how the two waves of a board divide its 4 x 2 output tiles (32 positions x 32 channels):
 //   false: each wave takes all 4 position tiles of one channel tile  (8 LDS + 2 L2 fragment loads / k-step)
 //   true : each wave takes 2 position tiles of both channel tiles    (4 LDS + 4 L2 fragment loads / k-step)
@@ -448,23 +454,10 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
             for (int n = 0; n < NW; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-        auto mfma_step = [&](const FragA &fa, const FragB &fb) {
-#if AZX_NET_ABLATE & 2
-#pragma unroll
-            for (int m = 0; m < MW; ++m) asm volatile("" :: "v"(fa.ah[m]), "v"(fa.al[m]), "v"(fb.bh[0]), "v"(fb.bl[0]));
-#else
-#pragma unroll
-            for (int m = 0; m < MW; ++m)
-#pragma unroll
-                for (int n = 0; n < NW; ++n) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.bh[n], fa.ah[m], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.bl[n], fa.ah[m], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.bh[n], fa.al[m], acc[m][n], 0, 0, 0);
-                }
-#endif
-        };
-
-        // k-step t = 0..35: stage t/2 (tap t/4, channel half (t/2)%2), 16-channel slice t%2
+        // k-step t = 0..35: stage t/2 (tap t/4, channel half (t/2)%2), 16-channel slice t%2.
+        // The prefetch loads are issued ONE PER MFMA, each in the shadow of the MFMA before it (an
+        // MFMA occupies the issue port for 8 of its 32 cycles): a block of loads ahead of the
+        // MFMAs would let the matrix pipe drain for ~70 cycles every k-step.
         int aoff[MW];
         tap_offsets(0, aoff);
         FragA fa[2];
@@ -472,16 +465,42 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
         load_b(fb[0], 0, stage);
         load_b(fb[1], 1, stage);
         load_a(fa[0], aoff, 0, 0);
+        constexpr int NMF = 3 * MW * NW, NLB = 2 * NW, NLA = 2 * MW;
 #pragma unroll
         for (int t = 0; t < 36; ++t) {
-            if (t + 2 < 36) load_b(fb[(t + 2) % 3], (t + 2) & 1, stage + (t + 2) / 2);
-            if (t + 1 < 36) {
-                if (((t + 1) & 3) == 0) tap_offsets((t + 1) / 4, aoff);
-                load_a(fa[(t + 1) & 1], aoff, ((t + 1) >> 1) & 1, (t + 1) & 1);
+            const FragA &ca = fa[t & 1];
+            const FragB &cb = fb[t % 3];
+            FragA &na = fa[(t + 1) & 1];
+            FragB &nb = fb[(t + 2) % 3];
+#pragma unroll
+            for (int i = 0; i < NMF; ++i) {
+                // ---- one prefetch load -------------------------------------------------------
+                if (i < NLA) {                            // activations first: they are due next k-step
+                    if (t + 1 < 36) {
+                        const int m = i >> 1, part = i & 1;
+                        if (i == 0 && ((t + 1) & 3) == 0) tap_offsets((t + 1) / 4, aoff);
+                        const unsigned char *pa = smem + aoff[m] + ((((t + 1) >> 1) & 1) * 32 + ((t + 1) & 1) * 16) * 2 + part * 128;
+                        if (part) na.al[m] = *reinterpret_cast<const f16x8 *>(pa);
+                        else na.ah[m] = *reinterpret_cast<const f16x8 *>(pa);
+                    }
+                } else if (i < NLA + NLB) {
+                    if (t + 2 < 36) {
+                        const int j = i - NLA, n = j >> 1, part = j & 1, kk2 = (t + 2) & 1, st2 = stage + (t + 2) / 2;
+                        const uint4 q = wsrc[(size_t)st2 * 512 + ((kk2 * 2 + nbase + n) * 2 + part) * 64 + lane];
+                        if (part) nb.bl[n] = *reinterpret_cast<const f16x8 *>(&q);
+                        else nb.bh[n] = *reinterpret_cast<const f16x8 *>(&q);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- one MFMA: the three split products of a tile are MW*NW instructions apart ----
+                {
+                    const int part = i / (MW * NW), mn = i % (MW * NW), m = mn / NW, n = mn % NW;
+                    const f16x8 wv = part == 1 ? cb.bl[n] : cb.bh[n];
+                    const f16x8 xv = part == 2 ? ca.al[m] : ca.ah[m];
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, xv, acc[m][n], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);           // keep the prefetches ahead of this k-step's MFMAs
-            mfma_step(fa[t & 1], fb[t % 3]);
-            __builtin_amdgcn_sched_barrier(0);
         }
         stage += 18;
         NT_MARK(2)
@@ -783,15 +802,49 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
 void azx_net_destroy(AzxNet *net) {
 #ifdef AZX_NET_STAMP
     {
-        unsigned long long h[8] = {0};
+        unsigned long long h[10] = {0};
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tower_stamp), sizeof h) == hipSuccess && h[7]) {
             static const char *nm[7] = {"stem", "residual load/setup", "k-loop (MFMA)", "barrier after k-loop",
                                         "epilogue", "barrier after epilogue", "output store"};
             unsigned long long tot = 0;
             for (int r = 0; r < 7; ++r) tot += h[r];
-            fprintf(stderr, "k_tower_f16x3 stamps over %llu blocks: %.0f cycles/block\n", h[7], (double)tot / h[7]);
+            fprintf(stderr, "k_tower_f16x3 stamps over %llu blocks: %.0f cycles/block, shader clock %.0f MHz during the kernel\n",
+                    h[7], (double)tot / h[7], h[8] ? 100.0 * (double)tot / (double)h[8] : 0.0);
             for (int r = 0; r < 7; ++r)
                 fprintf(stderr, "  %-24s %6.1f%%  %9.0f cycles/block\n", nm[r], 100.0 * h[r] / tot, (double)h[r] / h[7]);
+            {
+                std::vector<unsigned long long> tr(3 * 32768);
+                (void)hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(g_tower_trace), tr.size() * sizeof(unsigned long long));
+                std::map<unsigned long long, std::vector<std::pair<unsigned long long, unsigned long long>>> cu;
+                unsigned long long t0 = ~0ull, t1 = 0;
+                size_t nblk = 0;
+                for (int b = 0; b < 32768; ++b)
+                    if (tr[3 * b + 2]) {
+                        cu[tr[3 * b]].push_back({tr[3 * b + 1], tr[3 * b + 2]});
+                        t0 = std::min(t0, tr[3 * b + 1]);
+                        t1 = std::max(t1, tr[3 * b + 2]);
+                        ++nblk;
+                    }
+                double busy = 0, mn = 1e30, mx = 0, lastend_min = 1e30, lastend_max = 0;
+                size_t cmin = 1 << 30, cmax = 0;
+                for (auto &kv : cu) {
+                    double b = 0, le = 0;
+                    for (auto &iv : kv.second) { b += (double)(iv.second - iv.first); le = std::max(le, (double)(iv.second - t0)); }
+                    busy += b; mn = std::min(mn, b); mx = std::max(mx, b);
+                    cmin = std::min(cmin, kv.second.size()); cmax = std::max(cmax, kv.second.size());
+                    lastend_min = std::min(lastend_min, le); lastend_max = std::max(lastend_max, le);
+                }
+                fprintf(stderr, "  last launch: %zu blocks on %zu CUs, span %.1f us, blocks/CU %zu..%zu, mean resident blocks/CU %.2f, "
+                        "per-CU block-time %.0f..%.0f us, CU finish %.0f..%.0f us\n", nblk, cu.size(), (t1 - t0) / 100.0, cmin, cmax,
+                        busy / ((double)(t1 - t0) * cu.size()), mn / 100.0, mx / 100.0, lastend_min / 100.0, lastend_max / 100.0);
+            }
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_tower_f16x3<true>, F16X3_BPB * 128, net->lds_bytes);
+            hipFuncAttributes fa;
+            memset(&fa, 0, sizeof fa);
+            (void)hipFuncGetAttributes(&fa, (const void *)k_tower_f16x3<true>);
+            fprintf(stderr, "  runtime occupancy: %d blocks/CU (dynamic LDS %zu B, static %zu B, %d VGPRs, max threads %d)\n", nb,
+                    net->lds_bytes, (size_t)fa.sharedSizeBytes, fa.numRegs, fa.maxThreadsPerBlock);
         }
     }
 #endif

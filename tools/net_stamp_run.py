@@ -8,7 +8,7 @@ import numpy as np, torch
 from azalea_amd.network import HexNetwork
 torch.manual_seed(0)
 net = HexNetwork(board_size=11, num_blocks=6, base_chans=64).eval()
-E = eng.Engine(board_size=11, n_games=4096, simulations=400, search_batch_size=10, evaluator=eng.EVAL_RESNET, noise_scale=0.25)
+E = eng.Engine(board_size=11, n_games=int(sys.argv[1]) if len(sys.argv) > 1 else 4096, simulations=400, search_batch_size=10, evaluator=eng.EVAL_RESNET, noise_scale=0.25)
 E.set_weights({k: v.detach().numpy() for k, v in net.state_dict().items() if v.dtype == torch.float32})
 st = E.play_steps(1)
 print("net ms/launch", 1e3 * st["net_seconds"] / max(1, st["net_launches"]), "launches", st["net_launches"])
