@@ -84,6 +84,7 @@ SYMBOLS = {
     "azx_replay_fill": (C.c_int, [_vp, C.c_int64, C.c_int64, _i64p, C.POINTER(PlayStats)]),
     "azx_replay_collate": (C.c_int, [_vp, C.c_int64, _i64p, _vp, _vp, _vp, _vp, _vp, _vp, _i32p]),
     "azx_selftest_arith": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p]),
+    "azx_selftest_divide": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p]),
     "azx_selftest_dirichlet": (C.c_int, [C.c_int, C.c_double, C.c_int, C.c_int, C.c_uint32, _f32p]),
     "azx_debug_counters": (C.c_int, [_vp, _u64p]),
     "azx_debug_counters_raw": (C.c_int, [_vp, _u64p, C.c_int64]),

@@ -988,6 +988,27 @@ extern "C" int azx_selftest_arith(int device, int n, const float *a, const float
     return AZX_OK;
 }
 
+// ---- self-test hook (tests): the search kernel's unscaled divide and sqrt table ----------------
+extern "C" int azx_selftest_divide(int device, int n, const float *num, const float *den, float *quot,
+                                   float *sqrt_tab) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(AZX_ENODEV, "no HIP device visible");
+    if (n < 1 || !num || !den || !quot || !sqrt_tab) return fail(AZX_EINVAL, "bad argument");
+    HIPCHECK(hipSetDevice(device));
+    if (azx_init_geometry(device)) return fail(AZX_EHIP, "uploading the constant tables failed");
+    float *da, *db, *dq, *dr;
+    HIPCHECK(hipMalloc(&da, n * 4)); HIPCHECK(hipMalloc(&db, n * 4));
+    HIPCHECK(hipMalloc(&dq, n * 4)); HIPCHECK(hipMalloc(&dr, n * 4));
+    HIPCHECK(hipMemcpy(da, num, n * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(db, den, n * 4, hipMemcpyHostToDevice));
+    azx_launch_divide_test(da, db, dq, dr, n, nullptr);
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(quot, dq, n * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(sqrt_tab, dr, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dq); (void)hipFree(dr);
+    return AZX_OK;
+}
+
 // ---- device Dirichlet self-test hook (tests): n_rows draws of Dirichlet(alpha * 1_k) -------------
 extern "C" int azx_selftest_dirichlet(int device, double alpha, int k, int n_rows, uint32_t seed, float *out) {
     int ndev = 0;

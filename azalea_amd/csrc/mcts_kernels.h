@@ -24,5 +24,6 @@ void azx_launch_hex_replay(int N, int n_games, const int32_t *moves, const int32
                            int32_t *final_board, hipStream_t st);
 void azx_launch_arith(const float *a, const float *b, float *sq, float *dv, float *mul, int n,
                       hipStream_t st);
+void azx_launch_divide_test(const float *num, const float *den, float *q, float *rt, int n, hipStream_t st);
 void azx_launch_noise_test(float alpha, int k, int n_rows, uint32_t seed, float *out, hipStream_t st);
 int azx_init_geometry(int device);   // board geometry tables -> constant memory (once per device)

@@ -1404,6 +1404,26 @@ __global__ void k_arith(const float *a, const float *b, float *sq, float *dv, fl
     }
 }
 
+// ---- the score path's shortcuts against their IEEE definitions: q = num/den through
+// div2_unscaled (pairs of elements, as the kernel uses it) and rt = the sqrt table entry of the
+// integer den (0 beyond the table) ----------------------------------------------------------------
+__global__ void k_divide_test(const float *num, const float *den, float *q, float *rt, int n) {
+    const int i = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (i + 1 < n) {
+        const f2 a = {num[i], num[i + 1]}, d = {den[i], den[i + 1]};
+        const f2 r = div2_unscaled(a, d);
+        q[i] = r.x;
+        q[i + 1] = r.y;
+    } else if (i < n) {
+        const f2 a = {num[i], num[i]}, d = {den[i], den[i]};
+        q[i] = div2_unscaled(a, d).x;
+    }
+    for (int j = i; j < n && j < i + 2; ++j) {
+        const int v = (int)den[j];
+        rt[j] = (v >= 0 && v < AZX_SQRT_TAB) ? c_sqrt[v] : 0.0f;
+    }
+}
+
 // ---- device Dirichlet self-test: rows of k-cell noise exactly as k_mcts draws it ---------------
 __global__ __launch_bounds__(64) void k_noise_test(float alpha, int k, int n_rows, uint32_t seed, float *out) {
     const int lane = threadIdx.x, row = blockIdx.x;
@@ -1471,6 +1491,10 @@ void azx_launch_hex_replay(int N, int n_games, const int32_t *moves, const int32
 #define CALL(S) hipLaunchKernelGGL((k_hex_replay<S>), dim3(n_games), dim3(64), 0, st, N, n_games, moves, length, stride, result_out, nlegal_out, empties_out, final_board)
     DISPATCH_SLOTS(slots, CALL);
 #undef CALL
+}
+
+void azx_launch_divide_test(const float *num, const float *den, float *q, float *rt, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_divide_test, dim3((n / 2 + 256) / 256), dim3(256), 0, st, num, den, q, rt, n);
 }
 
 void azx_launch_arith(const float *a, const float *b, float *sq, float *dv, float *mul, int n,

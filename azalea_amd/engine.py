@@ -331,6 +331,16 @@ def selftest_arith(a, b, device=0):
     return sq, dv, mul
 
 
+def selftest_divide(num, den, device=0):
+    """azx_selftest_divide: (num/den through the kernel's unscaled divide, sqrt-table entry of den)."""
+    num = np.ascontiguousarray(num, np.float32)
+    den = np.ascontiguousarray(den, np.float32)
+    q, rt = np.zeros_like(num), np.zeros_like(num)
+    check(_lib.lib().azx_selftest_divide(device, len(num), _p(num, C.c_float), _p(den, C.c_float),
+                                         _p(q, C.c_float), _p(rt, C.c_float)))
+    return q, rt
+
+
 def selftest_dirichlet(alpha, k, n_rows, seed=1, device=0):
     out = np.zeros((n_rows, k), np.float32)
     check(_lib.lib().azx_selftest_dirichlet(device, float(alpha), k, n_rows, seed, _p(out, C.c_float)))

@@ -229,6 +229,13 @@ int azx_replay_collate(azx_engine *e, int64_t batch, const int64_t *indices, int
 int azx_selftest_arith(int device, int n, const float *a, const float *b, float *sq, float *dv,
                        float *mul);
 
+/* self-test of the two shortcuts in the search kernel's score path (mcts.py:132-134): quot[i] =
+ * num[i]/den[i] through its unscaled reciprocal-refine divide, and sqrt_tab[i] = the constant-memory
+ * sqrt table entry of the integer den[i] (0 beyond the table).  Both must equal the IEEE results
+ * for den in [1, 2^24] and num 0 or 2^-100 <= |num| <= 2^100. */
+int azx_selftest_divide(int device, int n, const float *num, const float *den, float *quot,
+                        float *sqrt_tab);
+
 /* throughput mode draws its Dirichlet noise on the device (mcts.py:128 uses numpy): n_rows
  * draws of Dirichlet(alpha * 1_k), k <= 128, exactly as the search kernel generates them, for
  * distribution tests. */

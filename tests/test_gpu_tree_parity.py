@@ -42,6 +42,32 @@ def test_f32_arithmetic_is_ieee_and_uncontracted(eng):
     assert np.array_equal(bits(mul), bits((np.float32(0.75) * a) * b + a))
 
 
+def test_score_path_divide_and_sqrt_table_are_ieee(eng):
+    """mcts.py:132-134 on the device: the unscaled reciprocal-refine divide equals numpy's float32
+    division bit for bit over its whole declared domain (visit counts 1..2^24; values 0, powers of
+    two down to 2^-83 / up to 2^24, sums of +-1 and tanh-like values, random mantissas), and the
+    constant-memory table holds np.sqrt of every integer it covers."""
+    rng = np.random.RandomState(11)
+    n = 1 << 20
+    den = np.concatenate([np.arange(1, 4097), rng.randint(1, 1 << 24, n - 4096)]).astype(np.float32)
+    mant = rng.uniform(1.0, 2.0, n).astype(np.float32)
+    expo = rng.randint(-83, 25, n)
+    num = np.ldexp(mant, expo).astype(np.float32) * rng.choice([-1.0, 1.0], n).astype(np.float32)
+    num[::7] = 0.0
+    num[1::7] = (rng.randint(-2000, 2000, len(num[1::7])) + rng.uniform(-1, 1, len(num[1::7]))).astype(np.float32)
+    num[2::7] = np.tanh(rng.normal(0, 2, len(num[2::7]))).astype(np.float32)
+    q, rt = eng.selftest_divide(num, den)
+    want = num / den
+    # a -0 numerator may come back as +0: the score adds 0.0 afterwards (mcts.py:135)
+    zero = want == 0
+    assert np.array_equal(bits(q)[~zero], bits(want)[~zero])
+    assert np.all(q[zero] == 0)
+    small = den < 4096
+    assert np.array_equal(bits(rt[small]), bits(np.sqrt(den[small])))
+    sq, _ = eng.selftest_divide(np.sqrt(np.arange(4096, dtype=np.float32)), np.arange(1, 4097, dtype=np.float32))
+    assert np.array_equal(bits(sq), bits(np.sqrt(np.arange(4096, dtype=np.float32)) / np.arange(1, 4097, dtype=np.float32)))
+
+
 @pytest.mark.parametrize("alpha,k", [(0.03, 121), (0.03, 7), (0.3, 64), (0.9, 30)])
 def test_device_dirichlet_noise_distribution(eng, alpha, k):
     """Throughput mode replaces rng.dirichlet (mcts.py:128) by a device sampler: rows must sum to
