@@ -17,6 +17,8 @@ Fixtures:
   g5_game_*.npz    play_game([AzaleaAgent(Policy(stub))]) full self-play traces
   g6_collate.npz   prep.torch_batch_replays on a small ReplayDataFrame
   g7_replay.npz    ReplayBuffer put/consume FIFO states and one shuffled DataLoader epoch
+  g9_train_step.npz  three supervised_step calls (policy_trainer.py:123-142) on a fixed batch with
+                   SGD(lr 0.1, momentum 0.9, weight_decay 1e-4): losses, outputs, updated tensors
   g8_checkpoint.npz  Policy.load of the shipped models/hex11-20180712-3362.policy.pth: schema,
                    per-tensor digests, forward outputs on 48 positions
 """
@@ -531,8 +533,51 @@ def make_g8():
          **{"w:" + k: sd[k].numpy() for k in names})
 
 
+# --------------------------------------------------------------------------- G9
+def make_g9():
+    """The trainer's inner step (policy_trainer.py:123-142 supervised_step, network.py:92-102 loss)
+    on a fixed batch of the recorded 11x11 game: train-mode BatchNorm, SGD with momentum and weight
+    decay as train() configures them (policy_trainer.py:57-60)."""
+    from azalea.policy_trainer import supervised_step
+    from azalea.replay_buffer import ReplayDataFrame
+    z = np.load(os.path.join(OUT, "g7_replay.npz"))
+    recs = []
+    from azalea.game.hex import HexGameState
+    from azalea.replay_buffer import ReplayRecord
+    for i in range(24):
+        lm = z["src_legal_moves"][i]
+        k = int((lm > 0).sum())
+        st = HexGameState(int(z["src_color"][i]), lm[:k].astype(np.int32), int(z["src_result"][i]),
+                          z["src_board"][i].astype(np.int32))
+        recs.append(ReplayRecord(st, z["src_moves_prob"][i, :k].astype(np.float32), np.float32(z["src_reward"][i])))
+    torch.manual_seed(77)
+    net = HexNetwork(board_size=11, num_blocks=2, base_chans=16)
+    net.encoder.register_forward_hook(
+        lambda mod, inp, out: out.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1))
+    init = {k: v.clone().numpy() for k, v in net.state_dict().items()}
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    out = {"w0:" + k: v for k, v in init.items()}
+    idx = [list(range(0, 16)), list(range(8, 24)), list(range(4, 20))]
+    out["batch_idx"] = np.array(idx, np.int32)
+    for step, ids in enumerate(idx):
+        batch = ref_prep.torch_batch_replays([recs[i] for i in ids])
+        o, loss = supervised_step(net, batch, train=True, optimizer=opt, device="cpu")
+        out["step%d_loss" % step] = np.float64(loss)
+        out["step%d_value_loss" % step] = np.float64(o["value_loss"])
+        out["step%d_moves_loss" % step] = np.float64(o["moves_loss"])
+        out["step%d_value" % step] = o["value"].numpy()
+        out["step%d_moves_logprob" % step] = o["moves_logprob"].numpy()
+    for k, v in net.state_dict().items():
+        out["w3:" + k] = v.numpy()
+    batch = ref_prep.torch_batch_replays([recs[i] for i in idx[0]])
+    o, loss = supervised_step(net, batch, train=False, device="cpu")
+    out["eval_loss"] = np.float64(loss)
+    out["eval_value"] = o["value"].numpy()
+    save("g9_train_step.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g8", "g9"]
     if "g1" in which:
         make_g1()
     if "g2" in which:
@@ -545,3 +590,5 @@ if __name__ == "__main__":
         make_g5_g6()
     if "g8" in which:
         make_g8()
+    if "g9" in which:
+        make_g9()

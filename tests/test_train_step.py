@@ -1,0 +1,81 @@
+"""The trainer's inner step against the reference's recorded one (golden G9:
+azalea/policy_trainer.py:123-142 on three fixed batches, SGD + momentum + weight decay,
+train-mode BatchNorm): losses, outputs and the updated tensors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from replay_golden import load_g7, source_frame
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def run_steps(device, tol_w):
+    from azalea_amd.network import HexNetwork
+    from azalea_amd.policy_trainer import supervised_step
+    from azalea_amd.prep import torch_batch_replays
+    z = np.load(os.path.join(GOLDEN, "g9_train_step.npz"))
+    frame = source_frame(load_g7())
+    net = HexNetwork(board_size=11, num_blocks=2, base_chans=16)
+    net.load_state_dict({k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith("w0:")})
+    net.to(device)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    for step, ids in enumerate(z["batch_idx"]):
+        batch = torch_batch_replays([frame[int(i)] for i in ids])
+        o, loss = supervised_step(net, batch, train=True, optimizer=opt, device=device)
+        assert abs(loss - float(z["step%d_loss" % step])) <= tol_w * 10
+        assert abs(o["value_loss"] - float(z["step%d_value_loss" % step])) <= tol_w * 10
+        assert abs(o["moves_loss"] - float(z["step%d_moves_loss" % step])) <= tol_w * 10
+        assert np.abs(o["value"].cpu().numpy() - z["step%d_value" % step]).max() <= tol_w * 10
+        legal = batch["legal_moves"].cpu().numpy() > 0
+        assert np.abs(o["moves_logprob"].cpu().numpy() - z["step%d_moves_logprob" % step])[legal].max() <= tol_w * 10
+    for k, v in net.state_dict().items():
+        want = z["w3:" + k]
+        if want.dtype.kind == "f":
+            assert np.abs(v.cpu().numpy() - want).max() <= tol_w, k
+        else:
+            assert np.array_equal(v.cpu().numpy(), want), k
+    batch = torch_batch_replays([frame[int(i)] for i in z["batch_idx"][0]])
+    o, loss = supervised_step(net, batch, train=False, device=device)
+    assert not net.training
+    assert abs(loss - float(z["eval_loss"])) <= tol_w * 10
+    assert np.abs(o["value"].cpu().numpy() - z["eval_value"]).max() <= tol_w * 10
+
+
+def test_supervised_step_matches_reference_cpu():
+    run_steps("cpu", 2e-6)
+
+
+@pytest.mark.gpu
+def test_supervised_step_matches_reference_gpu():
+    run_steps("cuda:0", 2e-4)
+
+
+@pytest.mark.gpu
+def test_train_loop_with_device_replay(tmp_path):
+    """policy_trainer.train end to end on the GPU: engine self-play -> HBM replay ring -> GPU collate
+    -> supervised_step; the checkpoint it writes loads back through Policy.load."""
+    from azalea_amd.policy import Policy
+    from azalea_amd.policy_trainer import initialize_replay_buffer, train
+    from azalea_amd.game.hex import HexGame
+    config = dict(seed=3, device="cuda:0", replaybuf_oversampling=2, batch_size=32, game="azalea_amd.game.hex.HexGame",
+                  board_size=5, replaybuf_size=128, lr_initial=0.05, momentum=0.9, l2_regularization=1e-4,
+                  lr_decay_epochs=1, lr_decay=0.5, total_epochs=2, network="HexNetwork", num_blocks=1, base_chans=8,
+                  simulations=20, search_batch_size=10, exploration_coef=0.5, exploration_depth=4,
+                  exploration_noise_alpha=0.3, exploration_noise_scale=0.25, exploration_temperature=1.0,
+                  log_interval=2, model_checkpoint_interval=0, selfplay_games=16)
+    policy = Policy()
+    policy.initialize(config)
+    before = {k: v.clone() for k, v in policy.net.state_dict().items()}
+    buf = initialize_replay_buffer(None, lambda: HexGame(5), config["replaybuf_size"])
+    n0 = len(buf)
+    path = train(policy, config, str(tmp_path), replaybuf=buf, device_replay=True)
+    assert os.path.exists(path)
+    after = policy.net.state_dict()
+    assert any(not torch.equal(before[k].cpu(), after[k].cpu()) for k in before)
+    q = Policy.load(path, device="cpu")
+    for k, v in after.items():
+        assert torch.equal(v.cpu(), q.net.state_dict()[k]), k
+    assert n0 >= config["replaybuf_size"]
