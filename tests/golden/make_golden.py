@@ -17,6 +17,7 @@ Fixtures:
   g5_game_*.npz    play_game([AzaleaAgent(Policy(stub))]) full self-play traces
   g6_collate.npz   prep.torch_batch_replays on a small ReplayDataFrame
   g7_replay.npz    ReplayBuffer put/consume FIFO states and one shuffled DataLoader epoch
+  g10_tournament.npz evaluation.evaluate round robin of three stub-net agents (per-game outcomes)
   g9_train_step.npz  three supervised_step calls (policy_trainer.py:123-142) on a fixed batch with
                    SGD(lr 0.1, momentum 0.9, weight_decay 1e-4): losses, outputs, updated tensors
   g8_checkpoint.npz  Policy.load of the shipped models/hex11-20180712-3362.policy.pth: schema,
@@ -576,8 +577,45 @@ def make_g9():
     save("g9_train_step.npz", **out)
 
 
+# --------------------------------------------------------------------------- G10
+def make_g10():
+    """evaluation.evaluate (evaluation.py:17-80): three agents, three rounds of the round robin,
+    in-process pool.  Per game: pair, seed, coin-flipped order, outcome; and the final tallies."""
+    from azalea import evaluation as ref_eval
+    n = 5
+    specs = [("hashprior", 20, 0.5, True, True), ("uniformhash", 30, 0.75, True, False),
+             ("hashprior", 40, 1.0, False, False)]
+    agents = []
+    for mode, sims, c, sampling, explore in specs:
+        policy = make_policy(mode, n, sims, 10, c, 4, 0.3, 0.25, 1.0)
+        policy.settings["move_sampling"] = sampling
+        policy.settings["move_exploration"] = explore
+        agents.append(AzaleaAgent(lambda n=n: HexGame(n), policy=policy, device="cpu"))
+    games = []
+    real_worker = ref_eval.worker
+
+    def logging_worker(pair, ags, seed):
+        rng = np.random.RandomState(seed)
+        order = int(rng.choice([-1, 1]))
+        pair2, outcome = real_worker(pair, ags, seed)
+        games.append((pair[0], pair[1], seed, order, int(outcome)))
+        return pair2, outcome
+    ref_eval.worker = logging_worker
+    try:
+        outcomes = ref_eval.evaluate(agents, 3, num_workers=0)
+    finally:
+        ref_eval.worker = real_worker
+    pairs = sorted(outcomes)
+    save("g10_tournament.npz", board=np.int32(n),
+         spec_mode=np.array([s[0] for s in specs]), spec_sims=np.array([s[1] for s in specs], np.int32),
+         spec_c=np.array([s[2] for s in specs], np.float64),
+         spec_sampling=np.array([s[3] for s in specs]), spec_explore=np.array([s[4] for s in specs]),
+         games=np.array(games, np.int64), pairs=np.array(pairs, np.int32),
+         tallies=np.array([outcomes[p] for p in pairs], np.int32))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g8", "g9", "g10"]
     if "g1" in which:
         make_g1()
     if "g2" in which:
@@ -592,3 +630,5 @@ if __name__ == "__main__":
         make_g8()
     if "g9" in which:
         make_g9()
+    if "g10" in which:
+        make_g10()
