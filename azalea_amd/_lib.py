@@ -62,6 +62,7 @@ SYMBOLS = {
     "azx_set_weights": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(_vp), _i64p, C.c_int]),
     "azx_set_prior_table": (C.c_int, [_vp, _f32p, C.c_int]),
     "azx_reset": (C.c_int, [_vp, _i32p, C.c_int, _i32p, _i32p, C.c_int]),
+    "azx_set_active": (C.c_int, [_vp, _i32p]),
     "azx_search": (C.c_int, [_vp, _f64p, C.c_int, C.c_int, C.c_double]),
     "azx_search_begin": (C.c_int, [_vp, _f64p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int)]),
     "azx_search_step": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -665,6 +665,18 @@ extern "C" int azx_hex_replay(int device, int board_size, int n_games, const int
     return AZX_OK;
 }
 
+// ---- which slots take part in the next searches (tournaments: only the games whose turn it is) --
+extern "C" int azx_set_active(azx_engine *e, const int32_t *active) {
+    if (!e || !active) return fail(AZX_EINVAL, "null argument");
+    DevEngine &d = e->d;
+    std::vector<int32_t> a((size_t)d.G);
+    for (int g = 0; g < d.G; ++g) a[g] = active[g] ? 1 : 0;
+    HIPCHECK(hipMemcpy2DAsync(&d.ghdr[0].active, sizeof(GameHdr), a.data(), sizeof(int32_t), sizeof(int32_t),
+                              (size_t)d.G, hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    return AZX_OK;
+}
+
 // ---- throughput mode ------------------------------------------------------------------------
 static int play_setup(azx_engine *e, int64_t q_rows, int ring) {
     DevEngine &d = e->d;

@@ -88,6 +88,11 @@ class Engine:
         check(self.L.azx_reset(self.h, _p(s, C.c_int32), ns, _p(mv, C.c_int32), _p(nm, C.c_int32), stride))
 
     # ---- search -------------------------------------------------------------------------
+    def set_active(self, mask):
+        m = np.ascontiguousarray(mask, np.int32)
+        assert m.shape == (self.G,)
+        check(self.L.azx_set_active(self.h, _p(m, C.c_int32)))
+
     def search(self, noise=None, noise_scale=0.0):
         """noise: float64 [G, n_select, stride] host Dirichlet rows, or None."""
         if noise is not None:

@@ -96,6 +96,11 @@ int azx_reset(azx_engine *e, const int32_t *slots, int n_slots, const int32_t *m
 
 /* ---- one search, split the way mcts.sample_paths is (mcts.py:258-293) ------------------ */
 
+/* Mark which slots take part in azx_search* / azx_advance (active[n_games], 0 = parked).  All
+ * slots are active after azx_create / azx_reset.  A tournament (evaluation.py:46-80) searches, per
+ * agent, only the games whose turn it is. */
+int azx_set_active(azx_engine *e, const int32_t *active);
+
 /* SearchTree.search for every active slot from its current root (search_tree.py:73-113).
  * noise: NULL -> no noise if noise_scale==0, else device RNG Dirichlet (throughput mode);
  * else host Dirichlet draws [n_games][n_select][noise_stride] f64, one row per select_leaf
