@@ -173,6 +173,19 @@ extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
         rc = azx_net_create(&e->net, d.N, cfg->num_blocks, cfg->base_chans, (int)E, e->stream);
         if (rc) { g_err = azx_net_error(); azx_destroy(e); return rc; }
     }
+    {   // inverse-CDF table of the device Dirichlet sampler for this engine's alpha
+        float *gt = nullptr;
+        rc = dev_alloc(e, &gt, AZX_GAMMA_TAB_FLOATS);
+        if (rc) { azx_destroy(e); return rc; }
+        std::vector<float> tab(AZX_GAMMA_TAB_FLOATS, 0.0f);
+        if (cfg->noise_alpha > 0.0) azx_gamma_table(cfg->noise_alpha, tab.data());
+        if (hipMemcpyAsync(gt, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+            hipStreamSynchronize(e->stream) != hipSuccess) {
+            azx_destroy(e);
+            return fail(AZX_EHIP, "uploading the gamma sampler table failed");
+        }
+        e->d.gamma_tab = gt;
+    }
     *out = e;
     {   // default uniform prior table: float32 1/k, the same bits as the IEEE division on device
         std::vector<float> tab(d.ncells + 1, 0.0f);
@@ -1029,10 +1042,17 @@ extern "C" int azx_selftest_dirichlet(int device, double alpha, int k, int n_row
     HIPCHECK(hipSetDevice(device));
     float *d = nullptr;
     HIPCHECK(hipMalloc(&d, sizeof(float) * (size_t)k * n_rows));
-    azx_launch_noise_test((float)alpha, k, n_rows, seed, d, nullptr);
+    if (!(alpha > 0.0)) return fail(AZX_EINVAL, "alpha must be positive");
+    std::vector<float> tab(AZX_GAMMA_TAB_FLOATS);
+    azx_gamma_table(alpha, tab.data());
+    float *dt = nullptr;
+    HIPCHECK(hipMalloc(&dt, tab.size() * sizeof(float)));
+    HIPCHECK(hipMemcpy(dt, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    azx_launch_noise_test((float)alpha, dt, k, n_rows, seed, d, nullptr);
     HIPCHECK(hipDeviceSynchronize());
     HIPCHECK(hipMemcpy(out, d, sizeof(float) * (size_t)k * n_rows, hipMemcpyDeviceToHost));
     (void)hipFree(d);
+    (void)hipFree(dt);
     return AZX_OK;
 }
 

@@ -90,6 +90,7 @@ struct DevEngine {
     int32_t n_select, noise_stride;
     double noise_scale;
     float noise_alpha;
+    const float *gamma_tab;    // [AZX_GAMMA_TAB_FLOATS] device gamma sampler table for noise_alpha (mcts_kernels.hip)
     int32_t device_noise;
     uint64_t seed;
     const float *prior_by_k;   // [ncells+1]

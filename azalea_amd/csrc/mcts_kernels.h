@@ -25,5 +25,8 @@ void azx_launch_hex_replay(int N, int n_games, const int32_t *moves, const int32
 void azx_launch_arith(const float *a, const float *b, float *sq, float *dv, float *mul, int n,
                       hipStream_t st);
 void azx_launch_divide_test(const float *num, const float *den, float *q, float *rt, int n, hipStream_t st);
-void azx_launch_noise_test(float alpha, int k, int n_rows, uint32_t seed, float *out, hipStream_t st);
+void azx_launch_noise_test(float alpha, const float *tab, int k, int n_rows, uint32_t seed, float *out, hipStream_t st);
+// inverse-CDF correction table of the device gamma sampler for one alpha: AZX_GAMMA_TAB_FLOATS floats
+#define AZX_GAMMA_TAB_FLOATS 802
+void azx_gamma_table(double alpha, float *tab);
 int azx_init_geometry(int device);   // board geometry tables -> constant memory (once per device)

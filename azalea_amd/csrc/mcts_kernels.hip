@@ -122,46 +122,36 @@ __device__ __forceinline__ float key_f32(uint32_t k) {
     return __int_as_float((int)((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k));
 }
 
-// log2 of a Gamma(alpha) variate for 0 < alpha < 1: Ahrens-Dieter GS rejection sampler, kept in
-// log space (for alpha = 0.03 x = p^(1/alpha) underflows float32 all the time; only the ratios
-// matter to the Dirichlet).  With b = 1 + alpha/e:  p = b*U1;  p <= 1: x = p^(1/alpha), accept
-// if U2 <= exp(-x);  else x = -ln((b-p)/alpha), accept if U2 <= x^(alpha-1).
-// `seed` is unique per (game, ply, select_leaf call, cell).  U1 is a mixed 32-bit hash of the
-// seed, U2 its multiplicative scramble (the pairs form a 2^32-point lattice over the unit
-// square, plenty for an accept test that passes ~98 % of the time).
-// Native-rate transcendentals on purpose: this is noise, not part of the bit-exact score path.
-struct GammaConst { float alpha, inv_alpha, b, bs24, bs25, am1; };
-__device__ __forceinline__ GammaConst gamma_const(float alpha) {
+// log2 of a Gamma(alpha) variate, 0 < alpha < 1, by inversion of the CDF -- no rejection loop (a
+// loop runs until the unluckiest of 64 lanes accepts).  Only ratios of the variates matter to the
+// Dirichlet, and for alpha = 0.03 x = u^(1/alpha) underflows float32 all the time, so everything
+// stays in log2:
+//     log2 x = (log2 u + log2 Gamma(alpha+1)) / alpha + delta(1 - u)
+// The first term is the inverse of the small-x form F(x) = x^alpha / Gamma(alpha+1) and exact to
+// float32 while x < 2^-24 (u < 0.6 for alpha = 0.03); delta, the smooth remainder, is tabulated by
+// the host in double precision (azx_gamma_table) on a grid that follows the float format of
+// y = 1 - u -- 32 points per octave from 2^-25 to 1, indexed by the exponent and top mantissa bits
+// of y, no second logarithm -- and interpolated linearly (|error| < 1e-4 in log2 x at the far
+// tail, far less elsewhere).  u and y come from the same 24 random bits, each exact in float32.
+#define AZX_GAMMA_TAB 801            // 25 octaves x 32 + 1
+struct GammaConst { float inv_alpha, c0; const float *tab; };
+__device__ __forceinline__ GammaConst gamma_const(float alpha, const float *tab) {
     GammaConst g;
-    g.alpha = alpha;
-    g.inv_alpha = __builtin_amdgcn_rcpf(alpha);
-    g.b = 1.0f + alpha * 0.36787944f;
-    g.bs24 = g.b * (1.0f / 16777216.0f);
-    g.bs25 = g.b * (0.5f / 16777216.0f);
-    g.am1 = alpha - 1.0f;
+    g.inv_alpha = 1.0f / alpha;
+    g.c0 = tab[AZX_GAMMA_TAB];       // log2 Gamma(alpha + 1), appended by the host
+    g.tab = tab;
     return g;
 }
-__device__ inline float log2_gamma_variate(uint32_t seed, const GammaConst &gc) {
-    float lx = 0.0f;
-    uint32_t x = seed;
-    for (uint32_t t = 0; t < 32; ++t) {
-        const uint32_t r0 = mix32(x);
-        uint32_t r1 = r0 * 0x9E3779B9u;
-        r1 ^= r1 >> 15;
-        x = r1 + 0x68bc21ebu;
-        // p = b * (r0>>8 + 0.5) / 2^24,  u2 = (r1>>8 + 0.5) / 2^24
-        const float p = __builtin_fmaf((float)(r0 >> 8), gc.bs24, gc.bs25);
-        const float u2 = __builtin_fmaf((float)(r1 >> 8), 1.0f / 16777216.0f, 0.5f / 16777216.0f);
-        if (p <= 1.0f) {
-            lx = __builtin_amdgcn_logf(p) * gc.inv_alpha;                      // log2 x
-            if (u2 <= __builtin_amdgcn_exp2f(__builtin_amdgcn_exp2f(lx) * -1.44269504f)) break;
-        } else {
-            const float xv = __builtin_amdgcn_logf((gc.b - p) * gc.inv_alpha) * -0.69314718f;
-            lx = __builtin_amdgcn_logf(xv);
-            if (u2 <= __builtin_amdgcn_exp2f(gc.am1 * lx)) break;
-        }
-    }
-    return lx;
+__device__ __forceinline__ float log2_gamma_variate(uint32_t seed, const GammaConst &gc) {
+    const uint32_t r = mix32(seed) >> 8;                                      // 24 random bits
+    const float u = __builtin_fmaf((float)r, 1.0f / 16777216.0f, 0.5f / 16777216.0f);
+    const float y = __builtin_fmaf((float)(r ^ 0xffffffu), 1.0f / 16777216.0f, 0.5f / 16777216.0f);   // 1 - u
+    const float lx0 = (__builtin_amdgcn_logf(u) + gc.c0) * gc.inv_alpha;
+    const uint32_t yb = (uint32_t)__float_as_int(y);
+    const int idx = (int)(yb >> 18) - ((127 - 25) << 5);                      // 0 .. 799
+    const float fr = (float)(yb & 0x3ffffu) * (1.0f / 262144.0f);
+    const float2 t = *reinterpret_cast<const float2 *>(gc.tab + idx);          // tab[idx], tab[idx + 1]
+    return lx0 + __builtin_fmaf(fr, t.y - t.x, t.x);
 }
 
 // scale * Dirichlet(alpha * 1_k) over the cells set in m[] (one value per lane-slot), the device
@@ -342,13 +332,14 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
     const int ply = gh->ply;
     const Masks<SLOTS> rootmk = make_masks<SLOTS>(root, lane, ncells);
 
-    unsigned long long c_selects = 0, c_depth = 0, c_kint = 0, c_kleaf = 0, c_evals = 0, c_term = 0;
+    // per-launch tallies (at most 16 * 410 * 169 < 2^32 each): 32-bit scalars
+    uint32_t c_selects = 0, c_depth = 0, c_kint = 0, c_kleaf = 0, c_evals = 0, c_term = 0;
     const bool inline_eval = (mode & MODE_INLINE) != 0;
     const bool need_colors = !inline_eval || E.evaluator == AZX_EVAL_UNIFORM_HASH;   // leaf boards leave the wave
     const float c32 = E.c_puct;
     const float keep32 = (float)(1.0 - E.noise_scale);   // python float -> f32 (weak scalar)
     const Philox ph = game_rng(E, gh->uid);
-    const GammaConst gconst = gamma_const(E.noise_alpha);
+    const GammaConst gconst = gamma_const(E.noise_alpha, E.gamma_tab);
 
     if (mode & MODE_BEGIN) {
         batches_left = num_batches;
@@ -504,7 +495,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                     if (len == 0) rst[s] = make_float4(0.f, 0.f, nd.pp, __int_as_float(AZX_LINK_UNEVAL));
                 }
             }
-            c_kleaf += (unsigned long long)k;
+            c_kleaf += (uint32_t)k;
         }
         const int newlink = (k > 0) ? fc : AZX_LINK_TERM(fc);
         if (len == 0) {                                   // the root itself
@@ -791,7 +782,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                 }
                 T_MARK(depth == 0 ? 0 : 1)
                 c_depth += 1;
-                c_kint += (unsigned long long)mk.k;
+                c_kint += (uint32_t)mk.k;
                 node = link + child_rank;
                 if (at_root) cell0 = best_cell;
                 else (void)cache_find(node, true, cnv, ctv);   // deeper path nodes enter the cache
@@ -1425,21 +1416,97 @@ __global__ void k_divide_test(const float *num, const float *den, float *q, floa
 }
 
 // ---- device Dirichlet self-test: rows of k-cell noise exactly as k_mcts draws it ---------------
-__global__ __launch_bounds__(64) void k_noise_test(float alpha, int k, int n_rows, uint32_t seed, float *out) {
+__global__ __launch_bounds__(64) void k_noise_test(float alpha, const float *tab, int k, int n_rows, uint32_t seed, float *out) {
     const int lane = threadIdx.x, row = blockIdx.x;
     if (row >= n_rows) return;
     uint64_t m[2];
     m[0] = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
     m[1] = k > 64 ? ((1ull << (k - 64)) - 1ull) : 0ull;
-    const GammaConst gc = gamma_const(alpha);
+    const GammaConst gc = gamma_const(alpha, tab);
     float nz[2];
     dirichlet_noise<2>(m, lane, mix32(seed ^ mix32((uint32_t)row + 0x632be5abu)), gc, 1.0f, nz);
     if (lane < k) out[(size_t)row * k + lane] = nz[0];
     if (64 + lane < k) out[(size_t)row * k + 64 + lane] = nz[1];
 }
 
-void azx_launch_noise_test(float alpha, int k, int n_rows, uint32_t seed, float *out, hipStream_t st) {
-    hipLaunchKernelGGL(k_noise_test, dim3(n_rows), dim3(64), 0, st, alpha, k, n_rows, seed, out);
+void azx_launch_noise_test(float alpha, const float *tab, int k, int n_rows, uint32_t seed, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_noise_test, dim3(n_rows), dim3(64), 0, st, alpha, tab, k, n_rows, seed, out);
+}
+
+// ---- host: the delta table of log2_gamma_variate for one alpha (double precision) ---------------
+namespace {
+// ln of the regularised lower / upper incomplete gamma function P(a,x), Q(a,x)
+void ln_inc_gamma(double a, double x, double *lnP, double *lnQ) {
+    const double lg = std::lgamma(a);
+    if (x < a + 1.0) {                       // series for P
+        double ap = a, sum = 1.0 / a, del = sum;
+        for (int n = 0; n < 2000; ++n) {
+            ap += 1.0;
+            del *= x / ap;
+            sum += del;
+            if (std::fabs(del) < std::fabs(sum) * 1e-17) break;
+        }
+        *lnP = -x + a * std::log(x) + std::log(sum) - lg;
+        const double P = std::exp(*lnP);
+        *lnQ = P < 1.0 ? std::log1p(-P) : -1e300;
+    } else {                                 // continued fraction for Q (modified Lentz)
+        const double tiny = 1e-300;
+        double b = x + 1.0 - a, c = 1.0 / tiny, d = 1.0 / b, h = d;
+        for (int i = 1; i < 5000; ++i) {
+            const double an = -i * (i - a);
+            b += 2.0;
+            d = an * d + b;
+            if (std::fabs(d) < tiny) d = tiny;
+            c = b + an / c;
+            if (std::fabs(c) < tiny) c = tiny;
+            d = 1.0 / d;
+            const double del = d * c;
+            h *= del;
+            if (std::fabs(del - 1.0) < 1e-16) break;
+        }
+        *lnQ = -x + a * std::log(x) + std::log(h) - lg;
+        const double Q = std::exp(*lnQ);
+        *lnP = Q < 1.0 ? std::log1p(-Q) : -1e300;
+    }
+}
+// ln x with P(a,x) = 1 - y, by bisection on ln x (matching ln P when y > 1/2, ln Q otherwise)
+double ln_gamma_quantile_from_y(double a, double y) {
+    const bool lower = y > 0.5;
+    const double target = lower ? std::log1p(-y) : std::log(y);
+    double lo = -800.0 / a - 50.0, hi = std::log(80.0);
+    if (lower) {   // tiny x: ln P = a ln x - lgamma(a+1) + O(x); start near there
+        const double est = (target + std::lgamma(a + 1.0)) / a;
+        lo = est - 2.0;
+        hi = std::min(hi, est + 40.0);
+    }
+    for (int it = 0; it < 200; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        double lp, lq;
+        const double x = std::exp(mid);
+        if (x <= 0.0) { lo = mid; continue; }
+        ln_inc_gamma(a, x, &lp, &lq);
+        const bool below = lower ? (lp < target) : (lq > target);   // P grows, Q falls with x
+        if (below) lo = mid; else hi = mid;
+    }
+    return 0.5 * (lo + hi);
+}
+}  // namespace
+
+void azx_gamma_table(double alpha, float *tab) {
+    const double ln2 = std::log(2.0);
+    const double c0 = std::lgamma(alpha + 1.0) / ln2;            // log2 Gamma(alpha + 1)
+    for (int j = 0; j < AZX_GAMMA_TAB; ++j) {
+        const int e = (j >> 5) - 25;                              // y = 2^e * (1 + (j & 31) / 32)
+        const double y = std::ldexp(1.0 + (j & 31) / 32.0, e);
+        double delta = 0.0;
+        if (y < 1.0) {
+            const double u = 1.0 - y;
+            const double lx0 = (std::log2(u) + c0) / alpha;
+            if (lx0 > -60.0) delta = ln_gamma_quantile_from_y(alpha, y) / ln2 - lx0;   // below: x^alpha form is exact
+        }
+        tab[j] = (float)delta;
+    }
+    tab[AZX_GAMMA_TAB] = (float)c0;
 }
 
 // ============================================================================================
