@@ -538,6 +538,307 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
 }
 
 // ============================================================================================
+// wide residual tower (C a multiple of 128, N <= 13: BASELINE configs[4], 13x13 / 19x256): one
+// launch per conv layer, activations in HBM.  A board's activations (169 x 256 x (hi,lo) f16 =
+// 173 KB) do not fit the 160 KB LDS, so the in-LDS fusion of k_tower_f16x3 is not available; at
+// 7.6 GFLOP per position the 13 MB of activation traffic per position is < 15 % of the MFMA time.
+//   * HBM layout per board: [cell][C hi f16 | C lo f16] (the same hi/lo split as above);
+//   * a 256-thread block computes ONE board x 128 output channels: wave (wm, wn) owns position
+//     tiles 3wm..3wm+2 and channel tiles of co_base + 64 wn (3 x 2 accumulator tiles, 18 MFMAs per
+//     16-channel k-step); grid = (boards, C / 128);
+//   * the input is staged through LDS in 64-channel chunks with the row format of k_tower_f16x3
+//     (128 B hi | 128 B lo | 16 B pad, conflict-free ds_read_b128 fragments, one zero row for the
+//     padding taps); weights stream from L2 in fragment order; the k-loop is the one of
+//     k_tower_f16x3 (one prefetch load in each MFMA's shadow);
+//   * epilogue: + folded-BN bias (+ residual, read from the block input's buffer) -> ReLU -> split
+//     -> HBM; conv2 of a Resblock writes over the block input in place (a block reads exactly the
+//     residual elements it overwrites); the last layer also writes the fp32 copy k_heads reads.
+// ============================================================================================
+#define WIDE_ROWB 272
+#define WIDE_MW 3
+#define WIDE_NW 2
+
+__global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3(NetDev P, int layer, const unsigned short *__restrict__ in,
+                                                            unsigned short *out, const unsigned short *resid,
+                                                            float *__restrict__ out32,
+                                                            const int32_t *__restrict__ n_eval_ptr, int n_eval_host) {
+    constexpr int MW = WIDE_MW, NW = WIDE_NW, ROWB = WIDE_ROWB;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
+    const int e = blockIdx.x;
+    if (e >= n_eval) return;
+    const int C = P.C, N = P.N, ncells = P.ncells;
+    const int NCH = C / 64, NT = C / 32;
+    const int co_base = blockIdx.y * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const size_t rowg = (size_t)C * 4;                   // bytes of one cell's activations in HBM
+    const unsigned char *gin = reinterpret_cast<const unsigned char *>(in) + (size_t)e * ncells * rowg;
+    const int zero_off = ncells * ROWB;
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+    unsigned long long tapok = 0ull;                     // bit tap*4 + m
+    int rbase[MW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int r = (MW * wm + m) * 32 + li;
+        const int ry = r / N, rx = r - ry * N;
+        rbase[m] = r * ROWB + 16 * lh;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = ry + tap / 3 - 1, xx = rx + tap % 3 - 1;
+            if (r < ncells && yy >= 0 && yy < N && xx >= 0 && xx < N) tapok |= 1ull << (tap * 4 + m);
+        }
+    }
+    const int zbase = zero_off + 16 * lh;
+    auto tap_offsets = [&](int tap, int *aoff) {
+        const int delta = ((tap / 3 - 1) * N + (tap % 3 - 1)) * ROWB;
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+            aoff[m] = ((tapok >> (tap * 4 + m)) & 1ull) ? rbase[m] + delta : zbase;
+    };
+    if (tid < ROWB / 4) reinterpret_cast<uint32_t *>(smem + zero_off)[tid] = 0u;
+
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    struct FragA { f16x8 ah[MW], al[MW]; };
+    struct FragB { f16x8 bh[NW], bl[NW]; };
+    const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.Wh);
+    const int nt0 = co_base / 32 + 2 * wn;               // this wave's first channel tile
+    // weights of k-step q (global index over layer, tap, chunk, half, kk): [q][ntile][part][lane]
+    auto wptr = [&](int q, int n, int part) -> const uint4 * {
+        return wsrc + ((size_t)q * (NT * 2) + (size_t)((nt0 + n) * 2 + part)) * 64 + lane;
+    };
+
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+        __syncthreads();                                 // the previous chunk has been consumed
+        for (int idx = tid; idx < ncells * 16; idx += 256) {
+            const int row = idx >> 4, piece = idx & 15;
+            const size_t src = (size_t)row * rowg + (piece < 8 ? (size_t)chunk * 128 + piece * 16
+                                                               : (size_t)C * 2 + (size_t)chunk * 128 + (piece - 8) * 16);
+            const int dst = row * ROWB + (piece < 8 ? piece * 16 : 128 + (piece - 8) * 16);
+            *reinterpret_cast<uint4 *>(smem + dst) = *reinterpret_cast<const uint4 *>(gin + src);
+        }
+        __syncthreads();
+        // k-step t = 0..35 of this chunk: tap t/4, channel half (t/2)%2, 16-channel slice t%2
+        auto qof = [&](int t) { return ((((layer * 9 + t / 4) * NCH + chunk) * 2 + ((t >> 1) & 1)) * 2 + (t & 1)); };
+        int aoff[MW];
+        tap_offsets(0, aoff);
+        FragA fa[2];
+        FragB fb[3];
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const uint4 q0h = *wptr(qof(0), n, 0), q0l = *wptr(qof(0), n, 1);
+            const uint4 q1h = *wptr(qof(1), n, 0), q1l = *wptr(qof(1), n, 1);
+            fb[0].bh[n] = *reinterpret_cast<const f16x8 *>(&q0h);
+            fb[0].bl[n] = *reinterpret_cast<const f16x8 *>(&q0l);
+            fb[1].bh[n] = *reinterpret_cast<const f16x8 *>(&q1h);
+            fb[1].bl[n] = *reinterpret_cast<const f16x8 *>(&q1l);
+        }
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            fa[0].ah[m] = *reinterpret_cast<const f16x8 *>(smem + aoff[m]);
+            fa[0].al[m] = *reinterpret_cast<const f16x8 *>(smem + aoff[m] + 128);
+        }
+        constexpr int NMF = 3 * MW * NW, NLB = 2 * NW, NLA = 2 * MW;
+#pragma unroll
+        for (int t = 0; t < 36; ++t) {
+            const FragA &ca = fa[t & 1];
+            const FragB &cb = fb[t % 3];
+            FragA &na = fa[(t + 1) & 1];
+            FragB &nb = fb[(t + 2) % 3];
+#pragma unroll
+            for (int i = 0; i < NMF; ++i) {
+                if (i < NLA) {                            // activations first: they are due next k-step
+                    if (t + 1 < 36) {
+                        const int m = i >> 1, part = i & 1;
+                        if (i == 0 && ((t + 1) & 3) == 0) tap_offsets((t + 1) / 4, aoff);
+                        const unsigned char *pa = smem + aoff[m] + ((((t + 1) >> 1) & 1) * 32 + ((t + 1) & 1) * 16) * 2 + part * 128;
+                        if (part) na.al[m] = *reinterpret_cast<const f16x8 *>(pa);
+                        else na.ah[m] = *reinterpret_cast<const f16x8 *>(pa);
+                    }
+                } else if (i < NLA + NLB) {
+                    if (t + 2 < 36) {
+                        const int j = i - NLA, n = j >> 1, part = j & 1;
+                        const uint4 q = *wptr(qof(t + 2), n, part);
+                        if (part) nb.bl[n] = *reinterpret_cast<const f16x8 *>(&q);
+                        else nb.bh[n] = *reinterpret_cast<const f16x8 *>(&q);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const int part = i / (MW * NW), mn = i % (MW * NW), m = mn / NW, n = mn % NW;
+                    const f16x8 wv = part == 1 ? cb.bl[n] : cb.bh[n];
+                    const f16x8 xv = part == 2 ? ca.al[m] : ca.ah[m];
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, xv, acc[m][n], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------
+    unsigned char *gout = reinterpret_cast<unsigned char *>(out) + (size_t)e * ncells * rowg;
+    const unsigned char *gres = resid ? reinterpret_cast<const unsigned char *>(resid) + (size_t)e * ncells * rowg : nullptr;
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+        const int cb0 = co_base + 64 * wn + 32 * n + 4 * lh;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int cb = cb0 + 8 * g4;
+            const float4 b4 = *reinterpret_cast<const float4 *>(P.bias + (size_t)layer * C + cb);
+            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int m = 0; m < MW; ++m) {
+                const int r = (MW * wm + m) * 32 + li;
+                if (r < ncells) {
+                    float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (gres) {
+                        const f16x4 rh = *reinterpret_cast<const f16x4 *>(gres + (size_t)r * rowg + cb * 2);
+                        const f16x4 rl = *reinterpret_cast<const f16x4 *>(gres + (size_t)r * rowg + (size_t)C * 2 + cb * 2);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) rv[j] = (float)rh[j] + (float)rl[j];
+                    }
+                    f16x4 h4, l4;
+                    float vv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acc[m][n][4 * g4 + j] + bv[j];
+                        v += rv[j];
+                        v = fmaxf(v, 0.0f);
+                        vv[j] = v;
+                        _Float16 hi, lo;
+                        split_f16(v, hi, lo);
+                        h4[j] = hi;
+                        l4[j] = lo;
+                    }
+                    *reinterpret_cast<f16x4 *>(gout + (size_t)r * rowg + cb * 2) = h4;
+                    *reinterpret_cast<f16x4 *>(gout + (size_t)r * rowg + (size_t)C * 2 + cb * 2) = l4;
+                    if (out32)
+                        *reinterpret_cast<float4 *>(out32 + ((size_t)e * ncells + r) * C + cb) =
+                            make_float4(vv[0], vv[1], vv[2], vv[3]);
+                }
+            }
+        }
+    }
+}
+
+// stem of the wide tower: the one-hot K = 27 product of k_tower_f16x3's stem, one board x 128
+// output channels per block, straight to the HBM activation layout
+__global__ __launch_bounds__(256, 2) void k_stem_wide_f16x3(NetDev P, const uint8_t *__restrict__ ev_board,
+                                                            unsigned short *out, float *__restrict__ out32,
+                                                            const int32_t *__restrict__ n_eval_ptr, int n_eval_host) {
+    constexpr int MW = WIDE_MW, NW = WIDE_NW;
+    __shared__ unsigned char cells[(AZX_MAX_BOARD + 2) * (AZX_MAX_BOARD + 2) + 15];
+    const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
+    const int e = blockIdx.x;
+    if (e >= n_eval) return;
+    const int C = P.C, N = P.N, ncells = P.ncells, NT = C / 32, NH = N + 2;
+    const int co_base = blockIdx.y * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const size_t rowg = (size_t)C * 4;
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const uint8_t *bd = ev_board + (size_t)e * AZX_CELL_STRIDE;
+    for (int i = tid; i < NH * NH; i += 256) {
+        const int y = i / NH - 1, x = i - (y + 1) * NH - 1;
+        cells[i] = (y >= 0 && y < N && x >= 0 && x < N) ? bd[y * N + x] : (uint8_t)3;
+    }
+    __syncthreads();
+    uint32_t onehot[MW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        onehot[m] = 0u;
+        const int r = (MW * wm + m) * 32 + li;
+        if (r < ncells) {
+            const int ry = r / N, rx = r - ry * N;
+            const unsigned char *c0 = cells + ry * NH + rx;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const uint32_t v = c0[(tap / 3) * NH + tap % 3];
+                onehot[m] |= (v < 3u ? 1u : 0u) << (3 * tap + v);
+            }
+        }
+    }
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+    const uint4 *ws = reinterpret_cast<const uint4 *>(P.Ws);   // [kk][ntile][hi,lo][lane]
+    const int nt0 = co_base / 32 + 2 * wn;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        f16x8 bfr[MW];
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            const uint32_t byte = (onehot[m] >> (16 * kk + 8 * lh)) & 0xffu;
+            uint4 q;
+            q.x = ((byte >> 0) & 1u) * 0x3C00u | ((byte >> 1) & 1u) * 0x3C000000u;
+            q.y = ((byte >> 2) & 1u) * 0x3C00u | ((byte >> 3) & 1u) * 0x3C000000u;
+            q.z = ((byte >> 4) & 1u) * 0x3C00u | ((byte >> 5) & 1u) * 0x3C000000u;
+            q.w = ((byte >> 6) & 1u) * 0x3C00u | ((byte >> 7) & 1u) * 0x3C000000u;
+            bfr[m] = *reinterpret_cast<const f16x8 *>(&q);
+        }
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const uint4 *pa = ws + ((size_t)(kk * NT + nt0 + n) * 2) * 64 + lane;
+            const uint4 qh = pa[0], ql = pa[64];
+            const f16x8 wh8 = *reinterpret_cast<const f16x8 *>(&qh);
+            const f16x8 wl8 = *reinterpret_cast<const f16x8 *>(&ql);
+#pragma unroll
+            for (int m = 0; m < MW; ++m) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh8, bfr[m], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl8, bfr[m], acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+    unsigned char *gout = reinterpret_cast<unsigned char *>(out) + (size_t)e * ncells * rowg;
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+        const int cb0 = co_base + 64 * wn + 32 * n + 4 * lh;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int cb = cb0 + 8 * g4;
+            const float4 b4 = *reinterpret_cast<const float4 *>(P.stem_b + cb);
+            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int m = 0; m < MW; ++m) {
+                const int r = (MW * wm + m) * 32 + li;
+                if (r < ncells) {
+                    f16x4 h4, l4;
+                    float vv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = fmaxf(acc[m][n][4 * g4 + j] + bv[j], 0.0f);
+                        vv[j] = v;
+                        _Float16 hi, lo;
+                        split_f16(v, hi, lo);
+                        h4[j] = hi;
+                        l4[j] = lo;
+                    }
+                    *reinterpret_cast<f16x4 *>(gout + (size_t)r * rowg + cb * 2) = h4;
+                    *reinterpret_cast<f16x4 *>(gout + (size_t)r * rowg + (size_t)C * 2 + cb * 2) = l4;
+                    if (out32)
+                        *reinterpret_cast<float4 *>(out32 + ((size_t)e * ncells + r) * C + cb) =
+                            make_float4(vv[0], vv[1], vv[2], vv[3]);
+                }
+            }
+        }
+    }
+}
+
+// ============================================================================================
 // generic VALU fallback (any channel count): one thread per output element, activations in HBM
 // ============================================================================================
 __global__ void k_stem_generic(NetDev P, const uint8_t *ev_board, const int32_t *n_eval_ptr,
@@ -737,6 +1038,7 @@ struct AzxNet {
     std::vector<void *> allocs;
     size_t persistent_allocs = 0;    // allocs[0..persistent) live as long as the net; the rest are the current weights
     float *act = nullptr, *act2 = nullptr, *act3 = nullptr;   // [E][ncells][C]
+    unsigned short *wideX = nullptr, *wideY = nullptr;        // wide tower: [E][ncells][C hi | C lo] f16
     float *logit = nullptr;                                     // [E][AZX_CELL_STRIDE]
     // host-forward staging
     uint8_t *hb_board = nullptr;
@@ -775,6 +1077,7 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     else if (chans == 64 && ncells <= 128) net->tower_variant = 1;   // <64,4,2,1,2>
     else if (chans == 64 && ncells <= 192) net->tower_variant = 2;   // <64,6,1,2,2>
     else if (chans == 32 && ncells <= 192) net->tower_variant = 3;   // <32,6,2,2,1>
+    else if (chans % 128 == 0 && ncells <= 192 && !want_fp32) net->tower_variant = 5;   // k_conv_wide_f16x3 per layer
     net->use_mfma = net->tower_variant != 0;
     const size_t E = max_evals;
     net->act = nalloc<float>(net, E * ncells * chans);
@@ -786,14 +1089,19 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
         net->act2 = nalloc<float>(net, E * ncells * chans);
         net->act3 = nalloc<float>(net, E * ncells * chans);
     }
+    if (net->tower_variant == 5) {
+        net->wideX = nalloc<unsigned short>(net, E * ncells * chans * 2);
+        net->wideY = nalloc<unsigned short>(net, E * ncells * chans * 2);
+    }
     if (!net->act || !net->logit || !net->hb_board || !net->hb_flip || !net->hb_value ||
-        (!net->use_mfma && (!net->act2 || !net->act3))) {
+        (!net->use_mfma && (!net->act2 || !net->act3)) || (net->tower_variant == 5 && (!net->wideX || !net->wideY))) {
         azx_net_destroy(net);
         return nfail(AZX_ENOMEM, "net: hipMalloc failed");
     }
     const int bpb = net->tower_variant == 2 ? 1 : 2;
     net->lds_bytes = (size_t)bpb * 2 * (ncells + 1) * (chans + 4) * sizeof(float);
     if (net->tower_variant == 4) net->lds_bytes = (size_t)F16X3_BPB * 128 * 272 + 272;
+    if (net->tower_variant == 5) net->lds_bytes = (size_t)(ncells + 1) * WIDE_ROWB;
     net->persistent_allocs = net->allocs.size();
     *out = net;
     return AZX_OK;
@@ -928,7 +1236,7 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
         for (int co = 0; co < C; ++co) bias[(size_t)l * C + co] = (float)sh[co];
     }
     std::vector<float> Wp;
-    if (net->use_mfma && net->tower_variant != 4) {
+    if (net->use_mfma && net->tower_variant < 4) {
         // B-fragment order: [layer][tap][q][ntile][lane(j + 32 h)][t] = W[tap][cin 8q+4h+t][cout 32 ntile + j]
         const int NT = C / 32, Q = C / 8;
         Wp.resize((size_t)L * 9 * Q * NT * 64 * 4);
@@ -945,48 +1253,47 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
                             }
     }
     std::vector<unsigned short> Wh, Ws;
-    if (net->tower_variant == 4) {
+    if (net->tower_variant == 4 || net->tower_variant == 5) {
+        const int NT = C / 32, NCH = C / 64;
+        auto f16bits = [](float w, int part) -> unsigned short {
+            const _Float16 hi = (_Float16)w;
+            const _Float16 lo = (_Float16)(w - (float)hi);
+            const _Float16 v = part ? lo : hi;
+            unsigned short bits;
+            memcpy(&bits, &v, 2);
+            return bits;
+        };
         // stem table as K = 27 (tap*3 + colour, padded to 32) x C weights:
         // [kk][ntile][part hi/lo][lane j + 32 h][t] = split(stemT[k = 16 kk + 8 h + t][cout 32 ntile + j])
-        Ws.resize((size_t)2 * 2 * 2 * 64 * 8);
+        Ws.resize((size_t)2 * NT * 2 * 64 * 8);
         size_t os = 0;
         for (int kk = 0; kk < 2; ++kk)
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
                 for (int part = 0; part < 2; ++part)
                     for (int ln = 0; ln < 64; ++ln)
                         for (int t = 0; t < 8; ++t) {
                             const int j = ln & 31, h = ln >> 5;
                             const int k = 16 * kk + 8 * h + t, co = 32 * nt + j;
-                            const float w = k < 27 ? stemT[(size_t)k * C + co] : 0.0f;
-                            const _Float16 hi = (_Float16)w;
-                            const _Float16 lo = (_Float16)(w - (float)hi);
-                            const _Float16 v = part ? lo : hi;
-                            unsigned short bits;
-                            memcpy(&bits, &v, 2);
-                            Ws[os++] = bits;
+                            Ws[os++] = f16bits(k < 27 ? stemT[(size_t)k * C + co] : 0.0f, part);
                         }
-        // f16x3 pack: [stage = (layer*9 + tap)*2 + half][kk][ntile][part hi/lo][lane j + 32 h][t]
-        //   = split(W[tap][cin 32 half + 16 kk + 8 h + t][cout 32 ntile + j])
-        Wh.resize((size_t)L * 18 * 2 * 2 * 2 * 64 * 8);
+        // conv weights, one 16-channel k-step after the other in the order the kernels walk them:
+        // [layer][tap][64-channel chunk][half][kk][ntile][part hi/lo][lane j + 32 h][t]
+        //   = split(W[tap][cin 64 chunk + 32 half + 16 kk + 8 h + t][cout 32 ntile + j])
+        Wh.resize((size_t)L * 9 * NCH * 2 * 2 * NT * 2 * 64 * 8);
         size_t o = 0;
         for (int l = 0; l < L; ++l)
             for (int tap = 0; tap < 9; ++tap)
-                for (int half = 0; half < 2; ++half)
-                    for (int kk = 0; kk < 2; ++kk)
-                        for (int nt = 0; nt < 2; ++nt)
-                            for (int part = 0; part < 2; ++part)
-                                for (int ln = 0; ln < 64; ++ln)
-                                    for (int t = 0; t < 8; ++t) {
-                                        const int j = ln & 31, h = ln >> 5;
-                                        const int ci = 32 * half + 16 * kk + 8 * h + t, co = 32 * nt + j;
-                                        const float w = Wg[(((size_t)l * 9 + tap) * C + ci) * C + co];
-                                        const _Float16 hi = (_Float16)w;
-                                        const _Float16 lo = (_Float16)(w - (float)hi);
-                                        const _Float16 v = part ? lo : hi;
-                                        unsigned short bits;
-                                        memcpy(&bits, &v, 2);
-                                        Wh[o++] = bits;
-                                    }
+                for (int ch = 0; ch < NCH; ++ch)
+                    for (int half = 0; half < 2; ++half)
+                        for (int kk = 0; kk < 2; ++kk)
+                            for (int nt = 0; nt < NT; ++nt)
+                                for (int part = 0; part < 2; ++part)
+                                    for (int ln = 0; ln < 64; ++ln)
+                                        for (int t = 0; t < 8; ++t) {
+                                            const int j = ln & 31, h = ln >> 5;
+                                            const int ci = 64 * ch + 32 * half + 16 * kk + 8 * h + t, co = 32 * nt + j;
+                                            Wh[o++] = f16bits(Wg[(((size_t)l * 9 + tap) * C + ci) * C + co], part);
+                                        }
     }
     // heads
     auto wvc = get("value_conv1.weight", (size_t)2 * C), wpc = get("move_conv1.weight", (size_t)4 * C);
@@ -1022,10 +1329,10 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
     d.stemT = upload(net, stemT);
     d.stem_b = upload(net, stem_b);
     d.Wg = upload(net, Wg);
-    d.Wp = (net->use_mfma && net->tower_variant != 4) ? upload(net, Wp) : nullptr;
+    d.Wp = (net->use_mfma && net->tower_variant < 4) ? upload(net, Wp) : nullptr;
     d.Wh = nullptr;
     d.Ws = nullptr;
-    if (net->tower_variant == 4) {
+    if (net->tower_variant == 4 || net->tower_variant == 5) {
         unsigned short *wsd = nalloc<unsigned short>(net, Ws.size());
         if (!wsd) return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
         (void)hipMemcpy(wsd, Ws.data(), Ws.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
@@ -1042,7 +1349,7 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
     d.fc3w = upload(net, *fc3w); d.fc3b = upload(net, *fc3b);
     d.mfcT = upload(net, mfcT); d.mfcb = upload(net, mfcb);
     if (!d.stemT || !d.stem_b || !d.Wg || !d.bias || !d.wv || !d.bv || !d.wp || !d.bp || !d.fc2T ||
-        !d.fc2b || !d.fc3w || !d.fc3b || !d.mfcT || !d.mfcb || (net->use_mfma && net->tower_variant != 4 && !d.Wp))
+        !d.fc2b || !d.fc3w || !d.fc3b || !d.mfcT || !d.mfcb || (net->use_mfma && net->tower_variant < 4 && !d.Wp))
         return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
     (void)hipDeviceSynchronize();
     net->ready = true;
@@ -1067,6 +1374,18 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
             const dim3 grid((max_n + F16X3_BPB - 1) / F16X3_BPB), block(F16X3_BPB * 128);
             if (split_m) hipLaunchKernelGGL(k_tower_f16x3<true>, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act);
             else hipLaunchKernelGGL(k_tower_f16x3<false>, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act);
+        } else if (net->tower_variant == 5) {
+            static bool attr5 = false;
+            if (!attr5) { (void)hipFuncSetAttribute((const void *)k_conv_wide_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr5 = true; }
+            const dim3 grid(max_n, d.C / 128), block(256);
+            hipLaunchKernelGGL(k_stem_wide_f16x3, grid, block, 0, st, d, boards, net->wideX,
+                               d.blocks == 0 ? net->act : (float *)nullptr, n_eval_ptr, n_host);
+            for (int b = 0; b < d.blocks; ++b) {
+                hipLaunchKernelGGL(k_conv_wide_f16x3, grid, block, lds, st, d, 2 * b, (const unsigned short *)net->wideX, net->wideY,
+                                   (const unsigned short *)nullptr, (float *)nullptr, n_eval_ptr, n_host);
+                hipLaunchKernelGGL(k_conv_wide_f16x3, grid, block, lds, st, d, 2 * b + 1, (const unsigned short *)net->wideY, net->wideX,
+                                   (const unsigned short *)net->wideX, b == d.blocks - 1 ? net->act : (float *)nullptr, n_eval_ptr, n_host);
+            }
         } else if (net->tower_variant == 1) {
             static bool attr1 = false;
             if (!attr1) { (void)hipFuncSetAttribute((const void *)k_tower_mfma<64, 4, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }

@@ -113,6 +113,38 @@ def test_forward_13x13_64ch_vs_oracle(eng, orc):
     E.close()
 
 
+@pytest.mark.parametrize("n,blocks,chans,count,use_oracle", [(13, 2, 128, 12, True), (11, 1, 128, 8, True),
+                                                             (13, 19, 256, 6, False), (5, 0, 128, 4, True)])
+def test_wide_tower_forward(eng, orc, n, blocks, chans, count, use_oracle):
+    """Channel counts that are multiples of 128 (BASELINE configs[4]: 13x13, 19x256) run one MFMA
+    launch per conv layer with activations in HBM (k_conv_wide_f16x3): <= 1e-4 against the torch
+    module (and the C oracle where it is quick enough)."""
+    import torch
+    from azalea_amd.network import HexNetwork
+    torch.manual_seed(n * 1000 + chans + blocks)
+    net = HexNetwork(board_size=n, num_blocks=blocks, base_chans=chans).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.3, 1.7)
+    state = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    rng = np.random.RandomState(n + blocks)
+    boards, lm = _random_positions(orc, n, count, rng)
+    E = eng.Engine(board_size=n, n_games=4, simulations=10, search_batch_size=10,
+                   evaluator=eng.EVAL_RESNET, num_blocks=blocks, base_chans=chans)
+    E.set_weights(state)
+    value, logprob = E.forward(boards, lm)
+    legal = lm > 0
+    with torch.no_grad():
+        t = net(torch.tensor(boards), torch.tensor(lm))
+    assert np.abs(value - t["value"].numpy()).max() <= TOL
+    assert np.abs(logprob - t["moves_logprob"].numpy())[legal].max() <= TOL
+    if use_oracle:
+        ov, olp = orc.Net(n, blocks, chans, state).forward(boards, lm)
+        assert np.abs(value - ov).max() <= TOL and np.abs(logprob - olp)[legal].max() <= TOL
+    E.close()
+
+
 def test_resnet_search_replayed_by_oracle(eng, orc):
     """Search with the device network; feed the SAME (value, prior) stream to the CPU oracle:
     trees must be identical bit for bit (visit counts, values, priors, topology), and the
