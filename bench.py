@@ -32,6 +32,17 @@ F16_MFMA_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md; the 
 FLOP_PER_POSITION_6x64_11 = 107851784
 
 
+def flop_per_position(n, blocks, chans):
+    """algorithmic flops of one evaluated position (2 per MAC; BN, ReLU, embedding,
+    softmax excluded): stem conv 3x3 4->C, 2*blocks convs 3x3 C->C, value/policy 1x1 convs, the
+    three FC layers.  (11, 6, 64) -> 107 851 784; (13, 19, 256) -> 7.58e9."""
+    cells = n * n
+    stem = cells * chans * 36 * 2
+    tower = 2 * blocks * cells * chans * chans * 9 * 2
+    heads = cells * chans * 2 * 2 + cells * chans * 4 * 2 + 2 * cells * 64 * 2 + 64 * 2 + 4 * cells * cells * 2
+    return stem + tower + heads
+
+
 def model_bytes(st):
     """SURVEY 8(d) algorithmic HBM bytes of the tree kernels (reference six-array data model):
     select: sum over scored interior nodes of (8 + 12 k_i); virtual loss apply+undo 32 D;
@@ -165,8 +176,12 @@ def main():
                 "workload": ("BASELINE configs[1]: %d concurrent %dx%d Hex games per GPU, HIP movegen+MCTS "
                              "kernels only, uniform priors (no net), %d sims/move (%d select_leaf calls)"
                              if args.workload == "tree" else
-                             "BASELINE configs[2]: %d concurrent %dx%d Hex games per GPU, %d sims/move (%d "
-                             "select_leaf calls), 6x64 resnet forward on split-f16 MFMA (fp32-accurate), random-init weights")
+                             ("BASELINE configs[2]" if (args.board, args.blocks, args.chans) == (11, 6, 64) else
+                              "BASELINE configs[4] shape on one GPU" if (args.board, args.blocks, args.chans) == (13, 19, 256)
+                              else "resnet self-play") +
+                             ": %d concurrent %dx%d Hex games per GPU, %d sims/move (%d select_leaf calls), " +
+                             "%dx%d resnet forward on split-f16 MFMA (fp32-accurate), random-init weights"
+                             % (args.blocks, args.chans))
                             % (args.games, args.board, args.board, args.sims,
                                (args.sims // args.batch + 1) * args.batch),
                 "games_per_gpu": args.games, "board": args.board, "simulations": args.sims,
@@ -204,12 +219,14 @@ def main():
             # HIP events on the engine stream.  ALGORITHMIC flops (107 851 784 per
             # evaluated position) over that time, against the dense MFMA peak of the dtype the tower
             # issues: f16 (the fp32 operands are carried as hi+lo f16 pairs, 3 MFMAs per product).
-            flops = st["evals"] * FLOP_PER_POSITION_6x64_11
+            flops = st["evals"] * flop_per_position(args.board, args.blocks, args.chans)
             net_s = st["net_seconds"] if st["net_seconds"] > 0 else st["seconds"]
             achieved = flops / net_s / 1e12
             line["dtype"] = "f16x3 (fp32 operands split hi+lo f16, fp32 accumulate)"
             line["roofline"] = {
-                "kernel": "k_tower_f16x3 + k_heads (6x64 resnet forward of one leaf batch)",
+                "kernel": ("k_tower_f16x3 + k_heads" if args.chans == 64 and args.board <= 11 else
+                           "k_conv_wide_f16x3 x %d + k_heads" % (2 * args.blocks) if args.chans % 128 == 0 else
+                           "tower + k_heads") + " (%dx%d resnet forward of one leaf batch)" % (args.blocks, args.chans),
                 "bound": "mfma", "achieved": achieved, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": achieved / F16_MFMA_PEAK_TF, "traffic": None,
                 "issued_mfma_tflops": 3.0 * achieved, "issued_frac": 3.0 * achieved / F16_MFMA_PEAK_TF,

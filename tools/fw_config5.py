@@ -6,9 +6,9 @@ from azalea_amd.network import HexNetwork
 torch.manual_seed(0)
 n, blocks, chans = 13, 19, 256
 net = HexNetwork(board_size=n, num_blocks=blocks, base_chans=chans).eval()
-E = eng.Engine(board_size=n, n_games=64, simulations=10, search_batch_size=10, evaluator=eng.EVAL_RESNET, num_blocks=blocks, base_chans=chans)
+E = eng.Engine(board_size=n, n_games=int(sys.argv[1]) if len(sys.argv) > 1 else 64, simulations=10, search_batch_size=10, evaluator=eng.EVAL_RESNET, num_blocks=blocks, base_chans=chans)
 E.set_weights({k: v.detach().numpy() for k, v in net.state_dict().items() if v.dtype == torch.float32})
-B = 256
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 boards = np.random.RandomState(0).randint(0, 3, (B, n, n)).astype(np.int32)
 lm = np.zeros((B, n * n), np.int32)
 for i in range(B):
