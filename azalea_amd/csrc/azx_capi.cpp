@@ -976,7 +976,12 @@ extern "C" int azx_replay_collate(azx_engine *e, int64_t batch, const int64_t *i
         void *p = nullptr;
         hipError_t err = hipMalloc(&p, (size_t)batch * sizeof(long long));
         if (err != hipSuccess) return fail(AZX_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(err));
-        e->ring_allocs.push_back(p);       // the old (smaller) one is freed with the ring
+        if (e->ring_idx) {                 // blocking calls: no kernel still reads the old index buffer
+            (void)hipFree(e->ring_idx);
+            e->ring_allocs.erase(std::remove(e->ring_allocs.begin(), e->ring_allocs.end(), (void *)e->ring_idx),
+                                 e->ring_allocs.end());
+        }
+        e->ring_allocs.push_back(p);
         e->ring_idx = (long long *)p;
         e->ring_idx_cap = batch;
     }
