@@ -317,3 +317,89 @@ def test_play_mode_whole_games(eng):
         assert rw[-1] == 1.0     # the last mover made the winning move
     assert st["selects"] > 0 and st["sum_k_leaf"] > 0
     E.close()
+
+
+def _check_root_invariants(E, sims_per_move):
+    """Size-independent properties of any search (mcts.py:62-92, :242-255): every backup passes
+    through exactly one root child, so the children's visits add up to the root's (one less when
+    the root was carried over from the previous move: its own expansion visit)."""
+    root = E.get_root()
+    k = root["k"]
+    for g in range(E.G):
+        if k[g] == 0:
+            continue
+        cv = root["child_visits"][g, :k[g]]
+        s, rv = float(cv.sum()), float(root["root_visits"][g])
+        assert s in (rv, rv - 1.0), (g, s, rv)
+        assert cv.min() >= 0 and np.all(cv == np.round(cv))
+        assert rv >= sims_per_move
+        assert 1 + k[g] <= root["num_nodes"][g]
+
+
+def test_full_size_tree_config_properties(eng, orc):
+    """BASELINE configs[1] at full size (4096 concurrent 11x11 games, 400 sims/move): too large for
+    the oracle to replay, so the run is checked through what must hold at any size -- exact
+    simulation counts, the root-visit checksum of every tree, and every harvested game being a
+    legal game of Hex that ends, and only ends, with the winning move of its last mover."""
+    n, G, sims = 11, 4096, 400
+    E = eng.Engine(board_size=n, n_games=G, simulations=sims, search_batch_size=10, evaluator=eng.EVAL_UNIFORM)
+    per_move = (sims // 10 + 1) * 10
+    st = E.play_steps(3)
+    assert st["plies"] == 3 * G and st["selects"] == 3 * G * per_move
+    assert 0 < st["evals"] <= st["selects"] + st["plies"] and st["sum_depth"] >= st["selects"]   # + one root evaluation per fresh root
+    E.search()
+    _check_root_invariants(E, per_move)
+    rows, st = E.play(30000)
+    assert st["selects"] == st["plies"] * per_move and st["positions"] == len(rows["reward"]) >= 30000
+    uid, board = rows["game_uid"], rows["board"].reshape(-1, n * n)
+    starts = np.flatnonzero(np.r_[True, uid[1:] != uid[:-1]])
+    ends = np.r_[starts[1:], len(uid)]
+    assert len(starts) == st["games"] and len(np.unique(uid)) == len(starts)
+    k = (board == 0).sum(1)
+    assert np.array_equal(k, rows["nlegal"])
+    assert np.abs(rows["moves_prob"].sum(1) - 1.0).max() < 1e-5
+    checked = 0
+    for s, e in zip(starts, ends):
+        b = board[s:e]
+        assert (b[0] == 0).all()
+        diff = (b[1:] != b[:-1])
+        assert (diff.sum(1) == 1).all()                         # one stone per ply
+        cells = diff.argmax(1)
+        rw = rows["reward"][s:e]
+        assert rw[-1] == 1.0 and np.array_equal(rw, np.where((np.arange(e - s) % 2) == ((e - s - 1) % 2), 1.0, -1.0))
+        if checked < 64:                                        # replay through the oracle's rules
+            h = orc.Hex(n)
+            for c in cells:
+                assert h.result == 0
+                h.step(int(c) + 1)
+            assert h.result == 0                                # the recorded rows stop before the winning move ...
+            last = h.legal_moves()
+            wins = 0
+            for mv in last:                                     # ... which exists for the mover of the last row
+                h2 = h.copy()
+                h2.step(int(mv))
+                wins += h2.result != 0
+            assert wins >= 1
+            checked += 1
+    E.close()
+
+
+def test_full_size_resnet_config_properties(eng):
+    """BASELINE configs[2] at full size (4096 games, 400 sims, 6x64 net): two lock-step moves."""
+    import torch
+    from azalea_amd.network import HexNetwork
+    torch.manual_seed(0)
+    net = HexNetwork(board_size=11, num_blocks=6, base_chans=64).eval()
+    E = eng.Engine(board_size=11, n_games=4096, simulations=400, search_batch_size=10, evaluator=eng.EVAL_RESNET)
+    E.set_weights({k: v.detach().numpy() for k, v in net.state_dict().items() if v.dtype == torch.float32})
+    st = E.play_steps(2)
+    assert st["plies"] == 2 * 4096 and st["selects"] == 2 * 4096 * 410
+    assert 0 < st["evals"] <= st["selects"] + 2 * 4096 and st["net_launches"] >= 2 * 41
+    E.search()
+    _check_root_invariants(E, 410)
+    root = E.get_root()
+    pr = root["child_prior"]
+    for g in range(0, 4096, 257):
+        kk = root["k"][g]
+        assert abs(pr[g, :kk].sum() - 1.0) < 1e-4 and (pr[g, :kk] > 0).all()
+    E.close()
