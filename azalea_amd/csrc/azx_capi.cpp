@@ -142,6 +142,7 @@ extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
     d.temperature = (float)cfg->temperature;
     e->num_batches = cfg->simulations / cfg->search_batch_size + 1;   // mcts.py:268
     e->selects_per_search = e->num_batches * cfg->search_batch_size;
+    d.selects_per_search = e->selects_per_search;
     int cap = cfg->nodes_per_game;
     // default: six moves' worth of expansions -- a sharply peaked network carries most of its tree
     // from move to move (the reference allows 10M nodes per game, search_tree.py:18)

@@ -62,6 +62,7 @@ enum {   // counters[] slots
 
 struct DevEngine {
     int32_t N, ncells, G, bs, cap, slots;
+    int32_t selects_per_search;   // (simulations / bs + 1) * bs, mcts.py:268
     float c_puct;
     int32_t evaluator, flags;
     // games

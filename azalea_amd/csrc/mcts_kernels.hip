@@ -1094,7 +1094,11 @@ __global__ __launch_bounds__(64) void k_advance(DevEngine E, const int32_t *move
         }
         if (child < 0 || clink == AZX_LINK_UNEVAL) {
             tree_reset<SLOTS>(E, g, th, nmk.k, lane);           // step to the unknown
-        } else if (E.flags & AZX_FLAG_NO_COMPACT) {
+        } else if ((E.flags & AZX_FLAG_NO_COMPACT) ||
+                   (long long)th->num_nodes + (long long)(E.selects_per_search + 1) * nmk.k <= (long long)E.cap) {
+            // re-root in place, like the reference (search_tree.py:127-130).  The arena is only
+            // compacted when the next search could run out of nodes (each select_leaf call and the
+            // root evaluation expand at most one node with at most k children).
             if (lane == 0) { th->root_id = child; th->root_k = nmk.k; }
         } else {
             // Cheney copy of the kept subtree, level by level (children of a level-L node: kL)

@@ -218,10 +218,12 @@ def canonical(d):
             bits(d["prior_prob"][order]))
 
 
-def test_many_games_vs_oracle_with_compaction(eng, orc):
+@pytest.mark.parametrize("nodes_per_game", [0, 30000], ids=["roomy-arena", "tight-arena"])
+def test_many_games_vs_oracle_with_compaction(eng, orc, nodes_per_game):
     """64 concurrent games from different positions, several searches + moves each: the
-    engine (arena compaction on) and the CPU oracle (reference never-free tree) must agree
-    bit-exactly on every game's kept subtree after every search."""
+    engine and the CPU oracle (reference never-free tree) must agree bit-exactly on every game's
+    kept subtree after every search -- with a roomy arena (moves re-root in place) and with one so
+    tight that the kept subtree has to be compacted into the other arena every other move."""
     n, G, sims = 11, 64, 100
     rng = np.random.RandomState(5)
     table = (np.float32(1.0) / np.arange(0, n * n + 1).clip(1).astype(np.float32)).astype(np.float32)
@@ -240,7 +242,7 @@ def test_many_games_vs_oracle_with_compaction(eng, orc):
             mv.append(m)
         prefixes.append(mv)
     E = eng.Engine(board_size=n, n_games=G, simulations=sims, search_batch_size=10,
-                   exploration_coef=0.5, evaluator=eng.EVAL_UNIFORM_HASH)
+                   exploration_coef=0.5, evaluator=eng.EVAL_UNIFORM_HASH, nodes_per_game=nodes_per_game)
     E.set_prior_table(table)
     E.reset(moves=prefixes)
     games, trees = [], []
@@ -254,6 +256,7 @@ def test_many_games_vs_oracle_with_compaction(eng, orc):
     alive = np.ones(G, bool)
     for rnd in range(4):
         E.search()
+        assert not E.get_status().any()
         root = E.get_root()
         move_ids = np.full(G, -1, np.int32)
         for g in range(G):
