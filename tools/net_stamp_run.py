@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from azalea_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libazx_netstamp.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get("AZX_STAMP_LIB", "libazx_netstamp.so"))
 from azalea_amd import engine as eng
 import numpy as np, torch
 from azalea_amd.network import HexNetwork
