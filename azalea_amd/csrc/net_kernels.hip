@@ -45,6 +45,7 @@ struct NetDev {
     const float *stemT;    // [9][3][C]   table[tap][cell value][cout], then one all-zero row
     const float *stem_b;   // [C]
     const unsigned short *Ws;  // f16x3 pack of stemT as an MFMA A operand: [2 kk][2 ntile][hi,lo][64 lanes][8] f16 bits
+    const unsigned short *Ws16, *Wh16;   // the same weights in 16x16x32 fragment order (k_tower_f16x3_s16)
     // tower (network.py:17-39, :50-52): BN folded into the conv weights
     const float *Wp;       // MFMA pack [layers][9][C/8][C/32][64][4]
     const unsigned short *Wh;  // f16x3 pack [layers*18 stages][2 kk][2 ntile][hi,lo][64 lanes][8] f16 bits
@@ -535,6 +536,239 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
     }
     NT_MARK(6)
     NT_FLUSH
+}
+
+// ============================================================================================
+// k_tower_f16x3_s16: the fused split-f16 tower on v_mfma_f32_16x16x32_f16.  Dense f16 MFMA on this
+// chip is power-limited: a saturated 32x32x16 stream holds ~1.5-1.6 GHz (~1.4-1.5 PFLOP/s on random
+// data), the 16x16x32 shape ~1.8 GHz (~1.75 PFLOP/s) -- tools/microbench/mfma_shapes.hip -- so the
+// same products are issued as 16x16 tiles.  Same block layout as k_tower_f16x3<true> (2 boards per
+// 256-thread block, a wave owns 64 positions x 64 channels = 4 x 4 tiles of 16 x 16), same LDS
+// image.  A k-step is one tap x 32 input channels (18 per layer): 8 weight fragments (4 channel
+// tiles x hi/lo, double-buffered, from L2) + 8 activation fragments (4 position tiles x hi/lo,
+// from LDS, single-buffered: tile m's registers are reloaded for the next k-step as soon as its
+// 12 MFMAs have issued) feed 48 MFMAs, one load in each of the first MFMAs' shadows.
+// ============================================================================================
+#ifndef AZX_S16_FENCE
+#define AZX_S16_FENCE 1   // scheduling fence after every third MFMA (measured best of none / 3rd / every)
+#endif
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P, const uint8_t *__restrict__ ev_board,
+                                                                        const int32_t *__restrict__ n_eval_ptr,
+                                                                        int n_eval_host, float *__restrict__ act_out) {
+    constexpr int C = 64, ROWB = 272, MT = 4, NT = 4;     // 16-row position tiles / 16-channel tiles per wave
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
+    const int e0 = blockIdx.x * F16X3_BPB;
+    if (e0 >= n_eval) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wb = wave >> 1, wh = wave & 1;             // board within the block, which half of its positions
+    const int N = P.N, ncells = P.ncells;
+    const int e = e0 + wb;
+    const bool live = e < n_eval;
+    const int board_b = 128 * ROWB;
+    const int x_off = wb * board_b;
+    unsigned char *X = smem + x_off;
+    const int zero_off = F16X3_BPB * board_b;
+    // lane (i = lane & 15: position inside a tile, h = lane >> 4: k-group of the operands / channel
+    // quad of the result).  Transposed product: D[channel 4h + reg][position i].
+    const int li = lane & 15, lh = lane >> 4;
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+    unsigned long long tapok = 0ull;                     // bit tap*4 + m
+    int rbase[MT], ry_[MT], rx_[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int r = 64 * wh + 16 * m + li;
+        const int ry = r / N, rx = r - ry * N;
+        ry_[m] = ry;
+        rx_[m] = rx;
+        rbase[m] = x_off + r * ROWB + 16 * lh;           // 8 channels (16 B) per k-group
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = ry + tap / 3 - 1, xx = rx + tap % 3 - 1;
+            if (r < ncells && yy >= 0 && yy < N && xx >= 0 && xx < N) tapok |= 1ull << (tap * 4 + m);
+        }
+    }
+    const int zbase = zero_off + 16 * lh;
+    auto act_offset = [&](int tap, int m) -> int {
+        const int delta = ((tap / 3 - 1) * N + (tap % 3 - 1)) * ROWB;
+        return ((tapok >> (tap * 4 + m)) & 1ull) ? rbase[m] + delta : zbase;
+    };
+
+    f32x4 res[MT][NT];
+    auto epilogue = [&](f32x4 (&acc)[MT][NT], const float *bias, auto kind_tag) {
+        constexpr int kind = decltype(kind_tag)::value;  // 0 conv1, 1 conv2 (+ residual), 2 stem
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int cb = 16 * n + 4 * lh;
+            const float4 b4 = *reinterpret_cast<const float4 *>(bias + cb);
+            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f16x4 h4, l4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[m][n][j] + bv[j];
+                    if (kind == 1) v += res[m][n][j];
+                    v = fmaxf(v, 0.0f);
+                    if (kind != 0) res[m][n][j] = v;
+                    _Float16 hi, lo;
+                    split_f16(v, hi, lo);
+                    h4[j] = hi;
+                    l4[j] = lo;
+                }
+                unsigned char *pw = X + (64 * wh + 16 * m + li) * ROWB + cb * 2;
+                *reinterpret_cast<f16x4 *>(pw) = h4;
+                *reinterpret_cast<f16x4 *>(pw + 128) = l4;
+            }
+        }
+    };
+
+    // ---- stem: one 32-wide k-step with one-hot activations (see k_tower_f16x3) ------------------
+    {
+        const int NH = N + 2;
+        unsigned char *cells = X + 121 * ROWB;
+        const uint8_t *bd = ev_board + (size_t)(live ? e : n_eval - 1) * AZX_CELL_STRIDE;
+        if (wh == 0) {
+            for (int i = lane; i < NH * NH; i += 64) {
+                const int y = i / NH - 1, x = i - (y + 1) * NH - 1;
+                cells[i] = (y >= 0 && y < N && x >= 0 && x < N) ? bd[y * N + x] : (uint8_t)3;
+            }
+        }
+        if (tid < ROWB / 4) reinterpret_cast<uint32_t *>(smem + zero_off)[tid] = 0u;
+        __syncthreads();
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint4 *ws = reinterpret_cast<const uint4 *>(P.Ws16);   // [ntile][hi,lo][lane]
+        f16x8 wfh[NT], wfl[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const uint4 qh = ws[(n * 2) * 64 + lane], ql = ws[(n * 2 + 1) * 64 + lane];
+            wfh[n] = *reinterpret_cast<const f16x8 *>(&qh);
+            wfl[n] = *reinterpret_cast<const f16x8 *>(&ql);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            uint32_t onehot = 0u;                        // bit k = 3*tap + colour of that neighbour
+            if (64 * wh + 16 * m + li < ncells) {
+                const unsigned char *c0 = cells + ry_[m] * NH + rx_[m];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const uint32_t v = c0[(tap / 3) * NH + tap % 3];
+                    onehot |= (v < 3u ? 1u : 0u) << (3 * tap + v);
+                }
+            }
+            const uint32_t byte = (onehot >> (8 * lh)) & 0xffu;      // k = 8 h + j
+            uint4 q;
+            q.x = ((byte >> 0) & 1u) * 0x3C00u | ((byte >> 1) & 1u) * 0x3C000000u;
+            q.y = ((byte >> 2) & 1u) * 0x3C00u | ((byte >> 3) & 1u) * 0x3C000000u;
+            q.z = ((byte >> 4) & 1u) * 0x3C00u | ((byte >> 5) & 1u) * 0x3C000000u;
+            q.w = ((byte >> 6) & 1u) * 0x3C00u | ((byte >> 7) & 1u) * 0x3C000000u;
+            const f16x8 xf = *reinterpret_cast<const f16x8 *>(&q);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[n], xf, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfl[n], xf, acc[m][n], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // every wave has read the staged cells: the tail rows are free again
+        epilogue(acc, P.stem_b, std::integral_constant<int, 2>{});
+    }
+    __syncthreads();
+
+    const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.Wh16);     // 512 uint4 per stage: [ntile 4][hi,lo][lane]
+    int stage = 0;
+    auto conv_layer = [&](int layer, auto residual_tag) {
+        constexpr bool residual = decltype(residual_tag)::value;
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f16x8 wh_[2][NT], wl_[2][NT];                    // weight fragments, double-buffered
+        f16x8 xh[MT], xl[MT];                            // activation fragments, one set: tile m's registers are
+                                                         // refilled while tile m+1 computes (tile MT-1 lags a step)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const uint4 qh = wsrc[(size_t)stage * 512 + (n * 2) * 64 + lane];
+            const uint4 ql = wsrc[(size_t)stage * 512 + (n * 2 + 1) * 64 + lane];
+            wh_[0][n] = *reinterpret_cast<const f16x8 *>(&qh);
+            wl_[0][n] = *reinterpret_cast<const f16x8 *>(&ql);
+        }
+#pragma unroll
+        for (int m = 0; m < MT - 1; ++m) {
+            const unsigned char *pa = smem + act_offset(0, m);
+            xh[m] = *reinterpret_cast<const f16x8 *>(pa);
+            xl[m] = *reinterpret_cast<const f16x8 *>(pa + 128);
+        }
+        // k-step t = 0..17: tap t/2, channels 32 (t%2) .. +31.  48 MFMAs, 16 loads: one load in every
+        // third MFMA's shadow (a 16x16x32 MFMA leaves 8 issue cycles free, one load fits, two do not)
+#pragma unroll
+        for (int t = 0; t < 18; ++t) {
+            const int cur = t & 1, nxt = cur ^ 1;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int q = 0; q < 3 * NT; ++q) {                // 12 MFMAs of position tile m
+                    const int n = q / 3, p = q % 3;
+                    if (q == 1 || q == 7) {                       // two of the next k-step's eight weight fragments
+                        if (t + 1 < 18) {
+                            const int idx = 2 * m + (q == 7), nn = idx >> 1, part = idx & 1;
+                            const uint4 qq = wsrc[(size_t)(stage + t + 1) * 512 + (nn * 2 + part) * 64 + lane];
+                            if (part) wl_[nxt][nn] = *reinterpret_cast<const f16x8 *>(&qq);
+                            else wh_[nxt][nn] = *reinterpret_cast<const f16x8 *>(&qq);
+                        }
+                    } else if (q == 4 || q == 10) {               // refill the tile that finished last
+                        const int mm = (m + MT - 1) % MT;         // m = 0 fills tile MT-1 for THIS k-step
+                        const int tt = m == 0 ? t : t + 1;
+                        if (tt < 18) {
+                            const unsigned char *pa = smem + act_offset(tt >> 1, mm) + (tt & 1) * 64 + (q == 10) * 128;
+                            if (q == 10) xl[mm] = *reinterpret_cast<const f16x8 *>(pa);
+                            else xh[mm] = *reinterpret_cast<const f16x8 *>(pa);
+                        }
+                    }
+#if AZX_S16_FENCE == 2
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                    const f16x8 wv = p == 1 ? wl_[cur][n] : wh_[cur][n];
+                    const f16x8 xv = p == 2 ? xl[m] : xh[m];
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, acc[m][n], 0, 0, 0);
+#if AZX_S16_FENCE == 2
+                    __builtin_amdgcn_sched_barrier(0);
+#elif AZX_S16_FENCE == 1
+                    if (q % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+            }
+        }
+        stage += 18;
+        __syncthreads();   // both waves of the board finished reading it
+        epilogue(acc, P.bias + layer * C, std::integral_constant<int, residual ? 1 : 0>{});
+        __syncthreads();   // the partner wave wrote the other rows of this board
+    };
+    for (int blk = 0; blk < P.blocks; ++blk) {
+        conv_layer(2 * blk, std::false_type{});
+        conv_layer(2 * blk + 1, std::true_type{});
+    }
+
+    if (live) {
+        float *out = act_out + (size_t)e * ncells * C;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int row = 64 * wh + 16 * m + li;
+            if (row < ncells) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    *reinterpret_cast<float4 *>(out + row * C + 16 * n + 4 * lh) =
+                        make_float4(res[m][n][0], res[m][n][1], res[m][n][2], res[m][n][3]);
+            }
+        }
+    }
 }
 
 // ============================================================================================
@@ -1295,6 +1529,43 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
                                             Wh[o++] = f16bits(Wg[(((size_t)l * 9 + tap) * C + ci) * C + co], part);
                                         }
     }
+    std::vector<unsigned short> Wh16, Ws16;
+    if (net->tower_variant == 4) {
+        auto f16bits = [](float w, int part) -> unsigned short {
+            const _Float16 hi = (_Float16)w;
+            const _Float16 lo = (_Float16)(w - (float)hi);
+            const _Float16 v = part ? lo : hi;
+            unsigned short bits;
+            memcpy(&bits, &v, 2);
+            return bits;
+        };
+        // 16x16x32 A-operand order: lane (j = lane & 15: output channel in the tile, h = lane >> 4: k-group)
+        // holds 8 consecutive k.  Stem: [ntile 4][hi,lo][lane][t] = split(stemT[k = 8 h + t][cout 16 ntile + j])
+        Ws16.resize((size_t)4 * 2 * 64 * 8);
+        size_t os = 0;
+        for (int nt = 0; nt < 4; ++nt)
+            for (int part = 0; part < 2; ++part)
+                for (int ln = 0; ln < 64; ++ln)
+                    for (int t = 0; t < 8; ++t) {
+                        const int j = ln & 15, h = ln >> 4, k = 8 * h + t, co = 16 * nt + j;
+                        Ws16[os++] = f16bits(k < 27 ? stemT[(size_t)k * C + co] : 0.0f, part);
+                    }
+        // convs: [stage = (layer*9 + tap)*2 + half][ntile 4][hi,lo][lane][t]
+        //   = split(W[tap][cin 32 half + 8 h + t][cout 16 ntile + j])
+        Wh16.resize((size_t)L * 18 * 4 * 2 * 64 * 8);
+        size_t o = 0;
+        for (int l = 0; l < L; ++l)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int half = 0; half < 2; ++half)
+                    for (int nt = 0; nt < 4; ++nt)
+                        for (int part = 0; part < 2; ++part)
+                            for (int ln = 0; ln < 64; ++ln)
+                                for (int t = 0; t < 8; ++t) {
+                                    const int j = ln & 15, h = ln >> 4;
+                                    const int ci = 32 * half + 8 * h + t, co = 16 * nt + j;
+                                    Wh16[o++] = f16bits(Wg[(((size_t)l * 9 + tap) * C + ci) * C + co], part);
+                                }
+    }
     // heads
     auto wvc = get("value_conv1.weight", (size_t)2 * C), wpc = get("move_conv1.weight", (size_t)4 * C);
     std::vector<double> scv, shv, scp, shp;
@@ -1342,6 +1613,15 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
         (void)hipMemcpy(wh, Wh.data(), Wh.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
         d.Wh = wh;
     }
+    d.Ws16 = d.Wh16 = nullptr;
+    if (net->tower_variant == 4) {
+        unsigned short *a = nalloc<unsigned short>(net, Ws16.size()), *b = nalloc<unsigned short>(net, Wh16.size());
+        if (!a || !b) return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
+        (void)hipMemcpy(a, Ws16.data(), Ws16.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+        (void)hipMemcpy(b, Wh16.data(), Wh16.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+        d.Ws16 = a;
+        d.Wh16 = b;
+    }
     d.bias = upload(net, bias);
     d.wv = upload(net, wv); d.bv = upload(net, bv);
     d.wp = upload(net, wp); d.bp = upload(net, bp);
@@ -1365,14 +1645,17 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
         const size_t lds = net->lds_bytes;
         if (net->tower_variant == 4) {
             static const bool split_m = getenv("AZX_TOWER_SPLIT") ? atoi(getenv("AZX_TOWER_SPLIT")) != 0 : true;
+            static const int shape = getenv("AZX_TOWER_SHAPE") ? atoi(getenv("AZX_TOWER_SHAPE")) : 32;
             static bool attr4 = false;
             if (!attr4) {
                 (void)hipFuncSetAttribute((const void *)k_tower_f16x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 (void)hipFuncSetAttribute((const void *)k_tower_f16x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute((const void *)k_tower_f16x3_s16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 attr4 = true;
             }
             const dim3 grid((max_n + F16X3_BPB - 1) / F16X3_BPB), block(F16X3_BPB * 128);
-            if (split_m) hipLaunchKernelGGL(k_tower_f16x3<true>, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act);
+            if (shape == 16) hipLaunchKernelGGL(k_tower_f16x3_s16, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act);
+            else if (split_m) hipLaunchKernelGGL(k_tower_f16x3<true>, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act);
             else hipLaunchKernelGGL(k_tower_f16x3<false>, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act);
         } else if (net->tower_variant == 5) {
             static bool attr5 = false;
