@@ -11,7 +11,6 @@ import logging
 import os
 import time
 from functools import partial
-from typing import Optional
 
 import numpy as np
 import torch

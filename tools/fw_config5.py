@@ -1,4 +1,5 @@
-import sys, os, time
+"""Diagnostic: forward time of the BASELINE configs[4] network (13x13, 19x256) through azx_forward."""
+import sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from azalea_amd import engine as eng

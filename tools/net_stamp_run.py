@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from azalea_amd import _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get("AZX_STAMP_LIB", "libazx_netstamp.so"))
 from azalea_amd import engine as eng
-import numpy as np, torch
+import torch
 from azalea_amd.network import HexNetwork
 torch.manual_seed(0)
 net = HexNetwork(board_size=11, num_blocks=6, base_chans=64).eval()
