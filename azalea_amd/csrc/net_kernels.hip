@@ -253,7 +253,8 @@ __device__ unsigned long long g_tower_trace[3 * 32768];   // per block of the la
 template <bool SPLIT_M>
 __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, const uint8_t *__restrict__ ev_board,
                                                          const int32_t *__restrict__ n_eval_ptr,
-                                                         int n_eval_host, float *__restrict__ act_out) {
+                                                         int n_eval_host, float *__restrict__ act_out,
+                                                         float *__restrict__ hfeat) {
     constexpr int C = 64, ROWB = 272;
     constexpr int MW = SPLIT_M ? 2 : 4, NW = SPLIT_M ? 2 : 1;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -517,8 +518,41 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
         conv_layer(2 * blk + 1, std::true_type{});
     }
 
+    // ---- heads' 1x1 convs + folded BN + ReLU (network.py:77, :83) straight from the registers:
+    // hfeat[e][o][cell], o = 0,1 value planes, 2..5 policy planes -- 6 floats per cell leave the
+    // kernel instead of 64.  A cell's 64 channels sit in the lanes li and li + 32.
+    if (SPLIT_M && hfeat != nullptr) {
+        float part[MW][6];
+#pragma unroll
+        for (int o = 0; o < 6; ++o) {
+            const float *w = o < 2 ? P.wv + o * C : P.wp + (o - 2) * C;
+#pragma unroll
+            for (int m = 0; m < MW; ++m) part[m][o] = 0.0f;
+#pragma unroll
+            for (int n = 0; n < NW; ++n)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(w + (nbase + n) * 32 + 4 * lh + 8 * g4);
+#pragma unroll
+                    for (int m = 0; m < MW; ++m)
+                        part[m][o] += res[m][n][4 * g4] * w4.x + res[m][n][4 * g4 + 1] * w4.y +
+                                      res[m][n][4 * g4 + 2] * w4.z + res[m][n][4 * g4 + 3] * w4.w;
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            const int row = (mbase + m) * 32 + li;
+#pragma unroll
+            for (int o = 0; o < 6; ++o) {
+                const float tot = part[m][o] + __shfl_xor(part[m][o], 32);
+                const float b = o < 2 ? P.bv[o] : P.bp[o - 2];
+                if (live && row < ncells && lh == (o & 1))
+                    hfeat[((size_t)e * 6 + o) * ncells + row] = fmaxf(tot + b, 0.0f);
+            }
+        }
+    }
     // ---- tower output (fp32, from registers) -> HBM [e][ncells][C] -----------------------------
-    if (live) {
+    if (live && act_out != nullptr) {
         float *out = act_out + (size_t)e * ncells * C;
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
@@ -1131,6 +1165,7 @@ __global__ void k_conv_generic(NetDev P, int layer, const float *in, const float
 // ============================================================================================
 #define HEADS_BPB 8
 __global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict__ act,
+                                               const float *__restrict__ hfeat,
                                                const uint8_t *__restrict__ ev_board,
                                                const int32_t *__restrict__ ev_flip,
                                                const int32_t *__restrict__ n_eval_ptr,
@@ -1150,7 +1185,13 @@ __global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict
     const int C = P.C, N = P.N, ncells = P.ncells;
 
     // ---- 1x1 convs + folded BN + ReLU (network.py:77, :83); flatten order (c, h, w) -----------
-    if (tid < ncells) {
+    if (hfeat != nullptr) {                           // already done by the tower kernel
+        for (int idx = tid; idx < HEADS_BPB * 6 * ncells; idx += 192) {
+            const int b = idx / (6 * ncells), f = idx - b * 6 * ncells;
+            const float v = b < nb ? hfeat[(size_t)(e0 + b) * 6 * ncells + f] : 0.0f;
+            if (f < 2 * ncells) hv[f][b] = v; else hp[f - 2 * ncells][b] = v;
+        }
+    } else if (tid < ncells) {
         for (int b = 0; b < HEADS_BPB; ++b) {
             float v0 = 0.f, v1 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
             if (b < nb) {
@@ -1274,6 +1315,7 @@ struct AzxNet {
     float *act = nullptr, *act2 = nullptr, *act3 = nullptr;   // [E][ncells][C]
     unsigned short *wideX = nullptr, *wideY = nullptr;        // wide tower: [E][ncells][C hi | C lo] f16
     float *logit = nullptr;                                     // [E][AZX_CELL_STRIDE]
+    float *hfeat = nullptr;                                     // [E][6][ncells] head features from the fused tower
     // host-forward staging
     uint8_t *hb_board = nullptr;
     int32_t *hb_flip = nullptr;
@@ -1316,6 +1358,7 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     const size_t E = max_evals;
     net->act = nalloc<float>(net, E * ncells * chans);
     net->logit = nalloc<float>(net, E * AZX_CELL_STRIDE);
+    if (net->tower_variant == 4) net->hfeat = nalloc<float>(net, E * 6 * ncells);
     net->hb_board = nalloc<uint8_t>(net, E * AZX_CELL_STRIDE);
     net->hb_flip = nalloc<int32_t>(net, E);
     net->hb_value = nalloc<float>(net, E);
@@ -1641,6 +1684,7 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
                     int n_host, int max_n, float *logit, float *value, float *prior, hipStream_t st) {
     const NetDev &d = net->d;
     if (max_n <= 0) return;
+    const float *hfeat = nullptr;    // set when the tower kernel already produced the heads' conv planes
     if (net->use_mfma) {
         const size_t lds = net->lds_bytes;
         if (net->tower_variant == 4) {
@@ -1655,8 +1699,11 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
             }
             const dim3 grid((max_n + F16X3_BPB - 1) / F16X3_BPB), block(F16X3_BPB * 128);
             if (shape == 16) hipLaunchKernelGGL(k_tower_f16x3_s16, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act);
-            else if (split_m) hipLaunchKernelGGL(k_tower_f16x3<true>, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act);
-            else hipLaunchKernelGGL(k_tower_f16x3<false>, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act);
+            else if (split_m) {
+                hipLaunchKernelGGL(k_tower_f16x3<true>, grid, block, lds, st, d, boards, n_eval_ptr, n_host,
+                                   (float *)nullptr, net->hfeat);
+                hfeat = net->hfeat;
+            } else hipLaunchKernelGGL(k_tower_f16x3<false>, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act, (float *)nullptr);
         } else if (net->tower_variant == 5) {
             static bool attr5 = false;
             if (!attr5) { (void)hipFuncSetAttribute((const void *)k_conv_wide_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr5 = true; }
@@ -1694,7 +1741,7 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
         if (x != net->act)   // heads read net->act
             (void)hipMemcpyAsync(net->act, x, (size_t)max_n * d.ncells * d.C * sizeof(float), hipMemcpyDeviceToDevice, st);
     }
-    hipLaunchKernelGGL(k_heads, dim3((max_n + HEADS_BPB - 1) / HEADS_BPB), dim3(192), 0, st, d, net->act, boards, flip, n_eval_ptr, n_host, logit, value, prior);
+    hipLaunchKernelGGL(k_heads, dim3((max_n + HEADS_BPB - 1) / HEADS_BPB), dim3(192), 0, st, d, net->act, hfeat, boards, flip, n_eval_ptr, n_host, logit, value, prior);
 }
 
 void azx_net_eval(AzxNet *net, const DevEngine &e, hipStream_t st) {
