@@ -150,8 +150,8 @@ __device__ __forceinline__ float log2_gamma_variate(uint32_t seed, const GammaCo
     const uint32_t yb = (uint32_t)__float_as_int(y);
     const int idx = (int)(yb >> 18) - ((127 - 25) << 5);                      // 0 .. 799
     const float fr = (float)(yb & 0x3ffffu) * (1.0f / 262144.0f);
-    const float2 t = *reinterpret_cast<const float2 *>(gc.tab + idx);          // tab[idx], tab[idx + 1]
-    return lx0 + __builtin_fmaf(fr, t.y - t.x, t.x);
+    const float t0 = gc.tab[idx], t1 = gc.tab[idx + 1];
+    return lx0 + __builtin_fmaf(fr, t1 - t0, t0);
 }
 
 // scale * Dirichlet(alpha * 1_k) over the cells set in m[] (one value per lane-slot), the device
@@ -227,16 +227,19 @@ __device__ __forceinline__ int flip_src(int o, int N) {
 struct Lds {
     int32_t *path;         // [bs][pstride] node ids along each selected path (index d = depth d+1)
     unsigned char *colors; // [bs][AZX_CELL_STRIDE] absolute colours at the leaf (only when leaf boards leave the wave)
+    float *gtab;           // [AZX_GAMMA_TAB + 1] the gamma sampler's table, staged once per launch
 };
 
 size_t azx_mcts_lds_bytes(int ncells, int bs) {
-    return (size_t)bs * (ncells + (ncells & 1)) * 4 + (size_t)bs * AZX_CELL_STRIDE + 64;
+    return (size_t)bs * (ncells + (ncells & 1)) * 4 + (size_t)bs * AZX_CELL_STRIDE + 64 +
+           (size_t)(AZX_GAMMA_TAB + 1) * 4;
 }
 
 __device__ __forceinline__ Lds carve_lds(unsigned char *raw, int ncells, int bs) {
     Lds L;
     L.path = reinterpret_cast<int32_t *>(raw);
     L.colors = reinterpret_cast<unsigned char *>(L.path + bs * (ncells + (ncells & 1)));
+    L.gtab = reinterpret_cast<float *>(L.colors + bs * AZX_CELL_STRIDE + 64);   // bs*192 and the rest are multiples of 8
     return L;
 }
 
@@ -339,7 +342,12 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
     const float c32 = E.c_puct;
     const float keep32 = (float)(1.0 - E.noise_scale);   // python float -> f32 (weak scalar)
     const Philox ph = game_rng(E, gh->uid);
-    const GammaConst gconst = gamma_const(E.noise_alpha, E.gamma_tab);
+    // the device sampler's table goes to LDS (two dependent lookups per cell and select)
+    if (E.noise_scale != 0.0 && E.device_noise) {
+        for (int i = lane; i < AZX_GAMMA_TAB + 1; i += 64) L.gtab[i] = E.gamma_tab[i];
+        lds_sync();
+    }
+    const GammaConst gconst = gamma_const(E.noise_alpha, L.gtab);
 
     if (mode & MODE_BEGIN) {
         batches_left = num_batches;
