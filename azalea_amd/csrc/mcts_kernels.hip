@@ -679,6 +679,13 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                         if (mk.m[s]) best_cell = s * 64 + (int)__ffsll((long long)mk.m[s]) - 1;
                     child_link = AZX_LINK_UNEVAL;
                 } else {
+                    // sqrt(sum of the children's visits), mcts.py:132.  The sum is an integer known
+                    // without adding anything up: root_sumn at the root, and below it every
+                    // evaluated node has been visited once more than its children together (its
+                    // own expansion), virtual losses included since they mark node and child alike.
+                    const int sumn = at_root ? root_sumn : (int)cur_nv - 1;
+                    const float sq = sumn < AZX_SQRT_TAB ? c_sqrt[sumn] : sqrtf((float)sumn);
+                    // (looked up before the children are fetched: the scalar load rides under the HBM one)
                     // ---- children statistics ------------------------------------------------
                     float4 st[SLOTS];
                     int rk[SLOTS];
@@ -705,12 +712,6 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                                 if (lane_bit(mk.m[s]) && rk[s] == r) { st[s].x = pnv; st[s].y = ptv; }
                         }
                     }
-                    // sqrt(sum of the children's visits), mcts.py:132.  The sum is an integer known
-                    // without adding anything up: root_sumn at the root, and below it every
-                    // evaluated node has been visited once more than its children together (its
-                    // own expansion), virtual losses included since they mark node and child alike.
-                    const int sumn = at_root ? root_sumn : (int)cur_nv - 1;
-                    const float sq = sumn < AZX_SQRT_TAB ? c_sqrt[sumn] : sqrtf((float)sumn);
                     // ---- Dirichlet noise at the root only (mcts.py:126-131, :114) ----------
                     float nz[SLOTS];
                     const bool noisy = at_root && E.noise_scale != 0.0;
