@@ -1,9 +1,11 @@
 // mcts_kernels.hip -- Hex movegen + flat-array PUCT search kernels for gfx950 (MI355X).
 //
-// One 64-lane wavefront owns one concurrent game.  The board lives in registers (lane l
-// holds cells l, l+64[, l+128]), the children of the node being scored are read with one
-// coalesced 16-byte load per lane, PUCT argmax / visit sums are wave reductions, and the
-// Hex win test is an O(1) wave-parallel group relabel (see HexWave in azx_dev.h).
+// One 64-lane wavefront owns one concurrent game.  The root board lives in registers (lane l
+// holds cells l, l+64[, l+128]; its stones also as scalar bitboards), the root's children and a
+// 64-entry cache of deeper nodes stay on chip for a whole launch, the children of a deeper node
+// are read with one coalesced 16-byte load per lane, the PUCT argmax is a wave reduction, a
+// descent only tracks occupied cells and the Hex win test runs at new leaves on the root's group
+// labels (O(1) wave-parallel relabel, HexWave in azx_dev.h).  DESIGN.md section 3.1 has the rest.
 //
 // Restates (bit-exact in float32, compile with -ffp-contract=off):
 //   azalea/mcts.py:46-76 select_batch, :79-92 apply_virtual_loss, :95-116 select_leaf,
