@@ -1174,22 +1174,46 @@ __global__ __launch_bounds__(64) void k_advance(DevEngine E, const int32_t *move
             if (lane == 0) { atomicAdd(E.q_count, (unsigned long long)(-(long long)rows)); gh->active = 0; }
             restart = false;
         } else {
-            for (int r = 0; r < rows; ++r) {
-                const size_t q = (size_t)((pos + r) % (unsigned long long)E.q_cap);
-                const size_t sr = ((size_t)g * E.ncells + r) * AZX_CELL_STRIDE;
-                for (int o = lane; o < AZX_CELL_STRIDE / 4; o += 64)
-                    reinterpret_cast<uint32_t *>(E.q_board + q * AZX_CELL_STRIDE)[o] =
-                        reinterpret_cast<const uint32_t *>(E.row_board + sr)[o];
-                for (int o = lane; o < AZX_CELL_STRIDE; o += 64)
-                    E.q_prob[q * AZX_CELL_STRIDE + o] = E.row_prob[sr + o];
-                if (lane == 0) {
-                    E.q_color[q] = r & 1;
-                    E.q_k[q] = E.row_k[(size_t)g * E.ncells + r];
-                    float rew = (float)(result - 2);           // play_game.py:64-65
-                    if (r & 1) rew = -rew;
-                    E.q_reward[q] = rew;
-                    E.q_uid[q] = gh->uid;
+            // the game's rows are contiguous at the source, and at the destination unless the ring
+            // wraps inside them: bulk 16-byte copies, four per lane in flight
+            const size_t q0 = (size_t)(pos % (unsigned long long)E.q_cap);
+            const int first = (int)min((unsigned long long)rows, (unsigned long long)E.q_cap - q0);   // rows before the wrap
+            auto copy16 = [&](void *dst, const void *src, int n16) {
+                uint4 *d = reinterpret_cast<uint4 *>(dst);
+                const uint4 *sp = reinterpret_cast<const uint4 *>(src);
+                for (int i0 = 0; i0 < n16; i0 += 256) {
+                    uint4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + u * 64 + lane;
+                        if (i < n16) v[u] = sp[i];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + u * 64 + lane;
+                        if (i < n16) d[i] = v[u];
+                    }
                 }
+            };
+            const size_t sr0 = (size_t)g * E.ncells * AZX_CELL_STRIDE;
+            for (int part = 0; part < 2; ++part) {
+                const int r0 = part ? first : 0, nr = part ? rows - first : first;
+                if (nr <= 0) continue;
+                const size_t qd = part ? 0 : q0;
+                copy16(E.q_board + qd * AZX_CELL_STRIDE, E.row_board + sr0 + (size_t)r0 * AZX_CELL_STRIDE,
+                       nr * (AZX_CELL_STRIDE / 16));
+                copy16(E.q_prob + qd * AZX_CELL_STRIDE, E.row_prob + sr0 + (size_t)r0 * AZX_CELL_STRIDE,
+                       nr * (AZX_CELL_STRIDE / 4));
+            }
+            const int64_t uid = gh->uid;
+            for (int r = lane; r < rows; r += 64) {
+                const size_t q = (size_t)((pos + r) % (unsigned long long)E.q_cap);
+                E.q_color[q] = r & 1;
+                E.q_k[q] = E.row_k[(size_t)g * E.ncells + r];
+                float rew = (float)(result - 2);               // play_game.py:64-65
+                if (r & 1) rew = -rew;
+                E.q_reward[q] = rew;
+                E.q_uid[q] = uid;
             }
             if (lane == 0) {
                 E.counters[(size_t)g * CTR_COUNT + CTR_GAMES] += 1ull;
