@@ -590,7 +590,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P, const uint8_t *__restrict__ ev_board,
                                                                         const int32_t *__restrict__ n_eval_ptr,
-                                                                        int n_eval_host, float *__restrict__ act_out) {
+                                                                        int n_eval_host, float *__restrict__ act_out,
+                                                                        float *__restrict__ hfeat) {
     constexpr int C = 64, ROWB = 272, MT = 4, NT = 4;     // 16-row position tiles / 16-channel tiles per wave
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
@@ -724,52 +725,46 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f16x8 wh_[2][NT], wl_[2][NT];                    // weight fragments, double-buffered
-        f16x8 xh[MT], xl[MT];                            // activation fragments, one set: tile m's registers are
-                                                         // refilled while tile m+1 computes (tile MT-1 lags a step)
+        // One register set for the weights and one for the activations (64 + 64 VGPRs would not fit
+        // beside the accumulators and the residual): a k-step runs as two halves, channel tiles
+        // {0,1} then {2,3}, over all four position tiles.  Weights {2,3} of this step are fetched
+        // during the first half, weights {0,1} of the next step during the second; position tile
+        // m's activations are refilled for the next step once its second-half MFMAs have issued
+        // (the last tile's during the next step's first half).
+        f16x8 wh_[NT], wl_[NT];
+        f16x8 xh[MT], xl[MT];
+        auto load_w = [&](int st, int nn, int part) {
+            const uint4 qq = wsrc[(size_t)st * 512 + (nn * 2 + part) * 64 + lane];
+            if (part) wl_[nn] = *reinterpret_cast<const f16x8 *>(&qq);
+            else wh_[nn] = *reinterpret_cast<const f16x8 *>(&qq);
+        };
+        auto load_x = [&](int tt, int mm, int part) {
+            const unsigned char *pa = smem + act_offset(tt >> 1, mm) + (tt & 1) * 64 + part * 128;
+            if (part) xl[mm] = *reinterpret_cast<const f16x8 *>(pa);
+            else xh[mm] = *reinterpret_cast<const f16x8 *>(pa);
+        };
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const uint4 qh = wsrc[(size_t)stage * 512 + (n * 2) * 64 + lane];
-            const uint4 ql = wsrc[(size_t)stage * 512 + (n * 2 + 1) * 64 + lane];
-            wh_[0][n] = *reinterpret_cast<const f16x8 *>(&qh);
-            wl_[0][n] = *reinterpret_cast<const f16x8 *>(&ql);
-        }
+        for (int i = 0; i < 4; ++i) load_w(stage, i >> 1, i & 1);
 #pragma unroll
-        for (int m = 0; m < MT - 1; ++m) {
-            const unsigned char *pa = smem + act_offset(0, m);
-            xh[m] = *reinterpret_cast<const f16x8 *>(pa);
-            xl[m] = *reinterpret_cast<const f16x8 *>(pa + 128);
-        }
-        // k-step t = 0..17: tap t/2, channels 32 (t%2) .. +31.  48 MFMAs, 16 loads: one load in every
-        // third MFMA's shadow (a 16x16x32 MFMA leaves 8 issue cycles free, one load fits, two do not)
+        for (int m = 0; m < MT - 1; ++m) { load_x(0, m, 0); load_x(0, m, 1); }
+        // k-step t = 0..17: tap t/2, channels 32 (t%2) .. +31: 2 x 24 MFMAs, 16 loads
 #pragma unroll
         for (int t = 0; t < 18; ++t) {
-            const int cur = t & 1, nxt = cur ^ 1;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                for (int q = 0; q < 3 * NT; ++q) {                // 12 MFMAs of position tile m
-                    const int n = q / 3, p = q % 3;
-                    if (q == 1 || q == 7) {                       // two of the next k-step's eight weight fragments
-                        if (t + 1 < 18) {
-                            const int idx = 2 * m + (q == 7), nn = idx >> 1, part = idx & 1;
-                            const uint4 qq = wsrc[(size_t)(stage + t + 1) * 512 + (nn * 2 + part) * 64 + lane];
-                            if (part) wl_[nxt][nn] = *reinterpret_cast<const f16x8 *>(&qq);
-                            else wh_[nxt][nn] = *reinterpret_cast<const f16x8 *>(&qq);
-                        }
-                    } else if (q == 4 || q == 10) {               // refill the tile that finished last
-                        const int mm = (m + MT - 1) % MT;         // m = 0 fills tile MT-1 for THIS k-step
-                        const int tt = m == 0 ? t : t + 1;
-                        if (tt < 18) {
-                            const unsigned char *pa = smem + act_offset(tt >> 1, mm) + (tt & 1) * 64 + (q == 10) * 128;
-                            if (q == 10) xl[mm] = *reinterpret_cast<const f16x8 *>(pa);
-                            else xh[mm] = *reinterpret_cast<const f16x8 *>(pa);
-                        }
+                for (int q = 0; q < 24; ++q) {
+                    const int m = q / 6, n = 2 * h + (q % 6) / 3, p = q % 3;
+                    if (q == 1 || q == 4 || q == 7 || q == 10) {
+                        const int idx = (q - 1) / 3;                       // 0..3: tile, part
+                        if (h == 0) load_w(stage + t, 2 + (idx >> 1), idx & 1);
+                        else if (t + 1 < 18) load_w(stage + t + 1, idx >> 1, idx & 1);
+                    } else if (h == 0 && (q == 13 || q == 16)) {
+                        load_x(t, MT - 1, q == 16);                        // the lagging last tile
+                    } else if (h == 1 && q >= 8 && (q % 6 == 2 || q % 6 == 5)) {
+                        if (t + 1 < 18) load_x(t + 1, q / 6 - 1, q % 6 == 5);   // tile q/6-1 is done for this step
                     }
-#if AZX_S16_FENCE == 2
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
-                    const f16x8 wv = p == 1 ? wl_[cur][n] : wh_[cur][n];
+                    const f16x8 wv = p == 1 ? wl_[n] : wh_[n];
                     const f16x8 xv = p == 2 ? xl[m] : xh[m];
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, acc[m][n], 0, 0, 0);
 #if AZX_S16_FENCE == 2
@@ -790,7 +785,34 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
         conv_layer(2 * blk + 1, std::true_type{});
     }
 
-    if (live) {
+    // heads' 1x1 convs + folded BN + ReLU (network.py:77, :83) from the registers, as in
+    // k_tower_f16x3: a cell's 64 channels sit in the four lanes li + 16 h
+    if (hfeat != nullptr) {
+#pragma unroll
+        for (int o = 0; o < 6; ++o) {
+            const float *w = o < 2 ? P.wv + o * C : P.wp + (o - 2) * C;
+            float part[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) part[m] = 0.0f;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(w + 16 * n + 4 * lh);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    part[m] += res[m][n][0] * w4.x + res[m][n][1] * w4.y + res[m][n][2] * w4.z + res[m][n][3] * w4.w;
+            }
+            const float b = o < 2 ? P.bv[o] : P.bp[o - 2];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float tot = part[m] + __shfl_xor(part[m], 16);
+                tot += __shfl_xor(tot, 32);
+                const int row = 64 * wh + 16 * m + li;
+                if (live && row < ncells && lh == (o & 3))
+                    hfeat[((size_t)e * 6 + o) * ncells + row] = fmaxf(tot + b, 0.0f);
+            }
+        }
+    }
+    if (live && act_out != nullptr) {
         float *out = act_out + (size_t)e * ncells * C;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -1689,7 +1711,7 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
         const size_t lds = net->lds_bytes;
         if (net->tower_variant == 4) {
             static const bool split_m = getenv("AZX_TOWER_SPLIT") ? atoi(getenv("AZX_TOWER_SPLIT")) != 0 : true;
-            static const int shape = getenv("AZX_TOWER_SHAPE") ? atoi(getenv("AZX_TOWER_SHAPE")) : 32;
+            static const int shape = getenv("AZX_TOWER_SHAPE") ? atoi(getenv("AZX_TOWER_SHAPE")) : 16;
             static bool attr4 = false;
             if (!attr4) {
                 (void)hipFuncSetAttribute((const void *)k_tower_f16x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1698,8 +1720,11 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
                 attr4 = true;
             }
             const dim3 grid((max_n + F16X3_BPB - 1) / F16X3_BPB), block(F16X3_BPB * 128);
-            if (shape == 16) hipLaunchKernelGGL(k_tower_f16x3_s16, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act);
-            else if (split_m) {
+            if (shape == 16 && split_m) {
+                hipLaunchKernelGGL(k_tower_f16x3_s16, grid, block, lds, st, d, boards, n_eval_ptr, n_host,
+                                   (float *)nullptr, net->hfeat);
+                hfeat = net->hfeat;
+            } else if (split_m) {
                 hipLaunchKernelGGL(k_tower_f16x3<true>, grid, block, lds, st, d, boards, n_eval_ptr, n_host,
                                    (float *)nullptr, net->hfeat);
                 hfeat = net->hfeat;
