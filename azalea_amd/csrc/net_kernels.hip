@@ -771,6 +771,10 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
                     __builtin_amdgcn_sched_barrier(0);
 #elif AZX_S16_FENCE == 1
                     if (q % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+#elif AZX_S16_FENCE == 3
+                    if (q % 6 == 5) __builtin_amdgcn_sched_barrier(0);
+#elif AZX_S16_FENCE == 4
+                    if (q % 2 == 1) __builtin_amdgcn_sched_barrier(0);
 #endif
                 }
             }
