@@ -1024,6 +1024,159 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3(NetDev P, int layer,
     }
 }
 
+// ---- the wide tower on v_mfma_f32_16x16x32_f16 (see k_tower_f16x3_s16 for why) ----------------
+// Same block decomposition as k_conv_wide_f16x3 (one board x 128 output channels per 256-thread
+// block, wave (wm, wn): 96 positions x 64 channels = 6 x 4 tiles of 16 x 16), same HBM layout and
+// LDS staging; a k-step is one tap x 32 channels of the staged 64-channel chunk (18 per chunk):
+// 72 MFMAs, 8 weight + 12 activation fragment loads, one register set each, two channel halves.
+#define WIDE16_MT 6
+#define WIDE16_NT 4
+__global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int layer, const unsigned short *__restrict__ in,
+                                                                unsigned short *out, const unsigned short *resid,
+                                                                float *__restrict__ out32,
+                                                                const int32_t *__restrict__ n_eval_ptr, int n_eval_host) {
+    constexpr int MT = WIDE16_MT, NT = WIDE16_NT, ROWB = WIDE_ROWB;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
+    const int e = blockIdx.x;
+    if (e >= n_eval) return;
+    const int C = P.C, N = P.N, ncells = P.ncells;
+    const int NCH = C / 64, NT16 = C / 16;
+    const int co_base = blockIdx.y * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 15, lh = lane >> 4;
+    const size_t rowg = (size_t)C * 4;
+    const unsigned char *gin = reinterpret_cast<const unsigned char *>(in) + (size_t)e * ncells * rowg;
+    const int zero_off = ncells * ROWB;
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+    unsigned long long tapok = 0ull;                     // bit tap*6 + m (54 bits)
+    int rbase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int r = 96 * wm + 16 * m + li;
+        const int ry = r / N, rx = r - ry * N;
+        rbase[m] = r * ROWB + 16 * lh;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = ry + tap / 3 - 1, xx = rx + tap % 3 - 1;
+            if (r < ncells && yy >= 0 && yy < N && xx >= 0 && xx < N) tapok |= 1ull << (tap * 6 + m);
+        }
+    }
+    const int zbase = zero_off + 16 * lh;
+    auto act_offset = [&](int tap, int m) -> int {
+        const int delta = ((tap / 3 - 1) * N + (tap % 3 - 1)) * ROWB;
+        return ((tapok >> (tap * 6 + m)) & 1ull) ? rbase[m] + delta : zbase;
+    };
+    if (tid < ROWB / 4) reinterpret_cast<uint32_t *>(smem + zero_off)[tid] = 0u;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.Wh16);
+    const int nt0 = co_base / 16 + 4 * wn;               // this wave's first 16-channel tile
+    // weights of k-step q (global index over layer, tap, chunk, half): [q][ntile][part][lane]
+    auto wptr = [&](int q, int n, int part) -> const uint4 * {
+        return wsrc + ((size_t)q * (NT16 * 2) + (size_t)((nt0 + n) * 2 + part)) * 64 + lane;
+    };
+
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+        __syncthreads();                                 // the previous chunk has been consumed
+        for (int idx = tid; idx < ncells * 16; idx += 256) {
+            const int row = idx >> 4, piece = idx & 15;
+            const size_t src = (size_t)row * rowg + (piece < 8 ? (size_t)chunk * 128 + piece * 16
+                                                               : (size_t)C * 2 + (size_t)chunk * 128 + (piece - 8) * 16);
+            const int dst = row * ROWB + (piece < 8 ? piece * 16 : 128 + (piece - 8) * 16);
+            *reinterpret_cast<uint4 *>(smem + dst) = *reinterpret_cast<const uint4 *>(gin + src);
+        }
+        __syncthreads();
+        // k-step t = 0..17 of this chunk: tap t/2, channels 32 (t%2) .. +31 of the chunk
+        auto qof = [&](int t) { return (((layer * 9 + t / 2) * NCH + chunk) * 2 + (t & 1)); };
+        f16x8 wh_[NT], wl_[NT];
+        f16x8 xh[MT], xl[MT];
+        auto load_w = [&](int t, int nn, int part) {
+            const uint4 qq = *wptr(qof(t), nn, part);
+            if (part) wl_[nn] = *reinterpret_cast<const f16x8 *>(&qq);
+            else wh_[nn] = *reinterpret_cast<const f16x8 *>(&qq);
+        };
+        auto load_x = [&](int tt, int mm, int part) {
+            const unsigned char *pa = smem + act_offset(tt >> 1, mm) + (tt & 1) * 64 + part * 128;
+            if (part) xl[mm] = *reinterpret_cast<const f16x8 *>(pa);
+            else xh[mm] = *reinterpret_cast<const f16x8 *>(pa);
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_w(0, i >> 1, i & 1);
+#pragma unroll
+        for (int m = 0; m < MT - 1; ++m) { load_x(0, m, 0); load_x(0, m, 1); }
+#pragma unroll
+        for (int t = 0; t < 18; ++t) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int q = 0; q < 6 * MT; ++q) {                 // 36 MFMAs: 6 position tiles x 2 channel tiles x 3
+                    const int m = q / 6, n = 2 * h + (q % 6) / 3, p = q % 3;
+                    if (q == 1 || q == 4 || q == 7 || q == 10) {
+                        const int idx = (q - 1) / 3;
+                        if (h == 0) load_w(t, 2 + (idx >> 1), idx & 1);
+                        else if (t + 1 < 18) load_w(t + 1, idx >> 1, idx & 1);
+                    } else if (h == 0 && (q == 13 || q == 16)) {
+                        load_x(t, MT - 1, q == 16);                // the lagging last tile
+                    } else if (h == 1 && q >= 8 && (q % 6 == 2 || q % 6 == 5)) {
+                        if (t + 1 < 18) load_x(t + 1, q / 6 - 1, q % 6 == 5);
+                    }
+                    const f16x8 wv = p == 1 ? wl_[n] : wh_[n];
+                    const f16x8 xv = p == 2 ? xl[m] : xh[m];
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, acc[m][n], 0, 0, 0);
+                    if (q % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------
+    unsigned char *gout = reinterpret_cast<unsigned char *>(out) + (size_t)e * ncells * rowg;
+    const unsigned char *gres = resid ? reinterpret_cast<const unsigned char *>(resid) + (size_t)e * ncells * rowg : nullptr;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int cb = co_base + 64 * wn + 16 * n + 4 * lh;
+        const float4 b4 = *reinterpret_cast<const float4 *>(P.bias + (size_t)layer * C + cb);
+        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r = 96 * wm + 16 * m + li;
+            if (r < ncells) {
+                float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (gres) {
+                    const f16x4 rh = *reinterpret_cast<const f16x4 *>(gres + (size_t)r * rowg + cb * 2);
+                    const f16x4 rl = *reinterpret_cast<const f16x4 *>(gres + (size_t)r * rowg + (size_t)C * 2 + cb * 2);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rv[j] = (float)rh[j] + (float)rl[j];
+                }
+                f16x4 h4, l4;
+                float vv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = fmaxf(acc[m][n][j] + bv[j] + rv[j], 0.0f);
+                    vv[j] = v;
+                    _Float16 hi, lo;
+                    split_f16(v, hi, lo);
+                    h4[j] = hi;
+                    l4[j] = lo;
+                }
+                *reinterpret_cast<f16x4 *>(gout + (size_t)r * rowg + cb * 2) = h4;
+                *reinterpret_cast<f16x4 *>(gout + (size_t)r * rowg + (size_t)C * 2 + cb * 2) = l4;
+                if (out32)
+                    *reinterpret_cast<float4 *>(out32 + ((size_t)e * ncells + r) * C + cb) =
+                        make_float4(vv[0], vv[1], vv[2], vv[3]);
+            }
+        }
+    }
+}
+
 // stem of the wide tower: the one-hot K = 27 product of k_tower_f16x3's stem, one board x 128
 // output channels per block, straight to the HBM activation layout
 __global__ __launch_bounds__(256, 2) void k_stem_wide_f16x3(NetDev P, const uint8_t *__restrict__ ev_board,
@@ -1599,7 +1752,8 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
                                         }
     }
     std::vector<unsigned short> Wh16, Ws16;
-    if (net->tower_variant == 4) {
+    if (net->tower_variant == 4 || net->tower_variant == 5) {
+        const int NT16 = C / 16, NCH = C / 64;
         auto f16bits = [](float w, int part) -> unsigned short {
             const _Float16 hi = (_Float16)w;
             const _Float16 lo = (_Float16)(w - (float)hi);
@@ -1609,31 +1763,33 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
             return bits;
         };
         // 16x16x32 A-operand order: lane (j = lane & 15: output channel in the tile, h = lane >> 4: k-group)
-        // holds 8 consecutive k.  Stem: [ntile 4][hi,lo][lane][t] = split(stemT[k = 8 h + t][cout 16 ntile + j])
-        Ws16.resize((size_t)4 * 2 * 64 * 8);
+        // holds 8 consecutive k.  Stem: [ntile][hi,lo][lane][t] = split(stemT[k = 8 h + t][cout 16 ntile + j])
+        Ws16.resize((size_t)NT16 * 2 * 64 * 8);
         size_t os = 0;
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NT16; ++nt)
             for (int part = 0; part < 2; ++part)
                 for (int ln = 0; ln < 64; ++ln)
                     for (int t = 0; t < 8; ++t) {
                         const int j = ln & 15, h = ln >> 4, k = 8 * h + t, co = 16 * nt + j;
                         Ws16[os++] = f16bits(k < 27 ? stemT[(size_t)k * C + co] : 0.0f, part);
                     }
-        // convs: [stage = (layer*9 + tap)*2 + half][ntile 4][hi,lo][lane][t]
-        //   = split(W[tap][cin 32 half + 8 h + t][cout 16 ntile + j])
-        Wh16.resize((size_t)L * 18 * 4 * 2 * 64 * 8);
+        // convs, one 32-channel k-step after the other:
+        // [layer][tap][64-channel chunk][half][ntile][hi,lo][lane][t]
+        //   = split(W[tap][cin 64 chunk + 32 half + 8 h + t][cout 16 ntile + j])
+        Wh16.resize((size_t)L * 9 * NCH * 2 * NT16 * 2 * 64 * 8);
         size_t o = 0;
         for (int l = 0; l < L; ++l)
             for (int tap = 0; tap < 9; ++tap)
-                for (int half = 0; half < 2; ++half)
-                    for (int nt = 0; nt < 4; ++nt)
-                        for (int part = 0; part < 2; ++part)
-                            for (int ln = 0; ln < 64; ++ln)
-                                for (int t = 0; t < 8; ++t) {
-                                    const int j = ln & 15, h = ln >> 4;
-                                    const int ci = 32 * half + 8 * h + t, co = 16 * nt + j;
-                                    Wh16[o++] = f16bits(Wg[(((size_t)l * 9 + tap) * C + ci) * C + co], part);
-                                }
+                for (int ch = 0; ch < NCH; ++ch)
+                    for (int half = 0; half < 2; ++half)
+                        for (int nt = 0; nt < NT16; ++nt)
+                            for (int part = 0; part < 2; ++part)
+                                for (int ln = 0; ln < 64; ++ln)
+                                    for (int t = 0; t < 8; ++t) {
+                                        const int j = ln & 15, h = ln >> 4;
+                                        const int ci = 64 * ch + 32 * half + 8 * h + t, co = 16 * nt + j;
+                                        Wh16[o++] = f16bits(Wg[(((size_t)l * 9 + tap) * C + ci) * C + co], part);
+                                    }
     }
     // heads
     auto wvc = get("value_conv1.weight", (size_t)2 * C), wpc = get("move_conv1.weight", (size_t)4 * C);
@@ -1683,7 +1839,7 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
         d.Wh = wh;
     }
     d.Ws16 = d.Wh16 = nullptr;
-    if (net->tower_variant == 4) {
+    if (net->tower_variant == 4 || net->tower_variant == 5) {
         unsigned short *a = nalloc<unsigned short>(net, Ws16.size()), *b = nalloc<unsigned short>(net, Wh16.size());
         if (!a || !b) return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
         (void)hipMemcpy(a, Ws16.data(), Ws16.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
@@ -1735,14 +1891,20 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
             } else hipLaunchKernelGGL(k_tower_f16x3<false>, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act, (float *)nullptr);
         } else if (net->tower_variant == 5) {
             static bool attr5 = false;
-            if (!attr5) { (void)hipFuncSetAttribute((const void *)k_conv_wide_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr5 = true; }
+            static const int wshape = getenv("AZX_TOWER_SHAPE") ? atoi(getenv("AZX_TOWER_SHAPE")) : 16;
+            if (!attr5) {
+                (void)hipFuncSetAttribute((const void *)k_conv_wide_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute((const void *)k_conv_wide_f16x3_s16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr5 = true;
+            }
+            auto conv = wshape == 16 ? k_conv_wide_f16x3_s16 : k_conv_wide_f16x3;
             const dim3 grid(max_n, d.C / 128), block(256);
             hipLaunchKernelGGL(k_stem_wide_f16x3, grid, block, 0, st, d, boards, net->wideX,
                                d.blocks == 0 ? net->act : (float *)nullptr, n_eval_ptr, n_host);
             for (int b = 0; b < d.blocks; ++b) {
-                hipLaunchKernelGGL(k_conv_wide_f16x3, grid, block, lds, st, d, 2 * b, (const unsigned short *)net->wideX, net->wideY,
+                hipLaunchKernelGGL(conv, grid, block, lds, st, d, 2 * b, (const unsigned short *)net->wideX, net->wideY,
                                    (const unsigned short *)nullptr, (float *)nullptr, n_eval_ptr, n_host);
-                hipLaunchKernelGGL(k_conv_wide_f16x3, grid, block, lds, st, d, 2 * b + 1, (const unsigned short *)net->wideY, net->wideX,
+                hipLaunchKernelGGL(conv, grid, block, lds, st, d, 2 * b + 1, (const unsigned short *)net->wideY, net->wideX,
                                    (const unsigned short *)net->wideX, b == d.blocks - 1 ? net->act : (float *)nullptr, n_eval_ptr, n_host);
             }
         } else if (net->tower_variant == 1) {
