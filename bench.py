@@ -226,7 +226,7 @@ def main():
             line["roofline"] = {
                 "kernel": (("k_tower_f16x3 + k_heads" if os.environ.get("AZX_TOWER_SHAPE") == "32" else
                             "k_tower_f16x3_s16 + k_heads") if args.chans == 64 and args.board <= 11 else
-                           "k_conv_wide_f16x3 x %d + k_heads" % (2 * args.blocks) if args.chans % 128 == 0 else
+                           ("k_conv_wide_f16x3" if os.environ.get("AZX_TOWER_SHAPE") == "32" else "k_conv_wide_f16x3_s16") + " x %d + k_heads" % (2 * args.blocks) if args.chans % 128 == 0 else
                            "tower + k_heads") + " (%dx%d resnet forward of one leaf batch)" % (args.blocks, args.chans),
                 "bound": "mfma", "achieved": achieved, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": achieved / F16_MFMA_PEAK_TF, "traffic": None,
