@@ -52,7 +52,9 @@ struct alignas(64) GameHdr {
     int64_t uid;       // global game index (seeds the device RNG stream)
     int32_t move_id;   // device-chosen child index of the last azx_play step
     int32_t n_rows;    // replay rows this game has written so far
-    int32_t pad[8];
+    int32_t gen;       // games this slot has started so far: uid = slot + n_games * gen (a fixed
+                       // seed reproduces every game whatever order the GPU schedules the slots in)
+    int32_t pad[7];
 };
 
 enum {   // counters[] slots
@@ -112,7 +114,7 @@ struct DevEngine {
     float *q_reward;        // [Q]
     int64_t *q_uid;         // [Q]
     unsigned long long *q_count;   // [1] rows appended
-    unsigned long long *next_uid;  // [1]
+    unsigned long long *next_uid;  // [1] (unused since uids are slot + n_games * generation)
     double *stat_sums;      // [G][8] per game: search_value, root_width, action_logprob, reward_last
 };
 

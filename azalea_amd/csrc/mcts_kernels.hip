@@ -14,6 +14,7 @@
 //   azalea/search_tree.py:59-71 reset, :115-132 move, :254-274 create_child_nodes;
 //   azalea/game/hex.py:137-231 rules, :72-122 perspective flip.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -162,25 +163,44 @@ __device__ __forceinline__ float log2_gamma_variate(uint32_t seed, const GammaCo
 template <int SLOTS>
 __device__ __forceinline__ void dirichlet_noise(const uint64_t *m, int lane, uint32_t stream,
                                                 const GammaConst &gc, float scale, float *nz) {
+    // every lane draws (the table index is valid for any 24 random bits), cells that are not legal
+    // are masked afterwards: no divergent region around the two table lookups, both in flight together
     float lg[SLOTS];
-    uint32_t kmax = 0u;
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        lg[s] = 0.0f;
-        if (lane_bit(m[s])) {
-            lg[s] = log2_gamma_variate(stream ^ ((uint32_t)(s * 64 + lane) * 0x9E3779B9u), gc);
-            const uint32_t k = f32_key(lg[s]);
-            kmax = k > kmax ? k : kmax;
-        }
-    }
-    const float mx = key_f32(wave_max_u32(kmax));   // >= one cell is set whenever this is called
+    for (int s = 0; s < SLOTS; ++s)
+        lg[s] = log2_gamma_variate(stream ^ ((uint32_t)(s * 64 + lane) * 0x9E3779B9u), gc);
+    // The variates only matter relative to each other.  The largest of k of them is almost always
+    // within 2^-60 .. 2^4 (it is below 2^-60 when every u < 0.29: 0.29^k), so they are first summed
+    // as they are; only when that sum underflows (late in a game, k of a few cells) is the maximum
+    // taken out in log space first.  Either way the result is w_i / sum(w) to float32 rounding.
     float sw = 0.0f;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-        nz[s] = lane_bit(m[s]) ? __builtin_amdgcn_exp2f(lg[s] - mx) : 0.0f;
+        nz[s] = lane_bit(m[s]) ? __builtin_amdgcn_exp2f(lg[s]) : 0.0f;
         sw += nz[s];
     }
-    sw = scale * __builtin_amdgcn_rcpf(wave_sum(sw));
+    float tot = wave_sum(sw);
+#ifdef AZX_NOISE_MAXFIRST   // diagnostic build: always take the rescaling path
+    if (true) {
+#else
+    if (!(tot >= 8.67361738e-19f)) {
+#endif                  // < 2^-60 (or no finite value at all): rescale
+        uint32_t kmax = 0u;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const uint32_t k = lane_bit(m[s]) ? f32_key(lg[s]) : 0u;
+            kmax = k > kmax ? k : kmax;
+        }
+        const float mx = key_f32(wave_max_u32(kmax));   // >= one cell is set whenever this is called
+        sw = 0.0f;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            nz[s] = lane_bit(m[s]) ? __builtin_amdgcn_exp2f(lg[s] - mx) : 0.0f;
+            sw += nz[s];
+        }
+        tot = wave_sum(sw);
+    }
+    sw = scale * __builtin_amdgcn_rcpf(tot);
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) nz[s] = nz[s] * sw;
 }
@@ -282,6 +302,13 @@ __device__ __forceinline__ bool value_in_fast_range(float v) {
     const float a = __builtin_fabsf(v);
     return v == 0.0f || (a >= 8.67361738e-19f && a <= 1.0e30f);
 }
+// copy of a wave-uniform value into a vector register AT THIS POINT of the program: the compiler
+// otherwise copies a scalar load's result where it is defined and waits for the load there
+__device__ __forceinline__ float late_vgpr(float s) {
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
 // wave-uniform float load on the scalar unit (lgkmcnt): keeps vmcnt free of read-after-store waits
 __device__ __forceinline__ float sload_f32(const float *p) {
     float v;
@@ -303,8 +330,20 @@ __device__ __forceinline__ float sload_f32(const float *p) {
 // Every update is still the same sequence of float32 additions per node as mcts.py:79-92 /
 // :242-255, so results are bit-identical to the sequential reference.
 // ============================================================================================
-template <int SLOTS>
-__global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batches) {
+// FAST = the throughput path of BASELINE configs[1] as its own instantiation: one launch per move
+// (MODE_BEGIN | MODE_INLINE), AZX_EVAL_UNIFORM with the default 1/k prior table, noise off or drawn
+// on the device.  The same source with those conditions folded at compile time: the evaluator
+// hand-off, host-noise and slow-divide paths disappear and with them the scalar registers that held
+// their pointers (the generic kernel spills ~40 SGPRs inside the select loop).  Results are
+// bit-identical to the generic instantiation (test_fast_kernel_matches_generic).
+#ifdef AZX_WPE
+#define AZX_MCTS_ATTR __attribute__((amdgpu_waves_per_eu(AZX_WPE, AZX_WPE)))
+#else
+#define AZX_MCTS_ATTR
+#endif
+template <int SLOTS, bool FAST>
+__global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode_arg, int num_batches) {
+    const int mode = FAST ? (MODE_BEGIN | MODE_INLINE) : mode_arg;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int lane = threadIdx.x;
     const int g = blockIdx.x;
@@ -326,7 +365,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
     int pending_root = th->pending_root;
     int select_count = th->select_count;
     float search_value = th->search_value;
-    bool slow_div = th->slow_div != 0;
+    bool slow_div = FAST ? false : th->slow_div != 0;   // FAST: values are 0 or -1 only
     Node *arena = E.arena[th->arena] + (size_t)g * E.cap;
 
     HexWave<SLOTS> root;
@@ -339,13 +378,13 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
 
     // per-launch tallies (at most 16 * 410 * 169 < 2^32 each): 32-bit scalars
     uint32_t c_selects = 0, c_depth = 0, c_kint = 0, c_kleaf = 0, c_evals = 0, c_term = 0;
-    const bool inline_eval = (mode & MODE_INLINE) != 0;
-    const bool need_colors = !inline_eval || E.evaluator == AZX_EVAL_UNIFORM_HASH;   // leaf boards leave the wave
+    const bool inline_eval = FAST || (mode & MODE_INLINE) != 0;
+    const bool need_colors = FAST ? false : (!inline_eval || E.evaluator == AZX_EVAL_UNIFORM_HASH);   // leaf boards leave the wave
     const float c32 = E.c_puct;
     const float keep32 = (float)(1.0 - E.noise_scale);   // python float -> f32 (weak scalar)
     const Philox ph = game_rng(E, gh->uid);
     // the device sampler's table goes to LDS (two dependent lookups per cell and select)
-    if (E.noise_scale != 0.0 && E.device_noise) {
+    if (E.noise_scale != 0.0 && (FAST || E.device_noise)) {
         for (int i = lane; i < AZX_GAMMA_TAB + 1; i += 64) L.gtab[i] = E.gamma_tab[i];
         lds_sync();
     }
@@ -560,17 +599,19 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
 
     auto inline_prior = [&](int k) -> float {
         // the default table is float32 1/k: the IEEE divide gives the same bits without a load
-        return E.prior_default ? 1.0f / (float)k : sload_f32(E.prior_by_k + k);
+        return (FAST || E.prior_default) ? 1.0f / (float)k : sload_f32(E.prior_by_k + k);
     };
 
     // =================================== BEGIN: root evaluation (mcts.py:272-273) ========
     if ((mode & MODE_BEGIN) && status == 0 && root_link == AZX_LINK_UNEVAL) {
+        if (!FAST) {
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int cell = s * 64 + lane;
-            if (cell < ncells) L.colors[cell] = (unsigned char)(root.c[s] & 3u);
+            for (int s = 0; s < SLOTS; ++s) {
+                const int cell = s * 64 + lane;
+                if (cell < ncells) L.colors[cell] = (unsigned char)(root.c[s] & 3u);
+            }
+            lds_sync();
         }
-        lds_sync();
         if (inline_eval) {
             expand(root_id, 0, 0, AZX_LINK_UNEVAL, root.winner != 0, rootmk.m, nullptr,
                    rootmk.k ? inline_prior(rootmk.k) : 0.0f);
@@ -597,7 +638,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
     }
 
     // =================================== APPLY: expand + backup pending leaves ============
-    if ((mode & MODE_APPLY) && pending > 0 && status == 0) {
+    if (!FAST && (mode & MODE_APPLY) && pending > 0 && status == 0) {
         const size_t lb = (size_t)g * bs;
         for (int i = 0; i < pending; ++i) {
             const int node = E.leaf_node[lb + i];
@@ -657,8 +698,12 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
             int link = root_link;
             int depth = 0, node = root_id, child_link = 0, cell0 = 0, cellL = 0;
             float cur_nv = 0.0f;               // num_visits (incl. virtual) of the node being scored
-            bool at_root = true;
-            for (;;) {
+            float cnv = 0.f, ctv = 0.f;
+            float sq_next_pend = 0.0f;
+            // one level of the descent; the root level is its own instantiation (children in
+            // registers, noise, loop-invariant masks), deeper levels are the loop below
+            auto level = [&](auto root_tag) __attribute__((always_inline)) {
+                constexpr bool at_root = decltype(root_tag)::value;
                 Masks<SLOTS> mk;
                 {
                     int k = 0;
@@ -671,7 +716,8 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                     mk.k = k;
                 }
                 int best_cell = 0x7fffffff, child_rank = 0;
-                float cnv = 0.f, ctv = 0.f;
+                cnv = 0.f;
+                ctv = 0.f;
                 if (!at_root && cur_nv == 1.0f) {
                     // A node visited once (its own expansion) has only unvisited children
                     // (sum of their visits == its visits - 1 == 0): every score is -0 + 0, so
@@ -686,8 +732,10 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                     // evaluated node has been visited once more than its children together (its
                     // own expansion), virtual losses included since they mark node and child alike.
                     const int sumn = at_root ? root_sumn : (int)cur_nv - 1;
-                    const float sq = sumn < AZX_SQRT_TAB ? c_sqrt[sumn] : sqrtf((float)sumn);
-                    // (looked up before the children are fetched: the scalar load rides under the HBM one)
+                    // Below the root the table entry was requested when the level above chose this
+                    // node (sq_next_pend) and is consumed after the children have been requested
+                    // (late_vgpr below), so the scalar load rides under the HBM one.
+                    const float sq_tab = at_root ? c_sqrt[sumn < AZX_SQRT_TAB ? sumn : AZX_SQRT_TAB - 1] : sq_next_pend;
                     // ---- children statistics ------------------------------------------------
                     float4 st[SLOTS];
                     int rk[SLOTS];
@@ -696,12 +744,13 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                         for (int s = 0; s < SLOTS; ++s) { st[s] = rst[s]; rk[s] = rrk[s]; }
                     } else {
 #pragma unroll
-                        for (int s = 0; s < SLOTS; ++s) {
-                            const bool empty = lane_bit(mk.m[s]);
-                            rk[s] = mk.base[s] + rank_below(mk.m[s]);
-                            st[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (empty) st[s] = *reinterpret_cast<const float4 *>(arena + link + rk[s]);
-                        }
+                        for (int s = 0; s < SLOTS; ++s) rk[s] = mk.base[s] + rank_below(mk.m[s]);
+                        // every lane loads -- occupied cells re-read child 0 and are masked out of the
+                        // argmax below -- so there is no divergent region around the loads and the
+                        // slots' requests are in flight together (one HBM round trip per level)
+                        const float4 *cblk = reinterpret_cast<const float4 *>(arena + link);
+#pragma unroll
+                        for (int s = 0; s < SLOTS; ++s) st[s] = cblk[lane_bit(mk.m[s]) ? rk[s] : 0];
                         // newer (num_visits, total_value) of cached children override HBM
                         uint64_t pm = __ballot(lane < n_c && c_id >= link && c_id < link + mk.k);
                         while (pm) {
@@ -717,7 +766,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                     // ---- Dirichlet noise at the root only (mcts.py:126-131, :114) ----------
                     float nz[SLOTS];
                     const bool noisy = at_root && E.noise_scale != 0.0;
-                    if (noisy && E.device_noise) {
+                    if (noisy && (FAST || E.device_noise)) {
                         const uint32_t noise_stream =
                             mix32(ph.k0 ^ mix32(ph.k1 + (uint32_t)ply * 0x632be5abu + (uint32_t)select_count));
                         dirichlet_noise<SLOTS>(mk.m, lane, noise_stream, gconst, (float)E.noise_scale, nz);
@@ -728,7 +777,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
 #pragma unroll
                     for (int s = 0; s < SLOTS; ++s) Pn[s] = st[s].z;
                     if (noisy) {
-                        if (E.device_noise) {
+                        if (FAST || E.device_noise) {
 #pragma unroll
                             for (int s = 0; s < SLOTS; ++s) Pn[s] = keep32 * Pn[s] + nz[s];
                         } else {
@@ -739,6 +788,11 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                                 if (lane_bit(mk.m[s]))
                                     Pn[s] = (float)((double)(keep32 * Pn[s]) + E.noise_scale * row[rk[s]]);
                         }
+                    }
+                    float sq = late_vgpr(sq_tab);
+                    if (sumn >= AZX_SQRT_TAB) {                // beyond the table (rare): a real branch
+                        asm volatile("");                      // (the compiler would otherwise run the
+                        sq = sqrtf((float)sumn);               // 18-instruction sqrtf every time and select)
                     }
                     uint32_t key[SLOTS], lkey = 0u;
                     auto score_slots = [&](auto exact_tag) {
@@ -808,10 +862,16 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                 }
                 T_MARK(2)
                 depth += 1;
-                at_root = false;
-                if (child_link < 0) break;                     // leaf: unevaluated or terminal
+                if (child_link >= 0) {                         // sqrt(visits - 1) for the level below
+                    const int sn = (int)cnv - 1;
+                    sq_next_pend = c_sqrt[sn < 0 ? 0 : (sn < AZX_SQRT_TAB ? sn : AZX_SQRT_TAB - 1)];
+                }
+            };
+            level(std::true_type{});
+            while (child_link >= 0) {                          // < 0: a leaf, unevaluated or terminal
                 link = child_link;
                 cur_nv = cnv;
+                level(std::false_type{});
             }
             select_count += 1;
             c_selects += 1;
@@ -909,7 +969,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
                 for (int s = 0; s < SLOTS; ++s) { lm[s] = rl64(m_mask[s], i); k += popc64(lm[s]); }
                 float v = -1.0f;
                 if (!terminal) {
-                    v = (E.evaluator == AZX_EVAL_UNIFORM_HASH)
+                    v = (!FAST && E.evaluator == AZX_EVAL_UNIFORM_HASH)
                             ? hash_value(L.colors + i * AZX_CELL_STRIDE, tm >> 1) : 0.0f;
                     c_evals += 1;
                     if (!value_in_fast_range(v)) slow_div = true;
@@ -979,7 +1039,7 @@ __global__ __launch_bounds__(64) void k_mcts(DevEngine E, int mode, int num_batc
         th->pending_root = pending_root;
         th->select_count = select_count;
         th->search_value = search_value;
-        th->slow_div = slow_div ? 1 : 0;
+        if (!FAST) th->slow_div = slow_div ? 1 : 0;
         if (c_selects) E.counters[(size_t)g * CTR_COUNT + CTR_SELECTS] += c_selects;
         if (c_depth) E.counters[(size_t)g * CTR_COUNT + CTR_SUM_DEPTH] += c_depth;
         if (c_kint) E.counters[(size_t)g * CTR_COUNT + CTR_SUM_K_INT] += c_kint;
@@ -1045,7 +1105,7 @@ __global__ __launch_bounds__(64) void k_reset(DevEngine E, const int32_t *slots,
         gh->active = 1;
         gh->move_id = -1;
         gh->n_rows = 0;
-        if (assign_uid) gh->uid = (int64_t)atomicAdd(E.next_uid, 1ull);
+        if (assign_uid) { gh->uid = (int64_t)g + (int64_t)E.G * gh->gen; gh->gen += 1; }
         th->arena = 0;
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -1236,7 +1296,8 @@ __global__ __launch_bounds__(64) void k_advance(DevEngine E, const int32_t *move
             gh->ply = 0;
             gh->move_id = -1;
             gh->n_rows = 0;
-            gh->uid = (int64_t)atomicAdd(E.next_uid, 1ull);
+            gh->uid = (int64_t)g + (int64_t)E.G * gh->gen;
+            gh->gen += 1;
         }
         __builtin_amdgcn_s_waitcnt(0);
         tree_reset<SLOTS>(E, g, th, E.ncells, lane);
@@ -1559,7 +1620,18 @@ void azx_gamma_table(double alpha, float *tab) {
 
 void azx_launch_mcts(const DevEngine &E, int mode, int num_batches, hipStream_t st) {
     const size_t lds = azx_mcts_lds_bytes(E.ncells, E.bs);
-#define CALL(S) hipLaunchKernelGGL((k_mcts<S>), dim3(E.G), dim3(64), lds, st, E, mode, num_batches)
+    // AZX_MCTS_GENERIC=1 keeps every launch on the generic instantiation (A/B and the equivalence test)
+    const char *fg = getenv("AZX_MCTS_GENERIC");     // read per launch: the equivalence test toggles it
+    const bool force_generic = fg && atoi(fg) != 0;
+    const bool fast = !force_generic && mode == (MODE_BEGIN | MODE_INLINE) && E.evaluator == AZX_EVAL_UNIFORM &&
+                      E.prior_default && (E.noise_scale == 0.0 || E.device_noise);
+    if (fast) {
+#define CALL(S) hipLaunchKernelGGL((k_mcts<S, true>), dim3(E.G), dim3(64), lds, st, E, mode, num_batches)
+        DISPATCH_SLOTS(E.slots, CALL);
+#undef CALL
+        return;
+    }
+#define CALL(S) hipLaunchKernelGGL((k_mcts<S, false>), dim3(E.G), dim3(64), lds, st, E, mode, num_batches)
     DISPATCH_SLOTS(E.slots, CALL);
 #undef CALL
 }

@@ -218,8 +218,9 @@ def canonical(d):
             bits(d["prior_prob"][order]))
 
 
+@pytest.mark.parametrize("hashed", [True, False], ids=["hash-generic-kernel", "uniform-fast-kernel"])
 @pytest.mark.parametrize("nodes_per_game", [0, 30000], ids=["roomy-arena", "tight-arena"])
-def test_many_games_vs_oracle_with_compaction(eng, orc, nodes_per_game):
+def test_many_games_vs_oracle_with_compaction(eng, orc, nodes_per_game, hashed):
     """64 concurrent games from different positions, several searches + moves each: the
     engine and the CPU oracle (reference never-free tree) must agree bit-exactly on every game's
     kept subtree after every search -- with a roomy arena (moves re-root in place) and with one so
@@ -241,9 +242,13 @@ def test_many_games_vs_oracle_with_compaction(eng, orc, nodes_per_game):
             h = h2
             mv.append(m)
         prefixes.append(mv)
+    # hashed: values from the fnv1a stub, explicit prior table -> the generic k_mcts instantiation;
+    # not hashed: value 0, the built-in 1/k table -> the FAST instantiation bench.py runs
     E = eng.Engine(board_size=n, n_games=G, simulations=sims, search_batch_size=10,
-                   exploration_coef=0.5, evaluator=eng.EVAL_UNIFORM_HASH, nodes_per_game=nodes_per_game)
-    E.set_prior_table(table)
+                   exploration_coef=0.5, evaluator=eng.EVAL_UNIFORM_HASH if hashed else eng.EVAL_UNIFORM,
+                   nodes_per_game=nodes_per_game)
+    if hashed:
+        E.set_prior_table(table)
     E.reset(moves=prefixes)
     games, trees = [], []
     for g in range(G):
@@ -252,7 +257,7 @@ def test_many_games_vs_oracle_with_compaction(eng, orc, nodes_per_game):
             h.step(m)
         games.append(h)
         trees.append(orc.Tree(1 << 17))
-    ev = orc.UniformEval(hash_value=True, prior_by_k=table)
+    ev = orc.UniformEval(hash_value=hashed, prior_by_k=table)
     alive = np.ones(G, bool)
     for rnd in range(4):
         E.search()
@@ -283,6 +288,42 @@ def test_many_games_vs_oracle_with_compaction(eng, orc, nodes_per_game):
             assert np.array_equal(gm["board"][g], games[g].board)
             assert gm["result"][g] == games[g].result
     E.close()
+
+
+def test_fast_kernel_matches_generic(eng):
+    """bench.py's k_mcts instantiation (FAST: one launch per move, uniform evaluator, device noise
+    folded at compile time) against the generic one, which the golden vectors and the oracle pin:
+    same seeds, device Dirichlet noise on, whole moves through play_steps -- every tree identical
+    bit for bit after each move, on 11x11 (2 cell slots) and 13x13 (3)."""
+    for n, G, sims in ((11, 48, 120), (13, 16, 60)):
+        dumps = {}
+        for generic in (1, 0):
+            os.environ["AZX_MCTS_GENERIC"] = str(generic)
+            try:
+                E = eng.Engine(board_size=n, n_games=G, simulations=sims, search_batch_size=10,
+                               exploration_coef=0.5, noise_alpha=0.03, noise_scale=0.25,
+                               exploration_depth=15, evaluator=eng.EVAL_UNIFORM, seed=77)
+                out = []
+                for _ in range(3):
+                    E.play_steps(1)
+                    gm = E.get_games()
+                    out.append((gm["board"].copy(), gm["ply"].copy()))
+                E.search(noise_scale=0.25)
+                root = E.get_root()
+                out.append((bits(root["child_visits"]), bits(root["child_value"]), root["num_nodes"].copy()))
+                out.append([canonical(E.tree_dump(g)) for g in range(0, G, 5)])
+                E.close()
+            finally:
+                os.environ.pop("AZX_MCTS_GENERIC", None)
+            dumps[generic] = out
+        a, b = dumps[1], dumps[0]
+        for x, y in zip(a[:3], b[:3]):
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+        for x, y in zip(a[3], b[3]):
+            assert np.array_equal(x, y)
+        for ta, tb in zip(a[4], b[4]):
+            for x, y in zip(ta, tb):
+                assert np.array_equal(x, y)
 
 
 def test_tree_full_sets_status(eng):
