@@ -399,9 +399,28 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
     }
 
     // ---- on-chip tree state ----------------------------------------------------------------
+    // Root children live in registers BY RANK (lane-slot j = child j, the layout they have in HBM):
+    // once 64 or fewer moves remain the whole root level -- noise, scores, argmax -- runs on one
+    // register slot.  rcell = the board cell of that child.
     float4 rst[SLOTS];                 // root children: {num_visits, total_value, prior, link}
-    int rrk[SLOTS];                    // child rank of this lane's cells at the root
+    int rcell[SLOTS];
     bool rempty[SLOTS];
+    const int k_root = rootmk.k;
+    uint64_t rootrm[SLOTS];            // lane masks of the root's children: ranks 64 s .. of k_root
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int n = k_root - 64 * s;
+        rootrm[s] = n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
+    }
+    {   // rank -> cell through LDS (the path area is free until the first descent)
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (lane_bit(rootmk.m[s])) L.path[rootmk.base[s] + rank_below(rootmk.m[s])] = s * 64 + lane;
+        lds_sync();
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) rcell[s] = (s * 64 + lane < k_root) ? L.path[s * 64 + lane] : 0;
+        lds_sync();
+    }
     float root_nv, root_tv;
     int root_link;
     {
@@ -411,11 +430,10 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
         root_link = rn.link;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            rempty[s] = lane_bit(rootmk.m[s]) && rootmk.k > 0;
-            rrk[s] = rootmk.base[s] + rank_below(rootmk.m[s]);
+            rempty[s] = s * 64 + lane < k_root;
             rst[s] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (root_link >= 0 && rempty[s])
-                rst[s] = *reinterpret_cast<const float4 *>(arena + root_link + rrk[s]);
+                rst[s] = *reinterpret_cast<const float4 *>(arena + root_link + s * 64 + lane);
         }
     }
     // sum of the root children's visit counts (the integer under the square root of mcts.py:132),
@@ -492,15 +510,15 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
         if (lane == n_c) { c_id = id; c_nv = nv0; c_tv = tv0; }
         return n_c++;
     };
-    auto root_child_add = [&](int cell, float dv, float dt) {
-        const int ln = cell & 63, sl = cell >> 6;
+    auto root_child_add = [&](int rank, float dv, float dt) {
+        const int ln = rank & 63, sl = rank >> 6;
         root_sumn += (int)dv;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s)
             if (s == sl && lane == ln) { rst[s].x += dv; rst[s].y += dt; }
     };
     // (num_visits += dv, total_value += +-amount) along one recorded path.  pth[d] is the node at
-    // depth d+1; the value added at the LEAF is `amount`, with `alternate` its sign flips at
+    // depth d+1, cell0 the RANK of the path's root child; the value added at the LEAF is `amount`, with `alternate` its sign flips at
     // every step towards the root (mcts.py:252); `with_root` includes the root (mcts.py:253).
     auto path_apply = [&](const int32_t *pth, int len, int cell0, float dv, float amount,
                           bool alternate, bool with_root) {
@@ -517,7 +535,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
     };
 
     // ---- create_child_nodes (search_tree.py:254-274) for one leaf; returns false when full.
-    // `cells` = first cell of the path | last cell << 16 (owner lanes of the link word).
+    // `cells` = rank of the path's root child | last cell << 16 (owner lanes of the link word).
     auto expand = [&](int node, int len, int cells, int lnk, bool terminal, const uint64_t *lm,
                       const float *prior_row, float prior_const) -> bool {
         if (lnk != AZX_LINK_UNEVAL) return true;          // re-selected terminal: mcts.py:237
@@ -541,8 +559,14 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                     nd.pp = prior_row ? prior_row[cell] : prior_const;
                     nd.link = AZX_LINK_UNEVAL;
                     arena[fc + rk] = nd;
-                    if (len == 0) rst[s] = make_float4(0.f, 0.f, nd.pp, __int_as_float(AZX_LINK_UNEVAL));
                 }
+            }
+            if (len == 0) {                               // the root's new children, by rank
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s)
+                    if (rempty[s])
+                        rst[s] = make_float4(0.f, 0.f, prior_row ? prior_row[rcell[s]] : prior_const,
+                                             __int_as_float(AZX_LINK_UNEVAL));
             }
             c_kleaf += (uint32_t)k;
         }
@@ -551,7 +575,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
             root_link = newlink;
             root_sumn = 0;
             if (lane == 0) arena[root_id].link = newlink;
-        } else if (len == 1) {                            // a root child: its link is in registers
+        } else if (len == 1) {                            // a root child (by rank): its link is in registers
             const int c0 = cells & 0xffff, ln = c0 & 63, sl = c0 >> 6;
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s)
@@ -702,10 +726,17 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
             float sq_next_pend = 0.0f;
             // one level of the descent; the root level is its own instantiation (children in
             // registers, noise, loop-invariant masks), deeper levels are the loop below
-            auto level = [&](auto root_tag) __attribute__((always_inline)) {
+            // RS = register slots the level's children occupy: ceil(k_root / 64) at the root (rank
+            // layout), SLOTS below it (lane = board cell)
+            auto level = [&](auto root_tag, auto rs_tag) __attribute__((always_inline)) {
                 constexpr bool at_root = decltype(root_tag)::value;
+                constexpr int RS = decltype(rs_tag)::value;
                 Masks<SLOTS> mk;
-                {
+                if (at_root) {
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) { mk.m[s] = rootrm[s]; mk.base[s] = 64 * s; }
+                    mk.k = k_root;
+                } else {
                     int k = 0;
 #pragma unroll
                     for (int s = 0; s < SLOTS; ++s) {
@@ -741,7 +772,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                     int rk[SLOTS];
                     if (at_root) {
 #pragma unroll
-                        for (int s = 0; s < SLOTS; ++s) { st[s] = rst[s]; rk[s] = rrk[s]; }
+                        for (int s = 0; s < SLOTS; ++s) { st[s] = rst[s]; rk[s] = 64 * s + lane; }
                     } else {
 #pragma unroll
                         for (int s = 0; s < SLOTS; ++s) rk[s] = mk.base[s] + rank_below(mk.m[s]);
@@ -764,27 +795,27 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                         }
                     }
                     // ---- Dirichlet noise at the root only (mcts.py:126-131, :114) ----------
-                    float nz[SLOTS];
+                    float nz[SLOTS] = {};
                     const bool noisy = at_root && E.noise_scale != 0.0;
                     if (noisy && (FAST || E.device_noise)) {
                         const uint32_t noise_stream =
                             mix32(ph.k0 ^ mix32(ph.k1 + (uint32_t)ply * 0x632be5abu + (uint32_t)select_count));
-                        dirichlet_noise<SLOTS>(mk.m, lane, noise_stream, gconst, (float)E.noise_scale, nz);
+                        dirichlet_noise<RS>(mk.m, lane, noise_stream, gconst, (float)E.noise_scale, nz);
                     }
                     // ---- score_actions (mcts.py:119-136), op by op in float32 --------------
                     // branch-free: every lane computes, non-legal lanes are masked at the end
                     float Pn[SLOTS];
 #pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) Pn[s] = st[s].z;
+                    for (int s = 0; s < RS; ++s) Pn[s] = st[s].z;
                     if (noisy) {
                         if (FAST || E.device_noise) {
 #pragma unroll
-                            for (int s = 0; s < SLOTS; ++s) Pn[s] = keep32 * Pn[s] + nz[s];
+                            for (int s = 0; s < RS; ++s) Pn[s] = keep32 * Pn[s] + nz[s];
                         } else {
                             const double *row = E.noise +
                                 ((size_t)g * E.n_select + select_count) * E.noise_stride;
 #pragma unroll
-                            for (int s = 0; s < SLOTS; ++s)
+                            for (int s = 0; s < RS; ++s)
                                 if (lane_bit(mk.m[s]))
                                     Pn[s] = (float)((double)(keep32 * Pn[s]) + E.noise_scale * row[rk[s]]);
                         }
@@ -798,8 +829,8 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                     auto score_slots = [&](auto exact_tag) {
                         constexpr bool kIeee = decltype(exact_tag)::value;
 #pragma unroll
-                        for (int s = 0; s < SLOTS; s += 2) {
-                            const int s1 = s + 1 < SLOTS ? s + 1 : s;
+                        for (int s = 0; s < RS; s += 2) {
+                            const int s1 = s + 1 < RS ? s + 1 : s;
                             const f2 nvj = {st[s].x, st[s1].x};
                             const f2 tvj = {st[s].y, st[s1].y};
                             const f2 P = {Pn[s], Pn[s1]};
@@ -826,30 +857,36 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                     if (slow_div) score_slots(std::true_type{});
                     else score_slots(std::false_type{});
                     // np.argmax: highest score, lowest index on ties (mcts.py:112): wave max of the
-                    // keys, then the lowest cell holding it
+                    // keys, then the lowest lane-slot holding it (ranks and cells ascend together)
+                    int best_idx = 0x7fffffff;
                     {
                         const uint32_t wmax = wave_max_u32(lkey);
-                        best_cell = 0x7fffffff;
 #pragma unroll
-                        for (int s = SLOTS - 1; s >= 0; --s) {
+                        for (int s = RS - 1; s >= 0; --s) {
                             const uint64_t eq = __ballot(key[s] == wmax) & mk.m[s];
-                            if (eq) best_cell = s * 64 + (int)__ffsll((long long)eq) - 1;
+                            if (eq) best_idx = s * 64 + (int)__ffsll((long long)eq) - 1;
                         }
                     }
-                    const int bl = best_cell & 63, bsl = best_cell >> 6;
+                    const int bl = best_idx & 63, bsl = best_idx >> 6;
 #pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) {
-                        const int r_ = __builtin_amdgcn_readlane(rk[s], bl);
+                    for (int s = 0; s < RS; ++s) {
+                        // at the root the lane-slot index is the child rank and the cell is looked up;
+                        // below it the index is the cell and the rank is looked up
+                        const int r_ = __builtin_amdgcn_readlane(at_root ? rcell[s] : rk[s], bl);
                         const int l_ = __builtin_amdgcn_readlane(__float_as_int(st[s].w), bl);
                         const float n_ = readlane_f(st[s].x, bl), t_ = readlane_f(st[s].y, bl);
-                        if (s == bsl) { child_rank = r_; child_link = l_; cnv = n_; ctv = t_; }
+                        if (s == bsl) {
+                            child_rank = at_root ? best_idx : r_;
+                            best_cell = at_root ? r_ : best_idx;
+                            child_link = l_; cnv = n_; ctv = t_;
+                        }
                     }
                 }
                 T_MARK(depth == 0 ? 0 : 1)
                 c_depth += 1;
                 c_kint += (uint32_t)mk.k;
                 node = link + child_rank;
-                if (at_root) cell0 = best_cell;
+                if (at_root) cell0 = child_rank;               // (the root child's rank: rst is by rank)
                 else (void)cache_find(node, true, cnv, ctv);   // deeper path nodes enter the cache
                 cellL = best_cell;
                 if (lane == 0) L.path[i * pstride + depth] = node | (best_cell << 24);
@@ -867,11 +904,13 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                     sq_next_pend = c_sqrt[sn < 0 ? 0 : (sn < AZX_SQRT_TAB ? sn : AZX_SQRT_TAB - 1)];
                 }
             };
-            level(std::true_type{});
+            if (SLOTS >= 3 && k_root > 128) level(std::true_type{}, std::integral_constant<int, SLOTS>{});
+            else if (k_root > 64) level(std::true_type{}, std::integral_constant<int, 2>{});
+            else level(std::true_type{}, std::integral_constant<int, 1>{});
             while (child_link >= 0) {                          // < 0: a leaf, unevaluated or terminal
                 link = child_link;
                 cur_nv = cnv;
-                level(std::false_type{});
+                level(std::false_type{}, std::integral_constant<int, SLOTS>{});
             }
             select_count += 1;
             c_selects += 1;
@@ -1028,7 +1067,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
     if (root_link >= 0) {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s)
-            if (rempty[s]) *reinterpret_cast<float4 *>(arena + root_link + rrk[s]) = rst[s];
+            if (rempty[s]) *reinterpret_cast<float4 *>(arena + root_link + s * 64 + lane) = rst[s];
     }
     if (lane == 0) {
         *reinterpret_cast<float2 *>(arena + root_id) = make_float2(root_nv, root_tv);
