@@ -23,6 +23,7 @@
 
 __constant__ uint64_t c_geo[AZX_GEO_CELLS * 4];
 __constant__ float c_sqrt[AZX_SQRT_TAB];
+__constant__ float c_invk[256];       // float32 1/k, the default uniform prior table (same bits as the IEEE divide)
 
 // fill c_geo for every supported board size (once per device)
 int azx_init_geometry(int device) {
@@ -51,6 +52,10 @@ int azx_init_geometry(int device) {
     static float rt[AZX_SQRT_TAB];
     for (int i = 0; i < AZX_SQRT_TAB; ++i) rt[i] = sqrtf((float)i);   // IEEE: same bits as np.sqrt(float32)
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_sqrt), rt, sizeof rt) != hipSuccess) return -1;
+    static float ik[256];
+    ik[0] = 0.0f;
+    for (int i = 1; i < 256; ++i) ik[i] = 1.0f / (float)i;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_invk), ik, sizeof ik) != hipSuccess) return -1;
     if (device >= 0 && device < 64) done[device] = true;
     return 0;
 }
@@ -389,6 +394,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
         lds_sync();
     }
     const GammaConst gconst = gamma_const(E.noise_alpha, L.gtab);
+    const uint32_t noise_base = mix32(ph.k0 ^ mix32(ph.k1 + (uint32_t)ply * 0x632be5abu));
 
     if (mode & MODE_BEGIN) {
         batches_left = num_batches;
@@ -436,6 +442,9 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                 rst[s] = *reinterpret_cast<const float4 *>(arena + root_link + s * 64 + lane);
         }
     }
+    float rkp[SLOTS];                  // (1 - eps) * prior of the root children
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) rkp[s] = keep32 * rst[s].z;
     // sum of the root children's visit counts (the integer under the square root of mcts.py:132),
     // kept as a scalar: every change of a root child's count goes through root_child_add
     int root_sumn = 0;
@@ -564,9 +573,11 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
             if (len == 0) {                               // the root's new children, by rank
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s)
-                    if (rempty[s])
+                    if (rempty[s]) {
                         rst[s] = make_float4(0.f, 0.f, prior_row ? prior_row[rcell[s]] : prior_const,
                                              __int_as_float(AZX_LINK_UNEVAL));
+                        rkp[s] = keep32 * rst[s].z;
+                    }
             }
             c_kleaf += (uint32_t)k;
         }
@@ -622,8 +633,9 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
     };
 
     auto inline_prior = [&](int k) -> float {
-        // the default table is float32 1/k: the IEEE divide gives the same bits without a load
-        return (FAST || E.prior_default) ? 1.0f / (float)k : sload_f32(E.prior_by_k + k);
+        // the default table is float32 1/k, kept in constant memory: one scalar load instead of the
+        // ten vector instructions of an IEEE divide
+        return (FAST || E.prior_default) ? c_invk[k & 255] : sload_f32(E.prior_by_k + k);
     };
 
     // =================================== BEGIN: root evaluation (mcts.py:272-273) ========
@@ -798,8 +810,9 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                     float nz[SLOTS] = {};
                     const bool noisy = at_root && E.noise_scale != 0.0;
                     if (noisy && (FAST || E.device_noise)) {
-                        const uint32_t noise_stream =
-                            mix32(ph.k0 ^ mix32(ph.k1 + (uint32_t)ply * 0x632be5abu + (uint32_t)select_count));
+                        // one stream word per (game, move, select): a Weyl sequence from the per-move
+                        // base through one mixer (splitmix construction)
+                        const uint32_t noise_stream = mix32(noise_base + (uint32_t)select_count * 0x9E3779B9u);
                         dirichlet_noise<RS>(mk.m, lane, noise_stream, gconst, (float)E.noise_scale, nz);
                     }
                     // ---- score_actions (mcts.py:119-136), op by op in float32 --------------
@@ -809,8 +822,10 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                     for (int s = 0; s < RS; ++s) Pn[s] = st[s].z;
                     if (noisy) {
                         if (FAST || E.device_noise) {
+                            // (1 - eps) * P, mcts.py:130: the same float32 product every select, so it
+                            // is formed once per launch (rkp) and only the noise is added here
 #pragma unroll
-                            for (int s = 0; s < RS; ++s) Pn[s] = keep32 * Pn[s] + nz[s];
+                            for (int s = 0; s < RS; ++s) Pn[s] = rkp[s] + nz[s];
                         } else {
                             const double *row = E.noise +
                                 ((size_t)g * E.n_select + select_count) * E.noise_stride;
@@ -920,11 +935,15 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
             if (child_link == AZX_LINK_UNEVAL) {
                 if (depth <= 2) {
                     // `last` has one stone on the path: OR the edge flags of the root groups around it
+                    // (the cell's whole geometry row in one scalar load: neighbour masks + edge flags)
                     const uint64_t *gp = c_geo + (size_t)(root.gbase + cellL) * 4;
-                    uint32_t flags = (uint32_t)(gp[3] >> (2 * (last - 1))) & 3u;
+                    uint64_t grow[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) grow[j] = gp[j];
+                    uint32_t flags = (uint32_t)(grow[3] >> (2 * (last - 1))) & 3u;
 #pragma unroll
                     for (int s = 0; s < SLOTS; ++s) {
-                        uint64_t m = gp[s] & (last == 1 ? root.occ[0][s] : root.occ[1][s]);
+                        uint64_t m = grow[s] & (last == 1 ? root.occ[0][s] : root.occ[1][s]);
                         while (m) {
                             const int j = (int)__ffsll((long long)m) - 1;
                             m &= m - 1;
