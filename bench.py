@@ -196,7 +196,7 @@ def main():
             b = model_bytes(st)
             achieved = b / st["mcts_seconds"] / 1e9 if st["mcts_seconds"] > 0 else 0.0
             line["roofline"] = {
-                "kernel": "k_mcts<2> (select+expand+backup, one launch per move)",
+                "kernel": "k_mcts<2, FAST> (select+expand+backup, one launch per move)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "bytes_per_launch": b / max(1, st["mcts_launches"]),
@@ -207,13 +207,13 @@ def main():
             }
             # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
             # (tools/prof_pmc.sh: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction)
-            tpath = os.path.join(ROOT, "profiles", "r1e_tree_pmc_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r1i_tree_pmc_traffic.json")
             default_cmd = (args.games, args.board, args.sims, args.batch, args.steps, args.warmup,
                            args.noise_scale) == (4096, 11, 400, 10, 130, 20, 0.25)
             if default_cmd and os.path.exists(tpath):
                 t = json.load(open(tpath))
                 line["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
-                line["roofline"]["traffic_source"] = "profiles/r1e_tree_pmc_traffic.json (PMC, same command)"
+                line["roofline"]["traffic_source"] = "profiles/r1i_tree_pmc_traffic.json (PMC, same command)"
         else:
             # dominant kernels: the residual tower + heads, one launch pair per leaf batch, timed with
             # HIP events on the engine stream.  ALGORITHMIC flops (107 851 784 per
