@@ -1029,12 +1029,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3(NetDev P, int layer,
 // block, wave (wm, wn): 96 positions x 64 channels = 6 x 4 tiles of 16 x 16), same HBM layout and
 // LDS staging; a k-step is one tap x 32 channels of the staged 64-channel chunk (18 per chunk):
 // 72 MFMAs, 8 weight + 12 activation fragment loads, one register set each, two channel halves.
+#ifndef WIDE_STAGE_GROUP
+#define WIDE_STAGE_GROUP 6
+#endif
 #define WIDE16_MT 6
 #define WIDE16_NT 4
 __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int layer, const unsigned short *__restrict__ in,
                                                                 unsigned short *out, const unsigned short *resid,
                                                                 float *__restrict__ out32,
-                                                                const int32_t *__restrict__ n_eval_ptr, int n_eval_host) {
+                                                                const int32_t *__restrict__ n_eval_ptr, int n_eval_host,
+                                                                int flipsh) {
     constexpr int MT = WIDE16_MT, NT = WIDE16_NT, ROWB = WIDE_ROWB;
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
@@ -1044,7 +1048,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     const int NCH = C / 64, NT16 = C / 16;
     const int co_base = blockIdx.y * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Position tiles: a board of up to 176 cells is eleven 16-row tiles, not twelve.  Wave wm = 0 holds
+    // tiles 0..5 and wm = 1 tiles 5..10 (rows 80..175); the shared tile 5 is computed by wm = 0 for the
+    // first two of the wave's four channel tiles and by wm = 1 for the other two, so each wave issues
+    // 22 tile products per k-step (6 x 2 + 5 x 2) instead of 24, one twelfth of which was padding.
     const int wm = wave & 1, wn = wave >> 1;
+    const int row0 = wm ? 80 : 0;
+    (void)flipsh;
     const int li = lane & 15, lh = lane >> 4;
     const size_t rowg = (size_t)C * 4;
     const unsigned char *gin = reinterpret_cast<const unsigned char *>(in) + (size_t)e * ncells * rowg;
@@ -1055,7 +1065,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     int rbase[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int r = 96 * wm + 16 * m + li;
+        const int r = row0 + 16 * m + li;
         const int ry = r / N, rx = r - ry * N;
         rbase[m] = r * ROWB + 16 * lh;
 #pragma unroll
@@ -1084,14 +1094,40 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
         return wsrc + ((size_t)q * (NT16 * 2) + (size_t)((nt0 + n) * 2 + part)) * 64 + lane;
     };
 
+    // the chunk loop, instantiated per wm (which tile product is the other wave's is a compile-time
+    // pattern: straight-line code either way; both paths pass the same barriers)
+    auto main_loop = [&](auto wm_tag) __attribute__((always_inline)) {
+    constexpr int WM = decltype(wm_tag)::value;
     for (int chunk = 0; chunk < NCH; ++chunk) {
         __syncthreads();                                 // the previous chunk has been consumed
-        for (int idx = tid; idx < ncells * 16; idx += 256) {
-            const int row = idx >> 4, piece = idx & 15;
-            const size_t src = (size_t)row * rowg + (piece < 8 ? (size_t)chunk * 128 + piece * 16
-                                                               : (size_t)C * 2 + (size_t)chunk * 128 + (piece - 8) * 16);
-            const int dst = row * ROWB + (piece < 8 ? piece * 16 : 128 + (piece - 8) * 16);
-            *reinterpret_cast<uint4 *>(smem + dst) = *reinterpret_cast<const uint4 *>(gin + src);
+        {
+            // all of a thread's pieces are requested before the first one is written to LDS (as a plain
+            // loop the compiler waited for each 16-byte load in turn: eleven memory round trips per
+            // chunk); the tail repeats the last piece instead of diverging
+            constexpr int NST = (AZX_MAX_BOARD * AZX_MAX_BOARD * 16 + 255) / 256;
+            constexpr int GRP = WIDE_STAGE_GROUP;            // pieces in flight per thread (register budget)
+            const int last = ncells * 16 - 1;
+            int tid_o = tid;                                 // opaque per chunk: the piece addresses are
+            asm volatile("" : "+v"(tid_o));                  // recomputed here, not hoisted and spilled
+#pragma unroll
+            for (int j0 = 0; j0 < NST; j0 += GRP) {
+                uint4 stg[GRP];
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const int idx = min(tid_o + 256 * (j0 + j), last);
+                    const int row = idx >> 4, piece = idx & 15;
+                    const size_t src = (size_t)row * rowg + (piece < 8 ? (size_t)chunk * 128 + piece * 16
+                                                                       : (size_t)C * 2 + (size_t)chunk * 128 + (piece - 8) * 16);
+                    if (j0 + j < NST) stg[j] = *reinterpret_cast<const uint4 *>(gin + src);
+                }
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const int idx = min(tid_o + 256 * (j0 + j), last);
+                    const int row = idx >> 4, piece = idx & 15;
+                    const int dst = row * ROWB + (piece < 8 ? piece * 16 : 128 + (piece - 8) * 16);
+                    if (j0 + j < NST) *reinterpret_cast<uint4 *>(smem + dst) = stg[j];
+                }
+            }
         }
         __syncthreads();
         // k-step t = 0..17 of this chunk: tap t/2, channels 32 (t%2) .. +31 of the chunk
@@ -1124,18 +1160,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
                         if (h == 0) load_w(t, 2 + (idx >> 1), idx & 1);
                         else if (t + 1 < 18) load_w(t + 1, idx >> 1, idx & 1);
                     } else if (h == 0 && (q == 13 || q == 16)) {
-                        load_x(t, MT - 1, q == 16);                // the lagging last tile
+                        load_x(t, MT - 1, q == 16);       // the lagging last tile
                     } else if (h == 1 && q >= 8 && (q % 6 == 2 || q % 6 == 5)) {
                         if (t + 1 < 18) load_x(t + 1, q / 6 - 1, q % 6 == 5);
                     }
                     const f16x8 wv = p == 1 ? wl_[n] : wh_[n];
                     const f16x8 xv = p == 2 ? xl[m] : xh[m];
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, acc[m][n], 0, 0, 0);
+                    if (!(WM == 0 ? (m == MT - 1 && n >= 2) : (m == 0 && n < 2)))
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, acc[m][n], 0, 0, 0);
                     if (q % 3 == 2) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
     }
+
+    };
+    if (wm == 0) main_loop(std::integral_constant<int, 0>{});
+    else main_loop(std::integral_constant<int, 1>{});
 
     // ---- epilogue -------------------------------------------------------------------------------
     unsigned char *gout = reinterpret_cast<unsigned char *>(out) + (size_t)e * ncells * rowg;
@@ -1145,14 +1186,25 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
         const int cb = co_base + 64 * wn + 16 * n + 4 * lh;
         const float4 b4 = *reinterpret_cast<const float4 *>(P.bias + (size_t)layer * C + cb);
         const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+        // the residual of all six position tiles is requested up front (rows past the board re-read the
+        // last cell, no divergence): one memory round trip per channel tile instead of one per tile
+        f16x4 rhv[MT], rlv[MT];
+        if (gres) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int rc = min(row0 + 16 * m + li, ncells - 1);
+                rhv[m] = *reinterpret_cast<const f16x4 *>(gres + (size_t)rc * rowg + cb * 2);
+                rlv[m] = *reinterpret_cast<const f16x4 *>(gres + (size_t)rc * rowg + (size_t)C * 2 + cb * 2);
+            }
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const int r = 96 * wm + 16 * m + li;
-            if (r < ncells) {
+            const int r = row0 + 16 * m + li;
+            const bool mine = !(wm == 0 ? (m == MT - 1 && n >= 2) : (m == 0 && n < 2));   // else the other wave's
+            if (r < ncells && mine) {
                 float rv[4] = {0.f, 0.f, 0.f, 0.f};
                 if (gres) {
-                    const f16x4 rh = *reinterpret_cast<const f16x4 *>(gres + (size_t)r * rowg + cb * 2);
-                    const f16x4 rl = *reinterpret_cast<const f16x4 *>(gres + (size_t)r * rowg + (size_t)C * 2 + cb * 2);
+                    const f16x4 rh = rhv[m], rl = rlv[m];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) rv[j] = (float)rh[j] + (float)rl[j];
                 }
@@ -1897,14 +1949,22 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
                 (void)hipFuncSetAttribute((const void *)k_conv_wide_f16x3_s16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 attr5 = true;
             }
-            auto conv = wshape == 16 ? k_conv_wide_f16x3_s16 : k_conv_wide_f16x3;
+            // which bit of the board index flips a block's long/short wave assignment (31 = never)
+            static const int stagger = getenv("AZX_WIDE_FLIP") ? atoi(getenv("AZX_WIDE_FLIP")) : 0;
             const dim3 grid(max_n, d.C / 128), block(256);
             hipLaunchKernelGGL(k_stem_wide_f16x3, grid, block, 0, st, d, boards, net->wideX,
                                d.blocks == 0 ? net->act : (float *)nullptr, n_eval_ptr, n_host);
             for (int b = 0; b < d.blocks; ++b) {
-                hipLaunchKernelGGL(conv, grid, block, lds, st, d, 2 * b, (const unsigned short *)net->wideX, net->wideY,
+                if (wshape == 16) {
+                    hipLaunchKernelGGL(k_conv_wide_f16x3_s16, grid, block, lds, st, d, 2 * b, (const unsigned short *)net->wideX, net->wideY,
+                                       (const unsigned short *)nullptr, (float *)nullptr, n_eval_ptr, n_host, stagger);
+                    hipLaunchKernelGGL(k_conv_wide_f16x3_s16, grid, block, lds, st, d, 2 * b + 1, (const unsigned short *)net->wideY, net->wideX,
+                                       (const unsigned short *)net->wideX, b == d.blocks - 1 ? net->act : (float *)nullptr, n_eval_ptr, n_host, stagger);
+                    continue;
+                }
+                hipLaunchKernelGGL(k_conv_wide_f16x3, grid, block, lds, st, d, 2 * b, (const unsigned short *)net->wideX, net->wideY,
                                    (const unsigned short *)nullptr, (float *)nullptr, n_eval_ptr, n_host);
-                hipLaunchKernelGGL(conv, grid, block, lds, st, d, 2 * b + 1, (const unsigned short *)net->wideY, net->wideX,
+                hipLaunchKernelGGL(k_conv_wide_f16x3, grid, block, lds, st, d, 2 * b + 1, (const unsigned short *)net->wideY, net->wideX,
                                    (const unsigned short *)net->wideX, b == d.blocks - 1 ? net->act : (float *)nullptr, n_eval_ptr, n_host);
             }
         } else if (net->tower_variant == 1) {
