@@ -1417,10 +1417,27 @@ __global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict
 
     // ---- 1x1 convs + folded BN + ReLU (network.py:77, :83); flatten order (c, h, w) -----------
     if (hfeat != nullptr) {                           // already done by the tower kernel
-        for (int idx = tid; idx < HEADS_BPB * 6 * ncells; idx += 192) {
-            const int b = idx / (6 * ncells), f = idx - b * 6 * ncells;
-            const float v = b < nb ? hfeat[(size_t)(e0 + b) * 6 * ncells + f] : 0.0f;
-            if (f < 2 * ncells) hv[f][b] = v; else hp[f - 2 * ncells][b] = v;
+        // board by board, a thread's features of a board requested together (no index division, no
+        // load-wait-store chain per element)
+        const int nf = 6 * ncells;
+        constexpr int NFT = (6 * AZX_MAX_CELLS + 191) / 192;
+#pragma unroll 2
+        for (int b = 0; b < HEADS_BPB; ++b) {
+            float v[NFT];
+            const float *src = hfeat + (size_t)(e0 + (b < nb ? b : 0)) * nf;
+#pragma unroll
+            for (int j = 0; j < NFT; ++j) {
+                const int f = tid + 192 * j;
+                v[j] = src[f < nf ? f : nf - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < NFT; ++j) {
+                const int f = tid + 192 * j;
+                if (f < nf) {
+                    const float x = b < nb ? v[j] : 0.0f;
+                    if (f < 2 * ncells) hv[f][b] = x; else hp[f - 2 * ncells][b] = x;
+                }
+            }
         }
     } else if (tid < ncells) {
         for (int b = 0; b < HEADS_BPB; ++b) {
@@ -1460,6 +1477,7 @@ __global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict
         float acc[HEADS_BPB];
 #pragma unroll
         for (int b = 0; b < HEADS_BPB; ++b) acc[b] = 0.f;
+#pragma unroll 8                                     // eight weight loads in flight per thread
         for (int i = 0; i < 2 * ncells; ++i) {
             const float w = P.fc2T[i * 64 + tid];
             const float4 x0 = *reinterpret_cast<const float4 *>(&hv[i][0]);
@@ -1474,6 +1492,7 @@ __global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict
         float acc[HEADS_BPB];
 #pragma unroll
         for (int b = 0; b < HEADS_BPB; ++b) acc[b] = 0.f;
+#pragma unroll 8
         for (int i = 0; i < 4 * ncells; ++i) {
             const float w = P.mfcT[(size_t)i * AZX_CELL_STRIDE + tid];
             const float4 x0 = *reinterpret_cast<const float4 *>(&hp[i][0]);
