@@ -418,6 +418,44 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
         const int n = k_root - 64 * s;
         rootrm[s] = n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
     }
+    // Winning moves at the root, per colour: an empty cell whose own edge flags OR-ed with the flags of
+    // the same-coloured groups around it reach both edges (hex.py:204-231 for one new stone).  A leaf
+    // at depth <= 2 has exactly one stone of the last mover on its path, so its win test is one bit
+    // of these masks -- computed once per launch instead of at every new leaf.
+    uint64_t winm[2][SLOTS];
+    {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (s * 64 + lane < ncells) L.path[s * 64 + lane] = (int32_t)root.c[s];
+        lds_sync();
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int cell = s * 64 + lane;
+            uint32_t f1 = 0u, f2 = 0u;
+            const bool empty = cell < ncells && (root.c[s] & 3u) == 0u;
+            if (empty) {
+                const uint64_t *gq = c_geo + (size_t)(root.gbase + cell) * 4;
+                const uint32_t edge = (uint32_t)gq[3];
+                f1 = edge & 3u;
+                f2 = (edge >> 2) & 3u;
+#pragma unroll
+                for (int t = 0; t < SLOTS; ++t) {
+                    uint64_t m = gq[t];
+                    while (m) {
+                        const int j = (int)__ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const uint32_t w = (uint32_t)L.path[t * 64 + j];
+                        const uint32_t fl = (w >> 2) & 3u;
+                        if ((w & 3u) == 1u) f1 |= fl;
+                        if ((w & 3u) == 2u) f2 |= fl;
+                    }
+                }
+            }
+            winm[0][s] = __ballot(empty && f1 == 3u);
+            winm[1][s] = __ballot(empty && f2 == 3u);
+        }
+        lds_sync();
+    }
     {   // rank -> cell through LDS (the path area is free until the first descent)
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s)
@@ -934,23 +972,12 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
             int winner = last;                                // a terminal link: the last mover won
             if (child_link == AZX_LINK_UNEVAL) {
                 if (depth <= 2) {
-                    // `last` has one stone on the path: OR the edge flags of the root groups around it
-                    // (the cell's whole geometry row in one scalar load: neighbour masks + edge flags)
-                    const uint64_t *gp = c_geo + (size_t)(root.gbase + cellL) * 4;
-                    uint64_t grow[4];
+                    // `last` has one stone on the path: the root's winning-move mask of that colour
+                    uint64_t wmask = 0ull;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) grow[j] = gp[j];
-                    uint32_t flags = (uint32_t)(grow[3] >> (2 * (last - 1))) & 3u;
-#pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) {
-                        uint64_t m = grow[s] & (last == 1 ? root.occ[0][s] : root.occ[1][s]);
-                        while (m) {
-                            const int j = (int)__ffsll((long long)m) - 1;
-                            m &= m - 1;
-                            flags |= ((uint32_t)__builtin_amdgcn_readlane((int)root.c[s], j) >> 2) & 3u;
-                        }
-                    }
-                    winner = flags == 3u ? last : 0;
+                    for (int s = 0; s < SLOTS; ++s)
+                        if (s == (cellL >> 6)) wmask = last == 1 ? winm[0][s] : winm[1][s];
+                    winner = ((wmask >> (cellL & 63)) & 1ull) ? last : 0;
                 } else {
                     // several stones of `last`: replay them on a copy of the root groups
                     lds_sync();
