@@ -502,7 +502,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
     int c_id = -1, n_c = 0;            // node cache: entry j lives in lane j
     float c_nv = 0.0f, c_tv = 0.0f;
     // per-leaf metadata of the batch in flight: leaf i lives in lane i (v_readlane to fetch)
-    int m_node = -1, m_len = 0, m_link = 0, m_tm = 0, m_cells = 0, m_uidx = 0;
+    int m_node = -1, m_len = 0, m_link = 0, m_tm = 0, m_cells = 0, m_uidx = 0, m_k = 0;
     float m_val = 0.0f;
     uint64_t m_mask[SLOTS];
 #pragma unroll
@@ -583,18 +583,35 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
 
     // ---- create_child_nodes (search_tree.py:254-274) for one leaf; returns false when full.
     // `cells` = rank of the path's root child | last cell << 16 (owner lanes of the link word).
-    auto expand = [&](int node, int len, int cells, int lnk, bool terminal, const uint64_t *lm,
+    // With one prior for every child (prior_row == nullptr: the uniform evaluator) the block is written
+    // by rank -- lane j stores child j, no masks needed (lm may be null, k_in = number of children);
+    // those children are later loaded by other lanes (lane = cell), so the caller fences once per batch.
+    auto expand = [&](int node, int len, int cells, int lnk, bool terminal, const uint64_t *lm, int k_in,
                       const float *prior_row, float prior_const) -> bool {
         if (lnk != AZX_LINK_UNEVAL) return true;          // re-selected terminal: mcts.py:237
         int k = 0;
         int base[SLOTS];
+        if (lm) {
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) { base[s] = k; k += popc64(lm[s]); }
+            for (int s = 0; s < SLOTS; ++s) { base[s] = k; k += popc64(lm[s]); }
+        } else {
+            k = k_in;
+        }
         if (terminal) k = 0;
         if (num_nodes + k > E.cap) { status = 1; return false; }   // SearchTreeFull
         const int fc = num_nodes;
         num_nodes += k;
         if (k > 0) {
+            if (!prior_row) {
+                Node nd;
+                nd.nv = 0.0f;
+                nd.tv = 0.0f;
+                nd.pp = prior_const;
+                nd.link = AZX_LINK_UNEVAL;
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s)
+                    if (s * 64 + lane < k) arena[fc + s * 64 + lane] = nd;
+            } else
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
                 if (lane_bit(lm[s])) {
@@ -687,8 +704,9 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
             lds_sync();
         }
         if (inline_eval) {
-            expand(root_id, 0, 0, AZX_LINK_UNEVAL, root.winner != 0, rootmk.m, nullptr,
+            expand(root_id, 0, 0, AZX_LINK_UNEVAL, root.winner != 0, nullptr, rootmk.k, nullptr,
                    rootmk.k ? inline_prior(rootmk.k) : 0.0f);
+            wave_mem_sync();
             c_evals += 1;
         } else {
             int e = 0;
@@ -730,7 +748,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
             float v = -1.0f;                                   // mcts.py:194-195
             if (!terminal) v = E.ev_value[ev];
             if (!value_in_fast_range(v)) slow_div = true;
-            if (!expand(node, len, cells, lnk, terminal, lm,
+            if (!expand(node, len, cells, lnk, terminal, lm, 0,
                         terminal ? nullptr : E.ev_prior + (size_t)ev * AZX_CELL_STRIDE, 0.0f))
                 break;
             if (!pending_root) {
@@ -1018,8 +1036,15 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                 m_link = child_link;
                 m_tm = (winner != 0 ? 1 : 0) | (mover << 1);
                 m_cells = cell0 | (cellL << 16);
+                if (inline_eval) {                             // one prior for all children: only their number
+                    int kl = 0;
 #pragma unroll
-                for (int s = 0; s < SLOTS; ++s) m_mask[s] = lmask[s];
+                    for (int s = 0; s < SLOTS; ++s) kl += popc64(lmask[s]);
+                    m_k = kl;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) m_mask[s] = lmask[s];
+                }
             }
             lds_sync();
             // ... and apply the virtual loss to its path (mcts.py:68, :79-92)
@@ -1048,10 +1073,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                 const int i = rl(m_uidx, u);
                 const int tm = rl(m_tm, i);
                 const bool terminal = (tm & 1) != 0;
-                uint64_t lm[SLOTS];
-                int k = 0;
-#pragma unroll
-                for (int s = 0; s < SLOTS; ++s) { lm[s] = rl64(m_mask[s], i); k += popc64(lm[s]); }
+                const int k = rl(m_k, i);
                 float v = -1.0f;
                 if (!terminal) {
                     v = (!FAST && E.evaluator == AZX_EVAL_UNIFORM_HASH)
@@ -1062,12 +1084,13 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                     c_term += 1;
                 }
                 const int lf_len = rl(m_len, i), lf_cells = rl(m_cells, i);
-                if (!expand(rl(m_node, i), lf_len, lf_cells, rl(m_link, i), terminal, lm, nullptr,
+                if (!expand(rl(m_node, i), lf_len, lf_cells, rl(m_link, i), terminal, nullptr, k, nullptr,
                             (!terminal && k) ? inline_prior(k) : 0.0f))
                     break;
                 path_apply(L.path + i * pstride, lf_len, lf_cells & 0xffff, 1.0f, v, true, true);
                 if (lane == u) m_val = v;
             }
+            wave_mem_sync();   // the children written by rank above are read by other lanes from here on
             if (status == 0) search_value += np_sum_vals(nu);   // mcts.py:287
             T_MARK(5)
         } else {
