@@ -771,13 +771,20 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
         // others to run alone with nothing to overlap their stalls.  Waves drop their own priority
         // as they progress, so the four games of a SIMD reach the end of the launch closer together
         // (measured: -9 % launch time; a finer, per-select dither of the four levels was slower).
+#ifndef AZX_NO_PRIO
         if (num_batches > 0) {
+#ifdef AZX_PRIO8   // diagnostic: eight progress levels dithered onto the four priorities
+            const int q8 = (8 * batches_left - 1) / num_batches;  // 7 .. 0
+            const int q = (q8 >> 1) + ((q8 & 1) & (batches_left & 1));
+#else
             const int q = (4 * batches_left - 1) / num_batches;   // 3 .. 0
+#endif
             if (q >= 3) __builtin_amdgcn_s_setprio(3);
             else if (q == 2) __builtin_amdgcn_s_setprio(2);
             else if (q == 1) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
         }
+#endif
         // ---- select_batch: bs sequential descents with virtual loss (mcts.py:62-70) ----
         for (int i = 0; i < bs; ++i) {
             // snapshot/restore (search_tree.py:150-154): the descent only tracks which cells are
