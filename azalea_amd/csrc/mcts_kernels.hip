@@ -1058,11 +1058,55 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
             path_apply(L.path + i * pstride, depth, cell0, 1.0f, 1.0f, false, false);
             T_MARK(3)
         }
+        int nu = 0;
+        if (FAST) {
+            // With the uniform evaluator every backed-up value is 0 or -1, so every num_visits and
+            // total_value is a small integer and float32 addition on them is exact in any order: the
+            // undo of the virtual losses (mcts.py:72), deduplicate_leaves (:139-152), expand_batch
+            // (:226-239) and backup_batch (:242-255) are folded into ONE pass over the batch's paths
+            // with the net change per node -- a first-seen leaf keeps the visit its virtual loss
+            // added and gives back the +1 of total_value (plus the alternating -1 of a terminal
+            // leaf), a duplicate gives back both -- instead of two passes of separate updates.
+            // Node ids are still handed out in list order of the first occurrences.
+            for (int i = 0; i < bs; ++i) {
+                const int id = rl(m_node, i);
+                const bool dup = __ballot(lane < i && m_node == id) != 0ull;
+                const int len = rl(m_len, i), cells = rl(m_cells, i);
+                bool term = false;
+                if (!dup) {
+                    term = (rl(m_tm, i) & 1) != 0;
+                    const int k = rl(m_k, i);
+                    if (term) c_term += 1; else c_evals += 1;
+                    if (!expand(id, len, cells, rl(m_link, i), term, nullptr, k, nullptr,
+                                (!term && k) ? inline_prior(k) : 0.0f))
+                        break;
+                    if (lane == nu) m_val = term ? -1.0f : 0.0f;
+                    nu += 1;
+                    root_nv += 1.0f;
+                    if (term) root_tv += (len & 1) ? 1.0f : -1.0f;
+                }
+                const float dvn = dup ? -1.0f : 0.0f;
+                // total_value change of the path node at depth d + 1
+                auto tvd = [&](int d) -> float {
+                    return term ? (((len - 1 - d) & 1) ? 0.0f : -2.0f) : -1.0f;
+                };
+                root_child_add(cells & 0xffff, dvn, tvd(0));
+                const int32_t *pth = L.path + i * pstride;
+                for (int d = 1; d < len; ++d) {
+                    const int slot = cache_find(pth[d] & 0xffffff, false, 0.f, 0.f);
+                    if (lane == slot) { c_nv += dvn; c_tv += tvd(d); }
+                }
+            }
+            batches_left -= 1;
+            wave_mem_sync();   // the children written by rank above are read by other lanes from here on
+            if (status == 0) search_value += np_sum_vals(nu);   // mcts.py:287
+            T_MARK(5)
+            continue;
+        }
         // undo the virtual losses in list order (mcts.py:72)
         for (int i = 0; i < bs; ++i)
             path_apply(L.path + i * pstride, rl(m_len, i), rl(m_cells, i) & 0xffff, -1.0f, -1.0f, false, false);
         // deduplicate_leaves: keep first occurrence by node id (mcts.py:139-152)
-        int nu = 0;
         for (int i = 0; i < bs; ++i) {
             const int id = rl(m_node, i);
             const bool dup = __ballot(lane < i && m_node == id) != 0ull;
