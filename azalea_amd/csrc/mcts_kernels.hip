@@ -492,6 +492,12 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
         for (int s = 0; s < SLOTS; ++s) t += (int)rst[s].x;
         root_sumn = wave_sum_i(t);
     }
+    // Everything loaded so far is waited for HERE, once per launch.  Without it the compiler, unable to
+    // prove that root_nv / root_tv had arrived on every path into the batch loop, put a full
+    // s_waitcnt vmcnt(0) in front of their update at every backed-up leaf -- which also waits for the
+    // child blocks the previous leaf's expansion had just stored (an HBM write round trip per leaf).
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    asm volatile("" : "+v"(root_nv), "+v"(root_tv));
     uint64_t rootall[SLOTS];           // cells that are not empty at the root: stones + off-board bits
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
@@ -1199,12 +1205,15 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
         th->select_count = select_count;
         th->search_value = search_value;
         if (!FAST) th->slow_div = slow_div ? 1 : 0;
-        if (c_selects) E.counters[(size_t)g * CTR_COUNT + CTR_SELECTS] += c_selects;
-        if (c_depth) E.counters[(size_t)g * CTR_COUNT + CTR_SUM_DEPTH] += c_depth;
-        if (c_kint) E.counters[(size_t)g * CTR_COUNT + CTR_SUM_K_INT] += c_kint;
-        if (c_kleaf) E.counters[(size_t)g * CTR_COUNT + CTR_SUM_K_LEAF] += c_kleaf;
-        if (c_evals) E.counters[(size_t)g * CTR_COUNT + CTR_EVALS] += c_evals;
-        if (c_term) E.counters[(size_t)g * CTR_COUNT + CTR_TERM_EVALS] += c_term;
+    }
+    // the six per-game tallies, one lane each (as six scalar read-modify-writes the compiler waited
+    // for each load in turn: six memory round trips at the end of every launch)
+    static_assert(CTR_SELECTS == 0 && CTR_SUM_DEPTH == 1 && CTR_SUM_K_INT == 2 && CTR_SUM_K_LEAF == 3 &&
+                  CTR_EVALS == 4 && CTR_TERM_EVALS == 5, "tally order");
+    if (lane < 6) {
+        const uint32_t add = lane == 0 ? c_selects : lane == 1 ? c_depth : lane == 2 ? c_kint
+                           : lane == 3 ? c_kleaf : lane == 4 ? c_evals : c_term;
+        if (add) E.counters[(size_t)g * CTR_COUNT + lane] += add;
     }
 }
 
