@@ -480,6 +480,8 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                 rst[s] = *reinterpret_cast<const float4 *>(arena + root_link + s * 64 + lane);
         }
     }
+    float sq_reg = 0.0f;               // window of the sqrt table around the root's visit sum
+    int sq_base = -1000;
     float rkp[SLOTS];                  // (1 - eps) * prior of the root children
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) rkp[s] = keep32 * rst[s].z;
@@ -496,8 +498,9 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
     // prove that root_nv / root_tv had arrived on every path into the batch loop, put a full
     // s_waitcnt vmcnt(0) in front of their update at every backed-up leaf -- which also waits for the
     // child blocks the previous leaf's expansion had just stored (an HBM write round trip per leaf).
+    float invk_reg = c_invk[(k_root - lane) & 255];   // see inline_prior
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-    asm volatile("" : "+v"(root_nv), "+v"(root_tv));
+    asm volatile("" : "+v"(root_nv), "+v"(root_tv), "+v"(invk_reg));
     uint64_t rootall[SLOTS];           // cells that are not empty at the root: stones + off-board bits
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
@@ -693,10 +696,16 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
         return (float)((double)(h & 0xffffu) / 32768.0 - 1.0);
     };
 
-    auto inline_prior = [&](int k) -> float {
-        // the default table is float32 1/k, kept in constant memory: one scalar load instead of the
-        // ten vector instructions of an IEEE divide
-        return (FAST || E.prior_default) ? c_invk[k & 255] : sload_f32(E.prior_by_k + k);
+    // A Hex position `len` plies below the root has exactly k_root - len legal moves, so the priors
+    // a search can need are 1/(k_root - j): lane j keeps that entry of the float32 1/k table (one
+    // vector load per launch) and an expansion reads it with v_readlane -- no memory access, where a
+    // scalar load per expansion cost its latency every time.
+    auto inline_prior = [&](int k, int len) -> float {
+        if (FAST || E.prior_default) {
+            if ((unsigned)len < 64u && k == k_root - len) return readlane_f(invk_reg, len);
+            return c_invk[k & 255];
+        }
+        return sload_f32(E.prior_by_k + k);
     };
 
     // =================================== BEGIN: root evaluation (mcts.py:272-273) ========
@@ -711,7 +720,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
         }
         if (inline_eval) {
             expand(root_id, 0, 0, AZX_LINK_UNEVAL, root.winner != 0, nullptr, rootmk.k, nullptr,
-                   rootmk.k ? inline_prior(rootmk.k) : 0.0f);
+                   rootmk.k ? inline_prior(rootmk.k, 0) : 0.0f);
             wave_mem_sync();
             c_evals += 1;
         } else {
@@ -847,7 +856,20 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                     // Below the root the table entry was requested when the level above chose this
                     // node (sq_next_pend) and is consumed after the children have been requested
                     // (late_vgpr below), so the scalar load rides under the HBM one.
-                    const float sq_tab = at_root ? c_sqrt[sumn < AZX_SQRT_TAB ? sumn : AZX_SQRT_TAB - 1] : sq_next_pend;
+                    float sq_tab = sq_next_pend;
+                    if (at_root) {
+                        // the root's sum only creeps upward (by one per descent, by the new visits per
+                        // batch): lane j holds the table entry sq_base + j, reloaded with one vector
+                        // load when the sum leaves the 64-entry window, read with v_readlane
+                        if ((unsigned)(sumn - sq_base) >= 64u) {
+                            sq_base = sumn;
+                            const int ix = sumn + lane;
+                            sq_reg = c_sqrt[ix < AZX_SQRT_TAB ? ix : AZX_SQRT_TAB - 1];
+                            __builtin_amdgcn_s_waitcnt(0x0F70);   // waited for here, not at every use
+                            asm volatile("" : "+v"(sq_reg));
+                        }
+                        sq_tab = readlane_f(sq_reg, sumn - sq_base);
+                    }
                     // ---- children statistics ------------------------------------------------
                     float4 st[SLOTS];
                     int rk[SLOTS];
@@ -1084,13 +1106,14 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                     const int k = rl(m_k, i);
                     if (term) c_term += 1; else c_evals += 1;
                     if (!expand(id, len, cells, rl(m_link, i), term, nullptr, k, nullptr,
-                                (!term && k) ? inline_prior(k) : 0.0f))
+                                (!term && k) ? inline_prior(k, len) : 0.0f))
                         break;
                     if (lane == nu) m_val = term ? -1.0f : 0.0f;
                     nu += 1;
                     root_nv += 1.0f;
                     if (term) root_tv += (len & 1) ? 1.0f : -1.0f;
                 }
+                T_MARK(4)
                 const float dvn = dup ? -1.0f : 0.0f;
                 // total_value change of the path node at depth d + 1
                 auto tvd = [&](int d) -> float {
@@ -1102,6 +1125,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                     const int slot = cache_find(pth[d] & 0xffffff, false, 0.f, 0.f);
                     if (lane == slot) { c_nv += dvn; c_tv += tvd(d); }
                 }
+                T_MARK(5)
             }
             batches_left -= 1;
             wave_mem_sync();   // the children written by rank above are read by other lanes from here on
@@ -1142,7 +1166,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                 }
                 const int lf_len = rl(m_len, i), lf_cells = rl(m_cells, i);
                 if (!expand(rl(m_node, i), lf_len, lf_cells, rl(m_link, i), terminal, nullptr, k, nullptr,
-                            (!terminal && k) ? inline_prior(k) : 0.0f))
+                            (!terminal && k) ? inline_prior(k, lf_len) : 0.0f))
                     break;
                 path_apply(L.path + i * pstride, lf_len, lf_cells & 0xffff, 1.0f, v, true, true);
                 if (lane == u) m_val = v;
