@@ -480,8 +480,6 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                 rst[s] = *reinterpret_cast<const float4 *>(arena + root_link + s * 64 + lane);
         }
     }
-    float sq_reg = 0.0f;               // window of the sqrt table around the root's visit sum
-    int sq_base = -1000;
     float rkp[SLOTS];                  // (1 - eps) * prior of the root children
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) rkp[s] = keep32 * rst[s].z;
@@ -582,7 +580,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
             root_nv += dv;
             root_tv += (alternate && (len & 1)) ? -amount : amount;
         }
-        if (len >= 1) root_child_add(cell0, dv, (alternate && ((len - 1) & 1)) ? -amount : amount);
+        if (len >= 1 && cell0 >= 0) root_child_add(cell0, dv, (alternate && ((len - 1) & 1)) ? -amount : amount);
         for (int d = 1; d < len; ++d) {
             const float a = (alternate && ((len - 1 - d) & 1)) ? -amount : amount;
             const int slot = cache_find(pth[d] & 0xffffff, false, 0.f, 0.f);
@@ -801,6 +799,120 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
         }
 #endif
         // ---- select_batch: bs sequential descents with virtual loss (mcts.py:62-70) ----
+        // score_actions (mcts.py:119-136) op by op in float32 over RS register slots + np.argmax
+        // (highest score, lowest index on ties, mcts.py:112): returns the winning lane-slot index.
+        // Branch-free: every lane computes, lanes outside `mm` are masked out of the maximum.
+        auto score_argmax = [&](auto rs_tag, const float4 *st, const float *Pn, const uint64_t *mm,
+                                float sq) __attribute__((always_inline)) -> int {
+            constexpr int RS = decltype(rs_tag)::value;
+            uint32_t key[SLOTS], lkey = 0u;
+            auto score_slots = [&](auto exact_tag) {
+                constexpr bool kIeee = decltype(exact_tag)::value;
+#pragma unroll
+                for (int s = 0; s < RS; s += 2) {
+                    const int s1 = s + 1 < RS ? s + 1 : s;
+                    const f2 nvj = {st[s].x, st[s1].x};
+                    const f2 tvj = {st[s].y, st[s1].y};
+                    const f2 P = {Pn[s], Pn[s1]};
+                    const f2 sq2 = {sq, sq}, one = {1.0f, 1.0f}, zero = {0.0f, 0.0f}, c2 = {c32, c32};
+                    const f2 dg = one + nvj;
+                    const f2 gap = kIeee ? div2_ieee(sq2, dg) : div2_unscaled(sq2, dg);   // mcts.py:132
+                    const f2 U = (c2 * P) * gap;                                       // mcts.py:133
+                    f2 dq;                                                             // clip(min=1)
+                    dq.x = __builtin_amdgcn_fmed3f(nvj.x, 1.0f, 3.0e38f);
+                    dq.y = __builtin_amdgcn_fmed3f(nvj.y, 1.0f, 3.0e38f);
+                    const f2 W = -tvj;                                                 // search_tree.py:203
+                    const f2 Q = kIeee ? div2_ieee(W, dq) : div2_unscaled(W, dq);     // mcts.py:134
+                    const f2 score = (Q + U) + zero;                    // mcts.py:135; -0.0 -> +0.0
+                    // order-preserving map float -> u32 (np.argmax compares values; equal
+                    // floats <=> equal keys once -0.0 is folded into +0.0)
+                    key[s] = lane_bit(mm[s]) ? f32_key(score.x) : 0u;
+                    lkey = key[s] > lkey ? key[s] : lkey;
+                    if (s1 != s) {
+                        key[s1] = lane_bit(mm[s1]) ? f32_key(score.y) : 0u;
+                        lkey = key[s1] > lkey ? key[s1] : lkey;
+                    }
+                }
+            };
+            if (slow_div) score_slots(std::true_type{});
+            else score_slots(std::false_type{});
+            int best_idx = 0x7fffffff;
+            const uint32_t wmax = wave_max_u32(lkey);
+#pragma unroll
+            for (int s = RS - 1; s >= 0; --s) {
+                const uint64_t eq = __ballot(key[s] == wmax) & mm[s];
+                if (eq) best_idx = s * 64 + (int)__ffsll((long long)eq) - 1;
+            }
+            return best_idx;
+        };
+        auto sqrt_of = [&](float sq_tab, int sumn) __attribute__((always_inline)) -> float {
+            float sq = late_vgpr(sq_tab);
+            if (sumn >= AZX_SQRT_TAB) {                // beyond the table (rare): a real branch
+                asm volatile("");                      // (the compiler would otherwise run the
+                sq = sqrtf((float)sumn);               // 18-instruction sqrtf every time and select)
+            }
+            return sq;
+        };
+
+        // The root level of descent `sel` (children in registers by rank, Dirichlet noise, mcts.py:114):
+        // pure function of the root state -- it is run for descent i + 1 while descent i's first child
+        // block is on its way from HBM (its only input from descent i, the virtual loss on i's root
+        // child, is applied as soon as that child is known).
+        int pk_rank = 0, pk_cell = 0, pk_link = 0;
+        float pk_nv = 0.0f;
+        auto root_pick = [&](int sel, auto rs_tag) __attribute__((always_inline)) {
+            constexpr int RS = decltype(rs_tag)::value;
+            // sqrt(sum of the children's visits), mcts.py:132: the sum is the integer root_sumn.  A scalar
+            // table load, requested first and consumed after the noise (a vector-register window of the
+            // table made the compiler wait for ALL vector memory here, i.e. for the child block in
+            // flight that this function is meant to overlap)
+            const int sumn = root_sumn;
+            const float sq_tab = c_sqrt[sumn < AZX_SQRT_TAB ? sumn : AZX_SQRT_TAB - 1];
+            float nz[SLOTS] = {};
+            const bool noisy = E.noise_scale != 0.0;
+            float Pn[SLOTS];
+#pragma unroll
+            for (int s = 0; s < RS; ++s) Pn[s] = rst[s].z;
+            if (noisy) {
+                if (FAST || E.device_noise) {
+                    // one stream word per (game, move, select): a Weyl sequence from the per-move
+                    // base through one mixer (splitmix construction)
+                    const uint32_t noise_stream = mix32(noise_base + (uint32_t)sel * 0x9E3779B9u);
+                    dirichlet_noise<RS>(rootrm, lane, noise_stream, gconst, (float)E.noise_scale, nz);
+                    // (1 - eps) * P, mcts.py:130: the same float32 product every select, so it
+                    // is formed once per launch (rkp) and only the noise is added here
+#pragma unroll
+                    for (int s = 0; s < RS; ++s) Pn[s] = rkp[s] + nz[s];
+                } else {
+                    const double *row = E.noise + ((size_t)g * E.n_select + sel) * E.noise_stride;
+#pragma unroll
+                    for (int s = 0; s < RS; ++s)
+                        if (lane_bit(rootrm[s]))
+                            Pn[s] = (float)((double)(keep32 * Pn[s]) + E.noise_scale * row[64 * s + lane]);
+                }
+            }
+            const float sq = sqrt_of(sq_tab, sumn);
+            const int best_idx = score_argmax(rs_tag, rst, Pn, rootrm, sq);
+            const int bl = best_idx & 63, bsl = best_idx >> 6;
+#pragma unroll
+            for (int s = 0; s < RS; ++s) {
+                const int c_ = __builtin_amdgcn_readlane(rcell[s], bl);
+                const int l_ = __builtin_amdgcn_readlane(__float_as_int(rst[s].w), bl);
+                const float n_ = readlane_f(rst[s].x, bl);
+                if (s == bsl) { pk_cell = c_; pk_link = l_; pk_nv = n_; }
+            }
+            pk_rank = best_idx;
+            T_MARK(0)
+            c_depth += 1;
+            c_kint += (uint32_t)k_root;
+        };
+        auto root_pick_any = [&](int sel) __attribute__((always_inline)) {
+            if (SLOTS >= 3 && k_root > 128) root_pick(sel, std::integral_constant<int, SLOTS>{});
+            else if (k_root > 64) root_pick(sel, std::integral_constant<int, (SLOTS < 2 ? SLOTS : 2)>{});
+            else root_pick(sel, std::integral_constant<int, 1>{});
+        };
+
+        root_pick_any(select_count);
         for (int i = 0; i < bs; ++i) {
             // snapshot/restore (search_tree.py:150-154): the descent only tracks which cells are
             // occupied (`all`), scalar bit-ors; the win test runs once, at a new leaf (interior
@@ -808,192 +920,109 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
             uint64_t all[SLOTS];
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) all[s] = rootall[s];
-            int mover = root.color;                           // colour placing the next stone
-            int link = root_link;
-            int depth = 0, node = root_id, child_link = 0, cell0 = 0, cellL = 0;
+            // ---- the root step of this descent, chosen by root_pick (search_tree.py:306-308) ----
+            const int cell0 = pk_rank;                        // (the root child's rank: rst is by rank)
+            int cellL = pk_cell;
+            int link = root_link, node = root_link + pk_rank, child_link = pk_link, depth = 1;
+            int mover = 3 - root.color;                       // colour placing the next stone
             float cur_nv = 0.0f;               // num_visits (incl. virtual) of the node being scored
-            float cnv = 0.f, ctv = 0.f;
+            float cnv = pk_nv, ctv = 0.f;
             float sq_next_pend = 0.0f;
-            // one level of the descent; the root level is its own instantiation (children in
-            // registers, noise, loop-invariant masks), deeper levels are the loop below
-            // RS = register slots the level's children occupy: ceil(k_root / 64) at the root (rank
-            // layout), SLOTS below it (lane = board cell)
-            auto level = [&](auto root_tag, auto rs_tag) __attribute__((always_inline)) {
-                constexpr bool at_root = decltype(root_tag)::value;
-                constexpr int RS = decltype(rs_tag)::value;
+            {
+                const uint64_t bit = 1ull << (pk_cell & 63);
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s)
+                    if (s == (pk_cell >> 6)) all[s] |= bit;
+            }
+            if (lane == 0) L.path[i * pstride] = node | (pk_cell << 24);
+            // its virtual loss (mcts.py:68) goes on at once: the next root level needs nothing else
+            root_child_add(cell0, 1.0f, 1.0f);
+            T_MARK(2)
+
+            // ---- levels below the root: lane = board cell, children from HBM ---------------------
+            float4 pst[SLOTS];                  // the requested child block
+            int prk[SLOTS];
+            bool pshort = false;
+            auto masks_of_all = [&]() __attribute__((always_inline)) -> Masks<SLOTS> {
                 Masks<SLOTS> mk;
-                if (at_root) {
+                int k = 0;
 #pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) { mk.m[s] = rootrm[s]; mk.base[s] = 64 * s; }
-                    mk.k = k_root;
-                } else {
-                    int k = 0;
-#pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) {
-                        mk.m[s] = ~all[s];
-                        mk.base[s] = k;
-                        k += popc64(mk.m[s]);
-                    }
-                    mk.k = k;
+                for (int s = 0; s < SLOTS; ++s) {
+                    mk.m[s] = ~all[s];
+                    mk.base[s] = k;
+                    k += popc64(mk.m[s]);
                 }
+                mk.k = k;
+                return mk;
+            };
+            auto deeper_issue = [&]() __attribute__((always_inline)) {
+                link = child_link;
+                cur_nv = cnv;
+                // sqrt(visits - 1) of this node: requested here, consumed after the children arrive
+                const int sn = (int)cur_nv - 1;
+                sq_next_pend = c_sqrt[sn < 0 ? 0 : (sn < AZX_SQRT_TAB ? sn : AZX_SQRT_TAB - 1)];
+                // A node visited once (its own expansion) has only unvisited children: no load
+                pshort = cur_nv == 1.0f;
+                if (!pshort) {
+                    const Masks<SLOTS> mk = masks_of_all();
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) prk[s] = mk.base[s] + rank_below(mk.m[s]);
+                    // every lane loads -- occupied cells re-read child 0 and are masked out of the
+                    // argmax below -- so there is no divergent region around the loads and the
+                    // slots' requests are in flight together (one HBM round trip per level)
+                    const float4 *cblk = reinterpret_cast<const float4 *>(arena + link);
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) pst[s] = cblk[lane_bit(mk.m[s]) ? prk[s] : 0];
+                }
+            };
+            auto deeper_finish = [&]() __attribute__((always_inline)) {
+                const Masks<SLOTS> mk = masks_of_all();
                 int best_cell = 0x7fffffff, child_rank = 0;
                 cnv = 0.f;
                 ctv = 0.f;
-                if (!at_root && cur_nv == 1.0f) {
-                    // A node visited once (its own expansion) has only unvisited children
-                    // (sum of their visits == its visits - 1 == 0): every score is -0 + 0, so
-                    // np.argmax takes child 0, an unevaluated leaf.  No load, no scoring.
+                if (pshort) {
+                    // (sum of the children's visits == its visits - 1 == 0): every score is -0 + 0, so
+                    // np.argmax takes child 0, an unevaluated leaf.  No scoring.
 #pragma unroll
                     for (int s = SLOTS - 1; s >= 0; --s)
                         if (mk.m[s]) best_cell = s * 64 + (int)__ffsll((long long)mk.m[s]) - 1;
                     child_link = AZX_LINK_UNEVAL;
                 } else {
-                    // sqrt(sum of the children's visits), mcts.py:132.  The sum is an integer known
-                    // without adding anything up: root_sumn at the root, and below it every
-                    // evaluated node has been visited once more than its children together (its
-                    // own expansion), virtual losses included since they mark node and child alike.
-                    const int sumn = at_root ? root_sumn : (int)cur_nv - 1;
-                    // Below the root the table entry was requested when the level above chose this
-                    // node (sq_next_pend) and is consumed after the children have been requested
-                    // (late_vgpr below), so the scalar load rides under the HBM one.
-                    float sq_tab = sq_next_pend;
-                    if (at_root) {
-                        // the root's sum only creeps upward (by one per descent, by the new visits per
-                        // batch): lane j holds the table entry sq_base + j, reloaded with one vector
-                        // load when the sum leaves the 64-entry window, read with v_readlane
-                        if ((unsigned)(sumn - sq_base) >= 64u) {
-                            sq_base = sumn;
-                            const int ix = sumn + lane;
-                            sq_reg = c_sqrt[ix < AZX_SQRT_TAB ? ix : AZX_SQRT_TAB - 1];
-                            __builtin_amdgcn_s_waitcnt(0x0F70);   // waited for here, not at every use
-                            asm volatile("" : "+v"(sq_reg));
-                        }
-                        sq_tab = readlane_f(sq_reg, sumn - sq_base);
+                    // sqrt(sum of the children's visits), mcts.py:132: every evaluated node has been
+                    // visited once more than its children together (its own expansion), virtual
+                    // losses included since they mark node and child alike.
+                    const int sumn = (int)cur_nv - 1;
+                    // newer (num_visits, total_value) of cached children override HBM
+                    uint64_t pm = __ballot(lane < n_c && c_id >= link && c_id < link + mk.k);
+                    while (pm) {
+                        const int j = (int)__ffsll((long long)pm) - 1;
+                        pm &= pm - 1;
+                        const int r = __builtin_amdgcn_readlane(c_id, j) - link;
+                        const float pnv = readlane_f(c_nv, j), ptv = readlane_f(c_tv, j);
+#pragma unroll
+                        for (int s = 0; s < SLOTS; ++s)
+                            if (lane_bit(mk.m[s]) && prk[s] == r) { pst[s].x = pnv; pst[s].y = ptv; }
                     }
-                    // ---- children statistics ------------------------------------------------
-                    float4 st[SLOTS];
-                    int rk[SLOTS];
-                    if (at_root) {
-#pragma unroll
-                        for (int s = 0; s < SLOTS; ++s) { st[s] = rst[s]; rk[s] = 64 * s + lane; }
-                    } else {
-#pragma unroll
-                        for (int s = 0; s < SLOTS; ++s) rk[s] = mk.base[s] + rank_below(mk.m[s]);
-                        // every lane loads -- occupied cells re-read child 0 and are masked out of the
-                        // argmax below -- so there is no divergent region around the loads and the
-                        // slots' requests are in flight together (one HBM round trip per level)
-                        const float4 *cblk = reinterpret_cast<const float4 *>(arena + link);
-#pragma unroll
-                        for (int s = 0; s < SLOTS; ++s) st[s] = cblk[lane_bit(mk.m[s]) ? rk[s] : 0];
-                        // newer (num_visits, total_value) of cached children override HBM
-                        uint64_t pm = __ballot(lane < n_c && c_id >= link && c_id < link + mk.k);
-                        while (pm) {
-                            const int j = (int)__ffsll((long long)pm) - 1;
-                            pm &= pm - 1;
-                            const int r = __builtin_amdgcn_readlane(c_id, j) - link;
-                            const float pnv = readlane_f(c_nv, j), ptv = readlane_f(c_tv, j);
-#pragma unroll
-                            for (int s = 0; s < SLOTS; ++s)
-                                if (lane_bit(mk.m[s]) && rk[s] == r) { st[s].x = pnv; st[s].y = ptv; }
-                        }
-                    }
-                    // ---- Dirichlet noise at the root only (mcts.py:126-131, :114) ----------
-                    float nz[SLOTS] = {};
-                    const bool noisy = at_root && E.noise_scale != 0.0;
-                    if (noisy && (FAST || E.device_noise)) {
-                        // one stream word per (game, move, select): a Weyl sequence from the per-move
-                        // base through one mixer (splitmix construction)
-                        const uint32_t noise_stream = mix32(noise_base + (uint32_t)select_count * 0x9E3779B9u);
-                        dirichlet_noise<RS>(mk.m, lane, noise_stream, gconst, (float)E.noise_scale, nz);
-                    }
-                    // ---- score_actions (mcts.py:119-136), op by op in float32 --------------
-                    // branch-free: every lane computes, non-legal lanes are masked at the end
                     float Pn[SLOTS];
 #pragma unroll
-                    for (int s = 0; s < RS; ++s) Pn[s] = st[s].z;
-                    if (noisy) {
-                        if (FAST || E.device_noise) {
-                            // (1 - eps) * P, mcts.py:130: the same float32 product every select, so it
-                            // is formed once per launch (rkp) and only the noise is added here
-#pragma unroll
-                            for (int s = 0; s < RS; ++s) Pn[s] = rkp[s] + nz[s];
-                        } else {
-                            const double *row = E.noise +
-                                ((size_t)g * E.n_select + select_count) * E.noise_stride;
-#pragma unroll
-                            for (int s = 0; s < RS; ++s)
-                                if (lane_bit(mk.m[s]))
-                                    Pn[s] = (float)((double)(keep32 * Pn[s]) + E.noise_scale * row[rk[s]]);
-                        }
-                    }
-                    float sq = late_vgpr(sq_tab);
-                    if (sumn >= AZX_SQRT_TAB) {                // beyond the table (rare): a real branch
-                        asm volatile("");                      // (the compiler would otherwise run the
-                        sq = sqrtf((float)sumn);               // 18-instruction sqrtf every time and select)
-                    }
-                    uint32_t key[SLOTS], lkey = 0u;
-                    auto score_slots = [&](auto exact_tag) {
-                        constexpr bool kIeee = decltype(exact_tag)::value;
-#pragma unroll
-                        for (int s = 0; s < RS; s += 2) {
-                            const int s1 = s + 1 < RS ? s + 1 : s;
-                            const f2 nvj = {st[s].x, st[s1].x};
-                            const f2 tvj = {st[s].y, st[s1].y};
-                            const f2 P = {Pn[s], Pn[s1]};
-                            const f2 sq2 = {sq, sq}, one = {1.0f, 1.0f}, zero = {0.0f, 0.0f}, c2 = {c32, c32};
-                            const f2 dg = one + nvj;
-                            const f2 gap = kIeee ? div2_ieee(sq2, dg) : div2_unscaled(sq2, dg);   // mcts.py:132
-                            const f2 U = (c2 * P) * gap;                                       // mcts.py:133
-                            f2 dq;                                                             // clip(min=1)
-                            dq.x = __builtin_amdgcn_fmed3f(nvj.x, 1.0f, 3.0e38f);
-                            dq.y = __builtin_amdgcn_fmed3f(nvj.y, 1.0f, 3.0e38f);
-                            const f2 W = -tvj;                                                 // search_tree.py:203
-                            const f2 Q = kIeee ? div2_ieee(W, dq) : div2_unscaled(W, dq);     // mcts.py:134
-                            const f2 score = (Q + U) + zero;                    // mcts.py:135; -0.0 -> +0.0
-                            // order-preserving map float -> u32 (np.argmax compares values; equal
-                            // floats <=> equal keys once -0.0 is folded into +0.0)
-                            key[s] = lane_bit(mk.m[s]) ? f32_key(score.x) : 0u;
-                            lkey = key[s] > lkey ? key[s] : lkey;
-                            if (s1 != s) {
-                                key[s1] = lane_bit(mk.m[s1]) ? f32_key(score.y) : 0u;
-                                lkey = key[s1] > lkey ? key[s1] : lkey;
-                            }
-                        }
-                    };
-                    if (slow_div) score_slots(std::true_type{});
-                    else score_slots(std::false_type{});
-                    // np.argmax: highest score, lowest index on ties (mcts.py:112): wave max of the
-                    // keys, then the lowest lane-slot holding it (ranks and cells ascend together)
-                    int best_idx = 0x7fffffff;
-                    {
-                        const uint32_t wmax = wave_max_u32(lkey);
-#pragma unroll
-                        for (int s = RS - 1; s >= 0; --s) {
-                            const uint64_t eq = __ballot(key[s] == wmax) & mk.m[s];
-                            if (eq) best_idx = s * 64 + (int)__ffsll((long long)eq) - 1;
-                        }
-                    }
+                    for (int s = 0; s < SLOTS; ++s) Pn[s] = pst[s].z;
+                    const float sq = sqrt_of(sq_next_pend, sumn);
+                    const int best_idx = score_argmax(std::integral_constant<int, SLOTS>{}, pst, Pn, mk.m, sq);
                     const int bl = best_idx & 63, bsl = best_idx >> 6;
 #pragma unroll
-                    for (int s = 0; s < RS; ++s) {
-                        // at the root the lane-slot index is the child rank and the cell is looked up;
-                        // below it the index is the cell and the rank is looked up
-                        const int r_ = __builtin_amdgcn_readlane(at_root ? rcell[s] : rk[s], bl);
-                        const int l_ = __builtin_amdgcn_readlane(__float_as_int(st[s].w), bl);
-                        const float n_ = readlane_f(st[s].x, bl), t_ = readlane_f(st[s].y, bl);
-                        if (s == bsl) {
-                            child_rank = at_root ? best_idx : r_;
-                            best_cell = at_root ? r_ : best_idx;
-                            child_link = l_; cnv = n_; ctv = t_;
-                        }
+                    for (int s = 0; s < SLOTS; ++s) {
+                        const int r_ = __builtin_amdgcn_readlane(prk[s], bl);
+                        const int l_ = __builtin_amdgcn_readlane(__float_as_int(pst[s].w), bl);
+                        const float n_ = readlane_f(pst[s].x, bl), t_ = readlane_f(pst[s].y, bl);
+                        if (s == bsl) { child_rank = r_; child_link = l_; cnv = n_; ctv = t_; }
                     }
+                    best_cell = best_idx;
                 }
-                T_MARK(depth == 0 ? 0 : 1)
+                T_MARK(1)
                 c_depth += 1;
                 c_kint += (uint32_t)mk.k;
                 node = link + child_rank;
-                if (at_root) cell0 = child_rank;               // (the root child's rank: rst is by rank)
-                else (void)cache_find(node, true, cnv, ctv);   // deeper path nodes enter the cache
+                (void)cache_find(node, true, cnv, ctv);       // deeper path nodes enter the cache
                 cellL = best_cell;
                 if (lane == 0) L.path[i * pstride + depth] = node | (best_cell << 24);
                 {                                              // search_tree.py:306-308, stones only
@@ -1005,18 +1034,24 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                 }
                 T_MARK(2)
                 depth += 1;
-                if (child_link >= 0) {                         // sqrt(visits - 1) for the level below
-                    const int sn = (int)cnv - 1;
-                    sq_next_pend = c_sqrt[sn < 0 ? 0 : (sn < AZX_SQRT_TAB ? sn : AZX_SQRT_TAB - 1)];
-                }
             };
-            if (SLOTS >= 3 && k_root > 128) level(std::true_type{}, std::integral_constant<int, SLOTS>{});
-            else if (k_root > 64) level(std::true_type{}, std::integral_constant<int, 2>{});
-            else level(std::true_type{}, std::integral_constant<int, 1>{});
-            while (child_link >= 0) {                          // < 0: a leaf, unevaluated or terminal
-                link = child_link;
-                cur_nv = cnv;
-                level(std::false_type{}, std::integral_constant<int, SLOTS>{});
+            const bool go_deeper = child_link >= 0;            // < 0: a leaf, unevaluated or terminal
+            if (go_deeper) deeper_issue();
+            __builtin_amdgcn_sched_barrier(0);                 // the requests leave before the next root level
+            if (i + 1 < bs) root_pick_any(select_count + 1);   // in the shadow of that load
+            if (go_deeper) {
+                if (!pshort) {
+                    // the child block is first touched HERE (the compiler otherwise copies parts of it
+                    // into other registers right behind the loads and waits for them there)
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s)
+                        asm volatile("" : "+v"(pst[s].x), "+v"(pst[s].y), "+v"(pst[s].z), "+v"(pst[s].w));
+                }
+                deeper_finish();
+                while (child_link >= 0) {
+                    deeper_issue();
+                    deeper_finish();
+                }
             }
             select_count += 1;
             c_selects += 1;
@@ -1083,7 +1118,8 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
             }
             lds_sync();
             // ... and apply the virtual loss to its path (mcts.py:68, :79-92)
-            path_apply(L.path + i * pstride, depth, cell0, 1.0f, 1.0f, false, false);
+            // (the root child's share went on right after the root step)
+            path_apply(L.path + i * pstride, depth, -1, 1.0f, 1.0f, false, false);
             T_MARK(3)
         }
         int nu = 0;
