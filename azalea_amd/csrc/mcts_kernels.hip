@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
     int c_id = -1, n_c = 0;            // node cache: entry j lives in lane j
     float c_nv = 0.0f, c_tv = 0.0f;
     // per-leaf metadata of the batch in flight: leaf i lives in lane i (v_readlane to fetch)
-    int m_node = -1, m_len = 0, m_link = 0, m_tm = 0, m_cells = 0, m_uidx = 0, m_k = 0;
+    int m_node = -1, m_len = 0, m_link = 0, m_tm = 0, m_cells = 0, m_uidx = 0, m_k = 0, m_slot1 = -1;
     float m_val = 0.0f;
     uint64_t m_mask[SLOTS];
 #pragma unroll
@@ -544,9 +544,11 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
         return res;
     };
 
+    bool memo_ok = true;               // no flush since the batch began: remembered entry indices hold
     auto cache_flush = [&]() {
         if (lane < n_c) *reinterpret_cast<float2 *>(arena + c_id) = make_float2(c_nv, c_tv);
         n_c = 0;
+        memo_ok = false;
         wave_mem_sync();
     };
     // entry index of node `id`; on a miss it is inserted with (nv0, tv0) when `known`
@@ -574,7 +576,9 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
     // (num_visits += dv, total_value += +-amount) along one recorded path.  pth[d] is the node at
     // depth d+1, cell0 the RANK of the path's root child; the value added at the LEAF is `amount`, with `alternate` its sign flips at
     // every step towards the root (mcts.py:252); `with_root` includes the root (mcts.py:253).
-    auto path_apply = [&](const int32_t *pth, int len, int cell0, float dv, float amount,
+    // slot1: cache entry of the depth-2 node as found during the descent (-1 = unknown): with it a
+    // path of length <= 2 -- most of them -- is updated without reading the path or searching the cache
+    auto path_apply = [&](const int32_t *pth, int len, int cell0, int slot1, float dv, float amount,
                           bool alternate, bool with_root) {
         if (with_root) {
             root_nv += dv;
@@ -583,7 +587,8 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
         if (len >= 1 && cell0 >= 0) root_child_add(cell0, dv, (alternate && ((len - 1) & 1)) ? -amount : amount);
         for (int d = 1; d < len; ++d) {
             const float a = (alternate && ((len - 1 - d) & 1)) ? -amount : amount;
-            const int slot = cache_find(pth[d] & 0xffffff, false, 0.f, 0.f);
+            const int slot = (d == 1 && slot1 >= 0 && memo_ok) ? slot1
+                                                               : cache_find(pth[d] & 0xffffff, false, 0.f, 0.f);
             if (lane == slot) { c_nv += dv; c_tv += a; }
         }
     };
@@ -765,7 +770,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                         terminal ? nullptr : E.ev_prior + (size_t)ev * AZX_CELL_STRIDE, 0.0f))
                 break;
             if (!pending_root) {
-                path_apply(L.path, len, cells & 0xffff, 1.0f, v, true, true);   // mcts.py:247-255
+                path_apply(L.path, len, cells & 0xffff, -1, 1.0f, v, true, true);   // mcts.py:247-255
                 if (lane == i) m_val = v;
             }
             lds_sync();
@@ -913,6 +918,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
         };
 
         root_pick_any(select_count);
+        memo_ok = true;
         for (int i = 0; i < bs; ++i) {
             // snapshot/restore (search_tree.py:150-154): the descent only tracks which cells are
             // occupied (`all`), scalar bit-ors; the win test runs once, at a new leaf (interior
@@ -928,6 +934,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
             float cur_nv = 0.0f;               // num_visits (incl. virtual) of the node being scored
             float cnv = pk_nv, ctv = 0.f;
             float sq_next_pend = 0.0f;
+            int slot1 = -1;                                    // cache entry of the depth-2 node, once known
             {
                 const uint64_t bit = 1ull << (pk_cell & 63);
 #pragma unroll
@@ -1022,7 +1029,10 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                 c_depth += 1;
                 c_kint += (uint32_t)mk.k;
                 node = link + child_rank;
-                (void)cache_find(node, true, cnv, ctv);       // deeper path nodes enter the cache
+                {                                              // deeper path nodes enter the cache
+                    const int ce = cache_find(node, true, cnv, ctv);
+                    if (depth == 1) slot1 = ce;
+                }
                 cellL = best_cell;
                 if (lane == 0) L.path[i * pstride + depth] = node | (best_cell << 24);
                 {                                              // search_tree.py:306-308, stones only
@@ -1106,6 +1116,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                 m_link = child_link;
                 m_tm = (winner != 0 ? 1 : 0) | (mover << 1);
                 m_cells = cell0 | (cellL << 16);
+                m_slot1 = slot1;
                 if (inline_eval) {                             // one prior for all children: only their number
                     int kl = 0;
 #pragma unroll
@@ -1119,7 +1130,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
             lds_sync();
             // ... and apply the virtual loss to its path (mcts.py:68, :79-92)
             // (the root child's share went on right after the root step)
-            path_apply(L.path + i * pstride, depth, -1, 1.0f, 1.0f, false, false);
+            path_apply(L.path + i * pstride, depth, -1, slot1, 1.0f, 1.0f, false, false);
             T_MARK(3)
         }
         int nu = 0;
@@ -1157,8 +1168,10 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                 };
                 root_child_add(cells & 0xffff, dvn, tvd(0));
                 const int32_t *pth = L.path + i * pstride;
+                const int s1 = rl(m_slot1, i);
                 for (int d = 1; d < len; ++d) {
-                    const int slot = cache_find(pth[d] & 0xffffff, false, 0.f, 0.f);
+                    const int slot = (d == 1 && s1 >= 0 && memo_ok) ? s1
+                                                                    : cache_find(pth[d] & 0xffffff, false, 0.f, 0.f);
                     if (lane == slot) { c_nv += dvn; c_tv += tvd(d); }
                 }
                 T_MARK(5)
@@ -1171,7 +1184,8 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
         }
         // undo the virtual losses in list order (mcts.py:72)
         for (int i = 0; i < bs; ++i)
-            path_apply(L.path + i * pstride, rl(m_len, i), rl(m_cells, i) & 0xffff, -1.0f, -1.0f, false, false);
+            path_apply(L.path + i * pstride, rl(m_len, i), rl(m_cells, i) & 0xffff, rl(m_slot1, i), -1.0f, -1.0f,
+                       false, false);
         // deduplicate_leaves: keep first occurrence by node id (mcts.py:139-152)
         for (int i = 0; i < bs; ++i) {
             const int id = rl(m_node, i);
@@ -1204,7 +1218,7 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
                 if (!expand(rl(m_node, i), lf_len, lf_cells, rl(m_link, i), terminal, nullptr, k, nullptr,
                             (!terminal && k) ? inline_prior(k, lf_len) : 0.0f))
                     break;
-                path_apply(L.path + i * pstride, lf_len, lf_cells & 0xffff, 1.0f, v, true, true);
+                path_apply(L.path + i * pstride, lf_len, lf_cells & 0xffff, rl(m_slot1, i), 1.0f, v, true, true);
                 if (lane == u) m_val = v;
             }
             wave_mem_sync();   // the children written by rank above are read by other lanes from here on
