@@ -207,13 +207,13 @@ def main():
             }
             # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
             # (tools/prof_pmc.sh: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction)
-            tpath = os.path.join(ROOT, "profiles", "r1l_tree_pmc_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r1m_tree_pmc_traffic.json")
             default_cmd = (args.games, args.board, args.sims, args.batch, args.steps, args.warmup,
                            args.noise_scale) == (4096, 11, 400, 10, 130, 20, 0.25)
             if default_cmd and os.path.exists(tpath):
                 t = json.load(open(tpath))
                 line["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
-                line["roofline"]["traffic_source"] = "profiles/r1l_tree_pmc_traffic.json (PMC, same command)"
+                line["roofline"]["traffic_source"] = "profiles/r1m_tree_pmc_traffic.json (PMC, same command)"
         else:
             # dominant kernels: the residual tower + heads, one launch pair per leaf batch, timed with
             # HIP events on the engine stream.  ALGORITHMIC flops (107 851 784 per
