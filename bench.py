@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--chans", type=int, default=64)
     ap.add_argument("--seed", type=int, default=0xBAD5EED5)
     ap.add_argument("--noise-scale", type=float, default=0.25)
+    ap.add_argument("--nodes-per-game", type=int, default=0,
+                    help="tree arena capacity per game (0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.steps is None:
@@ -126,6 +128,7 @@ def main():
                    search_batch_size=args.batch, exploration_coef=0.5, exploration_depth=15,
                    noise_alpha=0.03, noise_scale=args.noise_scale, temperature=1.0, evaluator=evaluator,
                    num_blocks=args.blocks, base_chans=args.chans, device=local_rank,
+                   nodes_per_game=args.nodes_per_game,
                    seed=args.seed + (rank << 40))
     net_state = None
     if args.workload == "resnet":
