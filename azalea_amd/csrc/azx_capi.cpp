@@ -163,7 +163,7 @@ extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
     A(d.leaf_mask, E * 4); A(d.path, E * pstride);
     A(d.ev_board, E * AZX_CELL_STRIDE); A(d.ev_src, E); A(d.ev_flip, E);
     A(d.ev_value, E); A(d.ev_prior, E * AZX_CELL_STRIDE); A(d.n_eval, 4);
-    A(d.counters, G * CTR_COUNT); A(d.q_count, 2); A(d.next_uid, 2); A(d.stat_sums, G * 8);
+    A(d.counters, G * CTR_COUNT); A(d.q_count, 2); A(d.stat_sums, G * 8);
     A(e->g_k, G); A(e->g_legal, G * d.ncells); A(e->g_nn, G);
     A(e->g_cv, G * d.ncells); A(e->g_cw, G * d.ncells); A(e->g_cp, G * d.ncells);
     A(e->g_rv, G); A(e->g_rw, G); A(e->g_sv, G);

@@ -114,7 +114,6 @@ struct DevEngine {
     float *q_reward;        // [Q]
     int64_t *q_uid;         // [Q]
     unsigned long long *q_count;   // [1] rows appended
-    unsigned long long *next_uid;  // [1] (unused since uids are slot + n_games * generation)
     double *stat_sums;      // [G][8] per game: search_value, root_width, action_logprob, reward_last
 };
 
