@@ -41,7 +41,8 @@ struct alignas(64) TreeHdr {
     int32_t select_count;  // select_leaf calls so far in this search (noise row index)
     float   search_value;  // mcts.py:287 accumulator (float32)
     int32_t slow_div;      // a backed-up value was outside the range the unscaled divide is exact for
-    int32_t pad[4];
+    int32_t defer_compact; // play mode: compact the arena (keep the subtree under root_id) before the next search
+    int32_t pad[3];
 };
 
 struct alignas(64) GameHdr {

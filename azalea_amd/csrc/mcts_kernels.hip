@@ -341,6 +341,68 @@ __device__ __forceinline__ float sload_f32(const float *p) {
 // hand-off, host-noise and slow-divide paths disappear and with them the scalar registers that held
 // their pointers (the generic kernel spills ~40 SGPRs inside the select loop).  Results are
 // bit-identical to the generic instantiation (test_fast_kernel_matches_generic).
+// ============================================================================================
+// Arena compaction: Cheney copy of the subtree under `child` into the other arena, level by level
+// (children of a level-L node: kL of them; the kept subtree keeps the reference's breadth-first
+// child order, search_tree.py:254-274).  `sh` = 64 ints of LDS.
+// ============================================================================================
+__device__ __forceinline__ void compact_tree(const DevEngine &E, int g, TreeHdr *th, int child, int k_child,
+                                             int lane, int *sh_old) {
+    const Node *src = E.arena[th->arena] + (size_t)g * E.cap;
+    Node *dst = E.arena[th->arena ^ 1] + (size_t)g * E.cap;
+    if (lane == 0) dst[0] = src[child];
+    wave_mem_sync();
+    int n_new = 1, lvl_start = 0, lvl_end = 1, kL = k_child;
+    while (lvl_start < lvl_end && kL > 0) {
+        for (int i0 = lvl_start; i0 < lvl_end; i0 += 64) {
+            const int i = i0 + lane;
+            int oldfc = -1;
+            if (i < lvl_end) oldfc = dst[i].link;
+            const bool has = oldfc >= 0;
+            const uint64_t hm = __ballot(has);
+            const int newfc = n_new + kL * rank_below(hm);
+            if (has) dst[i].link = newfc;
+            // the child blocks of this group's parents land back to back at n_new: one flat copy over
+            // (parent, child) pairs, four 16-byte loads in flight per lane
+            const int np = popc64(hm);
+            if (has) sh_old[rank_below(hm)] = oldfc;
+            lds_sync();
+            const int total = kL * np;
+            const float inv_k = 1.0f / (float)kL;
+            for (int t0 = 0; t0 < total; t0 += 256) {
+                Node v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u * 64 + lane;
+                    if (t < total) {
+                        const int pp = (int)(((float)t + 0.5f) * inv_k);   // t / kL (exact: t < 2^14)
+                        v[u] = src[sh_old[pp] + (t - pp * kL)];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u * 64 + lane;
+                    if (t < total) dst[n_new + t] = v[u];
+                }
+            }
+            lds_sync();
+            n_new += total;
+            wave_mem_sync();
+        }
+        lvl_start = lvl_end;
+        lvl_end = n_new;
+        kL -= 1;
+    }
+    if (lane == 0) {
+        th->arena ^= 1;
+        th->num_nodes = n_new;
+        th->root_id = 0;
+        th->root_k = k_child;
+        th->k0 = k_child;
+        th->defer_compact = 0;
+    }
+}
+
 #ifdef AZX_WPE
 #define AZX_MCTS_ATTR __attribute__((amdgpu_waves_per_eu(AZX_WPE, AZX_WPE)))
 #else
@@ -361,6 +423,13 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
 #endif
     TreeHdr *th = E.thdr + g;
     const Lds L = carve_lds(smem_raw, ncells, bs);
+    if ((mode & MODE_BEGIN) && th->defer_compact) {
+        // the arena compaction k_advance left to this launch (play mode): this game's copy runs
+        // beside the other games' searches
+        compact_tree(E, g, th, th->root_id, th->root_k, lane, reinterpret_cast<int *>(L.path));
+        __builtin_amdgcn_s_waitcnt(0);   // the header fields written by lane 0 are re-read below
+        wave_mem_sync();
+    }
 
     int num_nodes = th->num_nodes;
     const int root_id = th->root_id;
@@ -1313,6 +1382,7 @@ __device__ __forceinline__ void tree_reset(const DevEngine &E, int g, TreeHdr *t
         th->select_count = 0;
         th->search_value = 0.0f;
         th->slow_div = 0;
+        th->defer_compact = 0;
     }
 }
 
@@ -1361,6 +1431,7 @@ __global__ __launch_bounds__(64) void k_reset(DevEngine E, const int32_t *slots,
 // ============================================================================================
 template <int SLOTS>
 __global__ __launch_bounds__(64) void k_advance(DevEngine E, const int32_t *move_ids, int play_mode) {
+    __shared__ int sh_old[64];         // compaction: old first-child ids of a group's parents, by rank
     const int lane = threadIdx.x;
     const int g = blockIdx.x;
     GameHdr *gh = E.ghdr + g;
@@ -1414,41 +1485,13 @@ __global__ __launch_bounds__(64) void k_advance(DevEngine E, const int32_t *move
             // root evaluation expand at most one node with at most k children).
             if (lane == 0) { th->root_id = child; th->root_k = nmk.k; }
         } else {
-            // Cheney copy of the kept subtree, level by level (children of a level-L node: kL)
-            Node *dst = E.arena[th->arena ^ 1] + (size_t)g * E.cap;
-            if (lane == 0) dst[0] = src[child];
-            wave_mem_sync();
-            int n_new = 1, lvl_start = 0, lvl_end = 1, kL = nmk.k;
-            while (lvl_start < lvl_end && kL > 0) {
-                for (int i0 = lvl_start; i0 < lvl_end; i0 += 64) {
-                    const int i = i0 + lane;
-                    int oldfc = -1;
-                    if (i < lvl_end) oldfc = dst[i].link;
-                    const bool has = oldfc >= 0;
-                    const uint64_t hm = __ballot(has);
-                    const int newfc = n_new + kL * rank_below(hm);
-                    if (has) dst[i].link = newfc;
-                    uint64_t rem = hm;
-                    while (rem) {
-                        const int l = (int)__ffsll((long long)rem) - 1;
-                        rem &= rem - 1;
-                        const int o = __builtin_amdgcn_readlane(oldfc, l);
-                        const int nf = __builtin_amdgcn_readlane(newfc, l);
-                        for (int j = lane; j < kL; j += 64) dst[nf + j] = src[o + j];
-                    }
-                    n_new += kL * popc64(hm);
-                    wave_mem_sync();
-                }
-                lvl_start = lvl_end;
-                lvl_end = n_new;
-                kL -= 1;
-            }
-            if (lane == 0) {
-                th->arena ^= 1;
-                th->num_nodes = n_new;
-                th->root_id = 0;
-                th->root_k = nmk.k;
-                th->k0 = nmk.k;
+            if (play_mode) {
+                // play mode: re-root in place now and leave the copy to the next search launch, where
+                // it runs beside the other games' searches instead of holding up this whole launch
+                // (every launch has some games compacting; it was 70 % of k_advance's time)
+                if (lane == 0) { th->root_id = child; th->root_k = nmk.k; th->defer_compact = 1; }
+            } else {
+                compact_tree(E, g, th, child, nmk.k, lane, sh_old);
             }
         }
         if (lane == 0) {
@@ -1477,21 +1520,24 @@ __global__ __launch_bounds__(64) void k_advance(DevEngine E, const int32_t *move
             restart = false;
         } else {
             // the game's rows are contiguous at the source, and at the destination unless the ring
-            // wraps inside them: bulk 16-byte copies, four per lane in flight
+            // wraps inside them: bulk 16-byte copies, sixteen per lane in flight
             const size_t q0 = (size_t)(pos % (unsigned long long)E.q_cap);
             const int first = (int)min((unsigned long long)rows, (unsigned long long)E.q_cap - q0);   // rows before the wrap
             auto copy16 = [&](void *dst, const void *src, int n16) {
                 uint4 *d = reinterpret_cast<uint4 *>(dst);
                 const uint4 *sp = reinterpret_cast<const uint4 *>(src);
-                for (int i0 = 0; i0 < n16; i0 += 256) {
-                    uint4 v[4];
+                // sixteen 16-byte pieces in flight per lane: the launch lasts as long as its longest
+                // finished game takes to copy (one wave, ~100 KB), i.e. as many memory round trips
+                constexpr int U = 16;
+                for (int i0 = 0; i0 < n16; i0 += 64 * U) {
+                    uint4 v[U];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = i0 + u * 64 + lane;
-                        if (i < n16) v[u] = sp[i];
+                    for (int u = 0; u < U; ++u) {
+                        const int i = min(i0 + u * 64 + lane, n16 - 1);   // (the tail repeats the last piece)
+                        v[u] = sp[i];
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < U; ++u) {
                         const int i = i0 + u * 64 + lane;
                         if (i < n16) d[i] = v[u];
                     }
