@@ -74,6 +74,7 @@ struct azx_engine {
     // timing
     std::vector<hipEvent_t> ev_pool;
     std::vector<char> ev_tag;           // 0 = tree kernel, 1 = network (tower + heads)
+    std::vector<int> ev_weight;         // moves covered by the timed launch (k_play: several)
     size_t ev_used = 0;
     AzxNet *net = nullptr;
 };
@@ -286,6 +287,8 @@ static void time_begin(azx_engine *e, char tag = 0) {
     }
     if (e->ev_tag.size() < e->ev_pool.size() / 2) e->ev_tag.resize(e->ev_pool.size() / 2, 0);
     e->ev_tag[e->ev_used / 2] = tag;
+    if (e->ev_weight.size() < e->ev_pool.size() / 2) e->ev_weight.resize(e->ev_pool.size() / 2, 1);
+    e->ev_weight[e->ev_used / 2] = 1;
     (void)hipEventRecord(e->ev_pool[e->ev_used], e->stream);
 }
 static void time_end(azx_engine *e) {
@@ -298,7 +301,7 @@ static void time_collect(azx_engine *e, azx_play_stats *st) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e->ev_pool[i], e->ev_pool[i + 1]) == hipSuccess) {
             if (e->ev_tag[i / 2]) { st->net_seconds += ms * 1e-3; st->net_launches += 1; }
-            else { st->mcts_seconds += ms * 1e-3; st->mcts_launches += 1; }
+            else { st->mcts_seconds += ms * 1e-3; st->mcts_launches += e->ev_weight[i / 2]; }
         }
     }
     e->ev_used = 0;
@@ -779,7 +782,22 @@ extern "C" int azx_play_steps(azx_engine *e, int64_t plies, azx_play_stats *stat
     HIPCHECK(hipEventCreate(&t0));
     HIPCHECK(hipEventCreate(&t1));
     HIPCHECK(hipEventRecord(t0, e->stream));
-    for (int64_t p = 0; p < plies; ++p) TRY(enqueue_ply(e));
+    {
+        // the uniform-evaluator path plays the moves in persistent launches (k_play), at most
+        // PLAY_CHUNK moves each; its time is booked per move like the per-move launches'
+        const int PLAY_CHUNK = 256;
+        int64_t p = 0;
+        while (p < plies) {
+            const int n = (int)std::min<int64_t>(PLAY_CHUNK, plies - p);
+            time_begin(e);
+            const bool ok = azx_launch_play(e->d, e->num_batches, n, e->stream);
+            if (!ok) break;                 // (the begin event is simply overwritten by the next one)
+            time_end(e);
+            if (e->ev_used >= 2) e->ev_weight[e->ev_used / 2 - 1] = n;
+            p += n;
+        }
+        for (; p < plies; ++p) TRY(enqueue_ply(e));
+    }
     HIPCHECK(hipEventRecord(t1, e->stream));
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(e->stream));

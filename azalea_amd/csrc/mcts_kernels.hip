@@ -409,7 +409,7 @@ __device__ __forceinline__ void compact_tree(const DevEngine &E, int g, TreeHdr 
 #define AZX_MCTS_ATTR
 #endif
 template <int SLOTS, bool FAST>
-__global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode_arg, int num_batches) {
+__device__ __forceinline__ void mcts_body(const DevEngine &E, int mode_arg, int num_batches) {
     const int mode = FAST ? (MODE_BEGIN | MODE_INLINE) : mode_arg;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int lane = threadIdx.x;
@@ -1360,6 +1360,11 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode
     }
 }
 
+template <int SLOTS, bool FAST>
+__global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_mcts(DevEngine E, int mode_arg, int num_batches) {
+    mcts_body<SLOTS, FAST>(E, mode_arg, num_batches);
+}
+
 // ============================================================================================
 // reset + replay: HexGame.reset / step (hex.py:47-49, :172-179), SearchTree.reset
 // (search_tree.py:59-71).  One wavefront per listed slot.
@@ -1430,7 +1435,7 @@ __global__ __launch_bounds__(64) void k_reset(DevEngine E, const int32_t *slots,
 // In play mode a finished game is appended to the output queue and the slot restarts.
 // ============================================================================================
 template <int SLOTS>
-__global__ __launch_bounds__(64) void k_advance(DevEngine E, const int32_t *move_ids, int play_mode) {
+__device__ __forceinline__ void advance_body(const DevEngine &E, const int32_t *move_ids, int play_mode) {
     __shared__ int sh_old[64];         // compaction: old first-child ids of a group's parents, by rank
     const int lane = threadIdx.x;
     const int g = blockIdx.x;
@@ -1596,6 +1601,11 @@ __global__ __launch_bounds__(64) void k_advance(DevEngine E, const int32_t *move
 // root statistics: root.move_stats (search_tree.py:192-204) dense by child index
 // ============================================================================================
 template <int SLOTS>
+__global__ __launch_bounds__(64) void k_advance(DevEngine E, const int32_t *move_ids, int play_mode) {
+    advance_body<SLOTS>(E, move_ids, play_mode);
+}
+
+template <int SLOTS>
 __global__ __launch_bounds__(64) void k_gather_root(DevEngine E, int32_t *k_out, int32_t *legal,
                                                     float *cv, float *cw, float *cp, float *rv,
                                                     float *rw, int32_t *nn, float *sv) {
@@ -1639,7 +1649,7 @@ __global__ __launch_bounds__(64) void k_gather_root(DevEngine E, int32_t *k_out,
 // T>0: p ~ n^(1/T); T==0: uniform over the most-visited children.
 // ============================================================================================
 template <int SLOTS>
-__global__ __launch_bounds__(64) void k_choose(DevEngine E) {
+__device__ __forceinline__ void choose_body(const DevEngine &E) {
     const int lane = threadIdx.x;
     const int g = blockIdx.x;
     GameHdr *gh = E.ghdr + g;
@@ -1742,6 +1752,28 @@ __global__ __launch_bounds__(64) void k_choose(DevEngine E) {
 // ============================================================================================
 // rules only: replay move lists, reporting per-ply result / legal count / empties mask
 // ============================================================================================
+template <int SLOTS>
+__global__ __launch_bounds__(64) void k_choose(DevEngine E) {
+    choose_body<SLOTS>(E);
+}
+
+// Throughput mode with the inline uniform evaluator: `steps` whole moves of every game in ONE launch.
+// A wave owns its game from search to move draw to game step (and harvest / restart), and nothing
+// but the harvest queue's counter is shared between games, so there is no reason to line all games
+// up at three launch boundaries per move: each wave runs its own search -> choose -> advance loop,
+// and the harvest copies and arena compactions of some games overlap the searches of the others.
+template <int SLOTS>
+__global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_play(DevEngine E, int num_batches, int steps) {
+    for (int s = 0; s < steps; ++s) {
+        mcts_body<SLOTS, true>(E, MODE_BEGIN | MODE_INLINE, num_batches);
+        wave_mem_sync();
+        choose_body<SLOTS>(E);
+        wave_mem_sync();
+        advance_body<SLOTS>(E, nullptr, 1);
+        wave_mem_sync();
+    }
+}
+
 template <int SLOTS>
 __global__ __launch_bounds__(64) void k_hex_replay(int N, int n_games, const int32_t *moves,
                                                    const int32_t *length, int stride,
@@ -1922,6 +1954,19 @@ void azx_launch_mcts(const DevEngine &E, int mode, int num_batches, hipStream_t 
 #define CALL(S) hipLaunchKernelGGL((k_mcts<S, false>), dim3(E.G), dim3(64), lds, st, E, mode, num_batches)
     DISPATCH_SLOTS(E.slots, CALL);
 #undef CALL
+}
+
+// FAST conditions as in azx_launch_mcts; returns false (nothing launched) when they do not hold
+bool azx_launch_play(const DevEngine &E, int num_batches, int steps, hipStream_t st) {
+    const char *fg = getenv("AZX_MCTS_GENERIC");
+    const char *np = getenv("AZX_NO_PERSISTENT");
+    if ((fg && atoi(fg) != 0) || (np && atoi(np) != 0)) return false;
+    if (!(E.evaluator == AZX_EVAL_UNIFORM && E.prior_default && (E.noise_scale == 0.0 || E.device_noise))) return false;
+    const size_t lds = azx_mcts_lds_bytes(E.ncells, E.bs);
+#define CALL(S) hipLaunchKernelGGL((k_play<S>), dim3(E.G), dim3(64), lds, st, E, num_batches, steps)
+    DISPATCH_SLOTS(E.slots, CALL);
+#undef CALL
+    return true;
 }
 
 void azx_launch_reset(const DevEngine &E, const int32_t *slots, int n_slots, const int32_t *moves,

@@ -326,6 +326,37 @@ def test_fast_kernel_matches_generic(eng):
                 assert np.array_equal(x, y)
 
 
+def test_persistent_play_matches_per_move_launches(eng):
+    """azx_play_steps with the uniform evaluator runs whole moves in one persistent launch (k_play:
+    every wave loops search -> move draw -> game step on its own); three launches per move must
+    give the same games: boards, plies, finished-game counters and the trees of a following search,
+    over enough moves for games to finish, restart and compact their arenas."""
+    res = {}
+    for off in (1, 0):
+        os.environ["AZX_NO_PERSISTENT"] = str(off)
+        try:
+            E = eng.Engine(board_size=7, n_games=96, simulations=60, search_batch_size=10,
+                           exploration_coef=0.5, noise_alpha=0.03, noise_scale=0.25,
+                           exploration_depth=6, evaluator=eng.EVAL_UNIFORM, seed=5, nodes_per_game=9000)
+            st = E.play_steps(70)
+            gm = E.get_games()
+            E.search(noise_scale=0.25)
+            root = E.get_root()
+            res[off] = (gm["board"].copy(), gm["ply"].copy(), st["games"], st["plies"], st["selects"],
+                        st["positions"], bits(root["child_visits"]), root["num_nodes"].copy(),
+                        [canonical(E.tree_dump(g)) for g in range(0, 96, 7)])
+            E.close()
+        finally:
+            os.environ.pop("AZX_NO_PERSISTENT", None)
+    a, b = res[1], res[0]
+    assert a[2] > 96                      # games did finish and restart
+    for x, y in zip(a[:8], b[:8]):
+        assert np.array_equal(x, y)
+    for ta, tb in zip(a[8], b[8]):
+        for x, y in zip(ta, tb):
+            assert np.array_equal(x, y)
+
+
 def test_tree_full_sets_status(eng):
     E = eng.Engine(board_size=11, n_games=2, simulations=40, search_batch_size=10,
                    evaluator=eng.EVAL_UNIFORM, nodes_per_game=500)
