@@ -40,7 +40,8 @@ class PlayStats(C.Structure):
                 ("sum_root_width", C.c_double), ("sum_action_logprob", C.c_double),
                 ("sum_reward_last", C.c_double), ("seconds", C.c_double),
                 ("mcts_seconds", C.c_double), ("mcts_launches", C.c_int64),
-                ("net_seconds", C.c_double), ("net_launches", C.c_int64)]
+                ("net_seconds", C.c_double), ("net_launches", C.c_int64),
+                ("mcts_kernel_launches", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

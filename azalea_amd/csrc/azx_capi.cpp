@@ -301,7 +301,11 @@ static void time_collect(azx_engine *e, azx_play_stats *st) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e->ev_pool[i], e->ev_pool[i + 1]) == hipSuccess) {
             if (e->ev_tag[i / 2]) { st->net_seconds += ms * 1e-3; st->net_launches += 1; }
-            else { st->mcts_seconds += ms * 1e-3; st->mcts_launches += e->ev_weight[i / 2]; }
+            else {
+                st->mcts_seconds += ms * 1e-3;
+                st->mcts_launches += e->ev_weight[i / 2];
+                st->mcts_kernel_launches += 1;
+            }
         }
     }
     e->ev_used = 0;
@@ -828,8 +832,19 @@ static int play_until(azx_engine *e, int64_t min_positions, int64_t max_plies, a
     HIPCHECK(hipEventCreate(&t1));
     HIPCHECK(hipEventRecord(t0, e->stream));
     unsigned long long rows = 0;
-    for (int64_t p = 0; (max_plies <= 0 || p < max_plies) && (int64_t)rows < min_positions; ++p) {
-        TRY(enqueue_ply(e));
+    for (int64_t p = 0; (max_plies <= 0 || p < max_plies) && (int64_t)rows < min_positions;) {
+        // with the uniform evaluator a few moves per persistent launch (k_play) between looks at the
+        // queue; Player.read may return more than it was asked for anyway (whole games only)
+        const int chunk = (int)std::min<int64_t>(8, max_plies > 0 ? max_plies - p : 8);
+        time_begin(e);
+        if (azx_launch_play(d, e->num_batches, chunk, e->stream)) {
+            time_end(e);
+            if (e->ev_used >= 2) e->ev_weight[e->ev_used / 2 - 1] = chunk;
+            p += chunk;
+        } else {
+            TRY(enqueue_ply(e));
+            p += 1;
+        }
         HIPCHECK(hipMemcpyAsync(&rows, d.q_count, sizeof rows, hipMemcpyDeviceToHost, e->stream));
         HIPCHECK(hipStreamSynchronize(e->stream));
     }

@@ -5,7 +5,9 @@
 
 A "step" is one engine move: every one of the `--games` concurrent games runs a full
 400-simulation search ((400//10+1)*10 = 410 select_leaf calls, mcts.py:268), draws its move on
-the device and advances; finished games restart in place.  Inputs are synthetic (all games start
+the device and advances; finished games restart in place (with the uniform evaluator all timed
+moves run in one persistent launch, every game looping search -> move draw -> step on its own
+wavefront: K steps = K moves of each game).  Inputs are synthetic (all games start
 from the empty board, random-init weights for the resnet workload) and already resident in HBM
 when the timed region starts.
 
@@ -198,25 +200,31 @@ def main():
         if args.workload == "tree":
             b = model_bytes(st)
             achieved = b / st["mcts_seconds"] / 1e9 if st["mcts_seconds"] > 0 else 0.0
+            kl = max(1, st.get("mcts_kernel_launches") or st["mcts_launches"])
+            persistent = kl < st["mcts_launches"]
             line["roofline"] = {
-                "kernel": "k_mcts<2, FAST> (select+expand+backup, one launch per move)",
+                "kernel": ("k_play<2> (select+expand+backup, move draw and game step of every game; "
+                           "one persistent launch for all %d timed moves)" % args.steps) if persistent else
+                          "k_mcts<2, FAST> (select+expand+backup, one launch per move)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "bytes_per_launch": b / max(1, st["mcts_launches"]),
-                "avg_launch_ms": 1e3 * st["mcts_seconds"] / max(1, st["mcts_launches"]),
-                "launches": st["mcts_launches"],
+                "bytes_per_launch": b / kl,
+                "avg_launch_ms": 1e3 * st["mcts_seconds"] / kl,
+                "launches": kl,
+                "moves_per_launch": st["mcts_launches"] / kl,
+                "ms_per_move": 1e3 * st["mcts_seconds"] / max(1, st["mcts_launches"]),
                 "bytes_per_sim": b / max(1, st["selects"]),
                 "mean_depth": st["sum_depth"] / max(1, st["selects"]),
             }
             # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
             # (tools/prof_pmc.sh: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction)
-            tpath = os.path.join(ROOT, "profiles", "r1m_tree_pmc_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r1n_tree_pmc_traffic.json")
             default_cmd = (args.games, args.board, args.sims, args.batch, args.steps, args.warmup,
                            args.noise_scale) == (4096, 11, 400, 10, 130, 20, 0.25)
             if default_cmd and os.path.exists(tpath):
                 t = json.load(open(tpath))
                 line["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
-                line["roofline"]["traffic_source"] = "profiles/r1m_tree_pmc_traffic.json (PMC, same command)"
+                line["roofline"]["traffic_source"] = "profiles/r1n_tree_pmc_traffic.json (PMC, same command)"
         else:
             # dominant kernels: the residual tower + heads, one launch pair per leaf batch, timed with
             # HIP events on the engine stream.  ALGORITHMIC flops (107 851 784 per

@@ -179,9 +179,10 @@ typedef struct {
     double  sum_search_value, sum_root_width, sum_action_logprob, sum_reward_last;
     double  seconds;          /* device time of the call (hipEvents on the engine stream) */
     double  mcts_seconds;     /* device time in the tree kernels */
-    int64_t mcts_launches;
+    int64_t mcts_launches;    /* engine moves those launches covered (one per k_mcts search launch) */
     double  net_seconds;      /* device time in the network kernels (tower + heads), per batch */
     int64_t net_launches;
+    int64_t mcts_kernel_launches;   /* kernel launches behind mcts_seconds (k_play: many moves each) */
 } azx_play_stats;
 
 /* Self-play until >= min_positions rows from FINISHED games are available (whole games

@@ -27,18 +27,24 @@ for name in ("sq1", "sq2", "fetch", "write"):
             k = (row["Kernel_Name"][:40], row["Counter_Name"])
             agg[k][0] += float(row["Counter_Value"]); agg[k][1] += 1
     for (kn, cn), (v, n) in sorted(agg.items()):
-        if "k_mcts" in kn or "k_tower" in kn:
+        if "k_mcts" in kn or "k_tower" in kn or "k_play" in kn:
             print("%-42s %-26s per-dispatch %.6g (n=%d)" % (kn, cn, v / n, n))
 import json
 summ = {}
 for name in ("fetch", "write"):
     for f in glob.glob("%s/%s/**/*counter_collection.csv" % (out, name), recursive=True):
-        rows = [r for r in csv.DictReader(open(f)) if "k_mcts" in r["Kernel_Name"] or "k_tower" in r["Kernel_Name"]]
-        # skip the warm-up launches: keep the last STEPS dispatches of the dominant kernel
+        rows = [r for r in csv.DictReader(open(f)) if "k_mcts" in r["Kernel_Name"] or "k_tower" in r["Kernel_Name"]
+                or "k_play" in r["Kernel_Name"]]
+        # skip the warm-up launches: keep the last STEPS dispatches of the dominant kernel -- or, when
+        # the moves run in persistent k_play launches, the last dispatch (= all STEPS timed moves)
         import os
         steps = int(os.environ.get("STEPS", "12"))
+        persistent = any("k_play" in r["Kernel_Name"] for r in rows)
+        if persistent:
+            rows = [r for r in rows if "k_play" in r["Kernel_Name"]]
+            summ["moves_per_launch"] = steps
         for cn in set(r["Counter_Name"] for r in rows):
-            vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == cn][-steps:]
+            vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == cn][-(1 if persistent else steps):]
             summ[cn] = {"per_launch_mean": sum(vals) / max(1, len(vals)), "launches": len(vals)}
 if "FETCH_SIZE" in summ and "WRITE_SIZE" in summ:
     f, w = summ["FETCH_SIZE"]["per_launch_mean"], summ["WRITE_SIZE"]["per_launch_mean"]
