@@ -65,9 +65,9 @@ int azx_init_geometry(int device) {
 #ifdef AZX_STAMP
 #define T_DECL unsigned long long t_last = __builtin_amdgcn_s_memtime(), t_acc[6] = {0, 0, 0, 0, 0, 0};
 #define T_MARK(r) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[r] += t_now - t_last; t_last = t_now; }
-#if AZX_STAMP == 2   // load-balance diagnostic: slot 10 = this launch's wave lifetime, 11 = HW_ID, 12 = start time
+#if AZX_STAMP == 2   // load-balance diagnostic: slot 10 = this search's wave lifetime, 11 = HW_ID, 12 = start time, 13 = lifetimes summed
 #define T_FLUSH if (lane == 0) { unsigned long long *c_ = E.counters + (size_t)g * CTR_COUNT; \
-    c_[10] = __builtin_amdgcn_s_memtime() - t_start; c_[11] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32); c_[12] = t_start; }
+    c_[13] += __builtin_amdgcn_s_memtime() - t_start; c_[10] = __builtin_amdgcn_s_memtime() - t_start; c_[11] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32); c_[12] = t_start; }
 #else
 #define T_FLUSH if (lane == 0) { for (int r_ = 0; r_ < 6; ++r_) E.counters[(size_t)g * CTR_COUNT + 10 + r_] += t_acc[r_]; }
 #endif
