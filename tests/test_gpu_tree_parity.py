@@ -331,25 +331,32 @@ def test_persistent_play_matches_per_move_launches(eng):
     every wave loops search -> move draw -> game step on its own); three launches per move must
     give the same games: boards, plies, finished-game counters and the trees of a following search,
     over enough moves for games to finish, restart and compact their arenas."""
+    _persistent_vs_per_move(eng, 7, 96, 60, 9000, 70, expect_restarts=True)
+    _persistent_vs_per_move(eng, 13, 24, 40, 0, 12, expect_restarts=False)    # three cell slots per lane
+
+
+def _persistent_vs_per_move(eng, n, G, sims, nodes_per_game, moves, expect_restarts):
     res = {}
     for off in (1, 0):
         os.environ["AZX_NO_PERSISTENT"] = str(off)
         try:
-            E = eng.Engine(board_size=7, n_games=96, simulations=60, search_batch_size=10,
+            E = eng.Engine(board_size=n, n_games=G, simulations=sims, search_batch_size=10,
                            exploration_coef=0.5, noise_alpha=0.03, noise_scale=0.25,
-                           exploration_depth=6, evaluator=eng.EVAL_UNIFORM, seed=5, nodes_per_game=9000)
-            st = E.play_steps(70)
+                           exploration_depth=6, evaluator=eng.EVAL_UNIFORM, seed=5,
+                           nodes_per_game=nodes_per_game)
+            st = E.play_steps(moves)
             gm = E.get_games()
             E.search(noise_scale=0.25)
             root = E.get_root()
             res[off] = (gm["board"].copy(), gm["ply"].copy(), st["games"], st["plies"], st["selects"],
                         st["positions"], bits(root["child_visits"]), root["num_nodes"].copy(),
-                        [canonical(E.tree_dump(g)) for g in range(0, 96, 7)])
+                        [canonical(E.tree_dump(g)) for g in range(0, G, 7)])
             E.close()
         finally:
             os.environ.pop("AZX_NO_PERSISTENT", None)
     a, b = res[1], res[0]
-    assert a[2] > 96                      # games did finish and restart
+    if expect_restarts:
+        assert a[2] > G                   # games did finish and restart
     for x, y in zip(a[:8], b[:8]):
         assert np.array_equal(x, y)
     for ta, tb in zip(a[8], b[8]):
