@@ -28,6 +28,31 @@ def test_library_exports_every_declared_symbol():
     assert L.azx_version() >= 1
 
 
+def test_ctypes_structs_match_the_header(tmp_path):
+    """The two structs that cross the C ABI by pointer (azx_config in, azx_play_stats out) must have
+    the layout include/azx.h gives them: a C program compiled against the header prints size and
+    field offsets, the ctypes mirrors in azalea_amd/_lib.py must agree field by field."""
+    import ctypes as C
+    import subprocess
+    from azalea_amd import _lib
+    pairs = (("azx_config", _lib.Config), ("azx_play_stats", _lib.PlayStats))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "azx.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
+
+
 def test_engine_fails_loudly_without_gpu():
     from azalea_amd import _lib, engine
     if torch.cuda.is_available():
