@@ -102,7 +102,7 @@ static int dev_alloc(azx_engine *e, T **p, size_t count, bool zero = true) {
     } while (0)
 
 extern "C" const char *azx_last_error(void) { return g_err.c_str(); }
-extern "C" int azx_version(void) { return 1; }
+extern "C" int azx_version(void) { return 2; }   // 2: azx_play_stats grew mcts_kernel_launches
 
 extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
     if (!cfg || !out) return fail(AZX_EINVAL, "null argument");

@@ -74,7 +74,7 @@ typedef struct {
 typedef struct azx_engine azx_engine;
 
 const char *azx_last_error(void);
-int azx_version(void);
+int azx_version(void);            /* ABI revision: 2 since azx_play_stats carries mcts_kernel_launches */
 
 /* Policy.initialize / Policy.reset (policy.py:36-63, :76-80): allocate device arenas. */
 int azx_create(const azx_config *cfg, azx_engine **out);
