@@ -13,8 +13,8 @@ out, tag = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob("%s/sq1/**/*counter_collection.csv" % out, recursive=True):
     for row in csv.DictReader(open(f)):
-        if "k_mcts" in row["Kernel_Name"]:
+        if "k_mcts" in row["Kernel_Name"] or "k_play" in row["Kernel_Name"]:
             k = row["Counter_Name"]; agg[k][0] += float(row["Counter_Value"]); agg[k][1] += 1
-sims = 4096 * 410.0
+sims = 4096 * 410.0   # per move; k_play launches cover several moves (warm-up 3 + timed 12 here)
 print(tag, " ".join("%s/sim=%.1f" % (k.replace("SQ_INSTS_", ""), v / n / sims) for k, (v, n) in sorted(agg.items()) if k != "SQ_WAVES"))
 PY
