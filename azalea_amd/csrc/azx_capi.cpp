@@ -835,7 +835,10 @@ static int play_until(azx_engine *e, int64_t min_positions, int64_t max_plies, a
     for (int64_t p = 0; (max_plies <= 0 || p < max_plies) && (int64_t)rows < min_positions;) {
         // with the uniform evaluator a few moves per persistent launch (k_play) between looks at the
         // queue; Player.read may return more than it was asked for anyway (whole games only)
-        const int chunk = (int)std::min<int64_t>(8, max_plies > 0 ? max_plies - p : 8);
+        // (at most 2N - 1 moves, the shortest possible game: a slot then finishes at most one game
+        // per launch and the queue bound min_positions + n_games * cells still holds)
+        const int64_t most = std::min<int64_t>(8, 2 * d.N - 1);
+        const int chunk = (int)std::min<int64_t>(most, max_plies > 0 ? max_plies - p : most);
         time_begin(e);
         if (azx_launch_play(d, e->num_batches, chunk, e->stream)) {
             time_end(e);
