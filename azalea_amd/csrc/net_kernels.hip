@@ -1058,7 +1058,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     const int li = lane & 15, lh = lane >> 4;
     const size_t rowg = (size_t)C * 4;
     const unsigned char *gin = reinterpret_cast<const unsigned char *>(in) + (size_t)e * ncells * rowg;
+#ifdef AZX_WIDE_DMA
+    const int zero_off = ((ncells * ROWB + 4095) / 4096) * 4096;
+#else
     const int zero_off = ncells * ROWB;
+#endif
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
     unsigned long long tapok = 0ull;                     // bit tap*6 + m (54 bits)
@@ -1109,6 +1113,29 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
             const int last = ncells * 16 - 1;
             int tid_o = tid;                                 // opaque per chunk: the piece addresses are
             asm volatile("" : "+v"(tid_o));                  // recomputed here, not hoisted and spilled
+#ifdef AZX_WIDE_DMA
+            // diagnostic build: the chunk goes from HBM to LDS by LDS-DMA (global_load_lds_dwordx4: 64 lanes
+            // x 16 bytes land back to back at the wave's LDS base; each lane supplies the global address of
+            // the piece that belongs there -- row = piece / 17, the 17th piece of a row is its padding)
+            {
+                const int npieces = ncells * (ROWB / 16);
+                for (int j = 0; j < 16; ++j) {
+                    const int blk = j * 4 + wave;
+                    if (blk * 1024 >= zero_off) break;
+                    const int pc = blk * 64 + lane;
+                    int row = (pc * 61681) >> 20;                          // pc / 17
+                    int slot = pc - row * 17;
+                    if (pc >= npieces) { row = 0; slot = 16; }
+                    const size_t src = (size_t)row * rowg + (slot < 8 ? (size_t)chunk * 128 + slot * 16
+                                     : slot < 16 ? (size_t)C * 2 + (size_t)chunk * 128 + (slot - 8) * 16
+                                                 : (size_t)chunk * 128);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gin + src),
+                                                     (__attribute__((address_space(3))) void *)(smem + blk * 1024), 16, 0, 0);
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces have landed
+            }
+            if (false)
+#endif
 #pragma unroll
             for (int j0 = 0; j0 < NST; j0 += GRP) {
                 uint4 stg[GRP];
@@ -1629,6 +1656,9 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     net->lds_bytes = (size_t)bpb * 2 * (ncells + 1) * (chans + 4) * sizeof(float);
     if (net->tower_variant == 4) net->lds_bytes = (size_t)F16X3_BPB * 128 * 272 + 272;
     if (net->tower_variant == 5) net->lds_bytes = (size_t)(ncells + 1) * WIDE_ROWB;
+#ifdef AZX_WIDE_DMA   // the DMA staging writes whole 1 KiB pieces: the image is rounded up, the zero row behind it
+    if (net->tower_variant == 5) net->lds_bytes = (((size_t)ncells * WIDE_ROWB + 4095) / 4096) * 4096 + WIDE_ROWB;
+#endif
     net->persistent_allocs = net->allocs.size();
     *out = net;
     return AZX_OK;
