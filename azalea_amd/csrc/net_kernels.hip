@@ -1039,7 +1039,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
                                                                 float *__restrict__ out32,
                                                                 const int32_t *__restrict__ n_eval_ptr, int n_eval_host,
                                                                 int flipsh) {
+#ifdef AZX_WIDE_DB
+    constexpr int MT = WIDE16_MT, NT = WIDE16_NT, ROWB = 144;   // 32-channel chunks: 64 B hi | 64 B lo | 16 B pad
+#else
     constexpr int MT = WIDE16_MT, NT = WIDE16_NT, ROWB = WIDE_ROWB;
+#endif
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
     const int e = blockIdx.x;
@@ -1058,7 +1062,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     const int li = lane & 15, lh = lane >> 4;
     const size_t rowg = (size_t)C * 4;
     const unsigned char *gin = reinterpret_cast<const unsigned char *>(in) + (size_t)e * ncells * rowg;
-#ifdef AZX_WIDE_DMA
+#ifdef AZX_WIDE_DB
+    const int BUFB = ((ncells * ROWB + 1023) / 1024) * 1024;
+    const int zero_off = 2 * BUFB;
+#elif defined(AZX_WIDE_DMA)
     const int zero_off = ((ncells * ROWB + 4095) / 4096) * 4096;
 #else
     const int zero_off = ncells * ROWB;
@@ -1098,6 +1105,81 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
         return wsrc + ((size_t)q * (NT16 * 2) + (size_t)((nt0 + n) * 2 + part)) * 64 + lane;
     };
 
+#ifdef AZX_WIDE_DB
+    // Double-buffered 32-channel chunks staged by LDS-DMA: chunk c + 1 is requested into the other
+    // buffer before chunk c is computed (no registers involved), one barrier per chunk.
+    auto dma_chunk = [&](int c32, int buf) __attribute__((always_inline)) {
+        const int npieces = ncells * 9, nblk = (npieces + 63) / 64;
+        for (int j = 0; j < 8; ++j) {
+            const int blk = j * 4 + wave;
+            if (blk >= nblk) break;
+            const int pc = blk * 64 + lane;
+            int row = (pc * 58255) >> 19;                              // pc / 9
+            int slot = pc - row * 9;
+            if (pc >= npieces) { row = 0; slot = 8; }
+            const size_t src = (size_t)row * rowg + (slot < 4 ? (size_t)c32 * 64 + slot * 16
+                             : slot < 8 ? (size_t)C * 2 + (size_t)c32 * 64 + (slot - 4) * 16
+                                        : (size_t)c32 * 64);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gin + src),
+                                             (__attribute__((address_space(3))) void *)(smem + buf * BUFB + blk * 1024), 16, 0, 0);
+        }
+    };
+    auto main_loop = [&](auto wm_tag) __attribute__((always_inline)) {
+    constexpr int WM = decltype(wm_tag)::value;
+    dma_chunk(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (int chunk = 0; chunk < 2 * NCH; ++chunk) {
+        if (chunk + 1 < 2 * NCH) dma_chunk(chunk + 1, (chunk + 1) & 1);
+        const int bb = (chunk & 1) * BUFB;
+        // k-step t = 0..8 of this chunk: tap t, the chunk's 32 channels
+        auto qof = [&](int t) { return (((layer * 9 + t) * NCH + (chunk >> 1)) * 2 + (chunk & 1)); };
+        f16x8 wh_[NT], wl_[NT];
+        f16x8 xh[MT], xl[MT];
+        auto load_w = [&](int t, int nn, int part) {
+            const uint4 qq = *wptr(qof(t), nn, part);
+            if (part) wl_[nn] = *reinterpret_cast<const f16x8 *>(&qq);
+            else wh_[nn] = *reinterpret_cast<const f16x8 *>(&qq);
+        };
+        auto load_x = [&](int tt, int mm, int part) {
+            const int ao = act_offset(tt, mm);
+            const unsigned char *pa = smem + (ao >= zero_off ? ao : ao + bb) + part * 64;
+            if (part) xl[mm] = *reinterpret_cast<const f16x8 *>(pa);
+            else xh[mm] = *reinterpret_cast<const f16x8 *>(pa);
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_w(0, i >> 1, i & 1);
+#pragma unroll
+        for (int m = 0; m < MT - 1; ++m) { load_x(0, m, 0); load_x(0, m, 1); }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int q = 0; q < 6 * MT; ++q) {
+                    const int m = q / 6, n = 2 * h + (q % 6) / 3, p = q % 3;
+                    if (q == 1 || q == 4 || q == 7 || q == 10) {
+                        const int idx = (q - 1) / 3;
+                        if (h == 0) load_w(t, 2 + (idx >> 1), idx & 1);
+                        else if (t + 1 < 9) load_w(t + 1, idx >> 1, idx & 1);
+                    } else if (h == 0 && (q == 13 || q == 16)) {
+                        load_x(t, MT - 1, q == 16);
+                    } else if (h == 1 && q >= 8 && (q % 6 == 2 || q % 6 == 5)) {
+                        if (t + 1 < 9) load_x(t + 1, q / 6 - 1, q % 6 == 5);
+                    }
+                    const f16x8 wv = p == 1 ? wl_[n] : wh_[n];
+                    const f16x8 xv = p == 2 ? xl[m] : xh[m];
+                    if (!(WM == 0 ? (m == MT - 1 && n >= 2) : (m == 0 && n < 2)))
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, acc[m][n], 0, 0, 0);
+                    if (q % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's pieces of the next chunk have landed
+        __syncthreads();                      // ... everyone's have, and everyone is done with this buffer
+    }
+    };
+#else
     // the chunk loop, instantiated per wm (which tile product is the other wave's is a compile-time
     // pattern: straight-line code either way; both paths pass the same barriers)
     auto main_loop = [&](auto wm_tag) __attribute__((always_inline)) {
@@ -1202,6 +1284,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     }
 
     };
+#endif
     if (wm == 0) main_loop(std::integral_constant<int, 0>{});
     else main_loop(std::integral_constant<int, 1>{});
 
@@ -1656,6 +1739,9 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     net->lds_bytes = (size_t)bpb * 2 * (ncells + 1) * (chans + 4) * sizeof(float);
     if (net->tower_variant == 4) net->lds_bytes = (size_t)F16X3_BPB * 128 * 272 + 272;
     if (net->tower_variant == 5) net->lds_bytes = (size_t)(ncells + 1) * WIDE_ROWB;
+#ifdef AZX_WIDE_DB    // two 32-channel buffers (144-byte rows, rounded up to whole 1 KiB DMA pieces) + the zero row
+    if (net->tower_variant == 5) net->lds_bytes = 2 * ((((size_t)ncells * 144 + 1023) / 1024) * 1024) + 144;
+#endif
 #ifdef AZX_WIDE_DMA   // the DMA staging writes whole 1 KiB pieces: the image is rounded up, the zero row behind it
     if (net->tower_variant == 5) net->lds_bytes = (((size_t)ncells * WIDE_ROWB + 4095) / 4096) * 4096 + WIDE_ROWB;
 #endif
