@@ -14,6 +14,11 @@ MAX_BOARD = 13
 CELL_STRIDE = 192
 MAX_BATCH = 16
 
+
+def record_bytes(cells):
+    """AZX_RECORD_BYTES (include/azx.h): one fixed-size replay record."""
+    return (16 + 5 * cells + 15) // 16 * 16
+
 EVAL_RESNET, EVAL_UNIFORM, EVAL_UNIFORM_HASH, EVAL_EXTERNAL = 0, 1, 2, 3
 FLAG_NO_COMPACT = 1
 
@@ -29,7 +34,7 @@ class Config(C.Structure):
                 ("noise_scale", C.c_double), ("temperature", C.c_double),
                 ("evaluator", C.c_int32), ("num_blocks", C.c_int32), ("base_chans", C.c_int32),
                 ("nodes_per_game", C.c_int32), ("flags", C.c_int32), ("device", C.c_int32),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("game_index_stride", C.c_int32), ("game_index_offset", C.c_int32)]
 
 
 class PlayStats(C.Structure):
@@ -41,7 +46,7 @@ class PlayStats(C.Structure):
                 ("sum_reward_last", C.c_double), ("seconds", C.c_double),
                 ("mcts_seconds", C.c_double), ("mcts_launches", C.c_int64),
                 ("net_seconds", C.c_double), ("net_launches", C.c_int64),
-                ("mcts_kernel_launches", C.c_int64)]
+                ("mcts_kernel_launches", C.c_int64), ("sum_game_length", C.c_double)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -84,10 +89,14 @@ SYMBOLS = {
     "azx_replay_set_state": (C.c_int, [_vp, C.c_int64, C.c_int64]),
     "azx_replay_put": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, _i32p, _f32p, _f32p]),
     "azx_replay_fill": (C.c_int, [_vp, C.c_int64, C.c_int64, _i64p, C.POINTER(PlayStats)]),
+    "azx_play_device": (C.c_int, [_vp, C.c_int64, C.c_int64, _i64p, C.POINTER(PlayStats)]),
+    "azx_rows_pack": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
+    "azx_replay_put_records": (C.c_int, [_vp, C.c_int64, _vp]),
     "azx_replay_collate": (C.c_int, [_vp, C.c_int64, _i64p, _vp, _vp, _vp, _vp, _vp, _vp, _i32p]),
     "azx_selftest_arith": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p]),
     "azx_selftest_divide": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p]),
     "azx_selftest_dirichlet": (C.c_int, [C.c_int, C.c_double, C.c_int, C.c_int, C.c_uint32, _f32p]),
+    "azx_debug_choose": (C.c_int, [_vp, _i32p, _f32p]),
     "azx_debug_counters": (C.c_int, [_vp, _u64p]),
     "azx_debug_counters_raw": (C.c_int, [_vp, _u64p, C.c_int64]),
     "azx_stream": (_vp, [_vp]),

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -63,7 +64,11 @@ struct azx_engine {
     // play mode
     bool play_ready = false;
     int64_t q_alloc = 0;
+    int64_t q_rows_valid = 0;           // rows the last azx_play_device left in the queue
     std::vector<void *> q_allocs;
+    int32_t *export_board = nullptr;    // azx_play's device-side widening staging
+    float *export_prob = nullptr;
+    size_t export_cap = 0;
     // device-resident replay ring (azx_replay_*)
     ReplayRows ring = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int64_t ring_cap = 0, ring_size = 0, ring_write = 0;
@@ -95,6 +100,20 @@ static int dev_alloc(azx_engine *e, T **p, size_t count, bool zero = true) {
     return AZX_OK;
 }
 
+// Every entry point runs with the engine's device current and puts the caller's device back on
+// return (hipSetDevice is per host thread and also moves torch.cuda.current_device()).
+struct DevGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DevGuard() { if (changed) (void)hipSetDevice(prev); }
+    DevGuard(const DevGuard &) = delete;
+    DevGuard &operator=(const DevGuard &) = delete;
+};
+#define ENGINE_GUARD(e) DevGuard _dev_guard((e)->cfg.device)
+
 #define TRY(expr)            \
     do {                     \
         int _rc = (expr);    \
@@ -102,7 +121,7 @@ static int dev_alloc(azx_engine *e, T **p, size_t count, bool zero = true) {
     } while (0)
 
 extern "C" const char *azx_last_error(void) { return g_err.c_str(); }
-extern "C" int azx_version(void) { return 2; }   // 2: azx_play_stats grew mcts_kernel_launches
+extern "C" int azx_version(void) { return 3; }   // 3: azx_config.game_index_*, azx_play_stats.sum_game_length
 
 extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
     if (!cfg || !out) return fail(AZX_EINVAL, "null argument");
@@ -120,7 +139,12 @@ extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
         return fail(AZX_EINVAL, "unknown evaluator %d", cfg->evaluator);
     if (cfg->device < 0 || cfg->device >= ndev)
         return fail(AZX_EINVAL, "device %d not in [0, %d)", cfg->device, ndev);
-    HIPCHECK(hipSetDevice(cfg->device));
+    if (cfg->game_index_stride < 0 || cfg->game_index_offset < 0 ||
+        cfg->game_index_offset >= std::max(1, cfg->game_index_stride))
+        return fail(AZX_EINVAL, "game_index_offset %d outside [0, game_index_stride %d)", cfg->game_index_offset,
+                    std::max(1, cfg->game_index_stride));
+    DevGuard guard(cfg->device);
+    { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != cfg->device) return fail(AZX_EHIP, "hipSetDevice(%d) failed", cfg->device); }
     if (azx_init_geometry(cfg->device)) return fail(AZX_EHIP, "uploading the board geometry tables failed");
 
     azx_engine *e = new azx_engine();
@@ -137,6 +161,8 @@ extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
     d.evaluator = cfg->evaluator;
     d.flags = cfg->flags;
     d.seed = cfg->seed;
+    d.uid_stride = std::max(1, cfg->game_index_stride);
+    d.uid_offset = cfg->game_index_offset;
     d.noise_alpha = (float)cfg->noise_alpha;
     d.noise_scale = 0.0;
     d.exploration_depth = cfg->exploration_depth;
@@ -204,11 +230,14 @@ extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
 
 extern "C" void azx_destroy(azx_engine *e) {
     if (!e) return;
+    ENGINE_GUARD(e);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->net) azx_net_destroy(e->net);
     for (void *p : e->allocs) (void)hipFree(p);
     for (void *p : e->q_allocs) (void)hipFree(p);
     for (void *p : e->ring_allocs) (void)hipFree(p);
+    if (e->export_board) (void)hipFree(e->export_board);
+    if (e->export_prob) (void)hipFree(e->export_prob);
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -219,6 +248,7 @@ extern "C" void *azx_stream(azx_engine *e) { return e ? (void *)e->stream : null
 extern "C" int azx_set_weights(azx_engine *e, int n_tensors, const char *const *names,
                                const void *const *ptrs, const int64_t *counts, int on_device) {
     if (!e) return fail(AZX_EINVAL, "null engine");
+    ENGINE_GUARD(e);
     if (!e->net) return fail(AZX_ESTATE, "engine was not created with AZX_EVAL_RESNET");
     int rc = azx_net_set_weights(e->net, n_tensors, names, ptrs, counts, on_device);
     if (rc) g_err = azx_net_error();
@@ -227,6 +257,7 @@ extern "C" int azx_set_weights(azx_engine *e, int n_tensors, const char *const *
 
 extern "C" int azx_set_prior_table(azx_engine *e, const float *prior_by_k, int count) {
     if (!e || !prior_by_k) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     if (count < e->d.ncells + 1) return fail(AZX_EINVAL, "prior table needs %d entries", e->d.ncells + 1);
     if (!e->prior_table_dev) TRY(dev_alloc(e, &e->prior_table_dev, (size_t)e->d.ncells + 1));
     HIPCHECK(hipMemcpyAsync(e->prior_table_dev, prior_by_k, sizeof(float) * (e->d.ncells + 1),
@@ -240,6 +271,7 @@ extern "C" int azx_set_prior_table(azx_engine *e, const float *prior_by_k, int c
 extern "C" int azx_reset(azx_engine *e, const int32_t *slots, int n_slots, const int32_t *moves,
                          const int32_t *n_moves, int stride) {
     if (!e) return fail(AZX_EINVAL, "null engine");
+    ENGINE_GUARD(e);
     DevEngine &d = e->d;
     if (!slots) n_slots = d.G;
     if (n_slots < 1 || n_slots > d.G) return fail(AZX_EINVAL, "n_slots %d outside [1, %d]", n_slots, d.G);
@@ -291,9 +323,10 @@ static void time_begin(azx_engine *e, char tag = 0) {
     e->ev_weight[e->ev_used / 2] = 1;
     (void)hipEventRecord(e->ev_pool[e->ev_used], e->stream);
 }
-static void time_end(azx_engine *e) {
-    if (e->ev_used + 2 > e->ev_pool.size()) return;
+static void time_end(azx_engine *e, int weight = 1) {
+    if (e->ev_used + 2 > e->ev_pool.size()) return;     // pool full: time_begin recorded nothing either
     (void)hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream);
+    e->ev_weight[e->ev_used / 2] = weight;
     e->ev_used += 2;
 }
 static void time_collect(azx_engine *e, azx_play_stats *st) {
@@ -325,6 +358,12 @@ static int upload_noise(azx_engine *e, const double *noise, int n_select, int no
         return fail(AZX_EINVAL, "noise has %d rows, a search consumes %d", n_select, e->selects_per_search);
     const size_t need = (size_t)d.G * n_select * noise_stride;
     if (need > e->noise_cap) {
+        if (e->noise_dev) {      // searches are blocking: no kernel still reads the old rows
+            (void)hipFree(e->noise_dev);
+            e->allocs.erase(std::remove(e->allocs.begin(), e->allocs.end(), (void *)e->noise_dev), e->allocs.end());
+            e->noise_dev = nullptr;
+            e->noise_cap = 0;
+        }
         TRY(dev_alloc(e, &e->noise_dev, need, false));
         e->noise_cap = need;
     }
@@ -371,6 +410,7 @@ static int enqueue_search(azx_engine *e, bool timed) {
 extern "C" int azx_search(azx_engine *e, const double *noise, int n_select, int noise_stride,
                           double noise_scale) {
     if (!e) return fail(AZX_EINVAL, "null engine");
+    ENGINE_GUARD(e);
     if (e->d.evaluator == AZX_EVAL_EXTERNAL)
         return fail(AZX_ESTATE, "AZX_EVAL_EXTERNAL: drive azx_search_begin/step instead");
     TRY(upload_noise(e, noise, n_select, noise_stride, noise_scale));
@@ -391,6 +431,7 @@ static int read_pending(azx_engine *e, int *n_pending) {
 extern "C" int azx_search_begin(azx_engine *e, const double *noise, int n_select, int noise_stride,
                                 double noise_scale, int *n_pending) {
     if (!e || !n_pending) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     if (e->d.evaluator != AZX_EVAL_EXTERNAL && e->d.evaluator != AZX_EVAL_RESNET)
         return fail(AZX_ESTATE, "phase API needs AZX_EVAL_EXTERNAL (or RESNET)");
     TRY(upload_noise(e, noise, n_select, noise_stride, noise_scale));
@@ -407,6 +448,7 @@ extern "C" int azx_search_begin(azx_engine *e, const double *noise, int n_select
 
 extern "C" int azx_search_step(azx_engine *e, int *n_pending, int *done) {
     if (!e || !n_pending || !done) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     if (!e->ext_active) return fail(AZX_ESTATE, "azx_search_step without azx_search_begin");
     HIPCHECK(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), e->stream));
     if (e->ext_batches_done < e->num_batches) {
@@ -431,6 +473,7 @@ static int flip_cell(int cell, int N) {   // hex.py:107-111 (r,c) -> (N-1-c, N-1
 extern "C" int azx_get_leaves(azx_engine *e, int cap, int32_t *boards, int32_t *legal_moves,
                               int32_t *slot, int32_t *k, int *n_out) {
     if (!e || !n_out) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     DevEngine &d = e->d;
     int n = 0;
     TRY(read_pending(e, &n));
@@ -475,6 +518,7 @@ extern "C" int azx_get_leaves(azx_engine *e, int cap, int32_t *boards, int32_t *
 
 extern "C" int azx_put_evals(azx_engine *e, int n, const float *value, const float *prior) {
     if (!e || (n && (!value || !prior))) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     DevEngine &d = e->d;
     if (n != (int)e->ext_order.size())
         return fail(AZX_ESTATE, "azx_put_evals(%d) does not match %zu pending leaves", n, e->ext_order.size());
@@ -495,6 +539,7 @@ extern "C" int azx_put_evals(azx_engine *e, int n, const float *value, const flo
 
 extern "C" int azx_get_evals(azx_engine *e, int cap, float *value, float *prior, int *n_out) {
     if (!e || !n_out) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     DevEngine &d = e->d;
     const int n = (int)e->ext_order.size();
     if (n > cap) return fail(AZX_EINVAL, "%d evaluations, caller capacity %d", n, cap);
@@ -521,6 +566,7 @@ extern "C" int azx_get_root(azx_engine *e, int32_t *k, int32_t *legal_moves, flo
                             float *child_value, float *child_prior, float *root_visits,
                             float *root_value, int32_t *num_nodes, float *search_value) {
     if (!e) return fail(AZX_EINVAL, "null engine");
+    ENGINE_GUARD(e);
     DevEngine &d = e->d;
     const size_t G = d.G, GC = G * d.ncells;
     HIPCHECK(hipMemsetAsync(e->g_legal, 0, sizeof(int32_t) * GC, e->stream));
@@ -551,6 +597,7 @@ extern "C" int azx_get_root(azx_engine *e, int32_t *k, int32_t *legal_moves, flo
 
 extern "C" int azx_get_status(azx_engine *e, int32_t *status) {
     if (!e || !status) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     std::vector<TreeHdr> th(e->d.G);
     HIPCHECK(hipMemcpyAsync(th.data(), e->d.thdr, sizeof(TreeHdr) * th.size(), hipMemcpyDeviceToHost, e->stream));
     HIPCHECK(hipStreamSynchronize(e->stream));
@@ -561,6 +608,7 @@ extern "C" int azx_get_status(azx_engine *e, int32_t *status) {
 extern "C" int azx_get_games(azx_engine *e, int32_t *board, int32_t *color, int32_t *result,
                              int32_t *ply) {
     if (!e) return fail(AZX_EINVAL, "null engine");
+    ENGINE_GUARD(e);
     DevEngine &d = e->d;
     const size_t G = d.G;
     std::vector<uint32_t> hc(G * d.slots * 64);
@@ -581,6 +629,7 @@ extern "C" int azx_get_games(azx_engine *e, int32_t *board, int32_t *color, int3
 
 extern "C" int azx_advance(azx_engine *e, const int32_t *move_ids) {
     if (!e || !move_ids) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     DevEngine &d = e->d;
     HIPCHECK(hipMemcpyAsync(e->moveids_dev, move_ids, sizeof(int32_t) * d.G, hipMemcpyHostToDevice, e->stream));
     azx_launch_advance(d, e->moveids_dev, 0, e->stream);
@@ -594,6 +643,7 @@ extern "C" int azx_tree_dump(azx_engine *e, int slot, int cap, int32_t *parent, 
                              int32_t *num_children, float *num_visits, float *total_value,
                              float *prior_prob, int32_t *num_nodes, int32_t *root_id) {
     if (!e || !num_nodes || !root_id) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     DevEngine &d = e->d;
     if (slot < 0 || slot >= d.G) return fail(AZX_EINVAL, "slot %d out of range", slot);
     TreeHdr th;
@@ -635,6 +685,7 @@ extern "C" int azx_tree_dump(azx_engine *e, int slot, int cap, int32_t *parent, 
 extern "C" int azx_forward(azx_engine *e, int B, int K, const int32_t *boards,
                            const int32_t *legal_moves, float *value, float *moves_logprob) {
     if (!e) return fail(AZX_EINVAL, "null engine");
+    ENGINE_GUARD(e);
     if (!e->net) return fail(AZX_ESTATE, "engine was not created with AZX_EVAL_RESNET");
     int rc = azx_net_forward_host(e->net, B, K, boards, legal_moves, value, moves_logprob, e->stream);
     if (rc) g_err = azx_net_error();
@@ -649,7 +700,7 @@ extern "C" int azx_hex_replay(int device, int board_size, int n_games, const int
         return fail(AZX_ENODEV, "no HIP device visible: the engine has no CPU fallback");
     if (board_size < 2 || board_size > AZX_MAX_BOARD) return fail(AZX_EINVAL, "bad board_size");
     if (n_games < 1 || stride < 1 || !moves || !length) return fail(AZX_EINVAL, "bad argument");
-    HIPCHECK(hipSetDevice(device));
+    DevGuard guard(device);
     if (azx_init_geometry(device)) return fail(AZX_EHIP, "uploading the board geometry tables failed");
     const int ncells = board_size * board_size;
     for (int g = 0; g < n_games; ++g) {
@@ -689,6 +740,7 @@ extern "C" int azx_hex_replay(int device, int board_size, int n_games, const int
 // ---- which slots take part in the next searches (tournaments: only the games whose turn it is) --
 extern "C" int azx_set_active(azx_engine *e, const int32_t *active) {
     if (!e || !active) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     DevEngine &d = e->d;
     std::vector<int32_t> a((size_t)d.G);
     for (int g = 0; g < d.G; ++g) a[g] = active[g] ? 1 : 0;
@@ -701,6 +753,7 @@ extern "C" int azx_set_active(azx_engine *e, const int32_t *active) {
 // ---- throughput mode ------------------------------------------------------------------------
 static int play_setup(azx_engine *e, int64_t q_rows, int ring) {
     DevEngine &d = e->d;
+    e->q_rows_valid = 0;
     if (!e->play_ready) {
         const size_t rows = (size_t)d.G * d.ncells;
         TRY(dev_alloc(e, &d.row_board, rows * AZX_CELL_STRIDE));
@@ -765,6 +818,7 @@ static void fill_stats(const CounterSnap &a, const CounterSnap &b, azx_play_stat
     st->sum_root_width = b.s[1] - a.s[1];
     st->sum_action_logprob = b.s[2] - a.s[2];
     st->sum_reward_last = b.s[3] - a.s[3];
+    st->sum_game_length = b.s[4] - a.s[4];
 }
 
 static int enqueue_ply(azx_engine *e) {
@@ -776,6 +830,7 @@ static int enqueue_ply(azx_engine *e) {
 
 extern "C" int azx_play_steps(azx_engine *e, int64_t plies, azx_play_stats *stats) {
     if (!e || !stats) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     if (e->d.evaluator == AZX_EVAL_EXTERNAL) return fail(AZX_ESTATE, "play mode needs a device evaluator");
     memset(stats, 0, sizeof *stats);
     TRY(play_setup(e, std::max<int64_t>(e->q_alloc, 1 << 16), 1));
@@ -796,8 +851,7 @@ extern "C" int azx_play_steps(azx_engine *e, int64_t plies, azx_play_stats *stat
             time_begin(e);
             const bool ok = azx_launch_play(e->d, e->num_batches, n, e->stream);
             if (!ok) break;                 // (the begin event is simply overwritten by the next one)
-            time_end(e);
-            if (e->ev_used >= 2) e->ev_weight[e->ev_used / 2 - 1] = n;
+            time_end(e, n);
             p += n;
         }
         for (; p < plies; ++p) TRY(enqueue_ply(e));
@@ -824,6 +878,8 @@ static int play_until(azx_engine *e, int64_t min_positions, int64_t max_plies, a
     memset(stats, 0, sizeof *stats);
     const int64_t worst = min_positions + (int64_t)d.G * d.ncells;
     TRY(play_setup(e, worst, 0));
+    if (const char *dbg = getenv("AZX_DEBUG_QCAP"))     // tests: a queue too small, so that slots get parked
+        d.q_cap = std::max<int64_t>(1, std::min<int64_t>(d.q_cap, atoll(dbg)));
     TRY(upload_noise(e, nullptr, 0, 0, e->cfg.noise_scale));
     CounterSnap a, b;
     TRY(snap_counters(e, &a));
@@ -831,6 +887,8 @@ static int play_until(azx_engine *e, int64_t min_positions, int64_t max_plies, a
     HIPCHECK(hipEventCreate(&t0));
     HIPCHECK(hipEventCreate(&t1));
     HIPCHECK(hipEventRecord(t0, e->stream));
+    // games that finished while the queue was full (parked slots) hand their rows over first
+    azx_launch_advance(d, nullptr, 2, e->stream);
     unsigned long long rows = 0;
     for (int64_t p = 0; (max_plies <= 0 || p < max_plies) && (int64_t)rows < min_positions;) {
         // with the uniform evaluator a few moves per persistent launch (k_play) between looks at the
@@ -841,8 +899,7 @@ static int play_until(azx_engine *e, int64_t min_positions, int64_t max_plies, a
         const int chunk = (int)std::min<int64_t>(most, max_plies > 0 ? max_plies - p : most);
         time_begin(e);
         if (azx_launch_play(d, e->num_batches, chunk, e->stream)) {
-            time_end(e);
-            if (e->ev_used >= 2) e->ev_weight[e->ev_used / 2 - 1] = chunk;
+            time_end(e, chunk);
             p += chunk;
         } else {
             TRY(enqueue_ply(e));
@@ -870,6 +927,7 @@ extern "C" int azx_play(azx_engine *e, int64_t min_positions, int64_t max_plies,
                         int32_t *board, int32_t *color, int32_t *nlegal, float *moves_prob,
                         float *reward, int64_t *game_uid, azx_play_stats *stats) {
     if (!e || !stats) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     if (e->d.evaluator == AZX_EVAL_EXTERNAL) return fail(AZX_ESTATE, "play mode needs a device evaluator");
     DevEngine &d = e->d;
     const int64_t worst = min_positions + (int64_t)d.G * d.ncells;
@@ -880,21 +938,70 @@ extern "C" int azx_play(azx_engine *e, int64_t min_positions, int64_t max_plies,
     TRY(play_until(e, min_positions, max_plies, stats, &rows));
     if (rows == 0) return AZX_OK;
     const size_t n = (size_t)rows;
-    std::vector<uint8_t> hb(n * AZX_CELL_STRIDE);
-    std::vector<float> hp(n * AZX_CELL_STRIDE);
-    HIPCHECK(hipMemcpyAsync(hb.data(), d.q_board, hb.size(), hipMemcpyDeviceToHost, e->stream));
-    HIPCHECK(hipMemcpyAsync(hp.data(), d.q_prob, hp.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    // widen / densify on the device (k_rows_export), then one copy per output array
+    if (board || moves_prob) {
+        const size_t need = n * d.ncells;
+        if (need > e->export_cap) {
+            (void)hipStreamSynchronize(e->stream);
+            if (e->export_board) (void)hipFree(e->export_board);
+            if (e->export_prob) (void)hipFree(e->export_prob);
+            e->export_board = nullptr; e->export_prob = nullptr; e->export_cap = 0;
+            if (hipMalloc((void **)&e->export_board, need * sizeof(int32_t)) != hipSuccess ||
+                hipMalloc((void **)&e->export_prob, need * sizeof(float)) != hipSuccess)
+                return fail(AZX_ENOMEM, "hipMalloc of the export staging (%zu rows) failed", n);
+            e->export_cap = need;
+        }
+        azx_launch_rows_export(d.q_board, d.q_prob, (long long)n, d.ncells, e->export_board, e->export_prob, e->stream);
+        HIPCHECK(hipGetLastError());
+        if (board) HIPCHECK(hipMemcpyAsync(board, e->export_board, need * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+        if (moves_prob) HIPCHECK(hipMemcpyAsync(moves_prob, e->export_prob, need * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    }
     if (color) HIPCHECK(hipMemcpyAsync(color, d.q_color, n * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     if (nlegal) HIPCHECK(hipMemcpyAsync(nlegal, d.q_k, n * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     if (reward) HIPCHECK(hipMemcpyAsync(reward, d.q_reward, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     if (game_uid) HIPCHECK(hipMemcpyAsync(game_uid, d.q_uid, n * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
     HIPCHECK(hipStreamSynchronize(e->stream));
-    for (size_t r = 0; r < n; ++r) {
-        if (board)
-            for (int c = 0; c < d.ncells; ++c) board[r * d.ncells + c] = hb[r * AZX_CELL_STRIDE + c];
-        if (moves_prob)
-            for (int c = 0; c < d.ncells; ++c) moves_prob[r * d.ncells + c] = hp[r * AZX_CELL_STRIDE + c];
-    }
+    return AZX_OK;
+}
+
+extern "C" int azx_play_device(azx_engine *e, int64_t min_positions, int64_t max_plies, int64_t *rows_out,
+                               azx_play_stats *stats) {
+    if (!e || !stats || !rows_out) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
+    if (e->d.evaluator == AZX_EVAL_EXTERNAL) return fail(AZX_ESTATE, "play mode needs a device evaluator");
+    unsigned long long rows = 0;
+    TRY(play_until(e, min_positions, max_plies, stats, &rows));
+    e->q_rows_valid = (int64_t)rows;
+    *rows_out = (int64_t)rows;
+    return AZX_OK;
+}
+
+extern "C" int azx_rows_pack(azx_engine *e, int64_t first, int64_t n, void *records_dev) {
+    if (!e || (n > 0 && !records_dev)) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
+    if (first < 0 || n < 0 || first + n > e->q_rows_valid)
+        return fail(AZX_EINVAL, "rows [%lld, %lld) outside the %lld rows queued", (long long)first,
+                    (long long)(first + n), (long long)e->q_rows_valid);
+    if (n == 0) return AZX_OK;
+    DevEngine &d = e->d;
+    const ReplayRows src = {d.q_board, d.q_prob, d.q_color, d.q_k, d.q_reward};
+    azx_launch_rows_pack(src, (const long long *)d.q_uid, first, n, d.ncells, (uint8_t *)records_dev, e->stream);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    return AZX_OK;
+}
+
+extern "C" int azx_replay_put_records(azx_engine *e, int64_t n, const void *records_dev) {
+    if (!e || (n > 0 && !records_dev)) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
+    if (e->ring_cap == 0) return fail(AZX_ESTATE, "no replay ring: call azx_replay_create first");
+    if (n < 0) return fail(AZX_EINVAL, "n must be >= 0");
+    if (n == 0) return AZX_OK;
+    azx_launch_records_put((const uint8_t *)records_dev, e->ring, n, e->ring_cap, e->ring_write, e->d.ncells, e->stream);
+    HIPCHECK(hipGetLastError());
+    e->ring_write = (e->ring_write + n) % e->ring_cap;
+    e->ring_size = std::min<int64_t>(e->ring_cap, e->ring_size + n);
+    HIPCHECK(hipStreamSynchronize(e->stream));
     return AZX_OK;
 }
 
@@ -902,6 +1009,7 @@ extern "C" int azx_play(azx_engine *e, int64_t min_positions, int64_t max_plies,
 // prep.batch_replays collate (prep.py:24-39) without leaving HBM ---------------------------------
 extern "C" int azx_replay_create(azx_engine *e, int64_t capacity) {
     if (!e) return fail(AZX_EINVAL, "null engine");
+    ENGINE_GUARD(e);
     if (capacity < 1) return fail(AZX_EINVAL, "capacity must be >= 1");
     (void)hipStreamSynchronize(e->stream);
     for (void *p : e->ring_allocs) (void)hipFree(p);
@@ -927,6 +1035,7 @@ extern "C" int azx_replay_create(azx_engine *e, int64_t capacity) {
 
 extern "C" int azx_replay_state(azx_engine *e, int64_t *capacity, int64_t *size, int64_t *write_idx) {
     if (!e) return fail(AZX_EINVAL, "null engine");
+    ENGINE_GUARD(e);
     if (capacity) *capacity = e->ring_cap;
     if (size) *size = e->ring_size;
     if (write_idx) *write_idx = e->ring_write;
@@ -935,6 +1044,7 @@ extern "C" int azx_replay_state(azx_engine *e, int64_t *capacity, int64_t *size,
 
 extern "C" int azx_replay_set_state(azx_engine *e, int64_t size, int64_t write_idx) {
     if (!e) return fail(AZX_EINVAL, "null engine");
+    ENGINE_GUARD(e);
     if (e->ring_cap == 0) return fail(AZX_ESTATE, "no replay ring: call azx_replay_create first");
     if (size < 0 || size > e->ring_cap || write_idx < 0 || write_idx >= e->ring_cap)
         return fail(AZX_EINVAL, "size/write_idx outside the ring");
@@ -955,6 +1065,7 @@ static int ring_put(azx_engine *e, const ReplayRows &src, int64_t n) {
 extern "C" int azx_replay_put(azx_engine *e, int64_t n, const int32_t *board, const int32_t *color,
                               const int32_t *nlegal, const float *moves_prob, const float *reward) {
     if (!e || !board || !color || !nlegal || !moves_prob || !reward) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     if (e->ring_cap == 0) return fail(AZX_ESTATE, "no replay ring: call azx_replay_create first");
     if (n < 0) return fail(AZX_EINVAL, "n must be >= 0");
     if (n == 0) return AZX_OK;
@@ -986,6 +1097,7 @@ extern "C" int azx_replay_put(azx_engine *e, int64_t n, const int32_t *board, co
 extern "C" int azx_replay_fill(azx_engine *e, int64_t min_positions, int64_t max_plies,
                                int64_t *rows_out, azx_play_stats *stats) {
     if (!e || !stats) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     if (e->ring_cap == 0) return fail(AZX_ESTATE, "no replay ring: call azx_replay_create first");
     if (e->d.evaluator == AZX_EVAL_EXTERNAL) return fail(AZX_ESTATE, "play mode needs a device evaluator");
     unsigned long long rows = 0;
@@ -1004,6 +1116,7 @@ extern "C" int azx_replay_collate(azx_engine *e, int64_t batch, const int64_t *i
     if (!e || !indices || !color_dev || !legal_moves_dev || !result_dev || !board_dev || !moves_prob_dev ||
         !reward_dev || !max_k_out)
         return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     if (e->ring_cap == 0) return fail(AZX_ESTATE, "no replay ring: call azx_replay_create first");
     if (batch < 1 || batch > (1 << 24)) return fail(AZX_EINVAL, "batch outside [1, 2^24]");
     for (int64_t b = 0; b < batch; ++b)
@@ -1040,7 +1153,7 @@ extern "C" int azx_selftest_arith(int device, int n, const float *a, const float
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(AZX_ENODEV, "no HIP device visible");
-    HIPCHECK(hipSetDevice(device));
+    DevGuard guard(device);
     float *da, *db, *ds, *dd, *dm;
     HIPCHECK(hipMalloc(&da, n * 4)); HIPCHECK(hipMalloc(&db, n * 4)); HIPCHECK(hipMalloc(&ds, n * 4));
     HIPCHECK(hipMalloc(&dd, n * 4)); HIPCHECK(hipMalloc(&dm, n * 4));
@@ -1061,7 +1174,7 @@ extern "C" int azx_selftest_divide(int device, int n, const float *num, const fl
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(AZX_ENODEV, "no HIP device visible");
     if (n < 1 || !num || !den || !quot || !sqrt_tab) return fail(AZX_EINVAL, "bad argument");
-    HIPCHECK(hipSetDevice(device));
+    DevGuard guard(device);
     if (azx_init_geometry(device)) return fail(AZX_EHIP, "uploading the constant tables failed");
     float *da, *db, *dq, *dr;
     HIPCHECK(hipMalloc(&da, n * 4)); HIPCHECK(hipMalloc(&db, n * 4));
@@ -1081,7 +1194,7 @@ extern "C" int azx_selftest_dirichlet(int device, double alpha, int k, int n_row
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(AZX_ENODEV, "no HIP device visible");
     if (k < 1 || k > 128 || n_rows < 1 || !out) return fail(AZX_EINVAL, "bad argument");
-    HIPCHECK(hipSetDevice(device));
+    DevGuard guard(device);
     float *d = nullptr;
     HIPCHECK(hipMalloc(&d, sizeof(float) * (size_t)k * n_rows));
     if (!(alpha > 0.0)) return fail(AZX_EINVAL, "alpha must be positive");
@@ -1098,8 +1211,34 @@ extern "C" int azx_selftest_dirichlet(int device, double alpha, int k, int n_row
     return AZX_OK;
 }
 
+extern "C" int azx_debug_choose(azx_engine *e, int32_t *move_id, float *moves_prob) {
+    if (!e || !move_id || !moves_prob) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
+    DevEngine &d = e->d;
+    TRY(play_setup(e, std::max<int64_t>(e->q_alloc, 1 << 10), 1));
+    std::vector<GameHdr> before(d.G), after(d.G);
+    HIPCHECK(hipMemcpyAsync(before.data(), d.ghdr, sizeof(GameHdr) * d.G, hipMemcpyDeviceToHost, e->stream));
+    azx_launch_choose(d, e->stream);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(after.data(), d.ghdr, sizeof(GameHdr) * d.G, hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    std::vector<float> row(AZX_CELL_STRIDE);
+    for (int g = 0; g < d.G; ++g) {
+        const bool drew = after[g].n_rows == before[g].n_rows + 1;
+        move_id[g] = drew ? after[g].move_id : -1;
+        float *out = moves_prob + (size_t)g * d.ncells;
+        if (!drew) { std::fill(out, out + d.ncells, 0.0f); continue; }
+        HIPCHECK(hipMemcpyAsync(row.data(), d.row_prob + ((size_t)g * d.ncells + before[g].n_rows) * AZX_CELL_STRIDE,
+                                sizeof(float) * AZX_CELL_STRIDE, hipMemcpyDeviceToHost, e->stream));
+        HIPCHECK(hipStreamSynchronize(e->stream));
+        std::copy(row.begin(), row.begin() + d.ncells, out);
+    }
+    return AZX_OK;
+}
+
 extern "C" int azx_debug_counters_raw(azx_engine *e, uint64_t *out, int64_t n_games) {
     if (!e || !out) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     if (n_games != e->d.G) return fail(AZX_EINVAL, "n_games must equal the engine's game count");
     HIPCHECK(hipMemcpyAsync(out, e->d.counters, (size_t)n_games * CTR_COUNT * sizeof(unsigned long long),
                             hipMemcpyDeviceToHost, e->stream));
@@ -1109,6 +1248,7 @@ extern "C" int azx_debug_counters_raw(azx_engine *e, uint64_t *out, int64_t n_ga
 
 extern "C" int azx_debug_counters(azx_engine *e, uint64_t *out16) {
     if (!e || !out16) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
     CounterSnap snap;
     TRY(snap_counters(e, &snap));
     for (int j = 0; j < CTR_COUNT; ++j) out16[j] = snap.c[j];

@@ -55,7 +55,11 @@ struct alignas(64) GameHdr {
     int32_t n_rows;    // replay rows this game has written so far
     int32_t gen;       // games this slot has started so far: uid = slot + n_games * gen (a fixed
                        // seed reproduces every game whatever order the GPU schedules the slots in)
-    int32_t pad[7];
+    int32_t ply0;      // ply the game started from (azx_reset with a move prefix; 0 for restarts): its replay
+                       // row r was recorded at ply ply0 + r
+    int32_t parked;    // play mode: the game is finished but the harvest queue had no room for its rows; the slot
+                       // waits (active = 0) until the host has drained the queue (k_advance in unpark mode)
+    int32_t pad[5];
 };
 
 enum {   // counters[] slots
@@ -97,6 +101,7 @@ struct DevEngine {
     const float *gamma_tab;    // [AZX_GAMMA_TAB_FLOATS] device gamma sampler table for noise_alpha (mcts_kernels.hip)
     int32_t device_noise;
     uint64_t seed;
+    int32_t uid_stride, uid_offset;   // uid = (slot + G * gen) * uid_stride + uid_offset (azx_config.game_index_*)
     const float *prior_by_k;   // [ncells+1]
     int32_t prior_default;     // 1: prior_by_k is the default float32 1/k table
     unsigned long long *counters;   // [G][CTR_COUNT] per-game (no atomics); the host sums over games

@@ -103,6 +103,11 @@ struct Philox {
     }
 };
 __device__ __forceinline__ float u01(uint32_t x) { return ((x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+// global index of the gen-th game slot g starts (seeds come from the global game index, so
+// a fixed seed plays the same set of games on 1, 2 or 8 GPUs -- rank r of W passes stride W, offset r)
+__device__ __forceinline__ int64_t game_uid(const DevEngine &E, int g, int gen) {
+    return ((int64_t)g + (int64_t)E.G * gen) * E.uid_stride + E.uid_offset;
+}
 __device__ __forceinline__ Philox game_rng(const DevEngine &E, int64_t uid) {
     Philox ph;
     const uint64_t s = E.seed + (uint64_t)uid;
@@ -1422,7 +1427,9 @@ __global__ __launch_bounds__(64) void k_reset(DevEngine E, const int32_t *slots,
         gh->active = 1;
         gh->move_id = -1;
         gh->n_rows = 0;
-        if (assign_uid) { gh->uid = (int64_t)g + (int64_t)E.G * gh->gen; gh->gen += 1; }
+        gh->parked = 0;
+        gh->ply0 = ply;
+        if (assign_uid) { gh->uid = game_uid(E, g, gh->gen); gh->gen += 1; }
         th->arena = 0;
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -1441,10 +1448,13 @@ __device__ __forceinline__ void advance_body(const DevEngine &E, const int32_t *
     const int g = blockIdx.x;
     GameHdr *gh = E.ghdr + g;
     TreeHdr *th = E.thdr + g;
-    if (!gh->active) return;
+    // play_mode 2 = unpark: only the slots whose finished game found the harvest queue full take part,
+    // and they go straight to the harvest (the move was stepped when the game finished)
+    const bool parked = gh->parked != 0;
+    if (play_mode == 2 ? !parked : !gh->active) return;
     int status = th->status;
     const int mid = move_ids ? move_ids[g] : gh->move_id;
-    if (mid < 0 && status == 0) return;
+    if (!parked && mid < 0 && status == 0) return;
 
     HexWave<SLOTS> h;
     h.load(E.cells + (size_t)g * SLOTS * 64, lane);
@@ -1452,9 +1462,9 @@ __device__ __forceinline__ void advance_body(const DevEngine &E, const int32_t *
     h.color = gh->color;
     h.winner = gh->winner;
     int ply = gh->ply;
-    bool finished = false, errored = status != 0;
+    bool finished = parked, errored = !parked && status != 0;
 
-    if (!errored) {
+    if (!errored && !parked) {
         const Masks<SLOTS> mk = make_masks<SLOTS>(h, lane, E.ncells);
         // the mid-th legal move in ascending tile order (search_tree.py:306)
         int cell = -1;
@@ -1521,7 +1531,11 @@ __device__ __forceinline__ void advance_body(const DevEngine &E, const int32_t *
               (unsigned int)__builtin_amdgcn_readfirstlane((int)pos);
         if (!E.q_ring && pos + rows > (unsigned long long)E.q_cap) {
             // queue full: give the reservation back and park the slot until the host drains
-            if (lane == 0) { atomicAdd(E.q_count, (unsigned long long)(-(long long)rows)); gh->active = 0; }
+            if (lane == 0) {
+                atomicAdd(E.q_count, (unsigned long long)(-(long long)rows));
+                gh->active = 0;
+                gh->parked = 1;
+            }
             restart = false;
         } else {
             // the game's rows are contiguous at the source, and at the destination unless the ring
@@ -1559,12 +1573,13 @@ __device__ __forceinline__ void advance_body(const DevEngine &E, const int32_t *
                        nr * (AZX_CELL_STRIDE / 4));
             }
             const int64_t uid = gh->uid;
+            const int ply0 = gh->ply0;                         // row r was recorded at ply ply0 + r
             for (int r = lane; r < rows; r += 64) {
                 const size_t q = (size_t)((pos + r) % (unsigned long long)E.q_cap);
-                E.q_color[q] = r & 1;
+                E.q_color[q] = (ply0 + r) & 1;
                 E.q_k[q] = E.row_k[(size_t)g * E.ncells + r];
                 float rew = (float)(result - 2);               // play_game.py:64-65
-                if (r & 1) rew = -rew;
+                if ((ply0 + r) & 1) rew = -rew;
                 E.q_reward[q] = rew;
                 E.q_uid[q] = uid;
             }
@@ -1572,8 +1587,9 @@ __device__ __forceinline__ void advance_body(const DevEngine &E, const int32_t *
                 E.counters[(size_t)g * CTR_COUNT + CTR_GAMES] += 1ull;
                 E.counters[(size_t)g * CTR_COUNT + CTR_ROWS] += (unsigned long long)rows;
                 float last = (float)(result - 2);
-                if ((rows - 1) & 1) last = -last;
+                if ((ply0 + rows - 1) & 1) last = -last;
                 E.stat_sums[(size_t)g * 8 + 3] += (double)last;       // metrics['reward']
+                E.stat_sums[(size_t)g * 8 + 4] += (double)ply;        // game length from the empty board
             }
         }
     } else {
@@ -1589,7 +1605,9 @@ __device__ __forceinline__ void advance_body(const DevEngine &E, const int32_t *
             gh->ply = 0;
             gh->move_id = -1;
             gh->n_rows = 0;
-            gh->uid = (int64_t)g + (int64_t)E.G * gh->gen;
+            gh->ply0 = 0;
+            if (parked) { gh->parked = 0; gh->active = 1; }
+            gh->uid = game_uid(E, g, gh->gen);
             gh->gen += 1;
         }
         __builtin_amdgcn_s_waitcnt(0);

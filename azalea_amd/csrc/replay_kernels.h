@@ -17,3 +17,9 @@ void azx_launch_replay_put(const ReplayRows &src, const ReplayRows &ring, long l
 void azx_launch_replay_collate(const ReplayRows &ring, const long long *idx, int B, int ncells,
                                long long *color, int32_t *legal, long long *result, int32_t *board,
                                float *prob, float *reward, int32_t *max_k, hipStream_t st);
+void azx_launch_rows_export(const uint8_t *qb, const float *qp, long long n, int ncells, int32_t *board,
+                            float *prob, hipStream_t st);
+void azx_launch_rows_pack(const ReplayRows &src, const long long *uid, long long first, long long n, int ncells,
+                          uint8_t *rec, hipStream_t st);
+void azx_launch_records_put(const uint8_t *rec, const ReplayRows &ring, long long n, long long cap,
+                            long long write_idx, int ncells, hipStream_t st);

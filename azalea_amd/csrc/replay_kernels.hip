@@ -79,6 +79,87 @@ __global__ __launch_bounds__(64) void k_replay_collate(ReplayRows ring, const lo
     }
 }
 
+// azx_play's host hand-over: queue rows [0, n) widened on the device into the caller's layout (board
+// i32[n][ncells], moves_prob f32[n][ncells], row stride ncells), so the host side is one copy per array.
+__global__ __launch_bounds__(64) void k_rows_export(const uint8_t *qb, const float *qp, long long n, int ncells,
+                                                    int32_t *board, float *prob) {
+    const long long r = blockIdx.x;
+    if (r >= n) return;
+    for (int c = threadIdx.x; c < ncells; c += 64) {
+        board[r * ncells + c] = (int32_t)qb[r * AZX_CELL_STRIDE + c];
+        prob[r * ncells + c] = qp[r * AZX_CELL_STRIDE + c];
+    }
+}
+
+// ---- fixed-size replay records (the multi-GPU exchange unit) -------------------------
+// One record per row, AZX_RECORD_BYTES(ncells) bytes, 16-byte aligned fields:
+//   0 uid i64 | 8 reward f32 | 12 color i16 | 14 k i16 | 16 moves_prob f32[ncells] | 16+4*ncells board u8[ncells] | pad
+// Ranks pack their harvested rows (k_rows_pack), all-gather the records over xGMI (RCCL, device
+// tensors) and every rank appends all records to its ring (k_records_put) -- no host in the middle.
+__global__ __launch_bounds__(64) void k_rows_pack(ReplayRows src, const long long *uid, long long first, long long n,
+                                                  int ncells, uint8_t *rec) {
+    const long long i = blockIdx.x;
+    if (i >= n) return;
+    const long long r = first + i;
+    const int lane = threadIdx.x;
+    const size_t rb = AZX_RECORD_BYTES(ncells);
+    uint8_t *o = rec + (size_t)i * rb;
+    if (lane == 0) {
+        *reinterpret_cast<long long *>(o) = uid ? uid[r] : -1ll;
+        *reinterpret_cast<float *>(o + 8) = src.reward[r];
+        *reinterpret_cast<int16_t *>(o + 12) = (int16_t)src.color[r];
+        *reinterpret_cast<int16_t *>(o + 14) = (int16_t)src.k[r];
+    }
+    float *op = reinterpret_cast<float *>(o + 16);
+    uint8_t *ob = o + 16 + 4 * (size_t)ncells;
+    for (int c = lane; c < ncells; c += 64) {
+        op[c] = src.prob[r * AZX_CELL_STRIDE + c];
+        ob[c] = src.board[r * AZX_CELL_STRIDE + c];
+    }
+    for (size_t c = 16 + 5 * (size_t)ncells + lane; c < rb; c += 64) o[c] = 0;
+}
+
+// records [skip, n) enter the ring at (write_idx + i) mod cap, like k_replay_put
+__global__ __launch_bounds__(64) void k_records_put(const uint8_t *rec, ReplayRows ring, long long n, long long skip,
+                                                    long long cap, long long write_idx, int ncells) {
+    const long long i = skip + blockIdx.x;
+    if (i >= n) return;
+    const int lane = threadIdx.x;
+    const long long dst = (write_idx + i) % cap;
+    const uint8_t *o = rec + (size_t)i * AZX_RECORD_BYTES(ncells);
+    if (lane == 0) {
+        ring.reward[dst] = *reinterpret_cast<const float *>(o + 8);
+        ring.color[dst] = (int32_t)*reinterpret_cast<const int16_t *>(o + 12);
+        ring.k[dst] = (int32_t)*reinterpret_cast<const int16_t *>(o + 14);
+    }
+    const float *ip = reinterpret_cast<const float *>(o + 16);
+    const uint8_t *ib = o + 16 + 4 * (size_t)ncells;
+    for (int c = lane; c < AZX_CELL_STRIDE; c += 64) {
+        ring.prob[dst * AZX_CELL_STRIDE + c] = c < ncells ? ip[c] : 0.0f;
+        ring.board[dst * AZX_CELL_STRIDE + c] = c < ncells ? ib[c] : (uint8_t)0;
+    }
+}
+
+void azx_launch_rows_export(const uint8_t *qb, const float *qp, long long n, int ncells, int32_t *board,
+                            float *prob, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_rows_export, dim3((unsigned)n), dim3(64), 0, st, qb, qp, n, ncells, board, prob);
+}
+
+void azx_launch_rows_pack(const ReplayRows &src, const long long *uid, long long first, long long n, int ncells,
+                          uint8_t *rec, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_rows_pack, dim3((unsigned)n), dim3(64), 0, st, src, uid, first, n, ncells, rec);
+}
+
+void azx_launch_records_put(const uint8_t *rec, const ReplayRows &ring, long long n, long long cap,
+                            long long write_idx, int ncells, hipStream_t st) {
+    const long long skip = n > cap ? n - cap : 0;
+    if (n - skip <= 0) return;
+    hipLaunchKernelGGL(k_records_put, dim3((unsigned)(n - skip)), dim3(64), 0, st, rec, ring, n, skip, cap,
+                       write_idx, ncells);
+}
+
 void azx_launch_replay_put(const ReplayRows &src, const ReplayRows &ring, long long n, long long cap,
                            long long write_idx, hipStream_t st) {
     const long long skip = n > cap ? n - cap : 0;

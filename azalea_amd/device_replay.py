@@ -14,20 +14,24 @@ from typing import Dict, Iterator
 import numpy as np
 import torch
 
+from . import distributed as azdist
 from .replay_buffer import ReplayDataFrame
 
 _KEYS = ("color", "legal_moves", "result", "board", "moves_prob", "reward")
 
 
 class DeviceReplayBuffer:
-    def __init__(self, engine, capacity: int, contents: ReplayDataFrame = None):
+    def __init__(self, engine, capacity: int, contents: ReplayDataFrame = None, shared: bool = True):
         """`engine`: azalea_amd.engine.Engine whose self-play feeds the buffer (Player._get_engine).
-        `contents`: initial rows, like ReplayBuffer(contents)."""
+        `contents`: initial rows, like ReplayBuffer(contents).  `shared`: under torch.distributed every
+        rank plays its share of a refill and all ranks' rows enter every rank's ring."""
         self.engine = engine
         self.capacity = int(capacity)
         engine.replay_create(self.capacity)
         self.fresh_counter = 0
-        self.device = torch.device("cuda", engine.cfg.device)
+        self.shared = shared
+        self.last_exchange = None       # timing of the last shared refill (bench / diagnostics)
+        self.device = getattr(engine, "torch_device", None) or torch.device("cuda", engine.cfg.device)
         if contents is not None and len(contents):
             self.put(contents)
             self.fresh_counter = 0          # ReplayBuffer.__init__ starts with nothing fresh
@@ -63,7 +67,10 @@ class DeviceReplayBuffer:
             return {}
         if player is not None and hasattr(player, "prepare_device_engine"):
             player.prepare_device_engine(self.engine)     # push the trainer's current weights
-        rows, st = self.engine.replay_fill(int(np.ceil(refill)))
+        if self.shared and azdist.is_distributed():
+            rows, st = self._fill_shared(int(np.ceil(refill)))
+        else:
+            rows, st = self.engine.replay_fill(int(np.ceil(refill)))
         self.fresh_counter += rows
         games = max(1, st["games"])
         plies = max(1, st["plies"])
@@ -73,6 +80,45 @@ class DeviceReplayBuffer:
                 "search_value": games * st["sum_search_value"] / plies,
                 "search_root_width": games * st["sum_root_width"] / plies,
                 "action_logprob": games * st["sum_action_logprob"] / plies}
+
+    def _fill_shared(self, refill: int):
+        """One refill played by all ranks: each rank plays its share of whole games into its harvest
+        queue, packs the rows into fixed-size records ON THE DEVICE (k_rows_pack), the ranks all-gather
+        the record buffers (RCCL over xGMI; two collectives: counts, payload) and every rank appends
+        all of them, in rank order, to its HBM ring (k_records_put).  This replaces the reference's
+        pickled frames over worker pipes (process_pool.py:31-47, parallel_player.py:48-49); nothing but
+        the W row counts and the summed metrics visits the host."""
+        import time
+        eng = self.engine
+        quota = azdist.shard_quota(refill)
+        t0 = time.perf_counter()
+        if quota > 0:
+            n_local, st = eng.play_device(quota)
+        else:
+            n_local, st = 0, {}
+        t1 = time.perf_counter()
+        rec = torch.empty((n_local, eng.record_bytes), dtype=torch.uint8, device=self.device)
+        if n_local:
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)     # the caching allocator may recycle memory torch kernels still use
+            eng.rows_pack(0, n_local, rec.data_ptr())
+        t2 = time.perf_counter()
+        parts, counts = azdist.all_gather_records(rec)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        t3 = time.perf_counter()
+        for part, count in zip(parts, counts):
+            if count:
+                eng.replay_put_records(count, part.data_ptr())
+        t4 = time.perf_counter()
+        self.last_exchange = {"rows_per_rank": counts, "play_seconds": t1 - t0, "pack_seconds": t2 - t1,
+                              "allgather_seconds": t3 - t2, "ring_put_seconds": t4 - t3,
+                              "bytes_gathered": int(sum(counts)) * eng.record_bytes}
+        keys = ("games", "plies", "game_errors", "seconds", "sum_reward_last", "sum_search_value",
+                "sum_root_width", "sum_action_logprob")
+        total = azdist.all_reduce_metrics({k: float(st.get(k, 0.0)) for k in keys})
+        total["seconds"] /= max(1, len(counts))         # ranks play side by side
+        return int(sum(counts)), total
 
     # ---- minibatches --------------------------------------------------------------------------
     def sample(self, indices) -> Dict[str, torch.Tensor]:

@@ -3,15 +3,19 @@
 Self-play games are independent, so ranks never talk on the data path.  The only exchanges are
 (1) the replay-row all-gather when a Player.read is shared by all ranks and (2) a weight
 broadcast when the trainer updates the network.  Rows travel as ONE fixed-size
-byte record each (board u8[cells] | moves_prob f32[cells] | reward f32 | color i16 | k i16 |
-uid i64), padded to the largest per-rank count: two collectives per refill (counts, payload).
-Works with the gloo backend on CPU too (tests).
+byte record each (AZX_RECORD_BYTES, include/azx.h: uid i64 | reward f32 | color i16 | k i16 |
+moves_prob f32[cells] | board u8[cells]), padded to the largest per-rank count: two collectives
+per refill (counts, payload).  On the GPU path the records are packed from the engine's harvest
+queue by a kernel, gathered as device tensors and appended to the HBM ring by a kernel
+(DeviceReplayBuffer.consume); the host twins here serve Player.read's frames and the gloo tests.
 """
-from typing import Dict, Optional
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from . import _lib
 
 
 def is_distributed() -> bool:
@@ -25,64 +29,103 @@ def _comm_device() -> torch.device:
 
 
 def record_bytes(cells: int) -> int:
-    return cells + 4 * cells + 4 + 2 + 2 + 8
+    """AZX_RECORD_BYTES (include/azx.h)."""
+    return _lib.record_bytes(cells)
+
+
+def record_dtype(cells: int) -> np.dtype:
+    """numpy view of one record -- the layout k_rows_pack / k_records_put use on the device:
+    0 game_uid i64 | 8 reward f32 | 12 color i16 | 14 nlegal i16 | 16 moves_prob f32[cells] | board u8[cells] | pad."""
+    return np.dtype({"names": ["game_uid", "reward", "color", "nlegal", "moves_prob", "board"],
+                     "formats": ["<i8", "<f4", "<i2", "<i2", ("<f4", (cells,)), ("u1", (cells,))],
+                     "offsets": [0, 8, 12, 14, 16, 16 + 4 * cells],
+                     "itemsize": record_bytes(cells)})
 
 
 def pack_rows(rows: Dict[str, np.ndarray], cells: int) -> np.ndarray:
-    """rows as returned by Engine.play -> uint8 [P, record_bytes(cells)]."""
+    """rows as returned by Engine.play -> uint8 [P, record_bytes(cells)] (host twin of k_rows_pack)."""
     P = len(rows["reward"])
-    rec = np.zeros((P, record_bytes(cells)), np.uint8)
-    o = 0
-    rec[:, o:o + cells] = rows["board"].reshape(P, cells).astype(np.uint8); o += cells
-    rec[:, o:o + 4 * cells] = np.ascontiguousarray(rows["moves_prob"], np.float32).view(np.uint8).reshape(P, 4 * cells); o += 4 * cells
-    rec[:, o:o + 4] = np.ascontiguousarray(rows["reward"], np.float32).view(np.uint8).reshape(P, 4); o += 4
-    rec[:, o:o + 2] = np.ascontiguousarray(rows["color"], np.int16).view(np.uint8).reshape(P, 2); o += 2
-    rec[:, o:o + 2] = np.ascontiguousarray(rows["nlegal"], np.int16).view(np.uint8).reshape(P, 2); o += 2
-    rec[:, o:o + 8] = np.ascontiguousarray(rows["game_uid"], np.int64).view(np.uint8).reshape(P, 8)
-    return rec
+    rec = np.zeros(P, record_dtype(cells))
+    rec["game_uid"] = rows["game_uid"]
+    rec["reward"] = rows["reward"]
+    rec["color"] = rows["color"]
+    rec["nlegal"] = rows["nlegal"]
+    rec["moves_prob"] = np.asarray(rows["moves_prob"], np.float32).reshape(P, cells)
+    rec["board"] = np.asarray(rows["board"]).reshape(P, cells)
+    return rec.view(np.uint8).reshape(P, record_bytes(cells))
 
 
 def unpack_rows(rec: np.ndarray, board_size: int) -> Dict[str, np.ndarray]:
     cells = board_size * board_size
-    P = len(rec)
-    o = 0
-    board = rec[:, o:o + cells].astype(np.int32).reshape(P, board_size, board_size); o += cells
-    prob = np.ascontiguousarray(rec[:, o:o + 4 * cells]).view(np.float32).reshape(P, cells); o += 4 * cells
-    reward = np.ascontiguousarray(rec[:, o:o + 4]).view(np.float32).reshape(P); o += 4
-    color = np.ascontiguousarray(rec[:, o:o + 2]).view(np.int16).reshape(P).astype(np.int32); o += 2
-    k = np.ascontiguousarray(rec[:, o:o + 2]).view(np.int16).reshape(P).astype(np.int32); o += 2
-    uid = np.ascontiguousarray(rec[:, o:o + 8]).view(np.int64).reshape(P)
-    return dict(board=board, moves_prob=prob, reward=reward, color=color, nlegal=k, game_uid=uid)
+    r = np.ascontiguousarray(rec, np.uint8).reshape(-1, record_bytes(cells)).view(record_dtype(cells)).reshape(-1)
+    P = len(r)
+    return dict(board=r["board"].astype(np.int32).reshape(P, board_size, board_size),
+                moves_prob=np.ascontiguousarray(r["moves_prob"]), reward=np.ascontiguousarray(r["reward"]),
+                color=r["color"].astype(np.int32), nlegal=r["nlegal"].astype(np.int32),
+                game_uid=np.ascontiguousarray(r["game_uid"]))
+
+
+def empty_rows(board_size: int) -> Dict[str, np.ndarray]:
+    """A rank with nothing to contribute still joins the collectives with a 0-row table."""
+    return unpack_rows(np.zeros((0, record_bytes(board_size * board_size)), np.uint8), board_size)
+
+
+def all_gather_records(rec: torch.Tensor) -> Tuple[List[torch.Tensor], List[int]]:
+    """rec: uint8 [P, record_bytes] on the communication device (HBM under RCCL).  Two collectives:
+    the per-rank counts, then the records padded to the largest count -- a direct all-gather over
+    xGMI.  Returns the per-rank record tensors (views trimmed to their counts) and the counts, in rank
+    order; nothing touches the host except the W counts."""
+    world = dist.get_world_size()
+    dev = rec.device
+    counts_t = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts_t, torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev))
+    counts = [int(c) for c in counts_t.tolist()]
+    most = max(counts)
+    if most == 0:
+        return [rec[:0] for _ in range(world)], counts
+    if rec.shape[0] == most:
+        padded = rec.contiguous()
+    else:
+        padded = torch.zeros((most, rec.shape[1]), dtype=torch.uint8, device=dev)
+        padded[:rec.shape[0]] = rec
+    out = torch.empty((world * most, rec.shape[1]), dtype=torch.uint8, device=dev)   # rank blocks, concatenated
+    dist.all_gather_into_tensor(out, padded)
+    return [out[r * most:r * most + c] for r, c in enumerate(counts)], counts
 
 
 def all_gather_rows(rows: Dict[str, np.ndarray], board_size: int) -> Dict[str, np.ndarray]:
-    """Every rank contributes its rows; every rank gets all rows, in rank order."""
+    """Host rows (Player.read's frame path): every rank contributes its rows -- possibly none -- and every
+    rank gets all rows, in rank order."""
     if not is_distributed():
         return rows
     cells = board_size * board_size
-    dev = _comm_device()
-    world = dist.get_world_size()
-    local = torch.from_numpy(pack_rows(rows, cells)).to(dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([local.shape[0]], dtype=torch.int64, device=dev))
-    counts = [int(c.item()) for c in counts]
-    most = max(counts)
-    padded = torch.zeros((most, record_bytes(cells)), dtype=torch.uint8, device=dev)
-    padded[:local.shape[0]] = local
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded)
-    rec = torch.cat([p[:c] for p, c in zip(parts, counts)]).cpu().numpy()
+    local = torch.from_numpy(pack_rows(rows, cells)).to(_comm_device())
+    parts, _ = all_gather_records(local)
+    rec = torch.cat(parts).cpu().numpy() if parts else np.zeros((0, record_bytes(cells)), np.uint8)
     return unpack_rows(rec, board_size)
 
 
 def all_reduce_metrics(metrics: Dict[str, float]) -> Dict[str, float]:
-    """Sum the per-rank self-play metrics (parallel_player.py:50-51 sums over games)."""
+    """Sum the per-rank self-play metrics (parallel_player.py:50-51 sums over games).  Ranks may hold
+    different key sets (one that played nothing holds none), so the dicts themselves are gathered."""
     if not is_distributed():
         return metrics
-    keys = sorted(metrics)
-    t = torch.tensor([float(metrics[k]) for k in keys], dtype=torch.float64, device=_comm_device())
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return dict(zip(keys, t.tolist()))
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, {k: float(v) for k, v in metrics.items()})
+    total: Dict[str, float] = {}
+    for part in parts:
+        for k, v in part.items():
+            total[k] = total.get(k, 0.0) + v
+    return total
+
+
+def broadcast_int(value: int, src: int = 0) -> int:
+    """Every rank gets rank `src`'s integer (the shared seed base of the global game index)."""
+    if not is_distributed():
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=_comm_device())
+    dist.broadcast(t, src=src)
+    return int(t.item())
 
 
 def broadcast_weights(net: torch.nn.Module, src: int = 0) -> None:

@@ -20,12 +20,13 @@ class Engine:
     def __init__(self, board_size=11, n_games=1, simulations=400, search_batch_size=10,
                  exploration_coef=0.5, exploration_depth=15, noise_alpha=0.03, noise_scale=0.25,
                  temperature=1.0, evaluator=EVAL_UNIFORM, num_blocks=6, base_chans=64,
-                 nodes_per_game=0, flags=0, device=0, seed=0xBAD5EED5):
+                 nodes_per_game=0, flags=0, device=0, seed=0xBAD5EED5,
+                 game_index_stride=1, game_index_offset=0):
         self.L = _lib.lib()
         self.cfg = Config(board_size, n_games, simulations, search_batch_size,
                           float(np.float32(exploration_coef)), exploration_depth, noise_alpha,
                           noise_scale, temperature, evaluator, num_blocks, base_chans,
-                          nodes_per_game, flags, device, seed)
+                          nodes_per_game, flags, device, seed, game_index_stride, game_index_offset)
         self.h = C.c_void_p()
         check(self.L.azx_create(C.byref(self.cfg), C.byref(self.h)))
         self.n = board_size
@@ -254,6 +255,25 @@ class Engine:
         return dict(board=board[:n], color=color[:n], nlegal=nlegal[:n], moves_prob=prob[:n],
                     reward=reward[:n], game_uid=uid[:n]), st.as_dict()
 
+    def play_device(self, min_positions, max_plies=0):
+        """azx_play_device: whole games until >= min_positions rows sit in the harvest queue (in HBM)."""
+        st = PlayStats()
+        rows = C.c_int64(0)
+        check(self.L.azx_play_device(self.h, int(min_positions), int(max_plies), C.byref(rows), C.byref(st)))
+        return rows.value, st.as_dict()
+
+    def rows_pack(self, first, n, records_ptr):
+        """queue rows [first, first+n) -> fixed-size records in the device buffer at records_ptr."""
+        check(self.L.azx_rows_pack(self.h, int(first), int(n), C.c_void_p(int(records_ptr))))
+
+    def replay_put_records(self, n, records_ptr):
+        """n records from a device buffer into the replay ring (FIFO)."""
+        check(self.L.azx_replay_put_records(self.h, int(n), C.c_void_p(int(records_ptr))))
+
+    @property
+    def record_bytes(self):
+        return _lib.record_bytes(self.cells)
+
     def debug_counters(self):
         out = np.zeros(16, np.uint64)
         check(self.L.azx_debug_counters(self.h, _p(out, C.c_uint64)))
@@ -301,6 +321,13 @@ class Engine:
                                         C.byref(mk)))
         return mk.value
 
+    def debug_choose(self):
+        """azx_debug_choose: (move_id[G], moves_prob[G, cells]) of the device move draw on the current roots."""
+        mid = np.zeros(self.G, np.int32)
+        prob = np.zeros((self.G, self.cells), np.float32)
+        check(self.L.azx_debug_choose(self.h, _p(mid, C.c_int32), _p(prob, C.c_float)))
+        return mid, prob
+
     def debug_counters_raw(self):
         out = np.zeros((self.G, 16), np.uint64)
         check(self.L.azx_debug_counters_raw(self.h, _p(out, C.c_uint64), self.G))
@@ -325,6 +352,28 @@ def hex_replay(board_size, moves, lengths, device=0):
                                     stride, _p(res, C.c_int32), _p(nl, C.c_int32),
                                     _p(em, C.c_uint64), _p(fb, C.c_int32)))
     return res, nl, em, fb
+
+
+def random_prefixes(board_size, indices, max_len, seed, device=0):
+    """Seeded random legal move prefixes, one per global game index in `indices`, of uniformly drawn
+    lengths in [0, max_len] (cut one move short of a win if the random stones happen to finish the game).
+    Used to start a pool of concurrent games out of phase (bench.py: a pool that restarts finished games in
+    place is, in steady state, spread over all plies -- not lined up on the empty board).  Game i's prefix
+    depends on (seed, i) only, so it does not change with the number of ranks.  The rules run on the device
+    (azx_hex_replay)."""
+    idx = np.asarray(indices, np.int64)
+    cells = board_size * board_size
+    perms = np.empty((len(idx), cells), np.int32)
+    want = np.empty(len(idx), np.int64)
+    for j, i in enumerate(idx):
+        rng = np.random.RandomState((int(seed) + 0x9E3779B1 * int(i)) % (2 ** 32))
+        want[j] = rng.randint(0, max_len + 1)
+        perms[j] = rng.permutation(cells) + 1
+    res, _, _, _ = hex_replay(board_size, perms, np.full(len(idx), cells, np.int32), device=device)
+    won = res != 0
+    first_win = np.where(won.any(1), won.argmax(1), cells)      # stones on the board before the winning move
+    length = np.minimum(want, first_win)
+    return [perms[j, :length[j]].tolist() for j in range(len(idx))]
 
 
 def selftest_arith(a, b, device=0):

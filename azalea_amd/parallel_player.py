@@ -30,21 +30,40 @@ Metrics = Dict[str, float]
 
 
 def rows_to_frame(rows) -> ReplayDataFrame:
-    """Engine rows -> the reference's struct-of-lists frame (replay_buffer.py:11-38)."""
+    """Engine rows -> the reference's struct-of-lists frame (replay_buffer.py:11-38).  The per-row
+    arrays are cut out of whole-table numpy passes (one nonzero for every row's legal moves, one
+    astype per table); only the GameState constructors run per row."""
     frame = ReplayDataFrame()
+    P = len(rows["reward"])
+    if P == 0:
+        return frame
     n = rows["board"].shape[-1]
-    for i in range(len(rows["reward"])):
-        board = rows["board"][i].astype(np.int32).reshape(n, n)
-        legal = (np.flatnonzero(board.ravel() == 0) + 1).astype(np.int32)
-        k = int(rows["nlegal"][i])
-        assert k == len(legal)
-        frame.state.append(HexGameState(int(rows["color"][i]), legal, 0, board))
-        frame.moves_prob.append(rows["moves_prob"][i, :k].astype(np.float32))
-        frame.reward.append(np.float32(rows["reward"][i]))
+    boards = np.ascontiguousarray(rows["board"], np.int32).reshape(P, n, n)
+    flat = boards.reshape(P, n * n)
+    ri, ci = np.nonzero(flat == 0)                                   # row-major: ascending tiles per row
+    counts = np.bincount(ri, minlength=P)
+    k = np.asarray(rows["nlegal"], np.int64)
+    if not np.array_equal(counts, k):
+        raise AssertionError("replay rows: legal-move counts do not match the boards")
+    ends = np.cumsum(counts)
+    legal_all = (ci + 1).astype(np.int32)
+    probs = np.ascontiguousarray(rows["moves_prob"], np.float32)
+    color = np.asarray(rows["color"]).tolist()
+    reward = np.asarray(rows["reward"], np.float32)
+    state, mp = frame.state, frame.moves_prob
+    s = 0
+    for i in range(P):
+        e = int(ends[i])
+        state.append(HexGameState(color[i], legal_all[s:e], 0, boards[i]))
+        mp.append(probs[i, :e - s])
+        s = e
+    frame.reward.extend(reward)       # np.float32 scalars, like play_game.py:64-65
     return frame
 
 
 class Player:
+    MAX_BARREN_PRODUCTIONS = 1000     # consecutive productions without a finished game before read() gives up
+
     def __init__(self, pool, agents: Sequence, *, n_games: int = None, gather: bool = True):
         self.agents = agents
         self.running = True
@@ -54,24 +73,40 @@ class Player:
         self._engine = None
         self._engine_key = None
         self._seed_base = None
+        self._skipped = 0              # games dropped because of SearchTreeFull since the last read
 
     # ---- reference surface -------------------------------------------------------------------
     def read(self, size) -> Tuple[ReplayDataFrame, Metrics]:
-        """Whole games until at least `size` positions (parallel_player.py:41-52)."""
-        quota = azdist.shard_quota(size) if (self.gather and azdist.is_distributed()) else size
+        """Whole games until at least `size` positions (parallel_player.py:41-52).  A game that
+        overflowed its tree (SearchTreeFull) is skipped like the reference's worker does
+        (parallel_player.py:73-76) and counted in metrics['game_error']."""
+        shared = self.gather and azdist.is_distributed()
+        quota = azdist.shard_quota(size) if shared else size
         rows_list, metrics = [], defaultdict(float)
-        have = 0
+        have, barren = 0, 0
         while have < quota:
             if not self._games:
                 self._produce(quota - have)
+                if not self._games:
+                    barren += 1
+                    if barren > self.MAX_BARREN_PRODUCTIONS:
+                        raise RuntimeError("self-play produced no finished game in %d attempts" % barren)
+                    continue
             rows, gm = self._games.popleft()
             rows_list.append(rows)
             have += len(rows["reward"])
             for name, v in gm.items():
                 metrics[name] += v
-        rows = {k: np.concatenate([r[k] for r in rows_list]) for k in rows_list[0]}
-        if self.gather and azdist.is_distributed():
-            rows = azdist.all_gather_rows(rows, rows["board"].shape[-1])
+        if self._skipped:
+            metrics["game_error"] += self._skipped
+            self._skipped = 0
+        n = self.agents[0].game.board_size
+        if rows_list:
+            rows = {k: np.concatenate([r[k] for r in rows_list]) for k in rows_list[0]}
+        else:
+            rows = azdist.empty_rows(n)       # quota 0 (size < world): still join the collectives
+        if shared:
+            rows = azdist.all_gather_rows(rows, n)
             metrics = azdist.all_reduce_metrics(dict(metrics))
         return rows_to_frame(rows), dict(metrics)
 
@@ -118,6 +153,7 @@ class Player:
             _, frame, gm = play_game(self.agents, collect_data=True)
         except SearchTreeFull:
             logging.warning("game failed because of SearchTreeFull (skipped)")
+            self._skipped += 1
             return
         n = self.agents[0].game.board_size
         P = len(frame)
@@ -133,8 +169,10 @@ class Player:
 
     def _get_engine(self, pol: Policy):
         n = self.agents[0].game.board_size
-        rank = torch.distributed.get_rank() if azdist.is_distributed() else 0
-        key = (n, pol.simulations, pol.search_batch_size, float(pol.exploration_coef),
+        rank, world = ((torch.distributed.get_rank(), torch.distributed.get_world_size())
+                       if azdist.is_distributed() else (0, 1))
+        device = (pol.net.device.index or 0) if pol.net.device.type == "cuda" else 0
+        key = (n, device, pol.simulations, pol.search_batch_size, float(pol.exploration_coef),
                pol.exploration_depth, pol.exploration_noise_alpha, pol.exploration_noise_scale,
                pol.exploration_temperature, pol.num_blocks, pol.base_chans,
                bool(pol.settings.get("move_sampling")), bool(pol.settings.get("move_exploration")))
@@ -144,9 +182,9 @@ class Player:
             sampling = pol.settings.get("move_sampling", False)
             explore = sampling and pol.settings.get("move_exploration", False)
             if self._seed_base is None:
-                # each game draws from its own stream: seed base + global game index
-                self._seed_base = int(pol.rng.randint(0, 2 ** 31 - 1)) + (rank << 40)
-            device = pol.net.device.index or 0 if pol.net.device.type == "cuda" else 0
+                # each game draws from its own stream: seed base + GLOBAL game index; rank 0's
+                # base is shared, rank r of W plays the games r, r+W, ...: the set of games does not depend on W
+                self._seed_base = azdist.broadcast_int(int(pol.rng.randint(0, 2 ** 31 - 1)))
             self._engine = _eng.Engine(
                 board_size=n, n_games=self.n_games, simulations=pol.simulations,
                 search_batch_size=pol.search_batch_size, exploration_coef=pol.exploration_coef,
@@ -155,7 +193,7 @@ class Player:
                 noise_scale=pol.exploration_noise_scale if explore else 0.0,
                 temperature=pol.exploration_temperature if sampling else 0.0,
                 evaluator=_eng.EVAL_RESNET, num_blocks=pol.num_blocks, base_chans=pol.base_chans,
-                device=device, seed=self._seed_base)
+                device=device, seed=self._seed_base, game_index_stride=world, game_index_offset=rank)
             self._engine_key = key
         return self._engine
 
@@ -164,6 +202,7 @@ class Player:
         self._push_weights(eng, pol)
         rows, st = eng.play(max(1, int(want)))
         uid = rows["game_uid"]
+        self._skipped += int(st["game_errors"])
         if len(uid) == 0:
             return
         plies = max(1, st["plies"])
@@ -172,13 +211,10 @@ class Player:
                    "action_logprob": st["sum_action_logprob"] / plies}
         starts = np.flatnonzero(np.r_[True, uid[1:] != uid[:-1]])
         ends = np.r_[starts[1:], len(uid)]
-        errs = st["game_errors"]
         for s, e in zip(starts, ends):
             game = {k: v[s:e] for k, v in rows.items()}
             gm = dict(games=1, reward=float(game["reward"][-1]), moves_per_game=int(e - s),
-                      seconds_per_game=st["seconds"] / max(1, st["games"]), game_error=errs,
-                      **per_ply)
-            errs = 0
+                      seconds_per_game=st["seconds"] / max(1, st["games"]), **per_ply)
             self._games.append((game, gm))
 
     @staticmethod

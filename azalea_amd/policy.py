@@ -138,18 +138,18 @@ class Policy:
         return isinstance(self._net, HexNetwork)
 
     def _get_engine(self, board_size):
+        device = 0
+        if self._uses_device_net() and self._net.device.type == "cuda":
+            device = self._net.device.index or 0
         key = (board_size, self.simulations, self.search_batch_size, float(self.exploration_coef),
                self._uses_device_net(), getattr(self, "num_blocks", 0), getattr(self, "base_chans", 0),
-               self.keep_reference_arena)
+               self.keep_reference_arena, device)          # a net moved to another GPU gets a new engine there
         if self._engine is None or key != self._engine_key:
             if self._engine is not None:
                 self._engine.close()
             sel = (self.simulations // self.search_batch_size + 1) * self.search_batch_size
             cells = board_size * board_size
             cap = (sel + 1) * cells * (cells + 1) // 2 + 1024 if self.keep_reference_arena else 0
-            device = 0
-            if self._uses_device_net() and self._net.device.type == "cuda":
-                device = self._net.device.index or 0
             self._engine = _eng.Engine(
                 board_size=board_size, n_games=1, simulations=self.simulations,
                 search_batch_size=self.search_batch_size, exploration_coef=self.exploration_coef,

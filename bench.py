@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- self-play throughput of the HIP engine (games/s + MCTS sims/s, 11x11 Hex @ 400 sims).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tree|resnet]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload selfplay|resnet|tree]
 
 A "step" is one engine move: every one of the `--games` concurrent games runs a full
 400-simulation search ((400//10+1)*10 = 410 select_leaf calls, mcts.py:268), draws its move on
-the device and advances; finished games restart in place (with the uniform evaluator all timed
-moves run in one persistent launch, every game looping search -> move draw -> step on its own
-wavefront: K steps = K moves of each game).  Inputs are synthetic (all games start
-from the empty board, random-init weights for the resnet workload) and already resident in HBM
-when the timed region starts.
+the device and advances; finished games are harvested whole and their slots restart in place.
+Inputs are synthetic (random-init weights, device RNG) and already resident in HBM when the timed
+region starts.
 
-Default workload = BASELINE.json configs[1]: 4096 concurrent 11x11 games, HIP movegen + MCTS
-kernels only, uniform priors (no net) -- HBM-bound, priced against the SURVEY 8(d) byte model.
-`--workload resnet` = configs[2] (6x64 resnet forward per leaf batch, MFMA-bound).
+Default workload = the north-star headline, BASELINE.json configs[2]: 4096 concurrent 11x11 games,
+400 sims/move, 6x64 resnet forward on the MFMA cores (MFMA-bound; `roofline` prices the tower +
+heads launch pair).  The tree-only sub-benchmark, configs[1] (uniform priors, no net: HBM model of
+SURVEY 8(d)), is measured the same way right after it and nested in the same line as "tree".
+`--workload resnet` / `--workload tree` run one of the two alone (profiling).
 
-N>1 is launched by the driver with torch.distributed.run, one rank per GPU: games shard
-across ranks with no data-path collective (weak scaling); the barrier + max-over-ranks timing
-use RCCL.  One JSON line is printed by rank 0.
+Steady state: a pool that restarts finished games in place is, after its first game, spread over
+all plies.  Starting every slot from the empty board would time the opening only (no game can end
+in the first 2N-1 moves), so before the warm-up each slot is reset to a seeded random legal
+position of 0..`--desync` plies (untimed; `--desync 0` keeps the lock-step start).  `games_per_sec`
+= games finished inside the timed region / its duration; `games_per_sec_steady` = plies/s over the
+mean length of those games -- the two agree when the pool is in steady state.
+
+N>1 is launched by the driver with torch.distributed.run, one rank per GPU: games shard across
+ranks by global game index (rank r of W plays games r, r+W, ...: a fixed seed plays the same games
+whatever W is) with no data-path collective (weak scaling); the barrier + max-over-ranks timing
+use RCCL.  After the timed region the ranks exchange one replay refill the way a shared
+DeviceReplayBuffer.consume does (records packed on the device, all-gather, ring put) and report
+its duration as `replay_allgather`.  One JSON line is printed by rank 0.
 """
 import argparse
 import json
@@ -54,26 +64,204 @@ def model_bytes(st):
     return 8 * D + 12 * ki + 32 * D + 16 * (D + sel) + 28 * kl + 8 * ev
 
 
-def cpu_baseline(args, net_state=None):
+def cpu_baseline(args, workload, net_state=None):
     """The CPU oracle (oracle/, a C restatement pinned against the reference's golden vectors)
     timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import oracle as orc
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
-    if args.workload == "tree":
-        games, max_plies, net = 2 * threads, 300, None
+    if workload == "tree":
+        games, max_plies, net, start = 2 * threads, 300, None, 0
         sample = "%d whole games, uniform priors, %d sims/move, one game per thread" % (games, args.sims)
     else:
-        games, max_plies = threads, 2
+        games, max_plies, start = threads, 2, args.desync
         net = orc.Net(args.board, args.blocks, args.chans, net_state)
-        sample = "%d games x first %d plies, 6x64 resnet fp32 direct conv, %d sims/move" % (
-            games, max_plies, args.sims)
+        sample = ("%d games x %d plies each from seeded random mid-game positions (0..%d stones, like the "
+                  "GPU pool), %dx%d resnet fp32 direct conv, %d sims/move, one game per thread"
+                  % (games, max_plies, start, args.blocks, args.chans, args.sims))
     out = orc.bench_selfplay(args.board, args.sims, args.batch, games, threads, net=net,
-                             max_plies=max_plies, seed=args.seed)
+                             max_plies=max_plies, seed=args.seed, start_max=start)
     sims_per_s = out["selects"] / out["seconds"]
-    return {"value": sims_per_s, "unit": "sims/s", "cores": threads, "kind": "port",
-            "sample": sample, "seconds": out["seconds"], "plies": out["plies"],
-            "games_per_s": (out["games"] / out["seconds"]) if args.workload == "tree" else None}
+    base = {"value": sims_per_s, "unit": "sims/s", "cores": threads, "kind": "port",
+            "sample": sample, "seconds": out["seconds"], "plies": out["plies"]}
+    if workload == "tree":
+        base["games_per_s"] = out["games"] / out["seconds"]
+    else:
+        base["plies_per_s"] = out["plies"] / out["seconds"]
+    return base
+
+
+def pmc_traffic(name, key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
+    command (tools/prof_pmc_r2.sh: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction of
+    MI355X_MICROARCH.md).  Only attached when the file was recorded for exactly this configuration."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
+    t = json.load(open(path))
+    if t.get("bench_key") != key:
+        return None, None
+    return t.get("hbm_bytes_per_launch"), "profiles/%s (PMC, same command)" % name
+
+
+def run_workload(workload, args, rank, world, local_rank, steps, warmup, sync, torch):
+    """One engine, de-synchronised, warmed up and timed for `steps` moves.  Returns (st, elapsed, extras)."""
+    from azalea_amd import engine as eng
+    evaluator = eng.EVAL_UNIFORM if workload == "tree" else eng.EVAL_RESNET
+    E = eng.Engine(board_size=args.board, n_games=args.games, simulations=args.sims,
+                   search_batch_size=args.batch, exploration_coef=0.5, exploration_depth=15,
+                   noise_alpha=0.03, noise_scale=args.noise_scale, temperature=1.0, evaluator=evaluator,
+                   num_blocks=args.blocks, base_chans=args.chans, device=local_rank,
+                   nodes_per_game=args.nodes_per_game, seed=args.seed,
+                   game_index_stride=world, game_index_offset=rank)
+    extras = {"net_state": None}
+    if workload == "resnet":
+        from azalea_amd.network import HexNetwork
+        torch.manual_seed(0)
+        net = HexNetwork(board_size=args.board, num_blocks=args.blocks, base_chans=args.chans)
+        net.eval().to("cuda:%d" % local_rank)
+        sd = net.state_dict()
+        E.set_weights({k: (v.data_ptr(), v.numel()) for k, v in sd.items()
+                       if v.dtype == torch.float32}, on_device=True)
+        extras["net_state"] = {k: v.detach().cpu().numpy() for k, v in sd.items()}
+    if args.desync > 0:
+        import numpy as np
+        idx = np.arange(args.games, dtype=np.int64) * world + rank      # global game indices of the slots
+        E.reset(moves=eng.random_prefixes(args.board, idx, args.desync, args.seed, device=local_rank))
+    if warmup:
+        E.play_steps(warmup)
+    sync()
+    t0 = time.perf_counter()
+    st = E.play_steps(steps)          # blocks until the engine stream has drained
+    sync()
+    elapsed = time.perf_counter() - t0
+    extras["engine"] = E
+    return st, elapsed, extras
+
+
+def reduce_over_ranks(dist, torch, elapsed, sums):
+    if dist is None:
+        return elapsed, sums
+    cdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    s = torch.tensor(sums, device=cdev, dtype=torch.float64)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    return float(t.item()), [float(x) for x in s.tolist()]
+
+
+SUM_KEYS = ("selects", "games", "plies", "evals", "positions", "sum_game_length", "game_errors")
+
+
+def throughput_fields(st_sums, elapsed, steps):
+    selects, games, plies, evals, positions, glen, errors = st_sums
+    out = {"value": selects / elapsed, "unit": "sims/s",
+           "games_per_sec": games / elapsed, "plies_per_sec": plies / elapsed,
+           "mean_game_length": (glen / games) if games else None,
+           "games_per_sec_steady": (plies / elapsed) / (glen / games) if games and glen else None,
+           "ms_per_step": 1e3 * elapsed / steps,
+           "plies": plies, "games_finished": games, "game_errors": errors, "replay_rows": positions,
+           "evals": evals, "elapsed_s": elapsed}
+    return out
+
+
+def tree_roofline(st, args, steps, warmup):
+    b = model_bytes(st)
+    achieved = b / st["mcts_seconds"] / 1e9 if st["mcts_seconds"] > 0 else 0.0
+    kl = max(1, st.get("mcts_kernel_launches") or st["mcts_launches"])
+    persistent = kl < st["mcts_launches"]
+    roof = {
+        "kernel": ("k_play<2> (select+expand+backup, move draw and game step of every game; "
+                   "one persistent launch for all %d timed moves)" % steps) if persistent else
+                  "k_mcts<2, FAST> (select+expand+backup, one launch per move)",
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "bytes_per_launch": b / kl,
+        "avg_launch_ms": 1e3 * st["mcts_seconds"] / kl,
+        "launches": kl,
+        "moves_per_launch": st["mcts_launches"] / kl,
+        "ms_per_move": 1e3 * st["mcts_seconds"] / max(1, st["mcts_launches"]),
+        "bytes_per_sim": b / max(1, st["selects"]),
+        "mean_depth": st["sum_depth"] / max(1, st["selects"]),
+        "note": ("algorithmic bytes follow SURVEY 8(d)'s six-array reference model; the kernel keeps the root level "
+                 "on chip, so its measured HBM traffic is below the model and it is issue-bound, not HBM-bound "
+                 "(DESIGN 3.1)"),
+    }
+    key = [args.games, args.board, args.sims, args.batch, steps, warmup, args.noise_scale, args.desync]
+    roof["traffic"], src = pmc_traffic("r2_tree_pmc_traffic.json", key)
+    if src:
+        roof["traffic_source"] = src
+    return roof
+
+
+def resnet_roofline(st, args, steps, warmup):
+    # dominant kernels: the residual tower + heads, one launch pair per leaf batch, timed with HIP events on
+    # the engine stream.  ALGORITHMIC flops (SURVEY 8(d): 107 851 784 per evaluated position) over that
+    # time, against the dense MFMA peak of the dtype the tower issues: f16 (the fp32 operands are carried as
+    # hi+lo f16 pairs, 3 MFMAs per product).
+    flops = st["evals"] * flop_per_position(args.board, args.blocks, args.chans)
+    net_s = st["net_seconds"] if st["net_seconds"] > 0 else st["seconds"]
+    achieved = flops / net_s / 1e12
+    shape32 = os.environ.get("AZX_TOWER_SHAPE") == "32"
+    if args.chans == 64 and args.board <= 11:
+        kern = "k_tower_f16x3 + k_heads" if shape32 else "k_tower_f16x3_s16 + k_heads"
+    elif args.chans % 128 == 0:
+        kern = ("k_conv_wide_f16x3" if shape32 else "k_conv_wide_f16x3_s16") + " x %d + k_heads" % (2 * args.blocks)
+    else:
+        kern = "tower + k_heads"
+    roof = {
+        "kernel": kern + " (%dx%d resnet forward of one leaf batch)" % (args.blocks, args.chans),
+        "bound": "mfma", "achieved": achieved, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+        "frac": achieved / F16_MFMA_PEAK_TF, "traffic": None,
+        "issued_mfma_tflops": 3.0 * achieved, "issued_frac": 3.0 * achieved / F16_MFMA_PEAK_TF,
+        "vs_fp32_mfma_peak": achieved / F32_MFMA_PEAK_TF,
+        "avg_launch_ms": 1e3 * net_s / max(1, st["net_launches"]), "launches": st["net_launches"],
+        "positions_per_launch": st["evals"] / max(1, st["net_launches"]),
+        "flop_per_launch": flops / max(1, st["net_launches"]),
+        "net_share_of_step": net_s / st["seconds"] if st["seconds"] > 0 else None,
+        "tree_share_of_step": st["mcts_seconds"] / st["seconds"] if st["seconds"] > 0 else None,
+    }
+    key = [args.games, args.board, args.sims, args.batch, args.blocks, args.chans, steps, warmup,
+           args.noise_scale, args.desync]
+    roof["traffic"], src = pmc_traffic("r2_resnet_pmc_traffic.json", key)
+    if src:
+        roof["traffic_source"] = src
+    return roof
+
+
+def replay_exchange(E, st, dist, torch, local_rank):
+    """One replay refill the way a DeviceReplayBuffer shared by all ranks takes it: the rows this
+    rank harvested are packed into fixed-size records on the device, all-gathered over RCCL and appended to
+    the rank's HBM ring.  The bench's harvest queue wraps around, so the most recent rows are used."""
+    import numpy as np
+    world = dist.get_world_size() if dist is not None else 1
+    dev = torch.device("cuda", local_rank)
+    rows, st2 = E.play_device(1, max_plies=40)    # a short top-up through the Player.read path: whole games, queued
+    rb = E.record_bytes
+    E.replay_create(max(1, rows) * world + 1)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    rec = torch.empty((rows, rb), dtype=torch.uint8, device=dev)
+    if rows:
+        E.rows_pack(0, rows, rec.data_ptr())
+    t_pack = time.perf_counter() - t0
+    t_gather = 0.0
+    parts, counts = [rec], [rows]
+    if dist is not None:
+        from azalea_amd import distributed as azdist
+        t1 = time.perf_counter()
+        parts, counts = azdist.all_gather_records(rec)
+        torch.cuda.synchronize(dev)
+        t_gather = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    for p, c in zip(parts, counts):
+        if c:
+            E.replay_put_records(c, p.data_ptr())
+    t_put = time.perf_counter() - t2
+    total = int(np.sum(counts))
+    return {"ranks": world, "rows_per_rank": counts, "record_bytes": rb, "bytes_gathered": total * rb,
+            "pack_seconds": t_pack, "allgather_seconds": t_gather, "ring_put_seconds": t_put,
+            "path": "k_rows_pack -> all_gather(counts) + all_gather(records, device tensors) -> k_records_put"}
 
 
 def main():
@@ -81,7 +269,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["tree", "resnet"], default="tree")
+    ap.add_argument("--workload", choices=["selfplay", "tree", "resnet"], default="selfplay",
+                    help="selfplay = configs[2] headline with the configs[1] tree-only numbers nested (default)")
+    ap.add_argument("--tree-steps", type=int, default=130, help="timed moves of the nested tree-only run")
+    ap.add_argument("--tree-warmup", type=int, default=20)
     ap.add_argument("--games", type=int, default=4096)
     ap.add_argument("--board", type=int, default=11)
     ap.add_argument("--sims", type=int, default=400)
@@ -90,14 +281,21 @@ def main():
     ap.add_argument("--chans", type=int, default=64)
     ap.add_argument("--seed", type=int, default=0xBAD5EED5)
     ap.add_argument("--noise-scale", type=float, default=0.25)
+    ap.add_argument("--desync", type=int, default=None,
+                    help="start slot i from a seeded random legal position of 0..DESYNC plies (default: "
+                         "about one game length, 92 on 11x11; 0 = every game from the empty board)")
     ap.add_argument("--nodes-per-game", type=int, default=0,
                     help="tree arena capacity per game (0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-replay-exchange", action="store_true")
     args = ap.parse_args()
+    headline = "tree" if args.workload == "tree" else "resnet"
     if args.steps is None:
-        args.steps = 130 if args.workload == "tree" else 4
+        args.steps = 130 if headline == "tree" else 20
     if args.warmup is None:
-        args.warmup = 20 if args.workload == "tree" else 1
+        args.warmup = 20 if headline == "tree" else 5
+    if args.desync is None:
+        args.desync = int(round(0.76 * args.board * args.board))     # mean self-play game length, random-init net
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,137 +321,80 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine is HIP-only (no CPU fallback)")
 
-    from azalea_amd import engine as eng
-    evaluator = eng.EVAL_UNIFORM if args.workload == "tree" else eng.EVAL_RESNET
-    # per-game seeds come from the global game index: rank r owns uids r*2^40 + ...
-    E = eng.Engine(board_size=args.board, n_games=args.games, simulations=args.sims,
-                   search_batch_size=args.batch, exploration_coef=0.5, exploration_depth=15,
-                   noise_alpha=0.03, noise_scale=args.noise_scale, temperature=1.0, evaluator=evaluator,
-                   num_blocks=args.blocks, base_chans=args.chans, device=local_rank,
-                   nodes_per_game=args.nodes_per_game,
-                   seed=args.seed + (rank << 40))
-    net_state = None
-    if args.workload == "resnet":
-        from azalea_amd.network import HexNetwork
-        torch.manual_seed(0)
-        net = HexNetwork(board_size=args.board, num_blocks=args.blocks, base_chans=args.chans)
-        net.eval().to("cuda:%d" % local_rank)
-        sd = net.state_dict()
-        E.set_weights({k: (v.data_ptr(), v.numel()) for k, v in sd.items()
-                       if v.dtype == torch.float32}, on_device=True)
-        net_state = {k: v.detach().cpu().numpy() for k, v in sd.items()}
-
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    if args.warmup:
-        E.play_steps(args.warmup)
-    sync()
-    t0 = time.perf_counter()
-    st = E.play_steps(args.steps)          # blocks until the engine stream has drained
-    sync()
-    elapsed = time.perf_counter() - t0
+    # ---- headline workload --------------------------------------------------------------------
+    st, elapsed, ex = run_workload(headline, args, rank, world, local_rank, args.steps, args.warmup, sync, torch)
+    elapsed, sums = reduce_over_ranks(dist, torch, elapsed, [float(st[k]) for k in SUM_KEYS])
+    E = ex["engine"]
+    exchange = None
+    if headline == "resnet" and not args.no_replay_exchange:
+        exchange = replay_exchange(E, st, dist, torch, local_rank)
+    E.close()
 
-    sums = [float(st[k]) for k in ("selects", "games", "plies", "evals", "positions")]
-    if dist is not None:
-        cdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        s = torch.tensor(sums, device=cdev, dtype=torch.float64)
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        sums = [float(x) for x in s.tolist()]
-    selects, games, plies, evals, positions = sums
-
+    selects_per_search = (args.sims // args.batch + 1) * args.batch
+    common_cfg = {"games_per_gpu": args.games, "board": args.board, "simulations": args.sims,
+                  "search_batch_size": args.batch, "c_puct": 0.5, "noise": "dirichlet(0.03) eps 0.25, device RNG",
+                  "start": ("slots de-synchronised: slot i starts from a seeded random legal position of 0..%d "
+                            "plies (untimed), then %d warm-up moves" % (args.desync, args.warmup)) if args.desync
+                           else "all games from the empty board (lock-step)",
+                  "sharding": "games sharded across ranks by global game index, no data-path collective"}
+    line = None
     if rank == 0:
-        sims_per_s = selects / elapsed
-        line = {
-            "metric": "mcts_sims_per_sec", "value": sims_per_s, "unit": "sims/s",
-            "games_per_sec": games / elapsed,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": ("BASELINE configs[1]: %d concurrent %dx%d Hex games per GPU, HIP movegen+MCTS "
-                             "kernels only, uniform priors (no net), %d sims/move (%d select_leaf calls)"
-                             if args.workload == "tree" else
-                             ("BASELINE configs[2]" if (args.board, args.blocks, args.chans) == (11, 6, 64) else
-                              "BASELINE configs[4] shape on one GPU" if (args.board, args.blocks, args.chans) == (13, 19, 256)
-                              else "resnet self-play") +
-                             ": %d concurrent %dx%d Hex games per GPU, %d sims/move (%d select_leaf calls), " +
-                             "%dx%d resnet forward on split-f16 MFMA (fp32-accurate), random-init weights"
-                             % (args.blocks, args.chans))
-                            % (args.games, args.board, args.board, args.sims,
-                               (args.sims // args.batch + 1) * args.batch),
-                "games_per_gpu": args.games, "board": args.board, "simulations": args.sims,
-                "search_batch_size": args.batch, "c_puct": 0.5, "noise": "dirichlet(0.03) eps 0.25, device RNG",
-                "sharding": "games sharded across ranks, no data-path collective",
-            },
-            "plies": plies, "games_finished": games, "replay_rows": positions,
-            "evals": evals, "elapsed_s": elapsed,
-        }
-        # roofline of the dominant kernel, rank 0's own launches (HIP events on the engine stream)
-        if args.workload == "tree":
-            b = model_bytes(st)
-            achieved = b / st["mcts_seconds"] / 1e9 if st["mcts_seconds"] > 0 else 0.0
-            kl = max(1, st.get("mcts_kernel_launches") or st["mcts_launches"])
-            persistent = kl < st["mcts_launches"]
-            line["roofline"] = {
-                "kernel": ("k_play<2> (select+expand+backup, move draw and game step of every game; "
-                           "one persistent launch for all %d timed moves)" % args.steps) if persistent else
-                          "k_mcts<2, FAST> (select+expand+backup, one launch per move)",
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "bytes_per_launch": b / kl,
-                "avg_launch_ms": 1e3 * st["mcts_seconds"] / kl,
-                "launches": kl,
-                "moves_per_launch": st["mcts_launches"] / kl,
-                "ms_per_move": 1e3 * st["mcts_seconds"] / max(1, st["mcts_launches"]),
-                "bytes_per_sim": b / max(1, st["selects"]),
-                "mean_depth": st["sum_depth"] / max(1, st["selects"]),
-            }
-            # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-            # (tools/prof_pmc.sh: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction)
-            tpath = os.path.join(ROOT, "profiles", "r1n_tree_pmc_traffic.json")
-            default_cmd = (args.games, args.board, args.sims, args.batch, args.steps, args.warmup,
-                           args.noise_scale) == (4096, 11, 400, 10, 130, 20, 0.25)
-            if default_cmd and os.path.exists(tpath):
-                t = json.load(open(tpath))
-                line["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
-                line["roofline"]["traffic_source"] = "profiles/r1n_tree_pmc_traffic.json (PMC, same command)"
+        line = {"metric": "mcts_sims_per_sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic"}
+        line.update(throughput_fields(sums, elapsed, args.steps))
+        if headline == "tree":
+            wl = ("BASELINE configs[1]: %d concurrent %dx%d Hex games per GPU, HIP movegen+MCTS kernels only, "
+                  "uniform priors (no net), %d sims/move (%d select_leaf calls)"
+                  % (args.games, args.board, args.board, args.sims, selects_per_search))
+            line["roofline"] = tree_roofline(st, args, args.steps, args.warmup)
         else:
-            # dominant kernels: the residual tower + heads, one launch pair per leaf batch, timed with
-            # HIP events on the engine stream.  ALGORITHMIC flops (107 851 784 per
-            # evaluated position) over that time, against the dense MFMA peak of the dtype the tower
-            # issues: f16 (the fp32 operands are carried as hi+lo f16 pairs, 3 MFMAs per product).
-            flops = st["evals"] * flop_per_position(args.board, args.blocks, args.chans)
-            net_s = st["net_seconds"] if st["net_seconds"] > 0 else st["seconds"]
-            achieved = flops / net_s / 1e12
+            name = ("BASELINE configs[2]" if (args.board, args.blocks, args.chans) == (11, 6, 64) else
+                    "BASELINE configs[4] shape on one GPU" if (args.board, args.blocks, args.chans) == (13, 19, 256)
+                    else "resnet self-play")
+            wl = ("%s: %d concurrent %dx%d Hex games per GPU, %d sims/move (%d select_leaf calls), %dx%d resnet "
+                  "forward on split-f16 MFMA (fp32-accurate), random-init weights"
+                  % (name, args.games, args.board, args.board, args.sims, selects_per_search, args.blocks, args.chans))
             line["dtype"] = "f16x3 (fp32 operands split hi+lo f16, fp32 accumulate)"
-            line["roofline"] = {
-                "kernel": (("k_tower_f16x3 + k_heads" if os.environ.get("AZX_TOWER_SHAPE") == "32" else
-                            "k_tower_f16x3_s16 + k_heads") if args.chans == 64 and args.board <= 11 else
-                           ("k_conv_wide_f16x3" if os.environ.get("AZX_TOWER_SHAPE") == "32" else "k_conv_wide_f16x3_s16") + " x %d + k_heads" % (2 * args.blocks) if args.chans % 128 == 0 else
-                           "tower + k_heads") + " (%dx%d resnet forward of one leaf batch)" % (args.blocks, args.chans),
-                "bound": "mfma", "achieved": achieved, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": achieved / F16_MFMA_PEAK_TF, "traffic": None,
-                "issued_mfma_tflops": 3.0 * achieved, "issued_frac": 3.0 * achieved / F16_MFMA_PEAK_TF,
-                "vs_fp32_mfma_peak": achieved / F32_MFMA_PEAK_TF,
-                "avg_launch_ms": 1e3 * net_s / max(1, st["net_launches"]), "launches": st["net_launches"],
-                "positions_per_launch": st["evals"] / max(1, st["net_launches"]),
-                "net_share_of_step": net_s / st["seconds"] if st["seconds"] > 0 else None,
-            }
+            line["roofline"] = resnet_roofline(st, args, args.steps, args.warmup)
+            if exchange is not None:
+                line["replay_allgather"] = exchange
+        line["config"] = dict(workload=wl, **common_cfg)
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(args, net_state)
+                line["cpu_baseline"] = cpu_baseline(args, headline, ex["net_state"])
             except Exception as exc:  # the oracle is test infrastructure; report, don't fail the bench
                 line["cpu_baseline"] = {"error": repr(exc)}
+
+    # ---- nested tree-only sub-benchmark (configs[1]), measured the same way ---------------------
+    if args.workload == "selfplay":
+        st_t, el_t, ex_t = run_workload("tree", args, rank, world, local_rank, args.tree_steps, args.tree_warmup,
+                                        sync, torch)
+        el_t, sums_t = reduce_over_ranks(dist, torch, el_t, [float(st_t[k]) for k in SUM_KEYS])
+        ex_t["engine"].close()
+        if rank == 0:
+            tree = {"metric": "mcts_sims_per_sec", "steps": args.tree_steps, "warmup": args.tree_warmup, "dtype": "f32"}
+            tree.update(throughput_fields(sums_t, el_t, args.tree_steps))
+            tree["config"] = {"workload": ("BASELINE configs[1]: %d concurrent %dx%d Hex games per GPU, HIP movegen+MCTS "
+                                           "kernels only, uniform priors (no net), %d sims/move (%d select_leaf calls)"
+                                           % (args.games, args.board, args.board, args.sims, selects_per_search)),
+                              "start": common_cfg["start"].replace("%d warm-up" % args.warmup, "%d warm-up" % args.tree_warmup)}
+            tree["roofline"] = tree_roofline(st_t, args, args.tree_steps, args.tree_warmup)
+            if world == 1 and not args.no_cpu_baseline:
+                try:
+                    tree["cpu_baseline"] = cpu_baseline(args, "tree")
+                except Exception as exc:
+                    tree["cpu_baseline"] = {"error": repr(exc)}
+            line["tree"] = tree
+
+    if rank == 0:
         print(json.dumps(line))
-    E.close()
     if dist is not None:
         dist.destroy_process_group()
 

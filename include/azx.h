@@ -29,6 +29,8 @@ extern "C" {
 #define AZX_MAX_CELLS (AZX_MAX_BOARD * AZX_MAX_BOARD)
 #define AZX_CELL_STRIDE 192       /* per-position row stride of dense [*, cells] buffers */
 #define AZX_MAX_BATCH 16          /* search_batch_size upper bound */
+/* bytes of one fixed-size replay record (azx_rows_pack / azx_replay_put_records) for a board of `cells` cells */
+#define AZX_RECORD_BYTES(cells) ((size_t)((16 + 5 * (cells) + 15) / 16 * 16))
 
 enum {
     AZX_OK = 0,
@@ -69,12 +71,18 @@ typedef struct {
     int32_t flags;               /* AZX_FLAG_* */
     int32_t device;              /* HIP device ordinal */
     uint64_t seed;               /* base seed; game uid u draws from stream seed+u */
+    /* multi-GPU sharding: the j-th game this engine starts (j = slot + n_games * games
+     * the slot has started before) has global index uid = j * game_index_stride + game_index_offset.
+     * Rank r of W passes (W, r): a fixed seed then plays the same set of games whatever W is.
+     * 0 stride = 1 (single engine). */
+    int32_t game_index_stride;
+    int32_t game_index_offset;
 } azx_config;
 
 typedef struct azx_engine azx_engine;
 
 const char *azx_last_error(void);
-int azx_version(void);            /* ABI revision: 2 since azx_play_stats carries mcts_kernel_launches */
+int azx_version(void);            /* ABI revision: 3 = azx_config.game_index_*, azx_play_stats.sum_game_length */
 
 /* Policy.initialize / Policy.reset (policy.py:36-63, :76-80): allocate device arenas. */
 int azx_create(const azx_config *cfg, azx_engine **out);
@@ -183,6 +191,8 @@ typedef struct {
     double  net_seconds;      /* device time in the network kernels (tower + heads), per batch */
     int64_t net_launches;
     int64_t mcts_kernel_launches;   /* kernel launches behind mcts_seconds (k_play: many moves each) */
+    double  sum_game_length;  /* plies of the finished games, counted from the empty board (metrics: moves_per_game
+                                 of games that started from an azx_reset prefix; rows only cover the plies searched) */
 } azx_play_stats;
 
 /* Self-play until >= min_positions rows from FINISHED games are available (whole games
@@ -220,6 +230,25 @@ int azx_replay_put(azx_engine *e, int64_t n, const int32_t *board, const int32_t
  * into the ring.  *rows_out = rows added. */
 int azx_replay_fill(azx_engine *e, int64_t min_positions, int64_t max_plies, int64_t *rows_out,
                     azx_play_stats *stats);
+/* ---- multi-GPU replay exchange -------------------------------------------------------
+ * Replaces the reference's only data-parallel return path -- pickled ReplayDataFrames over worker pipes
+ * (process_pool.py:31-47, parallel_player.py:41-52) -- by one all-gather of fixed-size records between
+ * DEVICE buffers: every rank plays its share (azx_play_device), packs the harvested rows into records
+ * (azx_rows_pack), the caller all-gathers the record buffers (RCCL over xGMI) and appends all of them to
+ * its ring (azx_replay_put_records).  Record layout (AZX_RECORD_BYTES(cells) bytes):
+ *   0 game_uid i64 | 8 reward f32 | 12 color i16 | 14 nlegal i16 | 16 moves_prob f32[cells] |
+ *   16+4*cells board u8[cells] | zero padding to a multiple of 16. */
+
+/* Player.read(min_positions) that leaves the rows in the engine's harvest queue (whole games only,
+ * like azx_play); *rows_out = rows now queued, valid until the next azx_play* / azx_replay_fill call. */
+int azx_play_device(azx_engine *e, int64_t min_positions, int64_t max_plies, int64_t *rows_out,
+                    azx_play_stats *stats);
+/* queue rows [first, first+n) -> records in the DEVICE buffer records_dev (n * AZX_RECORD_BYTES). Blocking. */
+int azx_rows_pack(azx_engine *e, int64_t first, int64_t n, void *records_dev);
+/* ReplayBuffer.put of n records held in a DEVICE buffer: FIFO with the wrap-around / overflow behaviour
+ * of azx_replay_put.  Blocking. */
+int azx_replay_put_records(azx_engine *e, int64_t n, const void *records_dev);
+
 /* prep.batch_replays of the rows `indices[0..batch)` (host array; each < rows held) into DEVICE
  * buffers with row stride board_size^2: color i64[batch], legal_moves i32[batch][cells] (ascending
  * tile+1, zero padded), result i64[batch] (always 0), board i32[batch][cells],
@@ -246,6 +275,13 @@ int azx_selftest_divide(int device, int n, const float *num, const float *den, f
  * draws of Dirichlet(alpha * 1_k), k <= 128, exactly as the search kernel generates them, for
  * distribution tests. */
 int azx_selftest_dirichlet(int device, double alpha, int k, int n_rows, uint32_t seed, float *out);
+
+/* throughput mode's move draw on its own (tests): runs the device stand-in for as_distribution +
+ * rng.multinomial (search_tree.py:327-344, policy.py:142-160) on every active slot's CURRENT root
+ * statistics (call azx_search first) and returns the child index it drew, move_id[n_games] (-1: no draw),
+ * and the moves_prob row it recorded for the replay, moves_prob[n_games][cells] dense by child index.
+ * The slots are left with that row appended and the move pending: azx_reset them afterwards. */
+int azx_debug_choose(azx_engine *e, int32_t *move_id, float *moves_prob);
 
 /* raw device counters (16 x u64) since engine creation: selects, sum_depth, sum_k_interior,
  * sum_k_leaf, evals, terminal evals, games, errors, plies, rows, then diagnostic slots */

@@ -61,7 +61,7 @@ class BenchCfg(C.Structure):
                 ("n_games", C.c_int32), ("n_threads", C.c_int32), ("max_plies", C.c_int32),
                 ("use_net", C.c_int32), ("c_puct", C.c_double), ("noise_scale", C.c_double),
                 ("noise_alpha", C.c_double), ("temperature", C.c_double),
-                ("exploration_depth", C.c_int32), ("seed", C.c_uint64)]
+                ("exploration_depth", C.c_int32), ("seed", C.c_uint64), ("start_max", C.c_int32)]
 
 
 class BenchOut(C.Structure):
@@ -380,10 +380,10 @@ def play_game(n, evaluator, *, simulations, batch_size, c_puct, exploration_dept
 
 def bench_selfplay(n, simulations, batch_size, n_games, n_threads, net=None, c_puct=0.5,
                    noise_scale=0.25, noise_alpha=0.03, temperature=1.0, exploration_depth=15,
-                   seed=0xBAD5EED5, max_plies=300):
+                   seed=0xBAD5EED5, max_plies=300, start_max=0):
     cfg = BenchCfg(n, simulations, batch_size, n_games, n_threads, max_plies,
                    1 if net is not None else 0, c_puct, noise_scale, noise_alpha, temperature,
-                   exploration_depth, seed)
+                   exploration_depth, seed, start_max)
     out = BenchOut()
     lib().obench_selfplay(C.byref(cfg), net.h if net is not None else None, C.byref(out))
     return dict(games=out.games, plies=out.plies, selects=out.selects, evals=out.evals,

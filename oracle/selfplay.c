@@ -76,7 +76,19 @@ static void *worker(void *arg) {
         ohex_init(&game, n);
         otree_reset(tree);
         int ply = 0;
-        for (; ply < cfg->max_plies && !ohex_result(&game); ++ply) {
+        if (cfg->start_max > 0) {          /* random legal prefix: mid-game start (see obench_cfg_t) */
+            int want = (int)(rng_next(&rng) % (uint64_t)(cfg->start_max + 1));
+            while (ply < want) {
+                int k = ohex_legal_moves(&game, lm);
+                ohex_t trial = game;
+                ohex_step(&trial, lm[rng_next(&rng) % (uint64_t)k]);
+                if (ohex_result(&trial)) break;
+                game = trial;
+                ++ply;
+            }
+        }
+        const int ply0 = ply;
+        for (; ply - ply0 < cfg->max_plies && !ohex_result(&game); ++ply) {
             int k = ohex_legal_moves(&game, lm);
             if (cfg->noise_scale != 0.0) {            /* mcts.py:128, one draw per select_leaf */
                 for (int s = 0; s < sel_per_move; ++s) {
@@ -108,7 +120,7 @@ static void *worker(void *arg) {
             otree_move(tree, move_id);                 /* policy.py:170-176 */
             ohex_step(&game, lm[move_id]);
         }
-        w->plies += ply;
+        w->plies += ply - ply0;
         w->games += 1;
     }
     otree_free(tree);

@@ -15,6 +15,8 @@ Fixtures:
   g3_forward_*.npz HexNetwork.forward (weights + inputs + value/logprob)
   g4_search_*.npz  SearchTree.search with stub networks: evaluation tape + tree dump
   g5_game_*.npz    play_game([AzaleaAgent(Policy(stub))]) full self-play traces
+  g5r_game_11_6x64.npz  one self-play game with the REAL network (11x11, 40 sims, the seeded 6x64 net of
+                   g3_forward_11_6x64.npz): the trace plus every Network.run call's inputs and outputs
   g6_collate.npz   prep.torch_batch_replays on a small ReplayDataFrame
   g7_replay.npz    ReplayBuffer put/consume FIFO states and one shuffled DataLoader epoch
   g10_tournament.npz evaluation.evaluate round robin of three stub-net agents (per-game outcomes)
@@ -424,6 +426,80 @@ def make_g5_g6():
     make_g7(frames["b_11_s40"])
 
 
+# --------------------------------------------------------------------------- G5 with the real network
+class RunRecorder:
+    """Records every Network.run call the search makes (mcts.py:202-206): the flipped input boards, the
+    padded legal-move lists and the value / moves_logprob outputs, row by row in call order."""
+
+    def __init__(self, net):
+        self.net = net
+        self.calls, self.boards, self.moves, self.values, self.logprobs = [], [], [], [], []
+        self._orig = net.run
+
+    def __enter__(self):
+        def wrapped(batch, *a, **k):
+            out = self._orig(batch, *a, **k)
+            board = batch["board"].cpu().numpy()
+            lm = batch["legal_moves"].cpu().numpy()
+            value = out["value"].cpu().numpy()
+            lp = out["moves_logprob"].cpu().numpy()
+            self.calls.append(len(board))
+            for i in range(len(board)):
+                kk = int((lm[i] > 0).sum())
+                assert (lm[i, :kk] > 0).all()
+                self.boards.append(board[i].astype(np.int8))
+                self.moves.append(lm[i, :kk].astype(np.int16))
+                self.values.append(np.float32(value[i]))
+                self.logprobs.append(lp[i, :kk].astype(np.float32))
+            return out
+        self.net.run = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        self.net.run = self._orig
+
+
+def make_g5_real():
+    """BASELINE configs[0] in small: ONE self-play game on 11x11, 40 simulations per move, search batch 10,
+    the seeded 6x64 network of G3 (weights live in g3_forward_11_6x64.npz), the trainer's search
+    settings (hex11_train_config.yml:19-36) with move sampling and exploration on."""
+    n, sims, bs, c, depth, alpha, eps, temp, seed = 11, 40, 10, 0.5, 15, 0.03, 0.25, 1.0, 20240517
+    policy = make_policy("uniform0", n, sims, bs, c, depth, alpha, eps, temp)
+    policy.net = build_net(n, 6, 64, seed=1000 + n)          # the G3 network
+    policy.network_type, policy.num_blocks, policy.base_chans = "hex", 6, 64
+    policy.settings["move_sampling"] = True
+    policy.settings["move_exploration"] = True
+    agent = AzaleaAgent(lambda: HexGame(n), policy=policy, device="cpu")
+    agent.seed(seed)
+    with RunRecorder(policy.net) as rec, torch.no_grad():
+        result, frame, metrics = play_game([agent], collect_data=True)
+    P, K = len(frame), n * n
+    board = np.zeros((P, n, n), np.int8)
+    color = np.zeros(P, np.int8)
+    nlegal = np.zeros(P, np.int16)
+    lmoves = np.zeros((P, K), np.int16)
+    mprob = np.zeros((P, K), np.float32)
+    for i in range(P):
+        st = frame.state[i]
+        k = len(st.legal_moves)
+        board[i], color[i], nlegal[i] = st.board, st.color, k
+        lmoves[i, :k] = st.legal_moves
+        mprob[i, :k] = frame.moves_prob[i]
+    off = np.zeros(len(rec.moves) + 1, np.int64)
+    off[1:] = np.cumsum([len(m) for m in rec.moves])
+    mnames = sorted(k for k in metrics if k != "seconds_per_game")
+    save("g5r_game_11_6x64.npz",
+         cfg_n=np.int32(n), cfg_sims=np.int32(sims), cfg_batch=np.int32(bs), cfg_c=np.float64(c),
+         cfg_depth=np.int32(depth), cfg_alpha=np.float64(alpha), cfg_eps=np.float64(eps),
+         cfg_temp=np.float64(temp), cfg_seed=np.int64(seed), cfg_net=np.array("g3_forward_11_6x64.npz"),
+         result=np.int32(result), board=board, color=color, nlegal=nlegal, legal_moves=lmoves,
+         moves_prob=mprob, reward=np.array(frame.reward, np.float32),
+         metric_names=np.array(mnames), metric_values=np.array([float(metrics[k]) for k in mnames]),
+         run_calls=np.array(rec.calls, np.int32), run_off=off,
+         run_board=np.array(rec.boards, np.int8), run_moves=np.concatenate(rec.moves),
+         run_value=np.array(rec.values, np.float32), run_logprob=np.concatenate(rec.logprobs))
+
+
 # --------------------------------------------------------------------------- G7
 def collate_padded(recs, cells):
     """torch_batch_replays of recs, legal_moves / moves_prob widened to `cells` columns + the width"""
@@ -615,7 +691,9 @@ def make_g10():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g5r", "g8", "g9", "g10"]
+    if "g5r" in which:
+        make_g5_real()
     if "g1" in which:
         make_g1()
     if "g2" in which:

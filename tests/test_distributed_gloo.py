@@ -28,25 +28,116 @@ def _rows(rank, count, n=5):
                 game_uid=(np.arange(count) + (rank << 40)).astype(np.int64))
 
 
+class StubEngine:
+    """Stands in for azalea_amd.engine.Engine on the CPU: the harvest queue and the replay ring are numpy
+    tables of fixed-size records and the 'device' buffers are host tensors, so DeviceReplayBuffer's shared
+    refill (play_device -> rows_pack -> all-gather -> replay_put_records) runs over gloo exactly as it
+    does over RCCL.  Self-play is the random mover through the host game loop."""
+
+    def __init__(self, n, seed):
+        from azalea_amd import AzaleaAgent, HexGame, _lib
+        self.n, self.cells = n, n * n
+        self.record_bytes = _lib.record_bytes(self.cells)
+        self.torch_device = torch.device("cpu")
+        self.agent = AzaleaAgent(lambda: HexGame(n))
+        self.agent.seed(seed)
+        self.queue = np.zeros((0, self.record_bytes), np.uint8)
+        self.ring, self.size, self.write = None, 0, 0
+        self.uid = seed << 20
+
+    def replay_create(self, capacity):
+        self.ring, self.size, self.write = np.zeros((capacity, self.record_bytes), np.uint8), 0, 0
+
+    def replay_state(self):
+        return dict(capacity=len(self.ring), size=self.size, write_idx=self.write)
+
+    def play_device(self, min_positions, max_plies=0):
+        from azalea_amd import distributed as azd
+        from azalea_amd.play_game import play_game
+        recs, games = [], 0
+        while sum(len(r) for r in recs) < min_positions:
+            _, frame, gm = play_game([self.agent], collect_data=True)
+            P = len(frame)
+            prob = np.zeros((P, self.cells), np.float32)
+            for i, p in enumerate(frame.moves_prob):
+                prob[i, :len(p)] = p
+            rows = dict(board=np.stack([s.board for s in frame.state]), color=np.array([s.color for s in frame.state]),
+                        nlegal=np.array([len(s.legal_moves) for s in frame.state]), moves_prob=prob,
+                        reward=np.array(frame.reward, np.float32), game_uid=np.full(P, self.uid, np.int64))
+            self.uid += 1
+            games += 1
+            recs.append(azd.pack_rows(rows, self.cells))
+        self.queue = np.concatenate(recs)
+        return len(self.queue), dict(games=games, plies=len(self.queue), game_errors=0, seconds=0.0,
+                                     sum_reward_last=float(games), sum_search_value=0.0, sum_root_width=0.0,
+                                     sum_action_logprob=0.0)
+
+    @staticmethod
+    def _host(ptr, nbytes):
+        import ctypes
+        return np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(ptr))
+
+    def rows_pack(self, first, n, ptr):
+        self._host(ptr, n * self.record_bytes)[:] = self.queue[first:first + n].reshape(-1)
+
+    def replay_put_records(self, n, ptr):
+        rec = self._host(ptr, n * self.record_bytes).reshape(n, self.record_bytes)
+        for r in rec:                                   # replay_buffer.py:134-149: FIFO, oldest overwritten
+            self.ring[self.write] = r
+            self.write = (self.write + 1) % len(self.ring)
+            self.size = min(len(self.ring), self.size + 1)
+
+
+def _shared_device_replay(rank, world):
+    """DeviceReplayBuffer.consume under torch.distributed: every rank plays its share, every rank's ring
+    ends up with ALL ranks' rows, in rank order, and the fresh-example accounting sees all of them."""
+    from azalea_amd import distributed as azd
+    from azalea_amd.device_replay import DeviceReplayBuffer
+    E = StubEngine(4, seed=50 + rank)
+    buf = DeviceReplayBuffer(E, capacity=500)
+    m = buf.consume(40)
+    x = buf.last_exchange
+    counts = x["rows_per_rank"]
+    fails = [] if (len(counts) == world and all(c >= 20 for c in counts) and len(buf) == sum(counts)) else [100]
+    fails += [] if (buf.fresh_counter == sum(counts) - 40 and m["games"] >= 2 and m["moves_per_game"] == sum(counts)) else [101]
+    # every rank holds the same ring: rank 0's rows first, then rank 1's
+    digest = torch.tensor([int(E.ring[:E.size].astype(np.int64).sum()), E.size], dtype=torch.int64)
+    both = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(both, digest)
+    fails += [] if (torch.equal(both[0], both[1])) else [102]
+    mine = azd.unpack_rows(E.queue, 4)
+    lo = sum(counts[:rank])
+    held = azd.unpack_rows(E.ring[lo:lo + counts[rank]], 4)
+    fails += [] if (all(np.array_equal(mine[k], held[k]) for k in mine)) else [103]
+    # a refill smaller than the world: rank 1 plays nothing, still takes rank 0's rows
+    before = len(buf)
+    buf.fresh_counter = 0
+    buf.consume(0.5)                                    # refill = 0.5 - (-0.5) = 1 row: rank 0's quota is 1, rank 1's 0
+    c2 = buf.last_exchange["rows_per_rank"]
+    fails += [] if (c2[1] == 0 and c2[0] >= 1 and len(buf) == before + c2[0]) else [104]
+    return fails
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from azalea_amd import distributed as azd
     from azalea_amd.network import HexNetwork
+    fails = []
     counts = [7, 12]
     got = azd.all_gather_rows(_rows(rank, counts[rank]), 5)
     want = {k: np.concatenate([_rows(r, counts[r])[k] for r in range(world)]) for k in got}
-    ok = all(np.array_equal(got[k], want[k]) for k in got)
+    fails += [] if (all(np.array_equal(got[k], want[k]) for k in got)) else [1]
     m = azd.all_reduce_metrics({"games": 1 + rank, "reward": 0.5})
-    ok = ok and m == {"games": 3.0, "reward": 1.0}
-    ok = ok and [azd.shard_quota(25, r, 2) for r in range(2)] == [13, 12]
+    fails += [] if (m == {"games": 3.0, "reward": 1.0}) else [2]
+    fails += [] if ([azd.shard_quota(25, r, 2) for r in range(2)] == [13, 12]) else [3]
     torch.manual_seed(rank)
     net = HexNetwork(board_size=5, num_blocks=1, base_chans=8)
     azd.broadcast_weights(net, src=0)
     torch.manual_seed(0)
     ref = HexNetwork(board_size=5, num_blocks=1, base_chans=8)
-    ok = ok and all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), ref.state_dict().values()))
+    fails += [] if (all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), ref.state_dict().values()))) else [4]
     # Player.read sharded over ranks (random mover -> host loop): every rank ends with all rows
     from azalea_amd import AzaleaAgent, HexGame, Player
     agent = AzaleaAgent(lambda: HexGame(4))
@@ -56,9 +147,18 @@ def _worker(rank, world, port, out):
     pl.stop()
     sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([len(frame)]))
-    ok = ok and len(frame) >= 40 and sizes[0].item() == sizes[1].item()
-    ok = ok and metrics["moves_per_game"] == len(frame)
-    out[rank] = bool(ok)
+    fails += [] if (len(frame) >= 40 and sizes[0].item() == sizes[1].item()) else [5]
+    fails += [] if (metrics["moves_per_game"] == len(frame)) else [6]
+    # size < world: the trailing rank's quota is 0 -- it still joins both collectives with a 0-row table
+    pl = Player(None, [agent])
+    frame1, m1 = pl.read(1)
+    pl.stop()
+    dist.all_gather(sizes, torch.tensor([len(frame1)]))
+    fails += [] if (len(frame1) >= 1 and sizes[0].item() == sizes[1].item() and m1["games"] == 1) else [7]
+    fails += [] if ([azd.shard_quota(12.8, r, 16) for r in (0, 12, 13, 15)] == [1, 1, 0, 0]) else [8]
+    fails += [] if (azd.broadcast_int(1000 + rank) == 1000) else [9]
+    fails += _shared_device_replay(rank, world)
+    out[rank] = fails
     dist.destroy_process_group()
 
 
@@ -67,4 +167,4 @@ def test_world2_gloo_all_gather_and_broadcast():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    assert dict(out) == {0: True, 1: True}
+    assert dict(out) == {0: [], 1: []}      # numbers of the checks that failed, per rank

@@ -30,9 +30,32 @@ def _check_common(d, steps, warmup):
     assert "traffic" in r
 
 
+def test_default_line_is_the_selfplay_headline_with_the_tree_numbers_nested():
+    """The default workload is the north-star headline (configs[2]: resnet-driven self-play) from a
+    de-synchronised pool, with the configs[1] tree-only run nested as "tree"; small sizes here."""
+    d = _run("--steps", "2", "--warmup", "1", "--games", "64", "--sims", "40", "--tree-steps", "6",
+             "--tree-warmup", "2", "--board", "7", "--blocks", "1")
+    _check_common(d, 2, 1)
+    assert d["config"]["workload"].startswith("resnet self-play") and "de-synchronised" in d["config"]["start"]
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["unit"] == "TFLOP/s"
+    assert round(d["value"] * d["elapsed_s"]) == 64 * 2 * 50
+    assert d["plies"] == 64 * 2 and d["games_finished"] >= 0 and "games_per_sec_steady" in d
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "sims/s" and "mid-game" in c["sample"]
+    x = d["replay_allgather"]
+    assert x["ranks"] == 1 and x["record_bytes"] == 272 and sum(x["rows_per_rank"]) >= 1
+    t = d["tree"]
+    assert t["steps"] == 6 and t["warmup"] == 2 and t["roofline"]["bound"] == "hbm" and t["roofline"]["peak"] == 8000.0
+    assert round(t["value"] * t["elapsed_s"]) == 64 * 6 * 50
+    assert t["games_finished"] > 0 and t["mean_game_length"] > 0          # steady state: games do finish
+    assert abs(t["games_per_sec_steady"] * t["mean_game_length"] - t["plies_per_sec"]) < 1e-6 * t["plies_per_sec"]
+    assert t["cpu_baseline"]["kind"] == "port"
+
+
 def test_tree_bench_line():
-    d = _run("--steps", "3", "--warmup", "1", "--games", "256")
+    d = _run("--workload", "tree", "--steps", "3", "--warmup", "1", "--games", "256")
     _check_common(d, 3, 1)
+    assert d["config"]["workload"].startswith("BASELINE configs[1]")
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
     # 256 games x 3 moves x 410 select_leaf calls, exactly
     assert round(d["value"] * d["elapsed_s"]) == 256 * 3 * 410
@@ -42,7 +65,8 @@ def test_tree_bench_line():
 
 def test_resnet_bench_line():
     d = _run("--workload", "resnet", "--steps", "1", "--warmup", "1", "--games", "64", "--sims", "40",
-             "--no-cpu-baseline")
+             "--no-cpu-baseline", "--desync", "0")
     _check_common(d, 1, 1)
+    assert d["config"]["workload"].startswith("BASELINE configs[2]") and "lock-step" in d["config"]["start"]
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["unit"] == "TFLOP/s"
     assert round(d["value"] * d["elapsed_s"]) == 64 * 1 * 50

@@ -210,3 +210,77 @@ def test_policy_state_dict_roundtrip(tmp_path):
     for a, b in zip(p.net.state_dict().values(), q.net.state_dict().values()):
         assert torch.equal(a, b)
     assert q.rng.randint(1 << 30) == p.rng.randint(1 << 30)
+
+
+def test_player_read_survives_a_skipped_game(monkeypatch):
+    """parallel_player.py:71-76: a game that raises SearchTreeFull is skipped and reading goes on
+    (the reference's batch_examples just sees an empty frame); the skip shows up in game_error."""
+    from azalea_amd import AzaleaAgent, HexGame, Player
+    from azalea_amd import parallel_player as pp
+    from azalea_amd.policy import SearchTreeFull
+    real, calls = pp.play_game, []
+
+    def flaky(agents, **kw):
+        calls.append(1)
+        if len(calls) in (1, 3):
+            raise SearchTreeFull("too many nodes")
+        return real(agents, **kw)
+    monkeypatch.setattr(pp, "play_game", flaky)
+    agent = AzaleaAgent(lambda: HexGame(4))
+    agent.seed(3)
+    pl = Player(None, [agent])
+    frame, metrics = pl.read(20)
+    assert len(frame) >= 20 and metrics["games"] >= 2 and metrics["game_error"] == 2
+    frame, metrics = pl.read(5)
+    assert len(frame) >= 5 and metrics.get("game_error", 0) == 0
+    pl.stop()
+
+    def always(agents, **kw):
+        raise SearchTreeFull("too many nodes")
+    monkeypatch.setattr(pp, "play_game", always)
+    monkeypatch.setattr(pp.Player, "MAX_BARREN_PRODUCTIONS", 5)
+    with pytest.raises(RuntimeError):
+        Player(None, [agent]).read(5)
+
+
+def test_rows_to_frame_whole_table_passes():
+    """Engine rows -> ReplayDataFrame (the struct-of-lists contract of replay_buffer.py:11-38): dtypes,
+    ascending legal moves, moves_prob cut to k, np.float32 rewards; a mismatching nlegal is refused."""
+    from azalea_amd.parallel_player import rows_to_frame
+    rng = np.random.RandomState(2)
+    P, n = 37, 5
+    board = rng.randint(0, 3, (P, n, n)).astype(np.int32)
+    board[3] = 0
+    board[4] = 1                                     # no legal move at all
+    k = (board.reshape(P, -1) == 0).sum(1).astype(np.int32)
+    prob = rng.rand(P, n * n).astype(np.float32)
+    rows = dict(board=board, color=rng.randint(0, 2, P).astype(np.int32), nlegal=k, moves_prob=prob,
+                reward=rng.choice([-1.0, 1.0], P).astype(np.float32), game_uid=np.arange(P))
+    f = rows_to_frame(rows)
+    assert len(f) == P
+    for i in range(P):
+        st = f.state[i]
+        want = (np.flatnonzero(board[i].ravel() == 0) + 1).astype(np.int32)
+        assert st.legal_moves.dtype == np.int32 and np.array_equal(st.legal_moves, want)
+        assert st.board.dtype == np.int32 and np.array_equal(st.board, board[i]) and st.result == 0
+        assert st.color == rows["color"][i] and isinstance(st.color, int)
+        assert f.moves_prob[i].dtype == np.float32 and np.array_equal(f.moves_prob[i], prob[i, :k[i]])
+        assert type(f.reward[i]) is np.float32 and f.reward[i] == rows["reward"][i]
+    assert len(rows_to_frame({key: v[:0] for key, v in rows.items()})) == 0
+    rows["nlegal"] = k + 1
+    with pytest.raises(AssertionError):
+        rows_to_frame(rows)
+
+
+def test_record_layout_matches_the_header():
+    """AZX_RECORD_BYTES and the field offsets of the multi-GPU replay record (include/azx.h) against the
+    numpy view the host side packs with."""
+    from azalea_amd import _lib
+    from azalea_amd import distributed as azd
+    hdr = open(os.path.join(ROOT, "include", "azx.h")).read()
+    assert "((16 + 5 * (cells) + 15) / 16 * 16)" in hdr
+    for cells in (9, 25, 121, 169):
+        dt = azd.record_dtype(cells)
+        assert dt.itemsize == _lib.record_bytes(cells) == (16 + 5 * cells + 15) // 16 * 16
+        assert [dt.fields[f][1] for f in ("game_uid", "reward", "color", "nlegal", "moves_prob", "board")] == \
+            [0, 8, 12, 14, 16, 16 + 4 * cells]

@@ -209,3 +209,47 @@ def test_g5_full_game_trace(path):
     assert metrics["moves_per_game"] == len(rows)
     assert abs(np.mean([r["num_nodes"] for r in rows]) - metrics["search_tree_nodes"]) < 1e-6
     assert abs(np.mean([r["search_value"] for r in rows]) - metrics["search_value"]) < 1e-6
+
+
+# ------------------------------------------------------------------------------- G5 with the real network
+def test_g5r_real_net_game_from_the_reference_tape():
+    """BASELINE configs[0] in small (one 11x11 game, 40 sims, 6x64 net): the oracle, handed the
+    reference's own Network.run outputs in call order, must ask for exactly the inputs the reference's
+    search produced (flipped boards / move lists) and replay the recorded game bit for bit."""
+    from run_tape import RunTape
+    z = np.load(os.path.join(GOLDEN, "g5r_game_11_6x64.npz"))
+    tape = RunTape(z)
+
+    def fn(boards, lm):
+        value, logprob = tape.next_call(boards, lm)
+        return value, np.exp(logprob)          # mcts.py:206
+    result, rows, reward = orc.play_game(
+        int(z["cfg_n"]), orc.CallbackEval(fn), simulations=int(z["cfg_sims"]), batch_size=int(z["cfg_batch"]),
+        c_puct=float(z["cfg_c"]), exploration_depth=int(z["cfg_depth"]), noise_alpha=float(z["cfg_alpha"]),
+        noise_scale=float(z["cfg_eps"]), temperature=float(z["cfg_temp"]), seed=int(z["cfg_seed"]))
+    assert tape.row == len(tape) and tape.call == len(tape.calls)
+    assert result == int(z["result"]) and len(rows) == len(z["board"])
+    for i, r in enumerate(rows):
+        k = int(z["nlegal"][i])
+        assert np.array_equal(r["board"], z["board"][i]) and r["color"] == z["color"][i]
+        assert np.array_equal(r["legal_moves"], z["legal_moves"][i, :k])
+        assert np.array_equal(bits(r["moves_prob"]), bits(z["moves_prob"][i, :k])), i
+    assert np.array_equal(reward, z["reward"])
+
+
+def test_g5r_oracle_network_on_the_game_s_own_leaves():
+    """The oracle's fp32 network on positions the reference's search really evaluated (every 23rd
+    Network.run row of the recorded game, both colours, early to late) within 1e-4 of the reference."""
+    from run_tape import RunTape
+    z = np.load(os.path.join(GOLDEN, "g5r_game_11_6x64.npz"))
+    w = np.load(os.path.join(GOLDEN, str(z["cfg_net"])))
+    tape = RunTape(z)
+    n = int(z["cfg_n"])
+    rows = np.arange(0, len(tape), 23)
+    boards, lm = tape.inputs(rows, n)
+    net = orc.Net(n, 6, 64, {k[2:]: w[k] for k in w.files if k.startswith("w:")})
+    v, lp = net.forward(boards, lm)
+    assert np.abs(v - tape.value[rows]).max() <= 1e-4
+    for j, r in enumerate(rows):
+        a, b = int(tape.off[r]), int(tape.off[r + 1])
+        assert np.abs(lp[j, :b - a] - tape.logprob[a:b]).max() <= 1e-4
