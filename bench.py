@@ -17,10 +17,13 @@ SURVEY 8(d)), is measured the same way right after it and nested in the same lin
 
 Steady state: a pool that restarts finished games in place is, after its first game, spread over
 all plies.  Starting every slot from the empty board would time the opening only (no game can end
-in the first 2N-1 moves), so before the warm-up each slot is reset to a seeded random legal
-position of 0..`--desync` plies (untimed; `--desync 0` keeps the lock-step start).  `games_per_sec`
-= games finished inside the timed region / its duration; `games_per_sec_steady` = plies/s over the
-mean length of those games -- the two agree when the pool is in steady state.
+in the first 2N-1 moves), so before the warm-up the pool is put into its steady state, untimed:
+every slot starts from a seeded random legal position of 0..`--desync` plies and the cheap
+uniform-prior self-play (the configs[1] engine) then plays `--settle` moves per slot -- two to three
+game lengths, finished games restarting in place -- after which the resnet engine's slots are reset
+to those self-played positions (`--desync 0` keeps the lock-step start from the empty board).
+`games_per_sec` = games finished inside the timed region / its duration; `games_per_sec_steady` =
+plies/s over the mean length of those games -- the two agree when the pool is in steady state.
 
 N>1 is launched by the driver with torch.distributed.run, one rank per GPU: games shard across
 ranks by global game index (rank r of W plays games r, r+W, ...: a fixed seed plays the same games
@@ -104,16 +107,55 @@ def pmc_traffic(name, key):
     return t.get("hbm_bytes_per_launch"), "profiles/%s (PMC, same command)" % name
 
 
-def run_workload(workload, args, rank, world, local_rank, steps, warmup, sync, torch):
-    """One engine, de-synchronised, warmed up and timed for `steps` moves.  Returns (st, elapsed, extras)."""
+def make_engine(workload, args, rank, world, local_rank):
     from azalea_amd import engine as eng
     evaluator = eng.EVAL_UNIFORM if workload == "tree" else eng.EVAL_RESNET
-    E = eng.Engine(board_size=args.board, n_games=args.games, simulations=args.sims,
-                   search_batch_size=args.batch, exploration_coef=0.5, exploration_depth=15,
-                   noise_alpha=0.03, noise_scale=args.noise_scale, temperature=1.0, evaluator=evaluator,
-                   num_blocks=args.blocks, base_chans=args.chans, device=local_rank,
-                   nodes_per_game=args.nodes_per_game, seed=args.seed,
-                   game_index_stride=world, game_index_offset=rank)
+    return eng.Engine(board_size=args.board, n_games=args.games, simulations=args.sims,
+                      search_batch_size=args.batch, exploration_coef=0.5, exploration_depth=15,
+                      noise_alpha=0.03, noise_scale=args.noise_scale, temperature=1.0, evaluator=evaluator,
+                      num_blocks=args.blocks, base_chans=args.chans, device=local_rank,
+                      nodes_per_game=args.nodes_per_game, seed=args.seed,
+                      game_index_stride=world, game_index_offset=rank)
+
+
+def settle_pool(E, args, rank, world, local_rank):
+    """Untimed: random start positions, then `--settle` moves of uniform-prior self-play per slot on the
+    tree-only engine E, which leaves the pool in its steady state (slots spread over all plies the way a
+    long-running pool is)."""
+    import numpy as np
+    from azalea_amd import engine as eng
+    idx = np.arange(args.games, dtype=np.int64) * world + rank      # global game indices of the slots
+    E.reset(moves=eng.random_prefixes(args.board, idx, args.desync, args.seed, device=local_rank))
+    if args.settle:
+        E.play_steps(args.settle)
+
+
+def pool_positions(E):
+    """The pool's current positions as move lists (any alternating order of a position's stones is a legal
+    way to reach it: a position that is not won has no won sub-position)."""
+    import numpy as np
+    gm = E.get_games()
+    assert not gm["result"].any()
+    moves = []
+    for b in gm["board"].reshape(len(gm["board"]), -1):
+        xs, os_ = np.flatnonzero(b == 1) + 1, np.flatnonzero(b == 2) + 1
+        assert len(xs) - len(os_) in (0, 1)
+        seq = np.empty(len(xs) + len(os_), np.int64)
+        seq[0::2], seq[1::2] = xs, os_
+        moves.append(seq.tolist())
+    return moves
+
+
+def run_workload(workload, args, rank, world, local_rank, steps, warmup, sync, torch):
+    """One engine, its pool put into steady state (untimed), warmed up and timed for `steps` moves.
+    Returns (st, elapsed, extras)."""
+    start = None
+    if args.desync > 0 and workload != "tree":
+        T = make_engine("tree", args, rank, world, local_rank)
+        settle_pool(T, args, rank, world, local_rank)
+        start = pool_positions(T)
+        T.close()
+    E = make_engine(workload, args, rank, world, local_rank)
     extras = {"net_state": None}
     if workload == "resnet":
         from azalea_amd.network import HexNetwork
@@ -124,10 +166,10 @@ def run_workload(workload, args, rank, world, local_rank, steps, warmup, sync, t
         E.set_weights({k: (v.data_ptr(), v.numel()) for k, v in sd.items()
                        if v.dtype == torch.float32}, on_device=True)
         extras["net_state"] = {k: v.detach().cpu().numpy() for k, v in sd.items()}
-    if args.desync > 0:
-        import numpy as np
-        idx = np.arange(args.games, dtype=np.int64) * world + rank      # global game indices of the slots
-        E.reset(moves=eng.random_prefixes(args.board, idx, args.desync, args.seed, device=local_rank))
+    if start is not None:
+        E.reset(moves=start)
+    elif args.desync > 0:
+        settle_pool(E, args, rank, world, local_rank)
     if warmup:
         E.play_steps(warmup)
     sync()
@@ -187,7 +229,7 @@ def tree_roofline(st, args, steps, warmup):
                  "on chip, so its measured HBM traffic is below the model and it is issue-bound, not HBM-bound "
                  "(DESIGN 3.1)"),
     }
-    key = [args.games, args.board, args.sims, args.batch, steps, warmup, args.noise_scale, args.desync]
+    key = [args.games, args.board, args.sims, args.batch, steps, warmup, args.noise_scale, args.desync, args.settle]
     roof["traffic"], src = pmc_traffic("r2_tree_pmc_traffic.json", key)
     if src:
         roof["traffic_source"] = src
@@ -222,7 +264,7 @@ def resnet_roofline(st, args, steps, warmup):
         "tree_share_of_step": st["mcts_seconds"] / st["seconds"] if st["seconds"] > 0 else None,
     }
     key = [args.games, args.board, args.sims, args.batch, args.blocks, args.chans, steps, warmup,
-           args.noise_scale, args.desync]
+           args.noise_scale, args.desync, args.settle]
     roof["traffic"], src = pmc_traffic("r2_resnet_pmc_traffic.json", key)
     if src:
         roof["traffic_source"] = src
@@ -284,6 +326,9 @@ def main():
     ap.add_argument("--desync", type=int, default=None,
                     help="start slot i from a seeded random legal position of 0..DESYNC plies (default: "
                          "about one game length, 92 on 11x11; 0 = every game from the empty board)")
+    ap.add_argument("--settle", type=int, default=None,
+                    help="untimed moves of uniform-prior self-play per slot that bring the pool to its steady "
+                         "state before the warm-up (default 2 * board^2)")
     ap.add_argument("--nodes-per-game", type=int, default=0,
                     help="tree arena capacity per game (0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -296,6 +341,8 @@ def main():
         args.warmup = 20 if headline == "tree" else 5
     if args.desync is None:
         args.desync = int(round(0.76 * args.board * args.board))     # mean self-play game length, random-init net
+    if args.settle is None:
+        args.settle = 2 * args.board * args.board if args.desync else 0
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -339,8 +386,10 @@ def main():
     selects_per_search = (args.sims // args.batch + 1) * args.batch
     common_cfg = {"games_per_gpu": args.games, "board": args.board, "simulations": args.sims,
                   "search_batch_size": args.batch, "c_puct": 0.5, "noise": "dirichlet(0.03) eps 0.25, device RNG",
-                  "start": ("slots de-synchronised: slot i starts from a seeded random legal position of 0..%d "
-                            "plies (untimed), then %d warm-up moves" % (args.desync, args.warmup)) if args.desync
+                  "start": ("pool in steady state, slots de-synchronised (untimed set-up): seeded random legal positions "
+                            "of 0..%d plies, then %d moves of uniform-prior self-play per slot (finished games "
+                            "restart in place), the positions reached are the start; then %d warm-up moves"
+                            % (args.desync, args.settle, args.warmup)) if args.desync
                            else "all games from the empty board (lock-step)",
                   "sharding": "games sharded across ranks by global game index, no data-path collective"}
     line = None

@@ -238,15 +238,19 @@ def test_play_mode_skips_overflowing_games_and_returns_whole_ones(eng):
     """parallel_player.py:71-76 in throughput mode: a game whose tree overflows is dropped (counted in
     game_errors, its slot restarts) and only whole finished games are handed out."""
     n, G, sims = 7, 64, 30
-    sel = (sims // 10 + 1) * 10
-    # room for the first search of a game and a little more: a search later in the game overflows when
-    # the subtree carried over from the previous move is large
-    cap = (sel + 1) * n * n + 1 + 24
-    E = eng.Engine(board_size=n, n_games=G, simulations=sims, search_batch_size=10, exploration_depth=4,
-                   evaluator=eng.EVAL_UNIFORM, nodes_per_game=cap, seed=77)
-    rows, st = E.play(600, max_plies=400)
-    E.close()
-    assert st["game_errors"] > 0 and st["games"] > 0
+    # a first search of a 7x7 game expands ~40 leaves with 47-48 children each below the root's 49: about
+    # 1950 nodes, a little more or less from game to game (duplicate leaves, depth).  Arenas around that size
+    # make SOME searches overflow -- the game is dropped, its slot restarts with a new game -- while others
+    # get through; later searches need less (one child fewer per ply).
+    rows = st = None
+    for cap in (1990, 1975, 1960, 1945, 1930, 1915, 1900):
+        E = eng.Engine(board_size=n, n_games=G, simulations=sims, search_batch_size=10, exploration_depth=4,
+                       evaluator=eng.EVAL_UNIFORM, nodes_per_game=cap, seed=77)
+        rows, st = E.play(600, max_plies=400)
+        E.close()
+        if st["game_errors"] > 0 and st["games"] > 0:
+            break
+    assert st["game_errors"] > 0 and st["games"] > 0, (cap, st["game_errors"], st["games"])
     uid = rows["game_uid"]
     starts = np.flatnonzero(np.r_[True, uid[1:] != uid[:-1]])
     ends = np.r_[starts[1:], len(uid)]
