@@ -238,10 +238,15 @@ __device__ unsigned long long g_tower_trace[3 * 32768];   // per block of the la
     if (blockIdx.x < 32768) { const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xc = __builtin_amdgcn_s_getreg((31 << 11) | 20); \
         g_tower_trace[3 * blockIdx.x] = ((unsigned long long)(xc & 0xf) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf); \
         g_tower_trace[3 * blockIdx.x + 1] = nt_rt0; g_tower_trace[3 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime(); } }
+// the wide conv kernel's regions (every wave's lane 0): 0 prologue, 1 staging + barriers, 2 k-loop, 3 epilogue
+__device__ unsigned long long g_wide_stamp[10];
+#define WT_FLUSH if (lane == 0) { for (int r_ = 0; r_ < 7; ++r_) atomicAdd(&g_wide_stamp[r_], nt_acc[r_]); atomicAdd(&g_wide_stamp[7], 1ull); \
+    atomicAdd(&g_wide_stamp[8], __builtin_amdgcn_s_memrealtime() - nt_rt0); }
 #else
 #define NT_DECL
 #define NT_MARK(r)
 #define NT_FLUSH
+#define WT_FLUSH
 #endif
 
 #ifndef F16X3_BPB
@@ -1032,6 +1037,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3(NetDev P, int layer,
 #ifndef WIDE_STAGE_GROUP
 #define WIDE_STAGE_GROUP 6
 #endif
+// diagnostic builds (tools/ab_wide_ablate.sh; wrong results, timing only): 1 = stage chunk 0 only,
+// 2 = no epilogue memory traffic, 4 = weight fragments loaded once per chunk, 8 = activation fragments
+// loaded once per chunk
+#ifndef AZX_WIDE_ABLATE
+#define AZX_WIDE_ABLATE 0
+#endif
 #define WIDE16_MT 6
 #define WIDE16_NT 4
 __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int layer, const unsigned short *__restrict__ in,
@@ -1046,11 +1057,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
 #endif
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
-    const int e = blockIdx.x;
-    if (e >= n_eval) return;
     const int C = P.C, N = P.N, ncells = P.ncells;
     const int NCH = C / 64, NT16 = C / 16;
-    const int co_base = blockIdx.y * 128;
+    NT_DECL
+    // XCD-aware block order: consecutive workgroups go to the eight XCDs round-robin, each with its own L2.
+    // The C / 128 column blocks of a board are given indices 8 apart, so they run on the same XCD at about
+    // the same time and the second one finds the board's input in that L2 instead of fetching it from HBM
+    // again (with (board, column) as (x, y) the two were a whole launch wave apart).
+    // (grid = (8 C / 128, boards / 8): the linear workgroup id is blockIdx.y * gridDim.x + blockIdx.x)
+    const int e = blockIdx.y * 8 + (blockIdx.x & 7);
+    if (e >= n_eval) return;
+    const int co_base = (blockIdx.x >> 3) * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Position tiles: a board of up to 176 cells is eleven 16-row tiles, not twelve.  Wave wm = 0 holds
     // tiles 0..5 and wm = 1 tiles 5..10 (rows 80..175); the shared tile 5 is computed by wm = 0 for the
@@ -1070,7 +1087,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
 #else
     const int zero_off = ncells * ROWB;
 #endif
-    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
     unsigned long long tapok = 0ull;                     // bit tap*6 + m (54 bits)
     int rbase[MT];
@@ -1092,11 +1108,56 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     };
     if (tid < ROWB / 4) reinterpret_cast<uint32_t *>(smem + zero_off)[tid] = 0u;
 
+    // Output channels of this wave: 64 wn .. 64 wn + 63 of the block's 128.  The weights are packed so that
+    // accumulator register r of tile n in lane group lh is channel 32 (n >> 1) + 8 lh + 4 (n & 1) + r of
+    // those (see azx_net_set_weights): a lane holds 8 consecutive channels per tile pair, i.e. one 16-byte
+    // piece of the hi plane and one of the lo plane per row, and the four lane groups of a row together one
+    // full 64-byte line -- residual loads and output stores are whole lines, half as many instructions.
+    auto chan0 = [&](int np) -> int { return co_base + 64 * wn + 32 * np + 8 * lh; };
+    // The accumulators start from bias (+ residual), fetched here together with the first input chunk (one
+    // memory round trip, nothing else to do yet) instead of in the epilogue, where every wave of the block
+    // waited for it with the matrix pipe idle.
     f32x4 acc[MT][NT];
+    {
+        const unsigned char *gres0 = resid ? reinterpret_cast<const unsigned char *>(resid) + (size_t)e * ncells * rowg : nullptr;
+#if AZX_WIDE_ABLATE & 16
+        gres0 = nullptr;
+#endif
+        float bv[2][8];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+        for (int np = 0; np < 2; ++np) {
+            const float4 b0 = *reinterpret_cast<const float4 *>(P.bias + (size_t)layer * C + chan0(np));
+            const float4 b1 = *reinterpret_cast<const float4 *>(P.bias + (size_t)layer * C + chan0(np) + 4);
+            bv[np][0] = b0.x; bv[np][1] = b0.y; bv[np][2] = b0.z; bv[np][3] = b0.w;
+            bv[np][4] = b1.x; bv[np][5] = b1.y; bv[np][6] = b1.z; bv[np][7] = b1.w;
+        }
+        // three position tiles at a time: all their pieces requested together (48 registers in flight)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m0 = 0; m0 < MT; m0 += 3) {
+            f16x8 rh[3][2], rl[3][2];
+            if (gres0) {
+#pragma unroll
+                for (int mm = 0; mm < 3; ++mm) {
+                    const int rc = min(row0 + 16 * (m0 + mm) + li, ncells - 1);
+#pragma unroll
+                    for (int np = 0; np < 2; ++np) {
+                        rh[mm][np] = *reinterpret_cast<const f16x8 *>(gres0 + (size_t)rc * rowg + chan0(np) * 2);
+                        rl[mm][np] = *reinterpret_cast<const f16x8 *>(gres0 + (size_t)rc * rowg + (size_t)C * 2 + chan0(np) * 2);
+                    }
+                }
+            }
+#pragma unroll
+            for (int mm = 0; mm < 3; ++mm)
+#pragma unroll
+                for (int np = 0; np < 2; ++np)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float v = bv[np][j];
+                        if (gres0) v += (float)rh[mm][np][j] + (float)rl[mm][np][j];
+                        acc[m0 + mm][2 * np + (j >> 2)][j & 3] = v;
+                    }
+        }
+    }
 
     const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.Wh16);
     const int nt0 = co_base / 16 + 4 * wn;               // this wave's first 16-channel tile
@@ -1185,6 +1246,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     auto main_loop = [&](auto wm_tag) __attribute__((always_inline)) {
     constexpr int WM = decltype(wm_tag)::value;
     for (int chunk = 0; chunk < NCH; ++chunk) {
+#if AZX_WIDE_ABLATE & 1
+        if (chunk == 0)
+#endif
+        {
+        NT_MARK(chunk == 0 ? 0 : 2)
         __syncthreads();                                 // the previous chunk has been consumed
         {
             // all of a thread's pieces are requested before the first one is written to LDS (as a plain
@@ -1239,16 +1305,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
             }
         }
         __syncthreads();
+        NT_MARK(1)
+        }
         // k-step t = 0..17 of this chunk: tap t/2, channels 32 (t%2) .. +31 of the chunk
         auto qof = [&](int t) { return (((layer * 9 + t / 2) * NCH + chunk) * 2 + (t & 1)); };
         f16x8 wh_[NT], wl_[NT];
         f16x8 xh[MT], xl[MT];
         auto load_w = [&](int t, int nn, int part) {
+#if AZX_WIDE_ABLATE & 4
+            if (t > 0) return;
+#endif
             const uint4 qq = *wptr(qof(t), nn, part);
             if (part) wl_[nn] = *reinterpret_cast<const f16x8 *>(&qq);
             else wh_[nn] = *reinterpret_cast<const f16x8 *>(&qq);
         };
         auto load_x = [&](int tt, int mm, int part) {
+#if AZX_WIDE_ABLATE & 8
+            if (tt > 0) return;
+#endif
             const unsigned char *pa = smem + act_offset(tt >> 1, mm) + (tt & 1) * 64 + part * 128;
             if (part) xl[mm] = *reinterpret_cast<const f16x8 *>(pa);
             else xh[mm] = *reinterpret_cast<const f16x8 *>(pa);
@@ -1288,55 +1362,46 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     if (wm == 0) main_loop(std::integral_constant<int, 0>{});
     else main_loop(std::integral_constant<int, 1>{});
 
-    // ---- epilogue -------------------------------------------------------------------------------
+    // ---- epilogue: ReLU -> split -> HBM, one 16-byte piece per lane and plane -----------------------
+    NT_MARK(2)
     unsigned char *gout = reinterpret_cast<unsigned char *>(out) + (size_t)e * ncells * rowg;
-    const unsigned char *gres = resid ? reinterpret_cast<const unsigned char *>(resid) + (size_t)e * ncells * rowg : nullptr;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int cb = co_base + 64 * wn + 16 * n + 4 * lh;
-        const float4 b4 = *reinterpret_cast<const float4 *>(P.bias + (size_t)layer * C + cb);
-        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
-        // the residual of all six position tiles is requested up front (rows past the board re-read the
-        // last cell, no divergence): one memory round trip per channel tile instead of one per tile
-        f16x4 rhv[MT], rlv[MT];
-        if (gres) {
+    for (int m = 0; m < MT; ++m) {
+        const int r = row0 + 16 * m + li;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int rc = min(row0 + 16 * m + li, ncells - 1);
-                rhv[m] = *reinterpret_cast<const f16x4 *>(gres + (size_t)rc * rowg + cb * 2);
-                rlv[m] = *reinterpret_cast<const f16x4 *>(gres + (size_t)rc * rowg + (size_t)C * 2 + cb * 2);
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int r = row0 + 16 * m + li;
-            const bool mine = !(wm == 0 ? (m == MT - 1 && n >= 2) : (m == 0 && n < 2));   // else the other wave's
+        for (int np = 0; np < 2; ++np) {
+            bool mine = !(wm == 0 ? (m == MT - 1 && np == 1) : (m == 0 && np == 0));   // else the other wave's
+#if AZX_WIDE_ABLATE & 2
+            mine = mine && acc[m][2 * np][0] == 12345.678f;
+#endif
             if (r < ncells && mine) {
-                float rv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (gres) {
-                    const f16x4 rh = rhv[m], rl = rlv[m];
+                f16x8 h8, l8;
+                float vv[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) rv[j] = (float)rh[j] + (float)rl[j];
-                }
-                f16x4 h4, l4;
-                float vv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = fmaxf(acc[m][n][j] + bv[j] + rv[j], 0.0f);
+                for (int j = 0; j < 8; ++j) {
+                    const float v = fmaxf(acc[m][2 * np + (j >> 2)][j & 3], 0.0f);
                     vv[j] = v;
                     _Float16 hi, lo;
                     split_f16(v, hi, lo);
-                    h4[j] = hi;
-                    l4[j] = lo;
+                    h8[j] = hi;
+                    l8[j] = lo;
                 }
-                *reinterpret_cast<f16x4 *>(gout + (size_t)r * rowg + cb * 2) = h4;
-                *reinterpret_cast<f16x4 *>(gout + (size_t)r * rowg + (size_t)C * 2 + cb * 2) = l4;
-                if (out32)
-                    *reinterpret_cast<float4 *>(out32 + ((size_t)e * ncells + r) * C + cb) =
-                        make_float4(vv[0], vv[1], vv[2], vv[3]);
+                const int c0 = chan0(np);
+                *reinterpret_cast<f16x8 *>(gout + (size_t)r * rowg + c0 * 2) = h8;
+                *reinterpret_cast<f16x8 *>(gout + (size_t)r * rowg + (size_t)C * 2 + c0 * 2) = l8;
+                if (out32) {
+                    float *o32 = out32 + ((size_t)e * ncells + r) * C + c0;
+                    *reinterpret_cast<float4 *>(o32) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    *reinterpret_cast<float4 *>(o32 + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+                }
             }
         }
     }
+#ifdef AZX_NET_STAMP
+    __builtin_amdgcn_s_waitcnt(0);      // the stores have been acknowledged: their time belongs to the epilogue
+#endif
+    NT_MARK(3)
+    WT_FLUSH
 }
 
 // stem of the wide tower: the one-hot K = 27 product of k_tower_f16x3's stem, one board x 128
@@ -1754,6 +1819,20 @@ void azx_net_destroy(AzxNet *net) {
 #ifdef AZX_NET_STAMP
     {
         unsigned long long h[10] = {0};
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wide_stamp), sizeof h) == hipSuccess && h[7]) {
+            static const char *nm[4] = {"prologue (bias + residual, setup)", "staging + barriers", "k-loops (MFMA)", "epilogue (stores acknowledged)"};
+            unsigned long long tot = 0;
+            for (int r = 0; r < 4; ++r) tot += h[r];
+            fprintf(stderr, "k_conv_wide_f16x3_s16 stamps over %llu waves: %.0f cycles/wave, shader clock %.0f MHz during the kernel\n",
+                    h[7], (double)tot / h[7], h[8] ? 100.0 * (double)tot / (double)h[8] : 0.0);
+            for (int r = 0; r < 4; ++r)
+                fprintf(stderr, "  %-36s %6.1f%%  %9.0f cycles/wave\n", nm[r], 100.0 * h[r] / tot, (double)h[r] / h[7]);
+            unsigned long long z[10] = {0};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wide_stamp), z, sizeof z);
+        }
+    }
+    {
+        unsigned long long h[10] = {0};
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tower_stamp), sizeof h) == hipSuccess && h[7]) {
             static const char *nm[7] = {"stem", "residual load/setup", "k-loop (MFMA)", "barrier after k-loop",
                                         "epilogue", "barrier after epilogue", "output store"};
@@ -1974,7 +2053,14 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
                                 for (int ln = 0; ln < 64; ++ln)
                                     for (int t = 0; t < 8; ++t) {
                                         const int j = ln & 15, h = ln >> 4;
-                                        const int ci = 64 * ch + 32 * half + 8 * h + t, co = 16 * nt + j;
+                                        const int ci = 64 * ch + 32 * half + 8 * h + t;
+                                        int co = 16 * nt + j;
+                                        // wide tower: row j = 4 lh + r of tile n = nt % 4 of a wave's 64-channel
+                                        // group is channel 32 (n >> 1) + 8 lh + 4 (n & 1) + r of the group, so a
+                                        // lane's accumulators are 8 consecutive channels per tile pair
+                                        // (k_conv_wide_f16x3_s16's 16-byte epilogue pieces)
+                                        if (net->tower_variant == 5)
+                                            co = 64 * (nt / 4) + 32 * ((nt % 4) >> 1) + 8 * (j >> 2) + 4 * (nt & 1) + (j & 3);
                                         Wh16[o++] = f16bits(Wg[(((size_t)l * 9 + tap) * C + ci) * C + co], part);
                                     }
     }
@@ -2087,13 +2173,14 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
             // which bit of the board index flips a block's long/short wave assignment (31 = never)
             static const int stagger = getenv("AZX_WIDE_FLIP") ? atoi(getenv("AZX_WIDE_FLIP")) : 0;
             const dim3 grid(max_n, d.C / 128), block(256);
+            const dim3 grid16(8 * (d.C / 128), (max_n + 7) / 8);         // k_conv_wide_f16x3_s16's XCD-aware block order
             hipLaunchKernelGGL(k_stem_wide_f16x3, grid, block, 0, st, d, boards, net->wideX,
                                d.blocks == 0 ? net->act : (float *)nullptr, n_eval_ptr, n_host);
             for (int b = 0; b < d.blocks; ++b) {
                 if (wshape == 16) {
-                    hipLaunchKernelGGL(k_conv_wide_f16x3_s16, grid, block, lds, st, d, 2 * b, (const unsigned short *)net->wideX, net->wideY,
+                    hipLaunchKernelGGL(k_conv_wide_f16x3_s16, grid16, block, lds, st, d, 2 * b, (const unsigned short *)net->wideX, net->wideY,
                                        (const unsigned short *)nullptr, (float *)nullptr, n_eval_ptr, n_host, stagger);
-                    hipLaunchKernelGGL(k_conv_wide_f16x3_s16, grid, block, lds, st, d, 2 * b + 1, (const unsigned short *)net->wideY, net->wideX,
+                    hipLaunchKernelGGL(k_conv_wide_f16x3_s16, grid16, block, lds, st, d, 2 * b + 1, (const unsigned short *)net->wideY, net->wideX,
                                        (const unsigned short *)net->wideX, b == d.blocks - 1 ? net->act : (float *)nullptr, n_eval_ptr, n_host, stagger);
                     continue;
                 }
