@@ -76,6 +76,11 @@ def all_gather_records(rec: torch.Tensor) -> Tuple[List[torch.Tensor], List[int]
     xGMI.  Returns the per-rank record tensors (views trimmed to their counts) and the counts, in rank
     order; nothing touches the host except the W counts."""
     world = dist.get_world_size()
+    if rec.is_cuda and dist.get_backend() != "nccl":
+        # functional fallback (tests, bench.py with AZX_BENCH_BACKEND=gloo): the CPU backend cannot gather
+        # device tensors, so the records make a host round trip; RCCL gathers them in HBM
+        parts, counts = all_gather_records(rec.cpu())
+        return [p.to(rec.device) for p in parts], counts
     dev = rec.device
     counts_t = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts_t, torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev))

@@ -65,11 +65,14 @@ def save_checkpoint(policy, name, *, optimizer=None, replaybuf=None) -> str:
     return path
 
 
-def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False) -> str:
-    """The reference training loop (policy_trainer.py:23-119) over this package's Player."""
+def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False, history=None) -> str:
+    """The reference training loop (policy_trainer.py:23-119) over this package's Player.
+    `history`: optional dict; receives the learning rate each epoch trained with under "lr"."""
     os.makedirs("%s/checkpoints" % rundir, exist_ok=True)
     np.random.seed(config["seed"])
     torch.manual_seed(config["seed"])
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(config["seed"])          # policy_trainer.py:33
     policy.seed(config["seed"])
     device = torch.device(config["device"])
     oversampling = config["replaybuf_oversampling"]
@@ -98,6 +101,11 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
         batches = lambda: iter(loader)
     loss, step, start_time = 0.0, 0, time.time()
     for epoch in range(1, config["total_epochs"] + 1):
+        # the reference steps the schedule at the TOP of every epoch (policy_trainer.py:81): epoch e trains
+        # with lr_initial * lr_decay ** (e // lr_decay_epochs)
+        scheduler.step()
+        if history is not None:
+            history.setdefault("lr", []).append(optimizer.param_groups[0]["lr"])
         for batch in batches():
             batch = game_class.random_reflect(batch)
             output, loss_ = supervised_step(policy.net, batch, train=True, optimizer=optimizer, device=device)
@@ -110,6 +118,5 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
             if config.get("model_checkpoint_interval") and step % config["model_checkpoint_interval"] == 0:
                 save_checkpoint(policy, "%s/checkpoints/checkpoint.%d" % (rundir, step), optimizer=optimizer)
             step += 1
-        scheduler.step()
     player.stop()
     return save_checkpoint(policy, "%s/checkpoints/final" % rundir)

@@ -62,7 +62,7 @@ def test_train_loop_with_device_replay(tmp_path):
     from azalea_amd.game.hex import HexGame
     config = dict(seed=3, device="cuda:0", replaybuf_oversampling=2, batch_size=32, game="azalea_amd.game.hex.HexGame",
                   board_size=5, replaybuf_size=128, lr_initial=0.05, momentum=0.9, l2_regularization=1e-4,
-                  lr_decay_epochs=1, lr_decay=0.5, total_epochs=2, network="HexNetwork", num_blocks=1, base_chans=8,
+                  lr_decay_epochs=2, lr_decay=0.5, total_epochs=4, network="HexNetwork", num_blocks=1, base_chans=8,
                   simulations=20, search_batch_size=10, exploration_coef=0.5, exploration_depth=4,
                   exploration_noise_alpha=0.3, exploration_noise_scale=0.25, exploration_temperature=1.0,
                   log_interval=2, model_checkpoint_interval=0, selfplay_games=16)
@@ -71,8 +71,12 @@ def test_train_loop_with_device_replay(tmp_path):
     before = {k: v.clone() for k, v in policy.net.state_dict().items()}
     buf = initialize_replay_buffer(None, lambda: HexGame(5), config["replaybuf_size"])
     n0 = len(buf)
-    path = train(policy, config, str(tmp_path), replaybuf=buf, device_replay=True)
+    hist = {}
+    path = train(policy, config, str(tmp_path), replaybuf=buf, device_replay=True, history=hist)
     assert os.path.exists(path)
+    # the reference steps StepLR at the top of each epoch (policy_trainer.py:81): epoch e = 1..4 trains with
+    # lr_initial * lr_decay ** (e // lr_decay_epochs)
+    assert np.allclose(hist["lr"], [0.05 * 0.5 ** (e // 2) for e in (1, 2, 3, 4)])
     after = policy.net.state_dict()
     assert any(not torch.equal(before[k].cpu(), after[k].cpu()) for k in before)
     q = Policy.load(path, device="cpu")
