@@ -365,9 +365,12 @@ def _persistent_vs_per_move(eng, n, G, sims, nodes_per_game, moves, expect_resta
 
 
 def test_tree_full_sets_status(eng):
+    """search_tree.py:258-259: running out of nodes is reported per slot (SearchTreeFull) and the
+    arena bound is never crossed (play mode and Policy: tests/test_gpu_round2.py)."""
     E = eng.Engine(board_size=11, n_games=2, simulations=40, search_batch_size=10,
                    evaluator=eng.EVAL_UNIFORM, nodes_per_game=500)
     E.search()
+    assert (E.get_status() == 1).all()
     root = E.get_root()
     assert (root["num_nodes"] <= 500).all()
     E.close()
