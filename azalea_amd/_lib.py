@@ -83,6 +83,7 @@ SYMBOLS = {
     "azx_forward": (C.c_int, [_vp, C.c_int, C.c_int, _i32p, _i32p, _f32p, _f32p]),
     "azx_hex_replay": (C.c_int, [C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _i32p, _i32p, _u64p, _i32p]),
     "azx_play": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _i32p, _i32p, _i32p, _f32p, _f32p, _i64p, C.POINTER(PlayStats)]),
+    "azx_play_row_metrics": (C.c_int, [_vp, C.c_int64, _f32p, _i64p]),
     "azx_play_steps": (C.c_int, [_vp, C.c_int64, C.POINTER(PlayStats)]),
     "azx_replay_create": (C.c_int, [_vp, C.c_int64]),
     "azx_replay_state": (C.c_int, [_vp, _i64p, _i64p, _i64p]),

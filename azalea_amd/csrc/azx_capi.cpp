@@ -121,7 +121,7 @@ struct DevGuard {
     } while (0)
 
 extern "C" const char *azx_last_error(void) { return g_err.c_str(); }
-extern "C" int azx_version(void) { return 3; }   // 3: azx_config.game_index_*, azx_play_stats.sum_game_length
+extern "C" int azx_version(void) { return 3; }   // 3: azx_config.game_index_*, azx_play_stats.sum_game_length, record exchange, row metrics
 
 extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
     if (!cfg || !out) return fail(AZX_EINVAL, "null argument");
@@ -759,6 +759,7 @@ static int play_setup(azx_engine *e, int64_t q_rows, int ring) {
         TRY(dev_alloc(e, &d.row_board, rows * AZX_CELL_STRIDE));
         TRY(dev_alloc(e, &d.row_prob, rows * AZX_CELL_STRIDE));
         TRY(dev_alloc(e, &d.row_k, rows));
+        TRY(dev_alloc(e, &d.row_meta, rows * 4));
         e->play_ready = true;
     }
     if (q_rows > e->q_alloc) {
@@ -777,6 +778,7 @@ static int play_setup(azx_engine *e, int64_t q_rows, int ring) {
         TRY(qa((void **)&d.q_k, (size_t)q_rows * sizeof(int32_t)));
         TRY(qa((void **)&d.q_reward, (size_t)q_rows * sizeof(float)));
         TRY(qa((void **)&d.q_uid, (size_t)q_rows * sizeof(int64_t)));
+        TRY(qa((void **)&d.q_meta, (size_t)q_rows * 4 * sizeof(float)));
         e->q_alloc = q_rows;
     }
     d.q_cap = e->q_alloc;
@@ -936,6 +938,7 @@ extern "C" int azx_play(azx_engine *e, int64_t min_positions, int64_t max_plies,
                     (long long)cap, (long long)worst);
     unsigned long long rows = 0;
     TRY(play_until(e, min_positions, max_plies, stats, &rows));
+    e->q_rows_valid = (int64_t)rows;
     if (rows == 0) return AZX_OK;
     const size_t n = (size_t)rows;
     // widen / densify on the device (k_rows_export), then one copy per output array
@@ -973,6 +976,18 @@ extern "C" int azx_play_device(azx_engine *e, int64_t min_positions, int64_t max
     TRY(play_until(e, min_positions, max_plies, stats, &rows));
     e->q_rows_valid = (int64_t)rows;
     *rows_out = (int64_t)rows;
+    return AZX_OK;
+}
+
+extern "C" int azx_play_row_metrics(azx_engine *e, int64_t cap, float *metrics, int64_t *n_out) {
+    if (!e || !metrics || !n_out) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
+    const int64_t n = e->q_rows_valid;
+    if (n > cap) return fail(AZX_EINVAL, "%lld rows queued, caller capacity %lld", (long long)n, (long long)cap);
+    *n_out = n;
+    if (n == 0) return AZX_OK;
+    HIPCHECK(hipMemcpyAsync(metrics, e->d.q_meta, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
     return AZX_OK;
 }
 
@@ -1102,6 +1117,7 @@ extern "C" int azx_replay_fill(azx_engine *e, int64_t min_positions, int64_t max
     if (e->d.evaluator == AZX_EVAL_EXTERNAL) return fail(AZX_ESTATE, "play mode needs a device evaluator");
     unsigned long long rows = 0;
     TRY(play_until(e, min_positions, max_plies, stats, &rows));
+    e->q_rows_valid = (int64_t)rows;
     DevEngine &d = e->d;
     const ReplayRows src = {d.q_board, d.q_prob, d.q_color, d.q_k, d.q_reward};
     if (rows) TRY(ring_put(e, src, (int64_t)rows));

@@ -111,6 +111,8 @@ struct DevEngine {
     uint8_t *row_board;     // [G][ncells][AZX_CELL_STRIDE] absolute colours before the move
     float *row_prob;        // [G][ncells][AZX_CELL_STRIDE] moves_prob dense by child index
     int32_t *row_k;         // [G][ncells]
+    float *row_meta;        // [G][ncells][4] per-ply search metrics of the game in progress: search_value,
+                            // root width, log-probability of the move drawn (play_game.py:41-43 averages them per game)
     // ... and the output queue finished games are appended to (whole games only)
     int64_t q_cap;
     int32_t q_ring;         // 1: wrap around instead of stalling (bench)
@@ -119,6 +121,7 @@ struct DevEngine {
     int32_t *q_color, *q_k; // [Q]
     float *q_reward;        // [Q]
     int64_t *q_uid;         // [Q]
+    float *q_meta;          // [Q][4] the rows' per-ply search metrics
     unsigned long long *q_count;   // [1] rows appended
     double *stat_sums;      // [G][8] per game: search_value, root_width, action_logprob, reward_last
 };

@@ -1582,6 +1582,9 @@ __device__ __forceinline__ void advance_body(const DevEngine &E, const int32_t *
                 if ((ply0 + r) & 1) rew = -rew;
                 E.q_reward[q] = rew;
                 E.q_uid[q] = uid;
+                float4 mt = reinterpret_cast<const float4 *>(E.row_meta)[(size_t)g * E.ncells + r];
+                mt.w = r == 0 ? 1.0f : 0.0f;                   // marks the first row of a game
+                reinterpret_cast<float4 *>(E.q_meta)[q] = mt;
             }
             if (lane == 0) {
                 E.counters[(size_t)g * CTR_COUNT + CTR_GAMES] += 1ull;
@@ -1761,9 +1764,12 @@ __device__ __forceinline__ void choose_body(const DevEngine &E) {
         E.row_k[(size_t)g * E.ncells + row] = mk.k;
         gh->n_rows = row + 1;
         gh->move_id = chosen;
+        const float logp = __logf(chosen_w / tot);
         E.stat_sums[(size_t)g * 8 + 0] += (double)(th->search_value);
         E.stat_sums[(size_t)g * 8 + 1] += (double)width;
-        E.stat_sums[(size_t)g * 8 + 2] += (double)__logf(chosen_w / tot);
+        E.stat_sums[(size_t)g * 8 + 2] += (double)logp;
+        float4 *meta = reinterpret_cast<float4 *>(E.row_meta) + (size_t)g * E.ncells + row;
+        *meta = make_float4(th->search_value, (float)width, logp, 0.0f);
     }
 }
 

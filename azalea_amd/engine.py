@@ -35,6 +35,7 @@ class Engine:
         self.bs = search_batch_size
         self.num_batches = simulations // search_batch_size + 1          # mcts.py:268
         self.selects_per_search = self.num_batches * search_batch_size
+        self._last_rows = 0
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
@@ -252,14 +253,39 @@ class Engine:
                               _p(prob, C.c_float), _p(reward, C.c_float), _p(uid, C.c_int64),
                               C.byref(st)))
         n = st.positions
+        self._last_rows = int(n)
         return dict(board=board[:n], color=color[:n], nlegal=nlegal[:n], moves_prob=prob[:n],
                     reward=reward[:n], game_uid=uid[:n]), st.as_dict()
+
+    def game_metric_sums(self, rows=None):
+        """Sums over the games of the last play()/play_device()/replay_fill() call of each game's per-ply MEANS
+        of (search_value, search_root_width, action_logprob): what Player.read's metrics add up
+        (play_game.py:73-76, parallel_player.py:50-51)."""
+        m = self.play_row_metrics(rows)
+        if len(m) == 0:
+            return np.zeros(3)
+        starts = np.flatnonzero(m[:, 3] > 0.5)
+        if len(starts) == 0 or starts[0] != 0:
+            starts = np.r_[0, starts]
+        sums = np.add.reduceat(m[:, :3].astype(np.float64), starts, axis=0)
+        lens = np.diff(np.r_[starts, len(m)])
+        return (sums / lens[:, None]).sum(0)
+
+    def play_row_metrics(self, rows=None):
+        """azx_play_row_metrics: [rows, 4] = search_value, root width, log-prob of the move drawn, 0 for the
+        rows of the last play() / play_device() call (`rows`: how many that call returned, if known)."""
+        cap = int(rows) if rows is not None else self._last_rows
+        m = np.zeros((max(1, cap), 4), np.float32)
+        n = C.c_int64(0)
+        check(self.L.azx_play_row_metrics(self.h, max(1, cap), _p(m, C.c_float), C.byref(n)))
+        return m[:n.value]
 
     def play_device(self, min_positions, max_plies=0):
         """azx_play_device: whole games until >= min_positions rows sit in the harvest queue (in HBM)."""
         st = PlayStats()
         rows = C.c_int64(0)
         check(self.L.azx_play_device(self.h, int(min_positions), int(max_plies), C.byref(rows), C.byref(st)))
+        self._last_rows = int(rows.value)
         return rows.value, st.as_dict()
 
     def rows_pack(self, first, n, records_ptr):
@@ -308,6 +334,7 @@ class Engine:
         st = PlayStats()
         rows = C.c_int64(0)
         check(self.L.azx_replay_fill(self.h, int(min_positions), int(max_plies), C.byref(rows), C.byref(st)))
+        self._last_rows = int(rows.value)
         return rows.value, st.as_dict()
 
     def replay_collate(self, indices, out):

@@ -205,16 +205,16 @@ class Player:
         self._skipped += int(st["game_errors"])
         if len(uid) == 0:
             return
-        plies = max(1, st["plies"])
-        per_ply = {"search_value": st["sum_search_value"] / plies,
-                   "search_root_width": st["sum_root_width"] / plies,
-                   "action_logprob": st["sum_action_logprob"] / plies}
+        # play_game's per-game metrics are means over the game's own plies (play_game.py:73-76)
+        meta = eng.play_row_metrics()
         starts = np.flatnonzero(np.r_[True, uid[1:] != uid[:-1]])
         ends = np.r_[starts[1:], len(uid)]
         for s, e in zip(starts, ends):
             game = {k: v[s:e] for k, v in rows.items()}
+            mean = meta[s:e, :3].astype(np.float64).mean(0)
             gm = dict(games=1, reward=float(game["reward"][-1]), moves_per_game=int(e - s),
-                      seconds_per_game=st["seconds"] / max(1, st["games"]), **per_ply)
+                      seconds_per_game=st["seconds"] / max(1, st["games"]), search_value=float(mean[0]),
+                      search_root_width=float(mean[1]), action_logprob=float(mean[2]))
             self._games.append((game, gm))
 
     @staticmethod

@@ -203,6 +203,12 @@ int azx_play(azx_engine *e, int64_t min_positions, int64_t max_plies, int64_t ca
              int32_t *board, int32_t *color, int32_t *nlegal, float *moves_prob,
              float *reward, int64_t *game_uid, azx_play_stats *stats);
 
+/* per-ply search metrics of the rows the last azx_play / azx_play_device / azx_replay_fill call harvested, in row order:
+ * metrics[n][4] = {search_value (mcts.py:291), search_root_width (search_tree.py:110), log-probability of the
+ * move drawn (play_game.py:43), 1 on the first row of a game else 0}.  play_game averages them over a game's plies and Player.read sums
+ * those means over the games it returns (play_game.py:73-76, parallel_player.py:50-51). */
+int azx_play_row_metrics(azx_engine *e, int64_t cap, float *metrics, int64_t *n_out);
+
 /* bench hook: run `plies` lock-step engine moves on all slots (device RNG, finished games
  * restart in place), no row transfer; fills stats. */
 int azx_play_steps(azx_engine *e, int64_t plies, azx_play_stats *stats);

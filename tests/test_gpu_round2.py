@@ -468,10 +468,18 @@ def test_device_records_roundtrip_into_the_ring(eng):
     torch.cuda.synchronize()
     B.rows_pack(0, nrows, rec.data_ptr())
     host = rec.cpu().numpy()
-    assert np.array_equal(host, azd.pack_rows(rows, n * n))
     back = azd.unpack_rows(host, n)
+    # the device pack kernel and its numpy twin produce the same bytes for the same rows
+    assert np.array_equal(host, azd.pack_rows(back, n * n))
+    # same seed, same games -- but the ORDER games are harvested in follows the GPU's scheduling, so the two
+    # engines' queues are compared game by game
+    def by_uid(r):
+        order = np.argsort(r["game_uid"], kind="stable")
+        return {k: v[order] for k, v in r.items()}
+    a, b = by_uid(rows), by_uid(back)
     for k in rows:
-        assert np.array_equal(back[k].reshape(rows[k].shape), rows[k]), k
+        assert np.array_equal(b[k].reshape(a[k].shape), a[k]), k
+    rows = back                                               # B's own order from here on
     # two 'ranks' worth of records into B's ring vs the same rows put from the host into A's ring
     cap = 2 * nrows + 7
     A.replay_create(cap)
@@ -491,3 +499,32 @@ def test_device_records_roundtrip_into_the_ring(eng):
         assert np.array_equal(outs[0][k], outs[1][k]), k
     A.close()
     B.close()
+
+
+# ---- per-game metrics -----------------------------------------------------------------------------------
+def test_player_metrics_are_sums_of_per_game_means(eng):
+    """play_game averages a game's search metrics over ITS plies and Player.read sums those means over the
+    games it returns (play_game.py:41-43, :73-76; parallel_player.py:50-51).  The engine hands the per-ply
+    values over with the rows (azx_play_row_metrics): their per-game means match the engine's own tallies
+    and bound checks (root width <= legal moves, log-probabilities <= 0, one game-start mark per game)."""
+    n, G = 7, 32
+    E = eng.Engine(board_size=n, n_games=G, simulations=30, search_batch_size=10, exploration_depth=4,
+                   evaluator=eng.EVAL_UNIFORM, seed=3)
+    rows, st = E.play(400)
+    m = E.play_row_metrics()
+    P = len(rows["reward"])
+    assert m.shape == (P, 4)
+    uid = rows["game_uid"]
+    starts = np.flatnonzero(np.r_[True, uid[1:] != uid[:-1]])
+    assert np.array_equal(np.flatnonzero(m[:, 3] > 0.5), starts)
+    assert (m[:, 1] >= 1).all() and (m[:, 1] <= rows["nlegal"]).all() and (m[:, 1] == np.round(m[:, 1])).all()
+    assert (m[:, 2] <= 1e-6).all() and np.isfinite(m).all()
+    # the rows of finished games are a subset of all plies the call played: sums cannot exceed the call's tallies
+    assert m[:, 1].sum() <= st["sum_root_width"] + 1e-3
+    sums = E.game_metric_sums()
+    ends = np.r_[starts[1:], P]
+    want = np.zeros(3)
+    for s, e in zip(starts, ends):
+        want += m[s:e, :3].astype(np.float64).mean(0)
+    assert np.allclose(sums, want)
+    E.close()
