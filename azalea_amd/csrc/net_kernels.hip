@@ -1569,7 +1569,9 @@ __global__ void k_conv_generic(NetDev P, int layer, const float *in, const float
 // masked softmax over the legal (= empty) cells, written by ORIGINAL cell index.
 // One 192-thread block per board.
 // ============================================================================================
+#ifndef HEADS_BPB
 #define HEADS_BPB 8
+#endif
 __global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict__ act,
                                                const float *__restrict__ hfeat,
                                                const uint8_t *__restrict__ ev_board,
@@ -1578,17 +1580,21 @@ __global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict
                                                int n_eval_host, float *__restrict__ logit_out,
                                                float *__restrict__ value_out,
                                                float *__restrict__ prior_out) {
-    // 8 boards per block share every FC weight load (the policy FC matrix alone is 234 KB)
-    __shared__ __align__(16) float hv[2 * AZX_MAX_CELLS][HEADS_BPB];   // [feature][board]
-    __shared__ __align__(16) float hp[4 * AZX_MAX_CELLS][HEADS_BPB];
-    __shared__ float h2[64][HEADS_BPB];
-    __shared__ float lg[HEADS_BPB][AZX_CELL_STRIDE];
+    // HEADS_BPB boards per block share every FC weight load (the policy FC matrix alone is 234 KB).  8 is
+    // the measured optimum: 12 / 16 boards per block halve the weight traffic out of the L2 but leave fewer
+    // blocks to hide each thread's serial 484-step accumulation (+0.14 / +0.25 ms per launch, round 2)
+    extern __shared__ __align__(16) float hsm[];
     const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
     const int e0 = blockIdx.x * HEADS_BPB;
     if (e0 >= n_eval) return;
     const int nb = min(HEADS_BPB, n_eval - e0);
     const int tid = threadIdx.x;
     const int C = P.C, N = P.N, ncells = P.ncells;
+    typedef float (*rowsB)[HEADS_BPB];
+    rowsB hv = reinterpret_cast<rowsB>(hsm);                                  // [2 ncells][board]
+    rowsB hp = reinterpret_cast<rowsB>(hsm + 2 * ncells * HEADS_BPB);         // [4 ncells][board]
+    rowsB h2 = reinterpret_cast<rowsB>(hsm + 6 * ncells * HEADS_BPB);         // [64][board]
+    float (*lg)[AZX_CELL_STRIDE] = reinterpret_cast<float (*)[AZX_CELL_STRIDE]>(hsm + (6 * ncells + 64) * HEADS_BPB);
 
     // ---- 1x1 convs + folded BN + ReLU (network.py:77, :83); flatten order (c, h, w) -----------
     if (hfeat != nullptr) {                           // already done by the tower kernel
@@ -1655,10 +1661,11 @@ __global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict
 #pragma unroll 8                                     // eight weight loads in flight per thread
         for (int i = 0; i < 2 * ncells; ++i) {
             const float w = P.fc2T[i * 64 + tid];
-            const float4 x0 = *reinterpret_cast<const float4 *>(&hv[i][0]);
-            const float4 x1 = *reinterpret_cast<const float4 *>(&hv[i][4]);
-            acc[0] += x0.x * w; acc[1] += x0.y * w; acc[2] += x0.z * w; acc[3] += x0.w * w;
-            acc[4] += x1.x * w; acc[5] += x1.y * w; acc[6] += x1.z * w; acc[7] += x1.w * w;
+#pragma unroll
+            for (int b4 = 0; b4 < HEADS_BPB / 4; ++b4) {
+                const float4 x = *reinterpret_cast<const float4 *>(&hv[i][4 * b4]);
+                acc[4 * b4] += x.x * w; acc[4 * b4 + 1] += x.y * w; acc[4 * b4 + 2] += x.z * w; acc[4 * b4 + 3] += x.w * w;
+            }
         }
 #pragma unroll
         for (int b = 0; b < HEADS_BPB; ++b) h2[tid][b] = fmaxf(acc[b] + P.fc2b[tid], 0.f);
@@ -1670,10 +1677,11 @@ __global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict
 #pragma unroll 8
         for (int i = 0; i < 4 * ncells; ++i) {
             const float w = P.mfcT[(size_t)i * AZX_CELL_STRIDE + tid];
-            const float4 x0 = *reinterpret_cast<const float4 *>(&hp[i][0]);
-            const float4 x1 = *reinterpret_cast<const float4 *>(&hp[i][4]);
-            acc[0] += x0.x * w; acc[1] += x0.y * w; acc[2] += x0.z * w; acc[3] += x0.w * w;
-            acc[4] += x1.x * w; acc[5] += x1.y * w; acc[6] += x1.z * w; acc[7] += x1.w * w;
+#pragma unroll
+            for (int b4 = 0; b4 < HEADS_BPB / 4; ++b4) {
+                const float4 x = *reinterpret_cast<const float4 *>(&hp[i][4 * b4]);
+                acc[4 * b4] += x.x * w; acc[4 * b4 + 1] += x.y * w; acc[4 * b4 + 2] += x.z * w; acc[4 * b4 + 3] += x.w * w;
+            }
         }
         const float bias = P.mfcb[tid];
 #pragma unroll
@@ -2214,7 +2222,12 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
         if (x != net->act)   // heads read net->act
             (void)hipMemcpyAsync(net->act, x, (size_t)max_n * d.ncells * d.C * sizeof(float), hipMemcpyDeviceToDevice, st);
     }
-    hipLaunchKernelGGL(k_heads, dim3((max_n + HEADS_BPB - 1) / HEADS_BPB), dim3(192), 0, st, d, net->act, hfeat, boards, flip, n_eval_ptr, n_host, logit, value, prior);
+    {
+        const size_t hl = ((size_t)(6 * d.ncells + 64) * HEADS_BPB + (size_t)HEADS_BPB * AZX_CELL_STRIDE) * sizeof(float);
+        static size_t hl_set = 0;
+        if (hl > hl_set) { (void)hipFuncSetAttribute((const void *)k_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl); hl_set = hl; }
+        hipLaunchKernelGGL(k_heads, dim3((max_n + HEADS_BPB - 1) / HEADS_BPB), dim3(192), hl, st, d, net->act, hfeat, boards, flip, n_eval_ptr, n_host, logit, value, prior);
+    }
 }
 
 void azx_net_eval(AzxNet *net, const DevEngine &e, hipStream_t st) {
