@@ -1572,7 +1572,10 @@ __global__ void k_conv_generic(NetDev P, int layer, const float *in, const float
 #ifndef HEADS_BPB
 #define HEADS_BPB 8
 #endif
-__global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict__ act,
+#ifndef HEADS_KSPLIT
+#define HEADS_KSPLIT 1
+#endif
+__global__ __launch_bounds__(192 * HEADS_KSPLIT) void k_heads(NetDev P, const float *__restrict__ act,
                                                const float *__restrict__ hfeat,
                                                const uint8_t *__restrict__ ev_board,
                                                const int32_t *__restrict__ ev_flip,
@@ -1589,31 +1592,37 @@ __global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict
     if (e0 >= n_eval) return;
     const int nb = min(HEADS_BPB, n_eval - e0);
     const int tid = threadIdx.x;
+    // the two fully connected layers can be split over HEADS_KSPLIT thread groups along their input
+    // dimension (group 0 adds the partial sums and finishes); measured 1 = 2 = 3 within noise (round 2: the
+    // kernel is bound neither by the L2 weight traffic nor by the length of a thread's accumulation chain), so 1
+    const int part = tid / 192, t = tid - 192 * part;
     const int C = P.C, N = P.N, ncells = P.ncells;
     typedef float (*rowsB)[HEADS_BPB];
     rowsB hv = reinterpret_cast<rowsB>(hsm);                                  // [2 ncells][board]
     rowsB hp = reinterpret_cast<rowsB>(hsm + 2 * ncells * HEADS_BPB);         // [4 ncells][board]
     rowsB h2 = reinterpret_cast<rowsB>(hsm + 6 * ncells * HEADS_BPB);         // [64][board]
     float (*lg)[AZX_CELL_STRIDE] = reinterpret_cast<float (*)[AZX_CELL_STRIDE]>(hsm + (6 * ncells + 64) * HEADS_BPB);
+    float *psum = hsm + (6 * ncells + 64) * HEADS_BPB + HEADS_BPB * AZX_CELL_STRIDE;   // [KSPLIT-1][(64 + 192) * BPB]
 
     // ---- 1x1 convs + folded BN + ReLU (network.py:77, :83); flatten order (c, h, w) -----------
     if (hfeat != nullptr) {                           // already done by the tower kernel
         // board by board, a thread's features of a board requested together (no index division, no
         // load-wait-store chain per element)
         const int nf = 6 * ncells;
-        constexpr int NFT = (6 * AZX_MAX_CELLS + 191) / 192;
+        constexpr int NTH = 192 * HEADS_KSPLIT;
+        constexpr int NFT = (6 * AZX_MAX_CELLS + NTH - 1) / NTH;
 #pragma unroll 2
         for (int b = 0; b < HEADS_BPB; ++b) {
             float v[NFT];
             const float *src = hfeat + (size_t)(e0 + (b < nb ? b : 0)) * nf;
 #pragma unroll
             for (int j = 0; j < NFT; ++j) {
-                const int f = tid + 192 * j;
+                const int f = tid + NTH * j;
                 v[j] = src[f < nf ? f : nf - 1];
             }
 #pragma unroll
             for (int j = 0; j < NFT; ++j) {
-                const int f = tid + 192 * j;
+                const int f = tid + NTH * j;
                 if (f < nf) {
                     const float x = b < nb ? v[j] : 0.0f;
                     if (f < 2 * ncells) hv[f][b] = x; else hp[f - 2 * ncells][b] = x;
@@ -1654,41 +1663,65 @@ __global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict
         }
     }
     __syncthreads();
-    if (tid < 64) {                                   // value_fc2 + ReLU (network.py:79)
-        float acc[HEADS_BPB];
+    float acc2[HEADS_BPB], accm[HEADS_BPB];
 #pragma unroll
-        for (int b = 0; b < HEADS_BPB; ++b) acc[b] = 0.f;
+    for (int b = 0; b < HEADS_BPB; ++b) { acc2[b] = 0.f; accm[b] = 0.f; }
+    if (t < 64) {                                     // value_fc2 (network.py:79): this group's share of the inputs
+        const int i0 = (2 * ncells * part) / HEADS_KSPLIT, i1 = (2 * ncells * (part + 1)) / HEADS_KSPLIT;
 #pragma unroll 8                                     // eight weight loads in flight per thread
-        for (int i = 0; i < 2 * ncells; ++i) {
-            const float w = P.fc2T[i * 64 + tid];
+        for (int i = i0; i < i1; ++i) {
+            const float w = P.fc2T[i * 64 + t];
 #pragma unroll
             for (int b4 = 0; b4 < HEADS_BPB / 4; ++b4) {
                 const float4 x = *reinterpret_cast<const float4 *>(&hv[i][4 * b4]);
-                acc[4 * b4] += x.x * w; acc[4 * b4 + 1] += x.y * w; acc[4 * b4 + 2] += x.z * w; acc[4 * b4 + 3] += x.w * w;
+                acc2[4 * b4] += x.x * w; acc2[4 * b4 + 1] += x.y * w; acc2[4 * b4 + 2] += x.z * w; acc2[4 * b4 + 3] += x.w * w;
             }
         }
-#pragma unroll
-        for (int b = 0; b < HEADS_BPB; ++b) h2[tid][b] = fmaxf(acc[b] + P.fc2b[tid], 0.f);
     }
-    if (tid < ncells) {                               // move_fc (network.py:146)
-        float acc[HEADS_BPB];
-#pragma unroll
-        for (int b = 0; b < HEADS_BPB; ++b) acc[b] = 0.f;
+    if (t < ncells) {                                 // move_fc (network.py:146)
+        const int i0 = (4 * ncells * part) / HEADS_KSPLIT, i1 = (4 * ncells * (part + 1)) / HEADS_KSPLIT;
 #pragma unroll 8
-        for (int i = 0; i < 4 * ncells; ++i) {
-            const float w = P.mfcT[(size_t)i * AZX_CELL_STRIDE + tid];
+        for (int i = i0; i < i1; ++i) {
+            const float w = P.mfcT[(size_t)i * AZX_CELL_STRIDE + t];
 #pragma unroll
             for (int b4 = 0; b4 < HEADS_BPB / 4; ++b4) {
                 const float4 x = *reinterpret_cast<const float4 *>(&hp[i][4 * b4]);
-                acc[4 * b4] += x.x * w; acc[4 * b4 + 1] += x.y * w; acc[4 * b4 + 2] += x.z * w; acc[4 * b4 + 3] += x.w * w;
+                accm[4 * b4] += x.x * w; accm[4 * b4 + 1] += x.y * w; accm[4 * b4 + 2] += x.z * w; accm[4 * b4 + 3] += x.w * w;
             }
         }
-        const float bias = P.mfcb[tid];
+    }
+    if (HEADS_KSPLIT > 1) {
+        if (part > 0) {
+            float *ps = psum + (size_t)(part - 1) * (64 + 192) * HEADS_BPB;
+#pragma unroll
+            for (int b = 0; b < HEADS_BPB; ++b) {
+                if (t < 64) ps[b * 64 + t] = acc2[b];
+                if (t < ncells) ps[64 * HEADS_BPB + b * 192 + t] = accm[b];
+            }
+        }
+        __syncthreads();
+        if (part == 0) {
+            for (int pp = 0; pp < HEADS_KSPLIT - 1; ++pp) {
+                const float *ps = psum + (size_t)pp * (64 + 192) * HEADS_BPB;
+#pragma unroll
+                for (int b = 0; b < HEADS_BPB; ++b) {
+                    if (t < 64) acc2[b] += ps[b * 64 + t];
+                    if (t < ncells) accm[b] += ps[64 * HEADS_BPB + b * 192 + t];
+                }
+            }
+        }
+    }
+    if (part == 0 && t < 64) {                        // + bias, ReLU
+#pragma unroll
+        for (int b = 0; b < HEADS_BPB; ++b) h2[t][b] = fmaxf(acc2[b] + P.fc2b[t], 0.f);
+    }
+    if (part == 0 && t < ncells) {
+        const float bias = P.mfcb[t];
 #pragma unroll
         for (int b = 0; b < HEADS_BPB; ++b) {
-            const float logit = acc[b] + bias;
-            lg[b][tid] = logit;
-            if (b < nb) logit_out[(size_t)(e0 + b) * AZX_CELL_STRIDE + tid] = logit;
+            const float logit = accm[b] + bias;
+            lg[b][t] = logit;
+            if (b < nb) logit_out[(size_t)(e0 + b) * AZX_CELL_STRIDE + t] = logit;
         }
     }
     __syncthreads();
@@ -1701,7 +1734,7 @@ __global__ __launch_bounds__(192) void k_heads(NetDev P, const float *__restrict
     // masked softmax over the legal cells of the network-frame board (network.py:147-151),
     // prior = exp(log_softmax) (mcts.py:210); one wavefront per board, cells lane, lane+64, lane+128
     const int lane = tid & 63, wave = tid >> 6;
-    for (int b = wave; b < nb; b += 3) {
+    for (int b = wave; b < nb; b += 3 * HEADS_KSPLIT) {
         const int e = e0 + b;
         float x[3];
         bool legal[3];
@@ -2223,10 +2256,11 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
             (void)hipMemcpyAsync(net->act, x, (size_t)max_n * d.ncells * d.C * sizeof(float), hipMemcpyDeviceToDevice, st);
     }
     {
-        const size_t hl = ((size_t)(6 * d.ncells + 64) * HEADS_BPB + (size_t)HEADS_BPB * AZX_CELL_STRIDE) * sizeof(float);
+        const size_t hl = ((size_t)(6 * d.ncells + 64) * HEADS_BPB + (size_t)HEADS_BPB * AZX_CELL_STRIDE +
+                           (size_t)(HEADS_KSPLIT - 1) * (64 + 192) * HEADS_BPB) * sizeof(float);
         static size_t hl_set = 0;
         if (hl > hl_set) { (void)hipFuncSetAttribute((const void *)k_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl); hl_set = hl; }
-        hipLaunchKernelGGL(k_heads, dim3((max_n + HEADS_BPB - 1) / HEADS_BPB), dim3(192), hl, st, d, net->act, hfeat, boards, flip, n_eval_ptr, n_host, logit, value, prior);
+        hipLaunchKernelGGL(k_heads, dim3((max_n + HEADS_BPB - 1) / HEADS_BPB), dim3(192 * HEADS_KSPLIT), hl, st, d, net->act, hfeat, boards, flip, n_eval_ptr, n_host, logit, value, prior);
     }
 }
 
