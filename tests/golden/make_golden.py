@@ -77,7 +77,7 @@ def random_playout(n, rng):
 def make_g1():
     rng = np.random.RandomState(20240101)
     out = {}
-    for n, count in ((11, 300), (13, 60), (5, 100), (3, 40)):
+    for n, count in ((11, 800), (13, 260), (5, 100), (3, 40)):      # >= 1 000 on the two BASELINE board sizes
         cells = n * n
         mv = np.zeros((count, cells), np.int16)
         res = np.zeros((count, cells), np.int8)

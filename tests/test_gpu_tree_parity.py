@@ -98,13 +98,14 @@ def test_g1_movegen_on_device(eng, n):
     moves, res, nl = z["moves_%d" % n], z["result_%d" % n], z["nlegal_%d" % n]
     crc, length, final = z["legalcrc_%d" % n], z["length_%d" % n], z["final_%d" % n]
     r, k, em, fb = eng.hex_replay(n, moves.astype(np.int32), length.astype(np.int32))
+    # empties masks -> one bit per cell (little-endian bit order inside each 64-bit word)
+    bits_ = np.unpackbits(np.ascontiguousarray(em).view(np.uint8), axis=-1, bitorder="little")[..., :n * n]
     for g in range(len(moves)):
         L = int(length[g])
         assert np.array_equal(r[g, :L], res[g, :L])
         assert np.array_equal(k[g, :L], nl[g, :L])
         for p in range(L):
-            cells = [c for c in range(n * n) if (int(em[g, p, c >> 6]) >> (c & 63)) & 1]
-            lm = np.array(cells, np.int32) + 1
+            lm = (np.flatnonzero(bits_[g, p]) + 1).astype(np.int32)       # ascending legal moves (hex.py:151-159)
             assert len(lm) == nl[g, p]
             assert zlib.crc32(lm.tobytes()) == crc[g, p]
     assert np.array_equal(fb, final)
