@@ -1,0 +1,51 @@
+"""bench.py's host-side arithmetic (no GPU): the SURVEY 8(d) flop and byte models, the derived throughput
+fields, and that the committed PMC traffic files are keyed to the command the driver runs -- so that
+`roofline.traffic` is attached (not null) for `python bench.py --gpus 1 --steps 20 --warmup 5`."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_flop_model_matches_survey_8d():
+    assert bench.flop_per_position(11, 6, 64) == 107851784 == bench.FLOP_PER_POSITION_6x64_11
+    # 13x13, 19x256: stem 3 115 008 + 38 convs x 199 360 512 + heads
+    assert bench.flop_per_position(13, 19, 256) == 3115008 + 38 * 199360512 + (173056 + 346112 + 43264 + 128 + 228488)
+
+
+def test_byte_model_matches_survey_8d():
+    # one simulation through D = 2 interior nodes with 100 and 99 children, a leaf with 98 legal moves
+    st = dict(sum_depth=2, sum_k_interior=199, sum_k_leaf=98, selects=1, evals=1)
+    select = (8 + 12 * 100) + (8 + 12 * 99)
+    vloss = 32 * 2
+    backup = 16 * (2 + 1)
+    expand = 4 * 98 + 24 * 98 + 8
+    assert bench.model_bytes(st) == select + vloss + backup + expand
+
+
+def test_throughput_fields_are_consistent():
+    f = bench.throughput_fields([4100.0, 2.0, 10.0, 4000.0, 150.0, 180.0, 0.0], 2.0, 5)
+    assert f["value"] == 2050.0 and f["games_per_sec"] == 1.0 and f["plies_per_sec"] == 5.0
+    assert f["mean_game_length"] == 90.0 and abs(f["games_per_sec_steady"] - 5.0 / 90.0) < 1e-12
+    assert f["ms_per_step"] == 400.0 and f["games_finished"] == 2.0
+    g = bench.throughput_fields([4100.0, 0.0, 10.0, 4000.0, 0.0, 0.0, 0.0], 2.0, 5)
+    assert g["mean_game_length"] is None and g["games_per_sec_steady"] is None and g["games_per_sec"] == 0.0
+
+
+def test_committed_pmc_traffic_is_keyed_to_the_drivers_command():
+    # the defaults main() derives for `--steps 20 --warmup 5` on an 11x11 board
+    a = argparse.Namespace(games=4096, board=11, sims=400, batch=10, blocks=6, chans=64, noise_scale=0.25,
+                           desync=int(round(0.76 * 121)), settle=2 * 121)
+    key_r = [a.games, a.board, a.sims, a.batch, a.blocks, a.chans, 20, 5, a.noise_scale, a.desync, a.settle]
+    key_t = [a.games, a.board, a.sims, a.batch, 130, 20, a.noise_scale, a.desync, a.settle]
+    for name, key in (("r2_resnet_pmc_traffic.json", key_r), ("r2_tree_pmc_traffic.json", key_t)):
+        t = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert t["bench_key"] == key, name
+        traffic, src = bench.pmc_traffic(name, key)
+        assert traffic and traffic == t["hbm_bytes_per_launch"] and name in src
+        assert abs(t["hbm_bytes_per_launch"] - (2 * t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024) < 1.0
+    assert bench.pmc_traffic("r2_resnet_pmc_traffic.json", key_r[:-1] + [0]) == (None, None)
