@@ -74,10 +74,10 @@ def cpu_baseline(args, workload, net_state=None):
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     if workload == "tree":
-        games, max_plies, net, start = 2 * threads, 300, None, 0
+        games, max_plies, net, start = 8 * threads, 300, None, 0      # ~5 s on 64 threads
         sample = "%d whole games, uniform priors, %d sims/move, one game per thread" % (games, args.sims)
     else:
-        games, max_plies, start = threads, 2, args.desync
+        games, max_plies, start = threads, 4, args.desync              # ~13 s on 64 threads
         net = orc.Net(args.board, args.blocks, args.chans, net_state)
         sample = ("%d games x %d plies each from seeded random mid-game positions (0..%d stones, like the "
                   "GPU pool), %dx%d resnet fp32 direct conv, %d sims/move, one game per thread"
