@@ -271,14 +271,14 @@ def resnet_roofline(st, args, steps, warmup):
     return roof
 
 
-def replay_exchange(E, st, dist, torch, local_rank):
+def replay_exchange(E, dist, torch, local_rank):
     """One replay refill the way a DeviceReplayBuffer shared by all ranks takes it: the rows this
     rank harvested are packed into fixed-size records on the device, all-gathered over RCCL and appended to
     the rank's HBM ring.  The bench's harvest queue wraps around, so the most recent rows are used."""
     import numpy as np
     world = dist.get_world_size() if dist is not None else 1
     dev = torch.device("cuda", local_rank)
-    rows, st2 = E.play_device(1, max_plies=40)    # a short top-up through the Player.read path: whole games, queued
+    rows, _ = E.play_device(1, max_plies=40)    # a short top-up through the Player.read path: whole games, queued
     rb = E.record_bytes
     E.replay_create(max(1, rows) * world + 1)
     torch.cuda.synchronize(dev)
@@ -380,7 +380,7 @@ def main():
     E = ex["engine"]
     exchange = None
     if headline == "resnet" and not args.no_replay_exchange:
-        exchange = replay_exchange(E, st, dist, torch, local_rank)
+        exchange = replay_exchange(E, dist, torch, local_rank)
     E.close()
 
     selects_per_search = (args.sims // args.batch + 1) * args.batch

@@ -6,7 +6,7 @@ import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import argparse
-import numpy as np, torch
+import torch
 import bench
 from azalea_amd.network import HexNetwork
 
