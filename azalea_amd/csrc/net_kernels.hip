@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
                                                                 unsigned short *out, const unsigned short *resid,
                                                                 float *__restrict__ out32,
                                                                 const int32_t *__restrict__ n_eval_ptr, int n_eval_host,
-                                                                int flipsh) {
+                                                                int e_base, int e_end) {
 #ifdef AZX_WIDE_DB
     constexpr int MT = WIDE16_MT, NT = WIDE16_NT, ROWB = 144;   // 32-channel chunks: 64 B hi | 64 B lo | 16 B pad
 #else
@@ -1065,8 +1065,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     // the same time and the second one finds the board's input in that L2 instead of fetching it from HBM
     // again (with (board, column) as (x, y) the two were a whole launch wave apart).
     // (grid = (8 C / 128, boards / 8): the linear workgroup id is blockIdx.y * gridDim.x + blockIdx.x)
-    const int e = blockIdx.y * 8 + (blockIdx.x & 7);
-    if (e >= n_eval) return;
+    // [e_base, e_end): the boards of this launch (the host splits a layer's boards over two streams)
+    const int e = e_base + blockIdx.y * 8 + (blockIdx.x & 7);
+    if (e >= n_eval || e >= e_end) return;
     const int co_base = (blockIdx.x >> 3) * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Position tiles: a board of up to 176 cells is eleven 16-row tiles, not twelve.  Wave wm = 0 holds
@@ -1075,7 +1076,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     // 22 tile products per k-step (6 x 2 + 5 x 2) instead of 24, one twelfth of which was padding.
     const int wm = wave & 1, wn = wave >> 1;
     const int row0 = wm ? 80 : 0;
-    (void)flipsh;
     const int li = lane & 15, lh = lane >> 4;
     const size_t rowg = (size_t)C * 4;
     const unsigned char *gin = reinterpret_cast<const unsigned char *>(in) + (size_t)e * ncells * rowg;
@@ -1788,6 +1788,10 @@ struct AzxNet {
     float *hb_value = nullptr;
     size_t lds_bytes = 0;
     int tower_variant = 0;
+    // wide tower: the second half of a batch's boards runs its layer launches on a second stream
+    hipStream_t stream2[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    bool streams_ok = false;
 };
 
 template <typename T>
@@ -1857,6 +1861,16 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
 }
 
 void azx_net_destroy(AzxNet *net) {
+    if (net) {
+        for (int i = 0; i < 3; ++i) {
+            if (net->stream2[i]) { (void)hipStreamSynchronize(net->stream2[i]); (void)hipStreamDestroy(net->stream2[i]); }
+            if (net->ev_join[i]) (void)hipEventDestroy(net->ev_join[i]);
+            net->stream2[i] = nullptr;
+            net->ev_join[i] = nullptr;
+        }
+        if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
+        net->ev_fork = nullptr;
+    }
 #ifdef AZX_NET_STAMP
     {
         unsigned long long h[10] = {0};
@@ -2211,20 +2225,47 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
                 (void)hipFuncSetAttribute((const void *)k_conv_wide_f16x3_s16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 attr5 = true;
             }
-            // which bit of the board index flips a block's long/short wave assignment (31 = never)
-            static const int stagger = getenv("AZX_WIDE_FLIP") ? atoi(getenv("AZX_WIDE_FLIP")) : 0;
             const dim3 grid(max_n, d.C / 128), block(256);
-            const dim3 grid16(8 * (d.C / 128), (max_n + 7) / 8);         // k_conv_wide_f16x3_s16's XCD-aware block order
             hipLaunchKernelGGL(k_stem_wide_f16x3, grid, block, 0, st, d, boards, net->wideX,
                                d.blocks == 0 ? net->act : (float *)nullptr, n_eval_ptr, n_host);
-            for (int b = 0; b < d.blocks; ++b) {
-                if (wshape == 16) {
-                    hipLaunchKernelGGL(k_conv_wide_f16x3_s16, grid16, block, lds, st, d, 2 * b, (const unsigned short *)net->wideX, net->wideY,
-                                       (const unsigned short *)nullptr, (float *)nullptr, n_eval_ptr, n_host, stagger);
-                    hipLaunchKernelGGL(k_conv_wide_f16x3_s16, grid16, block, lds, st, d, 2 * b + 1, (const unsigned short *)net->wideY, net->wideX,
-                                       (const unsigned short *)net->wideX, b == d.blocks - 1 ? net->act : (float *)nullptr, n_eval_ptr, n_host, stagger);
-                    continue;
+            // A layer is one launch over all boards, and a launch ends with a partly filled round of blocks
+            // (9 964 blocks over 512 slots: 19.46 rounds, 2.7 % of a layer idle) -- 38 times per batch.  The
+            // boards are independent, so the batch is cut into AZX_WIDE_STREAMS parts that run their 38 launches
+            // on separate streams: one part's tail round fills up with the others' blocks, whichever layer
+            // those are in.
+            static const int wsplit = std::min(4, std::max(1, getenv("AZX_WIDE_STREAMS") ? atoi(getenv("AZX_WIDE_STREAMS")) : 2));
+            if (wshape == 16) {
+                int parts = wsplit;
+                if (parts > 1 && !net->ev_fork) {
+                    bool ok = hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) == hipSuccess;
+                    for (int i = 0; i < 3 && ok; ++i)
+                        ok = hipStreamCreateWithFlags(&net->stream2[i], hipStreamNonBlocking) == hipSuccess &&
+                             hipEventCreateWithFlags(&net->ev_join[i], hipEventDisableTiming) == hipSuccess;
+                    net->streams_ok = ok;
                 }
+                if (parts > 1 && !net->streams_ok) parts = 1;
+                const int per = (((max_n + parts - 1) / parts + 7) / 8) * 8;     // boards per part, whole groups of 8
+                if (per >= max_n) parts = 1;
+                if (parts > 1) (void)hipEventRecord(net->ev_fork, st);      // the stem (and everything before it) is done
+                for (int part = 0; part < parts; ++part) {
+                    hipStream_t s = part ? net->stream2[part - 1] : st;
+                    if (part) (void)hipStreamWaitEvent(s, net->ev_fork, 0);
+                    const int e0 = part * per, e1 = std::min(max_n, e0 + per);
+                    if (e1 <= e0) continue;
+                    const dim3 g(8 * (d.C / 128), (e1 - e0 + 7) / 8);
+                    for (int b = 0; b < d.blocks; ++b) {
+                        hipLaunchKernelGGL(k_conv_wide_f16x3_s16, g, block, lds, s, d, 2 * b, (const unsigned short *)net->wideX, net->wideY,
+                                           (const unsigned short *)nullptr, (float *)nullptr, n_eval_ptr, n_host, e0, e1);
+                        hipLaunchKernelGGL(k_conv_wide_f16x3_s16, g, block, lds, s, d, 2 * b + 1, (const unsigned short *)net->wideY, net->wideX,
+                                           (const unsigned short *)net->wideX, b == d.blocks - 1 ? net->act : (float *)nullptr, n_eval_ptr, n_host, e0, e1);
+                    }
+                    if (part) {
+                        (void)hipEventRecord(net->ev_join[part - 1], s);
+                        (void)hipStreamWaitEvent(st, net->ev_join[part - 1], 0);    // the heads read every board
+                    }
+                }
+            }
+            for (int b = 0; b < d.blocks && wshape != 16; ++b) {
                 hipLaunchKernelGGL(k_conv_wide_f16x3, grid, block, lds, st, d, 2 * b, (const unsigned short *)net->wideX, net->wideY,
                                    (const unsigned short *)nullptr, (float *)nullptr, n_eval_ptr, n_host);
                 hipLaunchKernelGGL(k_conv_wide_f16x3, grid, block, lds, st, d, 2 * b + 1, (const unsigned short *)net->wideY, net->wideX,
