@@ -588,6 +588,9 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
 // from LDS, single-buffered: tile m's registers are reloaded for the next k-step as soon as its
 // 12 MFMAs have issued) feed 48 MFMAs, one load in each of the first MFMAs' shadows.
 // ============================================================================================
+#ifndef AZX_S16_ZROW0
+#define AZX_S16_ZROW0 1
+#endif
 #ifndef AZX_S16_FENCE
 #define AZX_S16_FENCE 1   // scheduling fence after every third MFMA (measured best of none / 3rd / every)
 #endif
@@ -608,9 +611,14 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
     const int e = e0 + wb;
     const bool live = e < n_eval;
     const int board_b = 128 * ROWB;
+#if AZX_S16_ZROW0
+    const int zero_off = 0;                              // the shared all-zero row comes first: a padding tap is offset 0
+    const int x_off = ROWB + wb * board_b;
+#else
     const int x_off = wb * board_b;
-    unsigned char *X = smem + x_off;
     const int zero_off = F16X3_BPB * board_b;
+#endif
+    unsigned char *X = smem + x_off;
     // lane (i = lane & 15: position inside a tile, h = lane >> 4: k-group of the operands / channel
     // quad of the result).  Transposed product: D[channel 4h + reg][position i].
     const int li = lane & 15, lh = lane >> 4;
@@ -632,9 +640,21 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
         }
     }
     const int zbase = zero_off + 16 * lh;
+    // The 36 (tap, tile) fragment offsets are invariant over the layers; hoisted out of the block loop they
+    // would hold 36 VGPRs beside accumulators, residual and fragments (the kernel then spills 25 registers
+    // to scratch: 490 MB of HBM writes per launch).  The mask words pass through an opaque asm at the top of
+    // every layer, so an offset is formed where it is used (3 VALU in an MFMA's shadow) and lives for
+    // its two k-steps only.
+    uint32_t tapok_lo = (uint32_t)tapok, tapok_hi = (uint32_t)(tapok >> 32);
     auto act_offset = [&](int tap, int m) -> int {
         const int delta = ((tap / 3 - 1) * N + (tap % 3 - 1)) * ROWB;
-        return ((tapok >> (tap * 4 + m)) & 1ull) ? rbase[m] + delta : zbase;
+        const uint32_t word = tap < 8 ? tapok_lo : tapok_hi;
+#if AZX_S16_ZROW0
+        const int mask = (int)(word << (31 - ((tap * 4 + m) & 31))) >> 31;     // v_bfe_i32: 0 or -1
+        return mask & (rbase[m] + delta);
+#else
+        return ((word >> ((tap * 4 + m) & 31)) & 1u) ? rbase[m] + delta : zbase;
+#endif
     };
 
     f32x4 res[MT][NT];
@@ -725,6 +745,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
     int stage = 0;
     auto conv_layer = [&](int layer, auto residual_tag) {
         constexpr bool residual = decltype(residual_tag)::value;
+        asm volatile("" : "+v"(tapok_lo), "+v"(tapok_hi), "+v"(rbase[0]), "+v"(rbase[1]), "+v"(rbase[2]), "+v"(rbase[3]));
         f32x4 acc[MT][NT];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -1102,9 +1123,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
         }
     }
     const int zbase = zero_off + 16 * lh;
+    // The 54 (tap, tile) fragment offsets are invariant over the chunks; hoisted out of the chunk loop they hold
+    // 54 VGPRs and the kernel spills.  The mask words and row bases pass through an opaque asm at the top of
+    // every chunk, so an offset is formed where it is used and lives for its two k-steps only.
+    uint32_t tapok_lo = (uint32_t)tapok & 0x3fffffffu, tapok_hi = (uint32_t)(tapok >> 30);   // taps 0..4 | 5..8
     auto act_offset = [&](int tap, int m) -> int {
         const int delta = ((tap / 3 - 1) * N + (tap % 3 - 1)) * ROWB;
-        return ((tapok >> (tap * 6 + m)) & 1ull) ? rbase[m] + delta : zbase;
+        const uint32_t word = tap < 5 ? tapok_lo : tapok_hi;
+        const int bit = (tap < 5 ? tap : tap - 5) * 6 + m;
+        return ((word >> bit) & 1u) ? rbase[m] + delta : zbase;
     };
     if (tid < ROWB / 4) reinterpret_cast<uint32_t *>(smem + zero_off)[tid] = 0u;
 
@@ -1308,6 +1335,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
         NT_MARK(1)
         }
         // k-step t = 0..17 of this chunk: tap t/2, channels 32 (t%2) .. +31 of the chunk
+        asm volatile("" : "+v"(tapok_lo), "+v"(tapok_hi), "+v"(rbase[0]), "+v"(rbase[1]), "+v"(rbase[2]),
+                          "+v"(rbase[3]), "+v"(rbase[4]), "+v"(rbase[5]));
         auto qof = [&](int t) { return (((layer * 9 + t / 2) * NCH + chunk) * 2 + (t & 1)); };
         f16x8 wh_[NT], wl_[NT];
         f16x8 xh[MT], xl[MT];
