@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libazx_hip.so")
 MAX_BOARD = 13
 CELL_STRIDE = 192
 MAX_BATCH = 16
+ROW_METRICS = 8          # AZX_ROW_METRICS
 
 
 def record_bytes(cells):
@@ -77,6 +78,7 @@ SYMBOLS = {
     "azx_get_evals": (C.c_int, [_vp, C.c_int, _f32p, _f32p, C.POINTER(C.c_int)]),
     "azx_get_root": (C.c_int, [_vp, _i32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p, _f32p]),
     "azx_get_status": (C.c_int, [_vp, _i32p]),
+    "azx_get_tree_nodes": (C.c_int, [_vp, _i32p]),
     "azx_get_games": (C.c_int, [_vp, _i32p, _i32p, _i32p, _i32p]),
     "azx_advance": (C.c_int, [_vp, _i32p]),
     "azx_tree_dump": (C.c_int, [_vp, C.c_int, C.c_int, _i32p, _i32p, _i32p, _f32p, _f32p, _f32p, _i32p, _i32p]),
@@ -100,6 +102,8 @@ SYMBOLS = {
     "azx_debug_choose": (C.c_int, [_vp, _i32p, _f32p]),
     "azx_debug_counters": (C.c_int, [_vp, _u64p]),
     "azx_debug_counters_raw": (C.c_int, [_vp, _u64p, C.c_int64]),
+    "azx_kernel_info": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "azx_debug_set_queue_cap": (C.c_int, [_vp, C.c_int64]),
     "azx_stream": (_vp, [_vp]),
 }
 

@@ -82,6 +82,10 @@ struct azx_engine {
     std::vector<int> ev_weight;         // moves covered by the timed launch (k_play: several)
     size_t ev_used = 0;
     AzxNet *net = nullptr;
+    // diagnostic switches, read once at azx_create (azx_kernel_info reports them)
+    bool force_generic = false;         // AZX_MCTS_GENERIC: every tree launch on the generic instantiation
+    bool no_persistent = false;         // AZX_NO_PERSISTENT: per-move launches instead of k_play
+    int64_t dbg_qcap = 0;               // azx_debug_set_queue_cap
 };
 
 template <typename T>
@@ -121,7 +125,7 @@ struct DevGuard {
     } while (0)
 
 extern "C" const char *azx_last_error(void) { return g_err.c_str(); }
-extern "C" int azx_version(void) { return 3; }   // 3: azx_config.game_index_*, azx_play_stats.sum_game_length, record exchange, row metrics
+extern "C" int azx_version(void) { return 4; }   // 4: 8-float row metrics, azx_kernel_info, azx_debug_set_queue_cap
 
 extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
     if (!cfg || !out) return fail(AZX_EINVAL, "null argument");
@@ -149,6 +153,8 @@ extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
 
     azx_engine *e = new azx_engine();
     e->cfg = *cfg;
+    { const char *v = getenv("AZX_MCTS_GENERIC"); e->force_generic = v && atoi(v) != 0; }
+    { const char *v = getenv("AZX_NO_PERSISTENT"); e->no_persistent = v && atoi(v) != 0; }
     HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     DevEngine &d = e->d;
     memset(&d, 0, sizeof d);
@@ -244,6 +250,37 @@ extern "C" void azx_destroy(azx_engine *e) {
 }
 
 extern "C" void *azx_stream(azx_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+extern "C" int azx_kernel_info(azx_engine *e, char *buf, int cap) {
+    if (!e || !buf || cap < 1) return fail(AZX_EINVAL, "null argument");
+    const DevEngine &d = e->d;
+    const int S = d.slots <= 2 ? 2 : 3;
+    char tree[96], play[96];
+    if (d.evaluator == AZX_EVAL_UNIFORM || d.evaluator == AZX_EVAL_UNIFORM_HASH) {
+        // the FAST instantiation also needs the default prior table and device (or no) noise: decided per launch
+        DevEngine probe = d;
+        probe.device_noise = 1;
+        const bool fast = azx_mcts_fast_path(probe, MODE_BEGIN | MODE_INLINE, e->force_generic);
+        snprintf(tree, sizeof tree, "k_mcts<%d,%s>", S, fast ? "FAST (throughput mode; generic with host noise)" : "generic");
+        snprintf(play, sizeof play, "%s", fast && !e->no_persistent ? (S == 2 ? "k_play<2> (persistent)" : "k_play<3> (persistent)")
+                                                                       : "k_mcts + k_choose + k_advance per move");
+    } else {
+        snprintf(tree, sizeof tree, "k_mcts<%d,generic> (BEGIN / APPLY|SELECT / APPLY phases)", S);
+        snprintf(play, sizeof play, "phases + k_choose + k_advance per move");
+    }
+    std::string text = std::string("tree=") + tree + "; play=" + play + "; net=" +
+                       (e->net ? azx_net_kernel_info(e->net) : "none") +
+                       "; switches: AZX_MCTS_GENERIC=" + (e->force_generic ? "1" : "0") +
+                       " AZX_NO_PERSISTENT=" + (e->no_persistent ? "1" : "0");
+    snprintf(buf, (size_t)cap, "%s", text.c_str());
+    return (int)text.size();
+}
+
+extern "C" int azx_debug_set_queue_cap(azx_engine *e, int64_t rows) {
+    if (!e || rows < 0) return fail(AZX_EINVAL, "bad argument");
+    e->dbg_qcap = rows;
+    return AZX_OK;
+}
 
 extern "C" int azx_set_weights(azx_engine *e, int n_tensors, const char *const *names,
                                const void *const *ptrs, const int64_t *counts, int on_device) {
@@ -377,7 +414,7 @@ static int enqueue_search(azx_engine *e, bool timed) {
     DevEngine &d = e->d;
     if (d.evaluator == AZX_EVAL_UNIFORM || d.evaluator == AZX_EVAL_UNIFORM_HASH) {
         if (timed) time_begin(e);
-        azx_launch_mcts(d, MODE_BEGIN | MODE_INLINE, e->num_batches, e->stream);
+        azx_launch_mcts(d, MODE_BEGIN | MODE_INLINE, e->num_batches, e->stream, e->force_generic);
         if (timed) time_end(e);
         return AZX_OK;
     }
@@ -385,7 +422,7 @@ static int enqueue_search(azx_engine *e, bool timed) {
         if (!azx_net_ready(e->net)) return fail(AZX_ESTATE, "azx_set_weights has not been called");
         HIPCHECK(hipMemsetAsync(d.n_eval, 0, sizeof(int32_t), e->stream));
         if (timed) time_begin(e);
-        azx_launch_mcts(d, MODE_BEGIN, e->num_batches, e->stream);
+        azx_launch_mcts(d, MODE_BEGIN, e->num_batches, e->stream, e->force_generic);
         if (timed) time_end(e);
         if (timed) time_begin(e, 1);
         azx_net_eval(e->net, d, e->stream);
@@ -393,14 +430,14 @@ static int enqueue_search(azx_engine *e, bool timed) {
         for (int b = 0; b < e->num_batches; ++b) {
             HIPCHECK(hipMemsetAsync(d.n_eval, 0, sizeof(int32_t), e->stream));
             if (timed) time_begin(e);
-            azx_launch_mcts(d, MODE_APPLY | MODE_SELECT, e->num_batches, e->stream);
+            azx_launch_mcts(d, MODE_APPLY | MODE_SELECT, e->num_batches, e->stream, e->force_generic);
             if (timed) time_end(e);
             if (timed) time_begin(e, 1);
             azx_net_eval(e->net, d, e->stream);
             if (timed) time_end(e);
         }
         if (timed) time_begin(e);
-        azx_launch_mcts(d, MODE_APPLY, e->num_batches, e->stream);
+        azx_launch_mcts(d, MODE_APPLY, e->num_batches, e->stream, e->force_generic);
         if (timed) time_end(e);
         return AZX_OK;
     }
@@ -438,7 +475,7 @@ extern "C" int azx_search_begin(azx_engine *e, const double *noise, int n_select
     HIPCHECK(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), e->stream));
     if (e->d.evaluator == AZX_EVAL_RESNET && !azx_net_ready(e->net))
         return fail(AZX_ESTATE, "azx_set_weights has not been called");
-    azx_launch_mcts(e->d, MODE_BEGIN, e->num_batches, e->stream);
+    azx_launch_mcts(e->d, MODE_BEGIN, e->num_batches, e->stream, e->force_generic);
     if (e->d.evaluator == AZX_EVAL_RESNET) azx_net_eval(e->net, e->d, e->stream);
     HIPCHECK(hipGetLastError());
     e->ext_active = true;
@@ -452,12 +489,12 @@ extern "C" int azx_search_step(azx_engine *e, int *n_pending, int *done) {
     if (!e->ext_active) return fail(AZX_ESTATE, "azx_search_step without azx_search_begin");
     HIPCHECK(hipMemsetAsync(e->d.n_eval, 0, sizeof(int32_t), e->stream));
     if (e->ext_batches_done < e->num_batches) {
-        azx_launch_mcts(e->d, MODE_APPLY | MODE_SELECT, e->num_batches, e->stream);
+        azx_launch_mcts(e->d, MODE_APPLY | MODE_SELECT, e->num_batches, e->stream, e->force_generic);
         if (e->d.evaluator == AZX_EVAL_RESNET) azx_net_eval(e->net, e->d, e->stream);
         e->ext_batches_done += 1;
         *done = 0;
     } else {
-        azx_launch_mcts(e->d, MODE_APPLY, e->num_batches, e->stream);
+        azx_launch_mcts(e->d, MODE_APPLY, e->num_batches, e->stream, e->force_generic);
         e->ext_active = false;
         *done = 1;
     }
@@ -602,6 +639,16 @@ extern "C" int azx_get_status(azx_engine *e, int32_t *status) {
     HIPCHECK(hipMemcpyAsync(th.data(), e->d.thdr, sizeof(TreeHdr) * th.size(), hipMemcpyDeviceToHost, e->stream));
     HIPCHECK(hipStreamSynchronize(e->stream));
     for (int g = 0; g < e->d.G; ++g) status[g] = th[g].status;
+    return AZX_OK;
+}
+
+extern "C" int azx_get_tree_nodes(azx_engine *e, int32_t *nodes) {
+    if (!e || !nodes) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
+    std::vector<TreeHdr> th(e->d.G);
+    HIPCHECK(hipMemcpyAsync(th.data(), e->d.thdr, sizeof(TreeHdr) * th.size(), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    for (int g = 0; g < e->d.G; ++g) nodes[g] = th[g].num_nodes + th[g].dropped;
     return AZX_OK;
 }
 
@@ -759,7 +806,7 @@ static int play_setup(azx_engine *e, int64_t q_rows, int ring) {
         TRY(dev_alloc(e, &d.row_board, rows * AZX_CELL_STRIDE));
         TRY(dev_alloc(e, &d.row_prob, rows * AZX_CELL_STRIDE));
         TRY(dev_alloc(e, &d.row_k, rows));
-        TRY(dev_alloc(e, &d.row_meta, rows * 4));
+        TRY(dev_alloc(e, &d.row_meta, rows * AZX_ROW_METRICS));
         e->play_ready = true;
     }
     if (q_rows > e->q_alloc) {
@@ -778,7 +825,7 @@ static int play_setup(azx_engine *e, int64_t q_rows, int ring) {
         TRY(qa((void **)&d.q_k, (size_t)q_rows * sizeof(int32_t)));
         TRY(qa((void **)&d.q_reward, (size_t)q_rows * sizeof(float)));
         TRY(qa((void **)&d.q_uid, (size_t)q_rows * sizeof(int64_t)));
-        TRY(qa((void **)&d.q_meta, (size_t)q_rows * 4 * sizeof(float)));
+        TRY(qa((void **)&d.q_meta, (size_t)q_rows * AZX_ROW_METRICS * sizeof(float)));
         e->q_alloc = q_rows;
     }
     d.q_cap = e->q_alloc;
@@ -843,6 +890,7 @@ extern "C" int azx_play_steps(azx_engine *e, int64_t plies, azx_play_stats *stat
     HIPCHECK(hipEventCreate(&t0));
     HIPCHECK(hipEventCreate(&t1));
     HIPCHECK(hipEventRecord(t0, e->stream));
+    azx_launch_advance(e->d, nullptr, 2, e->stream);     // slots parked by an earlier azx_play* call rejoin (ring queue: always room)
     {
         // the uniform-evaluator path plays the moves in persistent launches (k_play), at most
         // PLAY_CHUNK moves each; its time is booked per move like the per-move launches'
@@ -851,7 +899,7 @@ extern "C" int azx_play_steps(azx_engine *e, int64_t plies, azx_play_stats *stat
         while (p < plies) {
             const int n = (int)std::min<int64_t>(PLAY_CHUNK, plies - p);
             time_begin(e);
-            const bool ok = azx_launch_play(e->d, e->num_batches, n, e->stream);
+            const bool ok = azx_launch_play(e->d, e->num_batches, n, e->stream, !e->force_generic && !e->no_persistent);
             if (!ok) break;                 // (the begin event is simply overwritten by the next one)
             time_end(e, n);
             p += n;
@@ -880,8 +928,8 @@ static int play_until(azx_engine *e, int64_t min_positions, int64_t max_plies, a
     memset(stats, 0, sizeof *stats);
     const int64_t worst = min_positions + (int64_t)d.G * d.ncells;
     TRY(play_setup(e, worst, 0));
-    if (const char *dbg = getenv("AZX_DEBUG_QCAP"))     // tests: a queue too small, so that slots get parked
-        d.q_cap = std::max<int64_t>(1, std::min<int64_t>(d.q_cap, atoll(dbg)));
+    if (e->dbg_qcap > 0)                                // tests (azx_debug_set_queue_cap): a queue too small, so that slots get parked
+        d.q_cap = std::max<int64_t>(1, std::min<int64_t>(d.q_cap, e->dbg_qcap));
     TRY(upload_noise(e, nullptr, 0, 0, e->cfg.noise_scale));
     CounterSnap a, b;
     TRY(snap_counters(e, &a));
@@ -900,7 +948,7 @@ static int play_until(azx_engine *e, int64_t min_positions, int64_t max_plies, a
         const int64_t most = std::min<int64_t>(8, 2 * d.N - 1);
         const int chunk = (int)std::min<int64_t>(most, max_plies > 0 ? max_plies - p : most);
         time_begin(e);
-        if (azx_launch_play(d, e->num_batches, chunk, e->stream)) {
+        if (azx_launch_play(d, e->num_batches, chunk, e->stream, !e->force_generic && !e->no_persistent)) {
             time_end(e, chunk);
             p += chunk;
         } else {
@@ -909,6 +957,16 @@ static int play_until(azx_engine *e, int64_t min_positions, int64_t max_plies, a
         }
         HIPCHECK(hipMemcpyAsync(&rows, d.q_count, sizeof rows, hipMemcpyDeviceToHost, e->stream));
         HIPCHECK(hipStreamSynchronize(e->stream));
+        // a bounded queue (azx_debug_set_queue_cap) below min_positions parks every slot sooner or later: with
+        // no slot left to play, return what the queue holds instead of spinning
+        if (e->dbg_qcap > 0 && (p & 7) == 0) {
+            std::vector<GameHdr> hh((size_t)d.G);
+            HIPCHECK(hipMemcpyAsync(hh.data(), d.ghdr, sizeof(GameHdr) * hh.size(), hipMemcpyDeviceToHost, e->stream));
+            HIPCHECK(hipStreamSynchronize(e->stream));
+            bool any = false;
+            for (const GameHdr &h : hh) any = any || h.active;
+            if (!any) break;
+        }
     }
     HIPCHECK(hipEventRecord(t1, e->stream));
     HIPCHECK(hipStreamSynchronize(e->stream));
@@ -986,7 +1044,7 @@ extern "C" int azx_play_row_metrics(azx_engine *e, int64_t cap, float *metrics, 
     if (n > cap) return fail(AZX_EINVAL, "%lld rows queued, caller capacity %lld", (long long)n, (long long)cap);
     *n_out = n;
     if (n == 0) return AZX_OK;
-    HIPCHECK(hipMemcpyAsync(metrics, e->d.q_meta, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipMemcpyAsync(metrics, e->d.q_meta, (size_t)n * AZX_ROW_METRICS * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHECK(hipStreamSynchronize(e->stream));
     return AZX_OK;
 }

@@ -42,7 +42,9 @@ struct alignas(64) TreeHdr {
     float   search_value;  // mcts.py:287 accumulator (float32)
     int32_t slow_div;      // a backed-up value was outside the range the unscaled divide is exact for
     int32_t defer_compact; // play mode: compact the arena (keep the subtree under root_id) before the next search
-    int32_t pad[3];
+    int32_t dropped;       // nodes discarded by arena compactions since the last reset: num_nodes + dropped is the
+                           // reference's never-reclaimed node count (search_tree.py:112 'search_tree_nodes')
+    int32_t pad[2];
 };
 
 struct alignas(64) GameHdr {
@@ -111,8 +113,9 @@ struct DevEngine {
     uint8_t *row_board;     // [G][ncells][AZX_CELL_STRIDE] absolute colours before the move
     float *row_prob;        // [G][ncells][AZX_CELL_STRIDE] moves_prob dense by child index
     int32_t *row_k;         // [G][ncells]
-    float *row_meta;        // [G][ncells][4] per-ply search metrics of the game in progress: search_value,
-                            // root width, log-probability of the move drawn (play_game.py:41-43 averages them per game)
+    float *row_meta;        // [G][ncells][8] per-ply search metrics of the game in progress: search_value, root
+                            // width, log-probability of the move drawn, (first-row flag), mean root-child visits,
+                            // tree nodes (search_tree.py:109-112; play_game.py:41-43 averages them per game)
     // ... and the output queue finished games are appended to (whole games only)
     int64_t q_cap;
     int32_t q_ring;         // 1: wrap around instead of stalling (bench)
@@ -121,7 +124,7 @@ struct DevEngine {
     int32_t *q_color, *q_k; // [Q]
     float *q_reward;        // [Q]
     int64_t *q_uid;         // [Q]
-    float *q_meta;          // [Q][4] the rows' per-ply search metrics
+    float *q_meta;          // [Q][8] the rows' per-ply search metrics (AZX_ROW_METRICS floats per row)
     unsigned long long *q_count;   // [1] rows appended
     double *stat_sums;      // [G][8] per game: search_value, root_width, action_logprob, reward_last
 };

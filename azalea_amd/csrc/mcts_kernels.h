@@ -12,8 +12,10 @@
 #define MODE_INLINE 8   // evaluator is inline (uniform priors): loop all batches in one launch
 
 size_t azx_mcts_lds_bytes(int ncells, int bs);
-void azx_launch_mcts(const DevEngine &E, int mode, int num_batches, hipStream_t st);
-bool azx_launch_play(const DevEngine &E, int num_batches, int steps, hipStream_t st);   // whole moves in one launch
+void azx_launch_mcts(const DevEngine &E, int mode, int num_batches, hipStream_t st, bool force_generic);
+bool azx_mcts_fast_path(const DevEngine &E, int mode, bool force_generic);   // would this launch take k_mcts<S, FAST>?
+// whole moves in one launch (k_play); returns false (nothing launched) when not `allowed` or not applicable
+bool azx_launch_play(const DevEngine &E, int num_batches, int steps, hipStream_t st, bool allowed);
 void azx_launch_reset(const DevEngine &E, const int32_t *slots, int n_slots, const int32_t *moves,
                       const int32_t *n_moves, int stride, int assign_uid, hipStream_t st);
 void azx_launch_advance(const DevEngine &E, const int32_t *move_ids, int play_mode, hipStream_t st);

@@ -400,6 +400,7 @@ __device__ __forceinline__ void compact_tree(const DevEngine &E, int g, TreeHdr 
     }
     if (lane == 0) {
         th->arena ^= 1;
+        th->dropped += th->num_nodes - n_new;
         th->num_nodes = n_new;
         th->root_id = 0;
         th->root_k = k_child;
@@ -1393,6 +1394,7 @@ __device__ __forceinline__ void tree_reset(const DevEngine &E, int g, TreeHdr *t
         th->search_value = 0.0f;
         th->slow_div = 0;
         th->defer_compact = 0;
+        th->dropped = 0;
     }
 }
 
@@ -1582,9 +1584,11 @@ __device__ __forceinline__ void advance_body(const DevEngine &E, const int32_t *
                 if ((ply0 + r) & 1) rew = -rew;
                 E.q_reward[q] = rew;
                 E.q_uid[q] = uid;
-                float4 mt = reinterpret_cast<const float4 *>(E.row_meta)[(size_t)g * E.ncells + r];
+                const float4 *ms = reinterpret_cast<const float4 *>(E.row_meta) + ((size_t)g * E.ncells + r) * 2;
+                float4 mt = ms[0];
                 mt.w = r == 0 ? 1.0f : 0.0f;                   // marks the first row of a game
-                reinterpret_cast<float4 *>(E.q_meta)[q] = mt;
+                reinterpret_cast<float4 *>(E.q_meta)[q * 2] = mt;
+                reinterpret_cast<float4 *>(E.q_meta)[q * 2 + 1] = ms[1];
             }
             if (lane == 0) {
                 E.counters[(size_t)g * CTR_COUNT + CTR_GAMES] += 1ull;
@@ -1698,6 +1702,10 @@ __device__ __forceinline__ void choose_body(const DevEngine &E) {
         mx = fmaxf(mx, nv[s]);
     }
     mx = wave_max(mx);
+    float nv_sum = 0.0f;                                 // visit counts are integers: the sum is exact in any order
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) nv_sum += nv[s];
+    nv_sum = wave_sum(nv_sum);
     float tot = 0.0f;
     int width = 0;
 #pragma unroll
@@ -1768,8 +1776,10 @@ __device__ __forceinline__ void choose_body(const DevEngine &E) {
         E.stat_sums[(size_t)g * 8 + 0] += (double)(th->search_value);
         E.stat_sums[(size_t)g * 8 + 1] += (double)width;
         E.stat_sums[(size_t)g * 8 + 2] += (double)logp;
-        float4 *meta = reinterpret_cast<float4 *>(E.row_meta) + (size_t)g * E.ncells + row;
-        *meta = make_float4(th->search_value, (float)width, logp, 0.0f);
+        // search_tree.py:109-112: width, mean child visits, nodes ever allocated, children
+        float4 *meta = reinterpret_cast<float4 *>(E.row_meta) + ((size_t)g * E.ncells + row) * 2;
+        meta[0] = make_float4(th->search_value, (float)width, logp, 0.0f);
+        meta[1] = make_float4(nv_sum / (float)mk.k, (float)(th->num_nodes + th->dropped), (float)mk.k, 0.0f);
     }
 }
 
@@ -1791,9 +1801,17 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_play(DevEngine E, int num_
     for (int s = 0; s < steps; ++s) {
         mcts_body<SLOTS, true>(E, MODE_BEGIN | MODE_INLINE, num_batches);
         wave_mem_sync();
-        choose_body<SLOTS>(E);
+        // The move draw and the game step read their engine fields (queue, row and statistics pointers: ~50
+        // scalar registers) from the kernel-argument segment again, through a pointer the compiler cannot see
+        // through: loaded at kernel entry they stay live -- spilled to VGPR lanes and reloaded -- across the
+        // whole search.
+        uint32_t koff = 0;
+        asm volatile("" : "+s"(koff));
+        const DevEngine *Ec = (const DevEngine *)((const __attribute__((address_space(4))) char *)
+                                                  __builtin_amdgcn_kernarg_segment_ptr() + koff);
+        choose_body<SLOTS>(*Ec);
         wave_mem_sync();
-        advance_body<SLOTS>(E, nullptr, 1);
+        advance_body<SLOTS>(*Ec, nullptr, 1);
         wave_mem_sync();
     }
 }
@@ -1962,14 +1980,16 @@ void azx_gamma_table(double alpha, float *tab) {
         else { CALL(3); }                                   \
     } while (0)
 
-void azx_launch_mcts(const DevEngine &E, int mode, int num_batches, hipStream_t st) {
+// force_generic (azx_create reads AZX_MCTS_GENERIC once per engine) keeps every launch on the generic
+// instantiation (A/B and the equivalence test)
+bool azx_mcts_fast_path(const DevEngine &E, int mode, bool force_generic) {
+    return !force_generic && mode == (MODE_BEGIN | MODE_INLINE) && E.evaluator == AZX_EVAL_UNIFORM &&
+           E.prior_default && (E.noise_scale == 0.0 || E.device_noise);
+}
+
+void azx_launch_mcts(const DevEngine &E, int mode, int num_batches, hipStream_t st, bool force_generic) {
     const size_t lds = azx_mcts_lds_bytes(E.ncells, E.bs);
-    // AZX_MCTS_GENERIC=1 keeps every launch on the generic instantiation (A/B and the equivalence test)
-    const char *fg = getenv("AZX_MCTS_GENERIC");     // read per launch: the equivalence test toggles it
-    const bool force_generic = fg && atoi(fg) != 0;
-    const bool fast = !force_generic && mode == (MODE_BEGIN | MODE_INLINE) && E.evaluator == AZX_EVAL_UNIFORM &&
-                      E.prior_default && (E.noise_scale == 0.0 || E.device_noise);
-    if (fast) {
+    if (azx_mcts_fast_path(E, mode, force_generic)) {
 #define CALL(S) hipLaunchKernelGGL((k_mcts<S, true>), dim3(E.G), dim3(64), lds, st, E, mode, num_batches)
         DISPATCH_SLOTS(E.slots, CALL);
 #undef CALL
@@ -1981,10 +2001,8 @@ void azx_launch_mcts(const DevEngine &E, int mode, int num_batches, hipStream_t 
 }
 
 // FAST conditions as in azx_launch_mcts; returns false (nothing launched) when they do not hold
-bool azx_launch_play(const DevEngine &E, int num_batches, int steps, hipStream_t st) {
-    const char *fg = getenv("AZX_MCTS_GENERIC");
-    const char *np = getenv("AZX_NO_PERSISTENT");
-    if ((fg && atoi(fg) != 0) || (np && atoi(np) != 0)) return false;
+bool azx_launch_play(const DevEngine &E, int num_batches, int steps, hipStream_t st, bool allowed) {
+    if (!allowed) return false;
     if (!(E.evaluator == AZX_EVAL_UNIFORM && E.prior_default && (E.noise_scale == 0.0 || E.device_noise))) return false;
     const size_t lds = azx_mcts_lds_bytes(E.ncells, E.bs);
 #define CALL(S) hipLaunchKernelGGL((k_play<S>), dim3(E.G), dim3(64), lds, st, E, num_batches, steps)

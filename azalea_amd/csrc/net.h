@@ -13,6 +13,7 @@ const char *azx_net_error();
 int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void *const *ptrs,
                         const int64_t *counts, int on_device);
 bool azx_net_ready(const AzxNet *net);
+const char *azx_net_kernel_info(const AzxNet *net);   // which tower / heads kernels this net launches
 // evaluate the packed requests ev_board[0 .. *d.n_eval) -> ev_value, ev_prior (by original cell)
 void azx_net_eval(AzxNet *net, const DevEngine &d, hipStream_t st);
 // Network.run on host arrays (network.py:87-105): value[B], moves_logprob[B][K]

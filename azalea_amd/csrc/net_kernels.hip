@@ -588,9 +588,6 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
 // from LDS, single-buffered: tile m's registers are reloaded for the next k-step as soon as its
 // 12 MFMAs have issued) feed 48 MFMAs, one load in each of the first MFMAs' shadows.
 // ============================================================================================
-#ifndef AZX_S16_ZROW0
-#define AZX_S16_ZROW0 1
-#endif
 #ifndef AZX_S16_FENCE
 #define AZX_S16_FENCE 1   // scheduling fence after every third MFMA (measured best of none / 3rd / every)
 #endif
@@ -611,13 +608,8 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
     const int e = e0 + wb;
     const bool live = e < n_eval;
     const int board_b = 128 * ROWB;
-#if AZX_S16_ZROW0
     const int zero_off = 0;                              // the shared all-zero row comes first: a padding tap is offset 0
     const int x_off = ROWB + wb * board_b;
-#else
-    const int x_off = wb * board_b;
-    const int zero_off = F16X3_BPB * board_b;
-#endif
     unsigned char *X = smem + x_off;
     // lane (i = lane & 15: position inside a tile, h = lane >> 4: k-group of the operands / channel
     // quad of the result).  Transposed product: D[channel 4h + reg][position i].
@@ -639,22 +631,18 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
             if (r < ncells && yy >= 0 && yy < N && xx >= 0 && xx < N) tapok |= 1ull << (tap * 4 + m);
         }
     }
-    const int zbase = zero_off + 16 * lh;
     // The 36 (tap, tile) fragment offsets are invariant over the layers; hoisted out of the block loop they
-    // would hold 36 VGPRs beside accumulators, residual and fragments (the kernel then spills 25 registers
-    // to scratch: 490 MB of HBM writes per launch).  The mask words pass through an opaque asm at the top of
-    // every layer, so an offset is formed where it is used (3 VALU in an MFMA's shadow) and lives for
-    // its two k-steps only.
+    // would hold 36 VGPRs beside accumulators, residual and fragments (the kernel then spilled 25 registers
+    // to scratch: 490 MB of HBM writes per launch).  The mask words and row bases pass through an opaque asm
+    // at the top of every layer, so an offset is formed where it is used (bit-field extract, add, and: three
+    // VALU in an MFMA's shadow; a padding tap reads the zero row at LDS offset 0) and lives for its two
+    // k-steps only.
     uint32_t tapok_lo = (uint32_t)tapok, tapok_hi = (uint32_t)(tapok >> 32);
     auto act_offset = [&](int tap, int m) -> int {
         const int delta = ((tap / 3 - 1) * N + (tap % 3 - 1)) * ROWB;
         const uint32_t word = tap < 8 ? tapok_lo : tapok_hi;
-#if AZX_S16_ZROW0
         const int mask = (int)(word << (31 - ((tap * 4 + m) & 31))) >> 31;     // v_bfe_i32: 0 or -1
         return mask & (rbase[m] + delta);
-#else
-        return ((word >> ((tap * 4 + m) & 31)) & 1u) ? rbase[m] + delta : zbase;
-#endif
     };
 
     f32x4 res[MT][NT];
@@ -1821,6 +1809,11 @@ struct AzxNet {
     hipStream_t stream2[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     bool streams_ok = false;
+    // diagnostic switches, read once per engine by azx_net_create (azx_net_kernel_info reports the outcome)
+    bool opt_split_m = true;    // AZX_TOWER_SPLIT=0: the 6x64 tower without the fused head convs / position split
+    int opt_shape = 16;         // AZX_TOWER_SHAPE=32: the 32x32x16 MFMA kernels
+    int opt_wsplit = 2;         // AZX_WIDE_STREAMS: streams the wide tower's layer launches are spread over
+    std::string info;
 };
 
 template <typename T>
@@ -1854,6 +1847,22 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     else if (chans == 32 && ncells <= 192) net->tower_variant = 3;   // <32,6,2,2,1>
     else if (chans % 128 == 0 && ncells <= 192 && !want_fp32) net->tower_variant = 5;   // k_conv_wide_f16x3 per layer
     net->use_mfma = net->tower_variant != 0;
+    { const char *v = getenv("AZX_TOWER_SPLIT"); net->opt_split_m = v ? atoi(v) != 0 : true; }
+    { const char *v = getenv("AZX_TOWER_SHAPE"); net->opt_shape = v ? atoi(v) : 16; }
+    { const char *v = getenv("AZX_WIDE_STREAMS"); net->opt_wsplit = std::min(4, std::max(1, v ? atoi(v) : 2)); }
+    {
+        char b[200];
+        const char *tower = "k_stem_generic + k_conv_generic (VALU)";
+        if (net->tower_variant == 4)
+            tower = net->opt_shape == 16 && net->opt_split_m ? "k_tower_f16x3_s16" : net->opt_split_m ? "k_tower_f16x3<true>" : "k_tower_f16x3<false>";
+        else if (net->tower_variant == 5) tower = net->opt_shape == 16 ? "k_stem_wide_f16x3 + k_conv_wide_f16x3_s16 per layer" : "k_stem_wide_f16x3 + k_conv_wide_f16x3 per layer";
+        else if (net->tower_variant == 1) tower = "k_tower_mfma<64,4,2,1,2> (fp32 MFMA)";
+        else if (net->tower_variant == 2) tower = "k_tower_mfma<64,6,1,2,2> (fp32 MFMA)";
+        else if (net->tower_variant == 3) tower = "k_tower_mfma<32,6,2,2,1> (fp32 MFMA)";
+        snprintf(b, sizeof b, "%s + k_heads (%dx%d on %dx%d; AZX_TOWER=%s AZX_TOWER_SHAPE=%d AZX_TOWER_SPLIT=%d AZX_WIDE_STREAMS=%d)",
+                 tower, blocks, chans, N, N, want_fp32 ? "fp32" : "default", net->opt_shape, (int)net->opt_split_m, net->opt_wsplit);
+        net->info = b;
+    }
     const size_t E = max_evals;
     net->act = nalloc<float>(net, E * ncells * chans);
     net->logit = nalloc<float>(net, E * AZX_CELL_STRIDE);
@@ -2227,8 +2236,8 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
     if (net->use_mfma) {
         const size_t lds = net->lds_bytes;
         if (net->tower_variant == 4) {
-            static const bool split_m = getenv("AZX_TOWER_SPLIT") ? atoi(getenv("AZX_TOWER_SPLIT")) != 0 : true;
-            static const int shape = getenv("AZX_TOWER_SHAPE") ? atoi(getenv("AZX_TOWER_SHAPE")) : 16;
+            const bool split_m = net->opt_split_m;
+            const int shape = net->opt_shape;
             static bool attr4 = false;
             if (!attr4) {
                 (void)hipFuncSetAttribute((const void *)k_tower_f16x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2248,7 +2257,7 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
             } else hipLaunchKernelGGL(k_tower_f16x3<false>, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act, (float *)nullptr);
         } else if (net->tower_variant == 5) {
             static bool attr5 = false;
-            static const int wshape = getenv("AZX_TOWER_SHAPE") ? atoi(getenv("AZX_TOWER_SHAPE")) : 16;
+            const int wshape = net->opt_shape;
             if (!attr5) {
                 (void)hipFuncSetAttribute((const void *)k_conv_wide_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 (void)hipFuncSetAttribute((const void *)k_conv_wide_f16x3_s16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2262,7 +2271,7 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
             // boards are independent, so the batch is cut into AZX_WIDE_STREAMS parts that run their 38 launches
             // on separate streams: one part's tail round fills up with the others' blocks, whichever layer
             // those are in.
-            static const int wsplit = std::min(4, std::max(1, getenv("AZX_WIDE_STREAMS") ? atoi(getenv("AZX_WIDE_STREAMS")) : 2));
+            const int wsplit = net->opt_wsplit;
             if (wshape == 16) {
                 int parts = wsplit;
                 if (parts > 1 && !net->ev_fork) {
@@ -2275,11 +2284,15 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
                 if (parts > 1 && !net->streams_ok) parts = 1;
                 const int per = (((max_n + parts - 1) / parts + 7) / 8) * 8;     // boards per part, whole groups of 8
                 if (per >= max_n) parts = 1;
-                if (parts > 1) (void)hipEventRecord(net->ev_fork, st);      // the stem (and everything before it) is done
+                // the stem (and everything before it) is done; if the fork cannot be recorded or waited for, a
+                // later part's convolutions could start before the stem has finished: fall back to one stream
+                if (parts > 1 && hipEventRecord(net->ev_fork, st) != hipSuccess) parts = 1;
+                for (int part = 1; part < parts; ++part)
+                    if (hipStreamWaitEvent(net->stream2[part - 1], net->ev_fork, 0) != hipSuccess) { parts = 1; break; }
+                const int per_ok = parts > 1 ? per : max_n;
                 for (int part = 0; part < parts; ++part) {
                     hipStream_t s = part ? net->stream2[part - 1] : st;
-                    if (part) (void)hipStreamWaitEvent(s, net->ev_fork, 0);
-                    const int e0 = part * per, e1 = std::min(max_n, e0 + per);
+                    const int e0 = part * per_ok, e1 = std::min(max_n, e0 + per_ok);
                     if (e1 <= e0) continue;
                     const dim3 g(8 * (d.C / 128), (e1 - e0 + 7) / 8);
                     for (int b = 0; b < d.blocks; ++b) {
@@ -2288,9 +2301,10 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
                         hipLaunchKernelGGL(k_conv_wide_f16x3_s16, g, block, lds, s, d, 2 * b + 1, (const unsigned short *)net->wideY, net->wideX,
                                            (const unsigned short *)net->wideX, b == d.blocks - 1 ? net->act : (float *)nullptr, n_eval_ptr, n_host, e0, e1);
                     }
-                    if (part) {
-                        (void)hipEventRecord(net->ev_join[part - 1], s);
-                        (void)hipStreamWaitEvent(st, net->ev_join[part - 1], 0);    // the heads read every board
+                    if (part) {     // the heads read every board; if the join cannot be expressed on the streams, block
+                        if (hipEventRecord(net->ev_join[part - 1], s) != hipSuccess ||
+                            hipStreamWaitEvent(st, net->ev_join[part - 1], 0) != hipSuccess)
+                            (void)hipStreamSynchronize(s);
                     }
                 }
             }
@@ -2333,6 +2347,8 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
         hipLaunchKernelGGL(k_heads, dim3((max_n + HEADS_BPB - 1) / HEADS_BPB), dim3(192 * HEADS_KSPLIT), hl, st, d, net->act, hfeat, boards, flip, n_eval_ptr, n_host, logit, value, prior);
     }
 }
+
+const char *azx_net_kernel_info(const AzxNet *net) { return net->info.c_str(); }
 
 void azx_net_eval(AzxNet *net, const DevEngine &e, hipStream_t st) {
     run_net(net, e.ev_board, e.ev_flip, e.n_eval, 0, net->max_evals, net->logit, e.ev_value, e.ev_prior, st);

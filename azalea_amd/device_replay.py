@@ -73,18 +73,22 @@ class DeviceReplayBuffer:
             rows, st = self.engine.replay_fill(int(np.ceil(refill)))
             st = dict(st, **self._game_sums(rows))
         self.fresh_counter += rows
-        return {"games": float(st["games"]), "reward": st["sum_reward_last"],
-                "moves_per_game": float(rows), "seconds_per_game": st["seconds"],
-                "game_error": float(st["game_errors"]),
-                "search_value": st["game_search_value"], "search_root_width": st["game_root_width"],
-                "action_logprob": st["game_action_logprob"]}
+        out = {"games": float(st["games"]), "reward": st["sum_reward_last"],
+               "moves_per_game": float(rows), "seconds_per_game": st["seconds"],
+               "game_error": float(st["game_errors"])}
+        out.update({k: float(st.get("game_" + k, 0.0)) for k in self._SEARCH_KEYS})
+        return out
+
+    # the per-ply search metrics play_game averages per game (search_tree.py:109-112, mcts.py:291, policy.py:164)
+    _SEARCH_KEYS = ("search_value", "search_root_width", "action_logprob", "search_root_visits",
+                    "search_tree_nodes", "search_root_children")
 
     def _game_sums(self, rows):
         """Per-game means of the search metrics, summed over the games just harvested (what Player.read's
         metrics hold); an engine without the per-row metric queue contributes zeros."""
         f = getattr(self.engine, "game_metric_sums", None)
-        sv, width, logp = f(rows) if (f is not None and rows) else (0.0, 0.0, 0.0)
-        return {"game_search_value": float(sv), "game_root_width": float(width), "game_action_logprob": float(logp)}
+        sums = f(rows) if (f is not None and rows) else {}
+        return {"game_" + k: float(sums.get(k, 0.0)) for k in self._SEARCH_KEYS}
 
     def _fill_shared(self, refill: int):
         """One refill played by all ranks: each rank plays its share of whole games into its harvest
@@ -119,8 +123,7 @@ class DeviceReplayBuffer:
         self.last_exchange = {"rows_per_rank": counts, "play_seconds": t1 - t0, "pack_seconds": t2 - t1,
                               "allgather_seconds": t3 - t2, "ring_put_seconds": t4 - t3,
                               "bytes_gathered": int(sum(counts)) * eng.record_bytes}
-        keys = ("games", "plies", "game_errors", "seconds", "sum_reward_last", "game_search_value",
-                "game_root_width", "game_action_logprob")
+        keys = ("games", "plies", "game_errors", "seconds", "sum_reward_last") + tuple("game_" + k for k in self._SEARCH_KEYS)
         st = dict(st, **self._game_sums(n_local))
         total = azdist.all_reduce_metrics({k: float(st.get(k, 0.0)) for k in keys})
         total["seconds"] /= max(1, len(counts))         # ranks play side by side

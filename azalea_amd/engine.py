@@ -199,6 +199,12 @@ class Engine:
         check(self.L.azx_get_status(self.h, _p(st, C.c_int32)))
         return st
 
+    def get_tree_nodes(self):
+        """SearchTree.num_nodes as the reference counts it (never reclaimed; search_tree.py:112)."""
+        nn = np.zeros(self.G, np.int32)
+        check(self.L.azx_get_tree_nodes(self.h, _p(nn, C.c_int32)))
+        return nn
+
     def get_games(self):
         G = self.G
         board = np.zeros((G, self.n, self.n), np.int32)
@@ -257,28 +263,47 @@ class Engine:
         return dict(board=board[:n], color=color[:n], nlegal=nlegal[:n], moves_prob=prob[:n],
                     reward=reward[:n], game_uid=uid[:n]), st.as_dict()
 
+    # azx_play_row_metrics columns -> the reference's per-ply metric names (search_tree.py:109-112, mcts.py:291,
+    # policy.py:164); column 3 flags the first row of a game
+    ROW_METRIC_COLUMNS = (("search_value", 0), ("search_root_width", 1), ("action_logprob", 2),
+                          ("search_root_visits", 4), ("search_tree_nodes", 5), ("search_root_children", 6))
+
     def game_metric_sums(self, rows=None):
         """Sums over the games of the last play()/play_device()/replay_fill() call of each game's per-ply MEANS
-        of (search_value, search_root_width, action_logprob): what Player.read's metrics add up
+        of the search metrics, by the reference's key names: what Player.read's metrics add up
         (play_game.py:73-76, parallel_player.py:50-51)."""
         m = self.play_row_metrics(rows)
+        names = [k for k, _ in self.ROW_METRIC_COLUMNS]
         if len(m) == 0:
-            return np.zeros(3)
+            return dict.fromkeys(names, 0.0)
         starts = np.flatnonzero(m[:, 3] > 0.5)
         if len(starts) == 0 or starts[0] != 0:
             starts = np.r_[0, starts]
-        sums = np.add.reduceat(m[:, :3].astype(np.float64), starts, axis=0)
+        cols = [c for _, c in self.ROW_METRIC_COLUMNS]
+        sums = np.add.reduceat(m[:, cols].astype(np.float64), starts, axis=0)
         lens = np.diff(np.r_[starts, len(m)])
-        return (sums / lens[:, None]).sum(0)
+        return dict(zip(names, (sums / lens[:, None]).sum(0).tolist()))
 
     def play_row_metrics(self, rows=None):
-        """azx_play_row_metrics: [rows, 4] = search_value, root width, log-prob of the move drawn, 0 for the
-        rows of the last play() / play_device() call (`rows`: how many that call returned, if known)."""
+        """azx_play_row_metrics: [rows, AZX_ROW_METRICS] for the rows of the last play() / play_device() call
+        (`rows`: how many that call returned, if known); columns: ROW_METRIC_COLUMNS, 3 = first row of a game."""
         cap = int(rows) if rows is not None else self._last_rows
-        m = np.zeros((max(1, cap), 4), np.float32)
+        m = np.zeros((max(1, cap), _lib.ROW_METRICS), np.float32)
         n = C.c_int64(0)
         check(self.L.azx_play_row_metrics(self.h, max(1, cap), _p(m, C.c_float), C.byref(n)))
         return m[:n.value]
+
+    def kernel_info(self):
+        """azx_kernel_info: which kernels this engine launches (and the diagnostic switches it was created under)."""
+        buf = C.create_string_buffer(1024)
+        n = self.L.azx_kernel_info(self.h, buf, len(buf))
+        if n < 0:
+            check(n)
+        return buf.value.decode()
+
+    def debug_set_queue_cap(self, rows):
+        """tests: bound the harvest queue of the following play calls (0 = no bound)."""
+        check(self.L.azx_debug_set_queue_cap(self.h, int(rows)))
 
     def play_device(self, min_positions, max_plies=0):
         """azx_play_device: whole games until >= min_positions rows sit in the harvest queue (in HBM)."""

@@ -81,6 +81,7 @@ class Player:
         overflowed its tree (SearchTreeFull) is skipped like the reference's worker does
         (parallel_player.py:73-76) and counted in metrics['game_error']."""
         shared = self.gather and azdist.is_distributed()
+        self._agree_seed_base()       # a collective when shared: every rank passes here, whatever its quota
         quota = azdist.shard_quota(size) if shared else size
         rows_list, metrics = [], defaultdict(float)
         have, barren = 0, 0
@@ -123,6 +124,7 @@ class Player:
         pol = self._device_policy()
         if pol is None:
             raise RuntimeError("device-resident replay needs a single agent whose Policy holds a HexNetwork")
+        self._agree_seed_base()
         return self._get_engine(pol)
 
     def prepare_device_engine(self, engine) -> None:
@@ -135,6 +137,20 @@ class Player:
     def _device_policy(self):
         pol = getattr(self.agents[0], "policy", None)
         return pol if isinstance(pol, Policy) and pol._uses_device_net() and len(self.agents) == 1 else None
+
+    def _agree_seed_base(self) -> None:
+        """Each game draws from its own stream: seed base + GLOBAL game index.  Ranks that share
+        their reads use rank 0's base (rank r of W plays the games r, r+W, ...: the set of games does not depend
+        on W).  The broadcast is a collective, so it happens where every rank is guaranteed to arrive -- at the
+        top of read() / device_engine() -- never inside the production path, which a rank with quota 0 or with
+        games still queued skips.  A Player that does not gather derives its base locally."""
+        if self._seed_base is not None:
+            return
+        pol = self._device_policy()
+        if pol is None:
+            return
+        local = int(pol.rng.randint(0, 2 ** 31 - 1))
+        self._seed_base = azdist.broadcast_int(local) if (self.gather and azdist.is_distributed()) else local
 
     def _produce(self, want: int) -> None:
         pol = self._device_policy()
@@ -181,10 +197,8 @@ class Player:
                 self._engine.close()
             sampling = pol.settings.get("move_sampling", False)
             explore = sampling and pol.settings.get("move_exploration", False)
-            if self._seed_base is None:
-                # each game draws from its own stream: seed base + GLOBAL game index; rank 0's
-                # base is shared, rank r of W plays the games r, r+W, ...: the set of games does not depend on W
-                self._seed_base = azdist.broadcast_int(int(pol.rng.randint(0, 2 ** 31 - 1)))
+            if self._seed_base is None:      # read() / device_engine() agree on it before any production
+                raise RuntimeError("Player: the seed base must be agreed before the engine is created")
             self._engine = _eng.Engine(
                 board_size=n, n_games=self.n_games, simulations=pol.simulations,
                 search_batch_size=pol.search_batch_size, exploration_coef=pol.exploration_coef,
@@ -209,12 +223,15 @@ class Player:
         meta = eng.play_row_metrics()
         starts = np.flatnonzero(np.r_[True, uid[1:] != uid[:-1]])
         ends = np.r_[starts[1:], len(uid)]
+        names = [k for k, _ in eng.ROW_METRIC_COLUMNS]
+        cols = [c for _, c in eng.ROW_METRIC_COLUMNS]
         for s, e in zip(starts, ends):
             game = {k: v[s:e] for k, v in rows.items()}
-            mean = meta[s:e, :3].astype(np.float64).mean(0)
+            mean = meta[s:e][:, cols].astype(np.float64).mean(0)
+            # the key set of play_game.py:69-76 over search_tree.py:109-112 / mcts.py:291 / policy.py:164
             gm = dict(games=1, reward=float(game["reward"][-1]), moves_per_game=int(e - s),
-                      seconds_per_game=st["seconds"] / max(1, st["games"]), search_value=float(mean[0]),
-                      search_root_width=float(mean[1]), action_logprob=float(mean[2]))
+                      seconds_per_game=st["seconds"] / max(1, st["games"]), game_error=0)
+            gm.update(zip(names, (float(x) for x in mean)))
             self._games.append((game, gm))
 
     @staticmethod

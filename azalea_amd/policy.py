@@ -245,7 +245,7 @@ class Policy:
                    "search_root_width": np.sum(visits > 0),
                    "search_root_visits": np.mean(visits),
                    "search_root_children": len(visits),
-                   "search_tree_nodes": int(root["num_nodes"][0])}
+                   "search_tree_nodes": int(eng.get_tree_nodes()[0])}
         move_id = np.argmax(self.rng.multinomial(1, probs))
         move = state.legal_moves[move_id]
         info = dict(prob=probs[move_id], value=value, moves=state.legal_moves, moves_prob=probs,

@@ -101,9 +101,12 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
         batches = lambda: iter(loader)
     loss, step, start_time = 0.0, 0, time.time()
     for epoch in range(1, config["total_epochs"] + 1):
-        # the reference steps the schedule at the TOP of every epoch (policy_trainer.py:81): epoch e trains
-        # with lr_initial * lr_decay ** (e // lr_decay_epochs)
-        scheduler.step()
+        # The reference calls scheduler.step() at the top of every epoch (policy_trainer.py:81) under the torch
+        # it pins (0.4.1 / 1.0.1), where StepLR starts at last_epoch = -1: epoch e trains with
+        # lr_initial * lr_decay ** ((e - 1) // lr_decay_epochs).  Modern torch counts the constructor as step 0,
+        # so the same schedule is "no step before epoch 1, one step before every later epoch".
+        if epoch > 1:
+            scheduler.step()
         if history is not None:
             history.setdefault("lr", []).append(optimizer.param_groups[0]["lr"])
         for batch in batches():

@@ -29,6 +29,7 @@ extern "C" {
 #define AZX_MAX_CELLS (AZX_MAX_BOARD * AZX_MAX_BOARD)
 #define AZX_CELL_STRIDE 192       /* per-position row stride of dense [*, cells] buffers */
 #define AZX_MAX_BATCH 16          /* search_batch_size upper bound */
+#define AZX_ROW_METRICS 8         /* floats per replay row returned by azx_play_row_metrics */
 /* bytes of one fixed-size replay record (azx_rows_pack / azx_replay_put_records) for a board of `cells` cells */
 #define AZX_RECORD_BYTES(cells) ((size_t)((16 + 5 * (cells) + 15) / 16 * 16))
 
@@ -82,7 +83,8 @@ typedef struct {
 typedef struct azx_engine azx_engine;
 
 const char *azx_last_error(void);
-int azx_version(void);            /* ABI revision: 3 = azx_config.game_index_*, azx_play_stats.sum_game_length */
+int azx_version(void);            /* ABI revision: 4 = 8-float row metrics, azx_kernel_info, azx_debug_set_queue_cap
+                                   * (3 = azx_config.game_index_*, azx_play_stats.sum_game_length) */
 
 /* Policy.initialize / Policy.reset (policy.py:36-63, :76-80): allocate device arenas. */
 int azx_create(const azx_config *cfg, azx_engine **out);
@@ -148,6 +150,10 @@ int azx_get_root(azx_engine *e, int32_t *k, int32_t *legal_moves, float *child_v
 /* per slot: 0 ok, 1 = the arena overflowed during the last search (SearchTreeFull,
  * search_tree.py:258-259): the caller skips the game as parallel_player.py:73-76 does */
 int azx_get_status(azx_engine *e, int32_t *status);
+/* per slot: SearchTree.num_nodes as the reference counts it (search_tree.py:112 'search_tree_nodes'): nodes
+ * allocated since the tree's last reset and never reclaimed (search_tree.py:115-132) -- the arena compaction
+ * here frees nodes, azx_get_root's num_nodes is the arena's live count. */
+int azx_get_tree_nodes(azx_engine *e, int32_t *nodes);
 
 /* game state per slot: HexGame.state (hex.py:55-60): board [n_games][cells] int32,
  * color (0/1), result (0/1/3), ply. */
@@ -204,9 +210,12 @@ int azx_play(azx_engine *e, int64_t min_positions, int64_t max_plies, int64_t ca
              float *reward, int64_t *game_uid, azx_play_stats *stats);
 
 /* per-ply search metrics of the rows the last azx_play / azx_play_device / azx_replay_fill call harvested, in row order:
- * metrics[n][4] = {search_value (mcts.py:291), search_root_width (search_tree.py:110), log-probability of the
- * move drawn (play_game.py:43), 1 on the first row of a game else 0}.  play_game averages them over a game's plies and Player.read sums
- * those means over the games it returns (play_game.py:73-76, parallel_player.py:50-51). */
+ * metrics[n][AZX_ROW_METRICS] = {search_value (mcts.py:291), search_root_width (search_tree.py:110), log-probability
+ * of the move drawn (play_game.py:43), 1 on the first row of a game else 0, search_root_visits (mean child
+ * visits, search_tree.py:110), search_tree_nodes (nodes allocated since the tree's last reset, never reclaimed:
+ * search_tree.py:112), search_root_children (search_tree.py:111), 0}.
+ * play_game averages them over a game's plies and Player.read sums those means over the games it returns
+ * (play_game.py:73-76, parallel_player.py:50-51). */
 int azx_play_row_metrics(azx_engine *e, int64_t cap, float *metrics, int64_t *n_out);
 
 /* bench hook: run `plies` lock-step engine moves on all slots (device RNG, finished games
@@ -294,6 +303,15 @@ int azx_debug_choose(azx_engine *e, int32_t *move_id, float *moves_prob);
 int azx_debug_counters(azx_engine *e, uint64_t *out16);
 /* the same counters per game slot, not summed: out[n_games][16] (diagnostics: load balance) */
 int azx_debug_counters_raw(azx_engine *e, uint64_t *out, int64_t n_games);
+
+/* Which kernels this engine launches, as one line of text ("tree=... play=... tower=... heads=..."): the
+ * diagnostic switches AZX_MCTS_GENERIC / AZX_NO_PERSISTENT / AZX_TOWER / AZX_TOWER_SHAPE / AZX_TOWER_SPLIT /
+ * AZX_WIDE_STREAMS are read ONCE, by azx_create, into the engine; this reports what they selected so a run
+ * can prove which kernels it used.  Returns the length of the full text (it is truncated to cap - 1 bytes). */
+int azx_kernel_info(azx_engine *e, char *buf, int cap);
+/* tests: bound the harvest queue of the following azx_play* calls to `rows` rows (0 = no bound) so that finished
+ * games find it full and park (parallel_player.py has no counterpart: its pipes block instead). */
+int azx_debug_set_queue_cap(azx_engine *e, int64_t rows);
 
 /* engine stream (hipStream_t) so callers can bracket work with HIP events */
 void *azx_stream(azx_engine *e);

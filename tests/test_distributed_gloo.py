@@ -118,6 +118,89 @@ def _shared_device_replay(rank, world):
     return fails
 
 
+class StubPlayEngine:
+    """Stands in for the Engine a device-policy Player creates (Player._get_engine): play() returns whole random
+    games keyed by the seed base and the global game index the Player configured it with."""
+    ROW_METRIC_COLUMNS = (("search_value", 0), ("search_root_width", 1), ("action_logprob", 2),
+                          ("search_root_visits", 4), ("search_tree_nodes", 5), ("search_root_children", 6))
+    created = []
+
+    def __init__(self, board_size, n_games, seed, game_index_stride, game_index_offset, **kw):
+        self.n, self.seed, self.stride, self.offset, self.started = board_size, seed, game_index_stride, game_index_offset, 0
+        self._rows = 0
+        StubPlayEngine.created.append(self)
+
+    def set_weights(self, *a, **k):
+        pass
+
+    def close(self):
+        pass
+
+    def play(self, want):
+        parts = []
+        while sum(len(p["reward"]) for p in parts) < want:
+            uid = self.started * self.stride + self.offset
+            self.started += 1
+            rows = _rows(0, 3 + uid % 4, self.n)
+            rows["game_uid"][:] = uid
+            rows["nlegal"][:] = 1
+            rows["board"][:] = 1
+            rows["board"][:, 0, 0] = 0
+            parts.append(rows)
+        out = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+        self._rows = len(out["reward"])
+        return out, dict(games=len(parts), game_errors=0, seconds=0.01)
+
+    def play_row_metrics(self):
+        return np.ones((self._rows, 8), np.float32)
+
+
+def _device_policy_player(rank, world):
+    """A Player whose policy holds a HexNetwork takes the engine path.  The shared seed base is agreed at the
+    top of read(), where every rank arrives -- also the rank whose quota is 0 (read(1), size < world) and a
+    rank that still has games queued -- and a Player that does not gather never enters a collective."""
+    from azalea_amd import AzaleaAgent, HexGame, Player, Policy
+    from azalea_amd import parallel_player as pp
+    real = pp._eng.Engine
+    pp._eng.Engine = StubPlayEngine
+    fails = []
+    try:
+        def make(seed):
+            cfg = dict(device="cpu", network="HexNetwork", board_size=4, num_blocks=1, base_chans=8, simulations=20,
+                       search_batch_size=10, exploration_coef=0.5, exploration_depth=3, exploration_noise_alpha=0.3,
+                       exploration_noise_scale=0.25, exploration_temperature=1.0, seed=seed)
+            pol = Policy()
+            pol.initialize(cfg)
+            pol.settings.update(move_sampling=True, move_exploration=True)
+            return AzaleaAgent(lambda: HexGame(4), policy=pol, device="cpu")
+        StubPlayEngine.created.clear()
+        pl = Player(None, [make(200 + rank)], n_games=8)      # ranks seeded differently
+        frame1, m1 = pl.read(1)                                # rank 1's quota is 0: it must not hang in a broadcast
+        bases = [None] * world
+        dist.all_gather_object(bases, pl._seed_base)
+        fails += [] if (bases[0] == bases[1] and bases[0] is not None) else [201]
+        fails += [] if (len(frame1) >= 1 and m1["games"] >= 1) else [202]
+        frame2, m2 = pl.read(30)                               # both ranks produce now; rank 0 may still hold queued games
+        sizes = [None] * world
+        dist.all_gather_object(sizes, len(frame2))
+        fails += [] if (sizes[0] == sizes[1] and len(frame2) >= 30) else [203]
+        engines = [e for e in StubPlayEngine.created]
+        if engines:                                            # rank r of W plays the games r, r + W, ...
+            fails += [] if ((engines[0].stride, engines[0].offset, engines[0].seed) == (world, rank, bases[0])) else [204]
+        fails += [] if (set(m2) >= {"search_root_visits", "search_root_children", "search_tree_nodes", "game_error"}) else [205]
+        pl.stop()
+        # gather=False: reads are independent, no collective anywhere (only rank 0 reads here)
+        if rank == 0:
+            solo = Player(None, [make(300)], n_games=8, gather=False)
+            f3, _ = solo.read(5)
+            fails += [] if len(f3) >= 5 else [206]
+            solo.stop()
+        dist.barrier()
+    finally:
+        pp._eng.Engine = real
+    return fails
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -158,6 +241,7 @@ def _worker(rank, world, port, out):
     fails += [] if ([azd.shard_quota(12.8, r, 16) for r in (0, 12, 13, 15)] == [1, 1, 0, 0]) else [8]
     fails += [] if (azd.broadcast_int(1000 + rank) == 1000) else [9]
     fails += _shared_device_replay(rank, world)
+    fails += _device_policy_player(rank, world)
     out[rank] = fails
     dist.destroy_process_group()
 

@@ -38,6 +38,14 @@ def _worker(rank, world, port, out):
     policy.initialize(cfg)
     policy.settings.update(move_sampling=True, move_exploration=True)
     agent = AzaleaAgent(lambda: HexGame(n), policy=policy, device="cuda:0")
+    # a first read smaller than the world: rank 1's quota is 0 and it creates no engine -- the shared seed base
+    # is agreed at the top of read(), so nobody waits in a broadcast the other rank never enters
+    early = Player(None, [agent], n_games=16)
+    f0, m0 = early.read(1)
+    n0 = [None] * world
+    dist.all_gather_object(n0, len(f0))
+    fails += [] if (n0[0] == n0[1] and len(f0) >= 1 and m0["games"] >= 1) else [10]
+    early.stop()
     player = Player(None, [agent], n_games=16)
     E = player.device_engine()
     # rank r of W plays the global games r, r + W, ...; the seed base is rank 0's

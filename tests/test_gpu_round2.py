@@ -392,15 +392,13 @@ def test_global_game_index_same_games_for_any_world_size(eng):
 # ---- parked slots ---------------------------------------------------------------------------------------
 def test_parked_slots_hand_their_games_over_on_the_next_read(eng):
     """A finished game that finds the harvest queue full parks its slot; the next read drains them first
-    (nothing is lost, nothing stays parked).  The queue bound is forced small through AZX_DEBUG_QCAP."""
+    (nothing is lost, nothing stays parked).  The queue bound is forced small through azx_debug_set_queue_cap."""
     n, G = 5, 32
     E = eng.Engine(board_size=n, n_games=G, simulations=20, search_batch_size=10, exploration_depth=3,
                    evaluator=eng.EVAL_UNIFORM, seed=9)
-    os.environ["AZX_DEBUG_QCAP"] = "40"
-    try:
-        rows1, st1 = E.play(200, max_plies=40)              # ~every slot finishes a game; the queue holds 40 rows
-    finally:
-        os.environ.pop("AZX_DEBUG_QCAP", None)
+    E.debug_set_queue_cap(40)
+    rows1, st1 = E.play(200, max_plies=40)                  # ~every slot finishes a game; the queue holds 40 rows
+    E.debug_set_queue_cap(0)
     assert 0 < len(rows1["reward"]) <= 40
     c = E.debug_counters()
     finished_so_far = int(c[6])
@@ -513,18 +511,60 @@ def test_player_metrics_are_sums_of_per_game_means(eng):
     rows, st = E.play(400)
     m = E.play_row_metrics()
     P = len(rows["reward"])
-    assert m.shape == (P, 4)
+    assert m.shape == (P, 8)
     uid = rows["game_uid"]
     starts = np.flatnonzero(np.r_[True, uid[1:] != uid[:-1]])
     assert np.array_equal(np.flatnonzero(m[:, 3] > 0.5), starts)
     assert (m[:, 1] >= 1).all() and (m[:, 1] <= rows["nlegal"]).all() and (m[:, 1] == np.round(m[:, 1])).all()
     assert (m[:, 2] <= 1e-6).all() and np.isfinite(m).all()
+    # search_tree.py:109-112: children = legal moves; mean child visits * children = an integer number of
+    # backed-up visits, at least one per root child that was visited; nodes ever allocated >= 1 + children and
+    # never fewer than the ply before in the same game (moves re-root, nothing is reclaimed)
+    k = rows["nlegal"].astype(np.float64)
+    assert np.array_equal(m[:, 6], rows["nlegal"].astype(np.float32))
+    tot = m[:, 4].astype(np.float64) * k
+    assert np.allclose(tot, np.round(tot), atol=1e-3) and (np.round(tot) >= m[:, 1]).all()
+    assert (m[:, 5] >= 1 + k).all() and (m[:, 5] == np.round(m[:, 5])).all()
+    ends = np.r_[starts[1:], P]
+    for s_, e_ in zip(starts, ends):
+        assert (np.diff(m[s_:e_, 5]) > 0).all()
     # the rows of finished games are a subset of all plies the call played: sums cannot exceed the call's tallies
     assert m[:, 1].sum() <= st["sum_root_width"] + 1e-3
     sums = E.game_metric_sums()
-    ends = np.r_[starts[1:], P]
-    want = np.zeros(3)
-    for s, e in zip(starts, ends):
-        want += m[s:e, :3].astype(np.float64).mean(0)
-    assert np.allclose(sums, want)
+    names = [name for name, _ in E.ROW_METRIC_COLUMNS]
+    cols = [c for _, c in E.ROW_METRIC_COLUMNS]
+    want = np.zeros(len(cols))
+    for s_, e_ in zip(starts, ends):
+        want += m[s_:e_][:, cols].astype(np.float64).mean(0)
+    assert sorted(sums) == sorted(names)
+    assert np.allclose([sums[nm] for nm in names], want)
     E.close()
+
+
+def test_throughput_and_parity_mode_report_the_same_metric_keys(eng):
+    """The dict Player.read sums in throughput mode (device rows + azx_play_row_metrics) has exactly the keys
+    play_game produces in parity mode (play_game.py:69-76 over search_tree.py:109-112, mcts.py:291,
+    policy.py:164), and on a fresh tree both modes count the same nodes: 1 + k + the expansions' children."""
+    import torch
+    from azalea_amd import AzaleaAgent, HexGame, Player, Policy
+    from azalea_amd.play_game import play_game
+    n, sims = 5, 20
+    cfg = dict(device="cuda", network="HexNetwork", board_size=n, num_blocks=1, base_chans=64,
+               simulations=sims, search_batch_size=10, exploration_coef=0.5, exploration_depth=4,
+               exploration_noise_alpha=0.03, exploration_noise_scale=0.25, exploration_temperature=1.0, seed=3)
+    torch.manual_seed(0)
+    policy = Policy()
+    policy.initialize(cfg)
+    policy.settings.update(move_sampling=True, move_exploration=True)
+    agent = AzaleaAgent(lambda: HexGame(n), policy=policy, device="cuda")
+    agent.seed(11)
+    _, _, parity = play_game([agent], collect_data=False)
+    player = Player(None, [agent], n_games=16)
+    frame, thru = player.read(60)
+    player.stop()
+    assert set(thru) == set(parity), (sorted(thru), sorted(parity))
+    g = thru["games"]
+    assert g >= 1
+    # per-game means are of the same magnitude in both modes (same search settings, same network)
+    for key in ("search_root_children", "search_root_visits", "search_tree_nodes", "search_root_width"):
+        assert 0.3 * parity[key] < thru[key] / g < 3.0 * parity[key], (key, thru[key] / g, parity[key])

@@ -264,6 +264,7 @@ def test_many_games_vs_oracle_with_compaction(eng, orc, nodes_per_game, hashed):
         E.search()
         assert not E.get_status().any()
         root = E.get_root()
+        ref_nodes = E.get_tree_nodes()
         move_ids = np.full(G, -1, np.int32)
         for g in range(G):
             if not alive[g]:
@@ -276,6 +277,7 @@ def test_many_games_vs_oracle_with_compaction(eng, orc, nodes_per_game, hashed):
             nv = root["child_visits"][g, :root["k"][g]]
             onv = trees[g].root_stats()[0]
             assert np.array_equal(bits(nv), bits(onv))
+            assert ref_nodes[g] == trees[g].num_nodes, (rnd, g)     # search_tree.py:112, compactions or not
             mid = int(np.argmax(nv))
             move_ids[g] = mid
             lm = games[g].legal_moves()

@@ -74,9 +74,9 @@ def test_train_loop_with_device_replay(tmp_path):
     hist = {}
     path = train(policy, config, str(tmp_path), replaybuf=buf, device_replay=True, history=hist)
     assert os.path.exists(path)
-    # the reference steps StepLR at the top of each epoch (policy_trainer.py:81): epoch e = 1..4 trains with
-    # lr_initial * lr_decay ** (e // lr_decay_epochs)
-    assert np.allclose(hist["lr"], [0.05 * 0.5 ** (e // 2) for e in (1, 2, 3, 4)])
+    # the reference steps StepLR at the top of each epoch (policy_trainer.py:81) under torch 0.4.1 / 1.0.1, whose
+    # constructor leaves last_epoch at -1: epoch e = 1..4 trains with lr_initial * lr_decay ** ((e - 1) // lr_decay_epochs)
+    assert np.allclose(hist["lr"], [0.05 * 0.5 ** ((e - 1) // 2) for e in (1, 2, 3, 4)])
     after = policy.net.state_dict()
     assert any(not torch.equal(before[k].cpu(), after[k].cpu()) for k in before)
     q = Policy.load(path, device="cpu")
