@@ -13,7 +13,12 @@ Default workload = the north-star headline, BASELINE.json configs[2]: 4096 concu
 400 sims/move, 6x64 resnet forward on the MFMA cores (MFMA-bound; `roofline` prices the tower +
 heads launch pair).  The tree-only sub-benchmark, configs[1] (uniform priors, no net: HBM model of
 SURVEY 8(d)), is measured the same way right after it and nested in the same line as "tree".
-`--workload resnet` / `--workload tree` run one of the two alone (profiling).
+`--workload resnet` / `--workload tree` run one of the two alone (profiling).  Two more legs are nested in the
+default line: "config5" -- BASELINE configs[4]'s shape on this one GPU (13x13, 19x256 resnet, 800 -> 810 sims,
+`--c5-games` games, one warm-up and one timed move) with its own `roofline` (the wide tower's per-layer MFMA
+kernel) and `cpu_baseline` -- and "api": the product surface the trainer calls (Player.read, parallel_player.py:
+24-28) driven for `--api-moves` engine moves after the pool transplant, rows/s over the last 60 of them beside
+the plies/s the engine played in the same window.
 
 Steady state: a pool that restarts finished games in place is, after its first game, spread over
 all plies.  Starting every slot from the empty board would time the opening only (no game can end
@@ -41,6 +46,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# committed rocprofv3 --pmc summaries of this round (tools/prof_r3.sh); attached only when their bench_key matches
+PMC_FILES = {"resnet": "r3_resnet_pmc_traffic.json", "tree": "r3_tree_pmc_traffic.json",
+             "config5": "r3_config5_pmc_traffic.json"}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TF = 157.3   # dense fp32 MFMA peak
 F16_MFMA_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline is 2:1 sparse)
@@ -67,36 +75,59 @@ def model_bytes(st):
     return 8 * D + 12 * ki + 32 * D + 16 * (D + sel) + 28 * kl + 8 * ev
 
 
-def cpu_baseline(args, workload, net_state=None):
+# the reference itself (pure-Python rules through the numba shim, torch CPU conv), timed in the
+# survey container on 8 cores -- it cannot travel to the GPU box, so it is carried here as context
+REFERENCE_SHIM = {
+    "resnet": {"sims_per_s": 3011.0, "cores": 8, "per_core": 376.4, "games_per_s": 0.068,
+               "single_thread_sims_per_s": 437.0,
+               "what": "reference parallel_player.Player + ProcessPool(8), 11x11, 400 sims, 6x64 (BASELINE.md section 2; "
+                       "measured in the survey container, not on this box)"},
+    "tree": {"sims_per_s": 870.0, "cores": 1, "per_core": 870.0,
+             "what": "reference MCTS only, stub net (uniform priors), 400 sims from the empty board, 1 process, "
+                     "pure-Python rules (BASELINE.md section 2; survey container)"},
+}
+
+
+def cpu_baseline(args, workload, net_state=None, sims=None, max_plies=None, games=None):
     """The CPU oracle (oracle/, a C restatement pinned against the reference's golden vectors)
-    timed on this box's host cores on a bounded sample of the same workload."""
+    timed on this box's host cores on a bounded sample of the same workload.  `per_core` puts it beside the
+    reference's own CPU path (`reference_shim`, BASELINE.md section 2: torch's conv2d, measured elsewhere)."""
     from oracle import oracle as orc
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
+    sims = args.sims if sims is None else sims
     if workload == "tree":
         games, max_plies, net, start = 8 * threads, 300, None, 0      # ~5 s on 64 threads
-        sample = "%d whole games, uniform priors, %d sims/move, one game per thread" % (games, args.sims)
+        sample = "%d whole games, uniform priors, %d sims/move, one game per thread" % (games, sims)
     else:
-        games, max_plies, start = threads, 4, args.desync              # ~13 s on 64 threads
+        games = threads if games is None else games
+        max_plies, start = (4 if max_plies is None else max_plies), args.desync   # ~13 s on 64 threads
         net = orc.Net(args.board, args.blocks, args.chans, net_state)
         sample = ("%d games x %d plies each from seeded random mid-game positions (0..%d stones, like the "
-                  "GPU pool), %dx%d resnet fp32 direct conv, %d sims/move, one game per thread"
-                  % (games, max_plies, start, args.blocks, args.chans, args.sims))
-    out = orc.bench_selfplay(args.board, args.sims, args.batch, games, threads, net=net,
+                  "GPU pool), %dx%d resnet fp32 on the host (blocked direct conv), %d sims/move, one game per thread"
+                  % (games, max_plies, start, args.blocks, args.chans, sims))
+        if sims != args.sims:
+            sample += (" -- a bounded sample: the GPU leg searches %d sims/move, at the oracle's rate one such ply "
+                       "would take minutes per thread; sims/s is set by the network forward either way" % args.sims)
+    out = orc.bench_selfplay(args.board, sims, args.batch, games, threads, net=net,
                              max_plies=max_plies, seed=args.seed, start_max=start)
     sims_per_s = out["selects"] / out["seconds"]
-    base = {"value": sims_per_s, "unit": "sims/s", "cores": threads, "kind": "port",
-            "sample": sample, "seconds": out["seconds"], "plies": out["plies"]}
+    base = {"value": sims_per_s, "unit": "sims/s", "cores": threads, "per_core": sims_per_s / threads,
+            "kind": "port", "sample": sample, "seconds": out["seconds"], "plies": out["plies"]}
     if workload == "tree":
         base["games_per_s"] = out["games"] / out["seconds"]
     else:
         base["plies_per_s"] = out["plies"] / out["seconds"]
+    ref = REFERENCE_SHIM.get("tree" if workload == "tree" else "resnet")
+    if ref and (workload == "tree" or (args.board, args.blocks, args.chans) == (11, 6, 64)):
+        base["reference_shim"] = dict(ref)
+        base["port_vs_reference_per_core"] = base["per_core"] / ref["per_core"]
     return base
 
 
 def pmc_traffic(name, key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
-    command (tools/prof_pmc_r2.sh: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction of
+    command (tools/prof_r3.sh: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction of
     MI355X_MICROARCH.md).  Only attached when the file was recorded for exactly this configuration."""
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
@@ -178,7 +209,78 @@ def run_workload(workload, args, rank, world, local_rank, steps, warmup, sync, t
     sync()
     elapsed = time.perf_counter() - t0
     extras["engine"] = E
+    extras["start"] = start
+    extras["kernels"] = E.kernel_info()
     return st, elapsed, extras
+
+
+def config5_args(args):
+    """BASELINE configs[4]'s board, network and search on ONE GPU: 13x13, 19x256, 800 sims/move (810 select_leaf
+    calls); `--c5-games` concurrent games (the 8-GPU config shards 8x as many)."""
+    a = argparse.Namespace(**vars(args))
+    a.board, a.blocks, a.chans, a.sims, a.games = 13, 19, 256, 800, args.c5_games
+    a.desync = int(round(0.76 * a.board * a.board))
+    a.settle = 2 * a.board * a.board
+    a.nodes_per_game = 0
+    return a
+
+
+def run_api(args, rank, world, local_rank, start, torch):
+    """The product surface for a whole game length: Player.read (parallel_player.py:24-28 -- what
+    ReplayBuffer.consume calls, replay_buffer.py:121-132) on a device-policy Player at the headline's
+    configuration, driven until every slot has played `--api-moves` moves since the pool was transplanted
+    (transplanted games only carry the rows played since; after a full game length every game handed over is
+    a whole one).  rows/s over the last 60 moves beside the plies/s the engine played in that window."""
+    from azalea_amd import AzaleaAgent, HexGame, Player, Policy
+    n = args.board
+    dev = "cuda:%d" % local_rank
+    cfg = dict(device=dev, network="HexNetwork", board_size=n, num_blocks=args.blocks, base_chans=args.chans,
+               simulations=args.sims, search_batch_size=args.batch, exploration_coef=0.5, exploration_depth=15,
+               exploration_noise_alpha=0.03, exploration_noise_scale=args.noise_scale,
+               exploration_temperature=1.0, seed=1)
+    torch.manual_seed(0)
+    policy = Policy()
+    policy.initialize(cfg)
+    policy.settings.update(move_sampling=True, move_exploration=True)
+    agent = AzaleaAgent(lambda: HexGame(n), policy=policy, device=dev)
+    player = Player(None, [agent], n_games=args.games, gather=False)
+    E = player.device_engine()
+    player.prepare_device_engine(E)
+    if start is not None:
+        E.reset(moves=start)
+    log = []                 # (wall at the end of the call, plies played so far, device seconds so far)
+    tot = {"plies": 0, "dev": 0.0}
+    real_play = E.play
+
+    def play(*a, **k):
+        rows, st = real_play(*a, **k)
+        tot["plies"] += st["plies"]
+        tot["dev"] += st["seconds"]
+        return rows, st
+    E.play = play
+    chunk = max(1, 8 * args.games)                 # ~8 engine moves' worth of rows per read in steady state
+    t0 = time.perf_counter()
+    reads = [(0.0, 0, 0, 0.0)]                      # wall, rows handed over, plies played, device seconds
+    rows_total, metrics_keys = 0, set()
+    while tot["plies"] < args.api_moves * args.games:
+        frame, metrics = player.read(chunk)
+        rows_total += len(frame)
+        metrics_keys |= set(metrics)
+        reads.append((time.perf_counter() - t0, rows_total, tot["plies"], tot["dev"]))
+    player.stop()
+    wall, _, plies, dev_s = reads[-1]
+    # the window: from the first read that ends at or after (api_moves - 60) moves to the last one
+    lo = next(i for i, r in enumerate(reads) if r[2] >= max(0, args.api_moves - 60) * args.games or i == len(reads) - 1)
+    lo = min(lo, len(reads) - 2)
+    w0, w1 = reads[lo], reads[-1]
+    dt = w1[0] - w0[0]
+    return {"surface": "Player.read (parallel_player.py:24-28) on the engine, gather off, %d games" % args.games,
+            "moves_since_transplant": plies / args.games, "reads": len(reads) - 1, "rows": rows_total, "seconds": wall,
+            "rows_per_sec": (w1[1] - w0[1]) / dt, "plies_per_sec": (w1[2] - w0[2]) / dt,
+            "rows_over_plies": (w1[1] - w0[1]) / max(1, w1[2] - w0[2]),
+            "window": "moves %.0f..%.0f after the transplant" % (w0[2] / args.games, w1[2] / args.games),
+            "rows_per_sec_whole_run": rows_total / wall,
+            "host_overhead_frac": (wall - dev_s) / wall, "metric_keys": sorted(metrics_keys)}
 
 
 def reduce_over_ranks(dist, torch, elapsed, sums):
@@ -230,7 +332,7 @@ def tree_roofline(st, args, steps, warmup):
                  "(DESIGN 3.1)"),
     }
     key = [args.games, args.board, args.sims, args.batch, steps, warmup, args.noise_scale, args.desync, args.settle]
-    roof["traffic"], src = pmc_traffic("r2_tree_pmc_traffic.json", key)
+    roof["traffic"], src = pmc_traffic(PMC_FILES["tree"], key)
     if src:
         roof["traffic_source"] = src
     return roof
@@ -265,9 +367,12 @@ def resnet_roofline(st, args, steps, warmup):
     }
     key = [args.games, args.board, args.sims, args.batch, args.blocks, args.chans, steps, warmup,
            args.noise_scale, args.desync, args.settle]
-    roof["traffic"], src = pmc_traffic("r2_resnet_pmc_traffic.json", key)
+    wide = args.chans % 128 == 0
+    roof["traffic"], src = pmc_traffic(PMC_FILES["config5" if wide else "resnet"], key)
     if src:
         roof["traffic_source"] = src
+        roof["traffic_scope"] = ("HBM bytes of one leaf-batch forward: the stem + %d per-layer launches (k_heads not counted)"
+                                 % (2 * args.blocks)) if wide else "HBM bytes of one k_tower_f16x3_s16 launch (k_heads not counted)"
     return roof
 
 
@@ -331,6 +436,10 @@ def main():
                          "state before the warm-up (default 2 * board^2)")
     ap.add_argument("--nodes-per-game", type=int, default=0,
                     help="tree arena capacity per game (0 = engine default)")
+    ap.add_argument("--c5-games", type=int, default=512, help="concurrent games of the nested configs[4]-shape leg")
+    ap.add_argument("--no-config5", action="store_true", help="skip the nested configs[4]-shape leg")
+    ap.add_argument("--api-moves", type=int, default=190,
+                    help="engine moves the nested product-surface leg (Player.read) is driven for; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-replay-exchange", action="store_true")
     args = ap.parse_args()
@@ -398,6 +507,9 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic"}
         line.update(throughput_fields(sums, elapsed, args.steps))
+        line["world"] = {"ranks": world, "backend": (dist.get_backend() if dist is not None else None),
+                         "games_per_rank": args.games}
+        line["kernels"] = ex["kernels"]
         if headline == "tree":
             wl = ("BASELINE configs[1]: %d concurrent %dx%d Hex games per GPU, HIP movegen+MCTS kernels only, "
                   "uniform priors (no net), %d sims/move (%d select_leaf calls)"
@@ -441,6 +553,39 @@ def main():
                 except Exception as exc:
                     tree["cpu_baseline"] = {"error": repr(exc)}
             line["tree"] = tree
+
+    # ---- nested configs[4]-shape leg: 13x13, 19x256, 810 selects, one warm-up + one timed move --------------
+    if args.workload == "selfplay" and not args.no_config5 and (args.board, args.blocks, args.chans) == (11, 6, 64):
+        a5 = config5_args(args)
+        st5, el5, ex5 = run_workload("resnet", a5, rank, world, local_rank, 1, 1, sync, torch)
+        el5, sums5 = reduce_over_ranks(dist, torch, el5, [float(st5[k]) for k in SUM_KEYS])
+        ex5["engine"].close()
+        if rank == 0:
+            c5 = {"metric": "mcts_sims_per_sec", "steps": 1, "warmup": 1,
+                  "dtype": "f16x3 (fp32 operands split hi+lo f16, fp32 accumulate)"}
+            c5.update(throughput_fields(sums5, el5, 1))
+            sel5 = (a5.sims // a5.batch + 1) * a5.batch
+            c5["config"] = {"workload": ("BASELINE configs[4] shape on one GPU: %d concurrent 13x13 Hex games, %d sims/move "
+                                         "(%d select_leaf calls), 19x256 resnet forward on split-f16 MFMA, random-init "
+                                         "weights" % (a5.games, a5.sims, sel5)),
+                            "games_per_gpu": a5.games, "board": 13, "simulations": a5.sims, "search_batch_size": a5.batch,
+                            "start": "steady-state pool as the headline's (0..%d plies, %d settle moves), 1 warm-up move"
+                                     % (a5.desync, a5.settle)}
+            c5["roofline"] = resnet_roofline(st5, a5, 1, 1)
+            c5["kernels"] = ex5["kernels"]
+            if world == 1 and not args.no_cpu_baseline:
+                try:      # 19x256 on the host: ~0.2 s per position and thread -> one ply of a 20-sim search per thread
+                    c5["cpu_baseline"] = cpu_baseline(a5, "resnet", ex5["net_state"], sims=20, max_plies=1)
+                except Exception as exc:
+                    c5["cpu_baseline"] = {"error": repr(exc)}
+            line["config5"] = c5
+
+    # ---- nested product-surface leg: Player.read for a whole game length -----------------------------------
+    if args.workload == "selfplay" and args.api_moves > 0 and world == 1:
+        api = run_api(args, rank, world, local_rank, ex.get("start"), torch)
+        if rank == 0:
+            line["api"] = api
+            line["rows_per_sec"] = api["rows_per_sec"]
 
     if rank == 0:
         print(json.dumps(line))

@@ -39,13 +39,27 @@ def test_throughput_fields_are_consistent():
 def test_committed_pmc_traffic_is_keyed_to_the_drivers_command():
     # the defaults main() derives for `--steps 20 --warmup 5` on an 11x11 board
     a = argparse.Namespace(games=4096, board=11, sims=400, batch=10, blocks=6, chans=64, noise_scale=0.25,
-                           desync=int(round(0.76 * 121)), settle=2 * 121)
+                           desync=int(round(0.76 * 121)), settle=2 * 121, c5_games=512, nodes_per_game=0)
+    a5 = bench.config5_args(a)
+    assert (a5.board, a5.blocks, a5.chans, a5.sims, a5.games, a5.desync, a5.settle) == (13, 19, 256, 800, 512, 128, 338)
     key_r = [a.games, a.board, a.sims, a.batch, a.blocks, a.chans, 20, 5, a.noise_scale, a.desync, a.settle]
     key_t = [a.games, a.board, a.sims, a.batch, 130, 20, a.noise_scale, a.desync, a.settle]
-    for name, key in (("r2_resnet_pmc_traffic.json", key_r), ("r2_tree_pmc_traffic.json", key_t)):
-        t = json.load(open(os.path.join(ROOT, "profiles", name)))
+    key_5 = [a5.games, a5.board, a5.sims, a5.batch, a5.blocks, a5.chans, 1, 1, a5.noise_scale, a5.desync, a5.settle]
+    for leg, key in (("resnet", key_r), ("tree", key_t), ("config5", key_5)):
+        name = bench.PMC_FILES[leg]
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):       # recorded on the GPU box once per round (tools/prof_r3.sh)
+            continue
+        t = json.load(open(path))
         assert t["bench_key"] == key, name
         traffic, src = bench.pmc_traffic(name, key)
         assert traffic and traffic == t["hbm_bytes_per_launch"] and name in src
         assert abs(t["hbm_bytes_per_launch"] - (2 * t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024) < 1.0
-    assert bench.pmc_traffic("r2_resnet_pmc_traffic.json", key_r[:-1] + [0]) == (None, None)
+        assert bench.pmc_traffic(name, key[:-1] + [0]) == (None, None)
+
+
+def test_cpu_baseline_carries_the_reference_shim_context():
+    # BASELINE.md section 2, the rows bench.py quotes beside the port's figures
+    r = bench.REFERENCE_SHIM["resnet"]
+    assert r["sims_per_s"] == 3011.0 and r["cores"] == 8 and abs(r["per_core"] - 3011.0 / 8) < 0.1
+    assert bench.REFERENCE_SHIM["tree"]["sims_per_s"] == 870.0

@@ -34,14 +34,22 @@ def test_default_line_is_the_selfplay_headline_with_the_tree_numbers_nested():
     """The default workload is the north-star headline (configs[2]: resnet-driven self-play) from a
     de-synchronised pool, with the configs[1] tree-only run nested as "tree"; small sizes here."""
     d = _run("--steps", "2", "--warmup", "1", "--games", "64", "--sims", "40", "--tree-steps", "6",
-             "--tree-warmup", "2", "--board", "7", "--blocks", "1")
+             "--tree-warmup", "2", "--board", "7", "--blocks", "1", "--api-moves", "70")
     _check_common(d, 2, 1)
+    assert "config5" not in d                                  # only nested under the 11x11 / 6x64 headline
+    a = d["api"]                                               # the product surface, a game length after the transplant
+    assert a["moves_since_transplant"] >= 70 and a["rows"] > 0 and d["rows_per_sec"] == a["rows_per_sec"] > 0
+    assert 0.5 < a["rows_over_plies"] < 1.5 and 0 <= a["host_overhead_frac"] < 1
+    assert {"search_root_visits", "search_root_children", "search_tree_nodes", "games"} <= set(a["metric_keys"])
+    assert d["world"] == {"ranks": 1, "backend": None, "games_per_rank": 64}
+    assert "k_mcts<2" in d["kernels"] and "k_heads" in d["kernels"] and "AZX_MCTS_GENERIC=0" in d["kernels"]
     assert d["config"]["workload"].startswith("resnet self-play") and "de-synchronised" in d["config"]["start"]
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["unit"] == "TFLOP/s"
     assert round(d["value"] * d["elapsed_s"]) == 64 * 2 * 50
     assert d["plies"] == 64 * 2 and d["games_finished"] >= 0 and "games_per_sec_steady" in d
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "sims/s" and "mid-game" in c["sample"]
+    assert abs(c["per_core"] * c["cores"] - c["value"]) < 1e-6 * c["value"] and "reference_shim" not in c   # not the 11x11 / 6x64 net
     x = d["replay_allgather"]
     assert x["ranks"] == 1 and x["record_bytes"] == 272 and sum(x["rows_per_rank"]) >= 1
     t = d["tree"]
@@ -49,7 +57,31 @@ def test_default_line_is_the_selfplay_headline_with_the_tree_numbers_nested():
     assert round(t["value"] * t["elapsed_s"]) == 64 * 6 * 50
     assert t["games_finished"] > 0 and t["mean_game_length"] > 0          # steady state: games do finish
     assert abs(t["games_per_sec_steady"] * t["mean_game_length"] - t["plies_per_sec"]) < 1e-6 * t["plies_per_sec"]
-    assert t["cpu_baseline"]["kind"] == "port"
+    assert t["cpu_baseline"]["kind"] == "port" and t["cpu_baseline"]["reference_shim"]["per_core"] == 870.0
+    assert "k_play<2> (persistent)" in t["kernels"]
+
+
+def test_default_line_nests_the_config5_shape_with_roofline_and_cpu_baseline():
+    """Under the real headline shape (11x11, 6x64) the line also carries BASELINE configs[4]'s shape on one GPU as
+    "config5" -- 13x13, 19x256, 810 select_leaf calls, one warm-up + one timed move -- with its own roofline and
+    cpu_baseline (few games here)."""
+    d = _run("--steps", "1", "--warmup", "1", "--games", "32", "--tree-steps", "4", "--tree-warmup", "1",
+             "--c5-games", "8", "--api-moves", "0", "--settle", "30")
+    _check_common(d, 1, 1)
+    assert d["config"]["workload"].startswith("BASELINE configs[2]") and "api" not in d
+    c = d["cpu_baseline"]
+    assert c["reference_shim"]["sims_per_s"] == 3011.0 and c["reference_shim"]["cores"] == 8
+    assert abs(c["port_vs_reference_per_core"] - c["per_core"] / c["reference_shim"]["per_core"]) < 1e-9
+    c5 = d["config5"]
+    assert c5["config"]["workload"].startswith("BASELINE configs[4] shape") and c5["steps"] == 1 and c5["warmup"] == 1
+    assert round(c5["value"] * c5["elapsed_s"]) == 8 * 810 and c5["plies"] == 8
+    r = c5["roofline"]
+    assert r["bound"] == "mfma" and "k_conv_wide_f16x3_s16 x 38" in r["kernel"] and r["peak"] == 2500.0
+    assert abs(r["flop_per_launch"] / r["positions_per_launch"] - 7.58e9) < 0.01e9
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    b = c5["cpu_baseline"]
+    assert b["kind"] == "port" and b["value"] > 0 and "bounded sample" in b["sample"] and "19x256" in b["sample"]
+    assert "k_conv_wide_f16x3_s16" in c5["kernels"]
 
 
 def test_tree_bench_line():
