@@ -547,6 +547,7 @@ def main():
                                            % (args.games, args.board, args.board, args.sims, selects_per_search)),
                               "start": common_cfg["start"].replace("%d warm-up" % args.warmup, "%d warm-up" % args.tree_warmup)}
             tree["roofline"] = tree_roofline(st_t, args, args.tree_steps, args.tree_warmup)
+            tree["kernels"] = ex_t["kernels"]
             if world == 1 and not args.no_cpu_baseline:
                 try:
                     tree["cpu_baseline"] = cpu_baseline(args, "tree")

@@ -1,31 +1,11 @@
 /* oracle/net.c -- CPU restatement of azalea/network.py's inference forward (HexNetwork).
  * TEST INFRASTRUCTURE ONLY (see oracle.h).  Plain fp32 direct convolution, eval-mode BatchNorm. */
-#include "oracle.h"
+#include "net_priv.h"
 
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-
-#define ONET_MAX_TENSORS 512
-
-struct onet {
-    int n, blocks, chans;
-    int nt;
-    char *names[ONET_MAX_TENSORS];
-    float *data[ONET_MAX_TENSORS];
-    int64_t count[ONET_MAX_TENSORS];
-    /* packed, built lazily by finalize() */
-    int ready;
-    float *emb;         /* [3][4]                  network.py:125 */
-    float *w_stem;      /* [3][3][4][C]            network.py:47 */
-    float *s_stem, *b_stem;           /* folded BN scale/shift, network.py:48 */
-    float **w_blk;      /* 2*blocks x [3][3][C][C] network.py:20-23 */
-    float **s_blk, **b_blk;
-    float *w_vc, *s_vc, *b_vc;        /* [C][2]   network.py:54-55 */
-    float *w_pc, *s_pc, *b_pc;        /* [C][4]   network.py:59-60 */
-    const float *fc2_w, *fc2_b, *fc3_w, *fc3_b, *mfc_w, *mfc_b;   /* network.py:56-57, :127 */
-};
 
 onet_t *onet_new(int n, int blocks, int chans) {
     onet_t *net = (onet_t *)calloc(1, sizeof(onet_t));
@@ -108,7 +88,7 @@ static float *pack_conv(const float *w, int cout, int cin, int ks) {
     return p;
 }
 
-static void finalize(onet_t *net) {
+void onet_finalize(onet_t *net) {
     if (net->ready) return;
     const int C = net->chans, n2 = net->n * net->n;
     char nm[256];
@@ -172,11 +152,61 @@ static void conv3x3_bn(int n, int cin, int cout, const float *in, const float *w
         }
 }
 
+/* value / policy heads + masked log_softmax of one position (network.py:77-84, :146-151) */
+void onet_heads(const onet_t *net, const float *a, int K, const int32_t *lm, float *value, float *lp,
+                float *vh, float *ph, float *logit) {
+    const int n2 = net->n * net->n, C = net->chans;
+    /* value head, network.py:77-81; flatten order (c, h, w) */
+    for (int p = 0; p < n2; ++p)
+        for (int o = 0; o < 2; ++o) {
+            float acc = 0.0f;
+            for (int i = 0; i < C; ++i) acc += a[(size_t)p * C + i] * net->w_vc[i * 2 + o];
+            float v = acc * net->s_vc[o] + net->b_vc[o];
+            vh[o * n2 + p] = v > 0.0f ? v : 0.0f;
+        }
+    float h2[64];
+    for (int o = 0; o < 64; ++o) {
+        float acc = 0.0f;
+        const float *wr = net->fc2_w + (size_t)o * 2 * n2;
+        for (int i = 0; i < 2 * n2; ++i) acc += vh[i] * wr[i];
+        acc += net->fc2_b[o];
+        h2[o] = acc > 0.0f ? acc : 0.0f;
+    }
+    float v3 = 0.0f;
+    for (int i = 0; i < 64; ++i) v3 += h2[i] * net->fc3_w[i];
+    v3 += net->fc3_b[0];
+    *value = tanhf(v3);
+    /* policy head, network.py:83-84, :146-151 */
+    for (int p = 0; p < n2; ++p)
+        for (int o = 0; o < 4; ++o) {
+            float acc = 0.0f;
+            for (int i = 0; i < C; ++i) acc += a[(size_t)p * C + i] * net->w_pc[i * 4 + o];
+            float v = acc * net->s_pc[o] + net->b_pc[o];
+            ph[o * n2 + p] = v > 0.0f ? v : 0.0f;
+        }
+    for (int t = 0; t < n2; ++t) {
+        float acc = 0.0f;
+        const float *wr = net->mfc_w + (size_t)t * 4 * n2;
+        for (int i = 0; i < 4 * n2; ++i) acc += ph[i] * wr[i];
+        logit[t] = acc + net->mfc_b[t];
+    }
+    float mx = -INFINITY;
+    for (int j = 0; j < K; ++j) {
+        int tile = lm[j] > 0 ? lm[j] - 1 : 0;          /* clamp(min=0), network.py:147 */
+        lp[j] = lm[j] == 0 ? -99.0f : logit[tile];     /* network.py:150 */
+        if (lp[j] > mx) mx = lp[j];
+    }
+    double sum = 0.0;
+    for (int j = 0; j < K; ++j) sum += exp((double)lp[j] - (double)mx);
+    float lse = (float)((double)mx + log(sum));
+    for (int j = 0; j < K; ++j) lp[j] = lp[j] - lse;   /* network.py:151 */
+}
+
 /* HexNetwork.forward (network.py:134-152) over Network.forward (network.py:68-85) */
 void onet_forward(const onet_t *cnet, int B, int K, const int32_t *boards,
                   const int32_t *legal_moves, float *value, float *logprob) {
     onet_t *net = (onet_t *)cnet;
-    finalize(net);
+    onet_finalize(net);
     const int n = net->n, n2 = n * n, C = net->chans;
     float *x0 = (float *)malloc(sizeof(float) * n2 * 4);
     float *a = (float *)malloc(sizeof(float) * n2 * C);
@@ -195,52 +225,7 @@ void onet_forward(const onet_t *cnet, int B, int K, const int32_t *boards,
             conv3x3_bn(n, C, C, b, net->w_blk[2 * blk + 1], net->s_blk[2 * blk + 1], net->b_blk[2 * blk + 1], a, c);
             float *t = a; a = c; c = t;
         }
-        /* value head, network.py:77-81; flatten order (c, h, w) */
-        for (int p = 0; p < n2; ++p)
-            for (int o = 0; o < 2; ++o) {
-                float acc = 0.0f;
-                for (int i = 0; i < C; ++i) acc += a[(size_t)p * C + i] * net->w_vc[i * 2 + o];
-                float v = acc * net->s_vc[o] + net->b_vc[o];
-                vh[o * n2 + p] = v > 0.0f ? v : 0.0f;
-            }
-        float h2[64];
-        for (int o = 0; o < 64; ++o) {
-            float acc = 0.0f;
-            const float *wr = net->fc2_w + (size_t)o * 2 * n2;
-            for (int i = 0; i < 2 * n2; ++i) acc += vh[i] * wr[i];
-            acc += net->fc2_b[o];
-            h2[o] = acc > 0.0f ? acc : 0.0f;
-        }
-        float v3 = 0.0f;
-        for (int i = 0; i < 64; ++i) v3 += h2[i] * net->fc3_w[i];
-        v3 += net->fc3_b[0];
-        value[s] = tanhf(v3);
-        /* policy head, network.py:83-84, :146-151 */
-        for (int p = 0; p < n2; ++p)
-            for (int o = 0; o < 4; ++o) {
-                float acc = 0.0f;
-                for (int i = 0; i < C; ++i) acc += a[(size_t)p * C + i] * net->w_pc[i * 4 + o];
-                float v = acc * net->s_pc[o] + net->b_pc[o];
-                ph[o * n2 + p] = v > 0.0f ? v : 0.0f;
-            }
-        for (int t = 0; t < n2; ++t) {
-            float acc = 0.0f;
-            const float *wr = net->mfc_w + (size_t)t * 4 * n2;
-            for (int i = 0; i < 4 * n2; ++i) acc += ph[i] * wr[i];
-            logit[t] = acc + net->mfc_b[t];
-        }
-        const int32_t *lm = legal_moves + (size_t)s * K;
-        float *lp = logprob + (size_t)s * K;
-        float mx = -INFINITY;
-        for (int j = 0; j < K; ++j) {
-            int tile = lm[j] > 0 ? lm[j] - 1 : 0;          /* clamp(min=0), network.py:147 */
-            lp[j] = lm[j] == 0 ? -99.0f : logit[tile];     /* network.py:150 */
-            if (lp[j] > mx) mx = lp[j];
-        }
-        double sum = 0.0;
-        for (int j = 0; j < K; ++j) sum += exp((double)lp[j] - (double)mx);
-        float lse = (float)((double)mx + log(sum));
-        for (int j = 0; j < K; ++j) lp[j] = lp[j] - lse;   /* network.py:151 */
+        onet_heads(net, a, K, legal_moves + (size_t)s * K, value + s, logprob + (size_t)s * K, vh, ph, logit);
     }
     free(x0); free(a); free(b); free(c); free(vh); free(ph); free(logit);
 }

@@ -102,6 +102,7 @@ def lib():
         L.onet_set.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64]
         L.onet_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.onet_forward_fast.argtypes = L.onet_forward.argtypes
         L.obench_selfplay.argtypes = [C.POINTER(BenchCfg), C.c_void_p, C.POINTER(BenchOut)]
         _lib = L
     return _lib
@@ -287,13 +288,15 @@ class Net:
             _lib.onet_free(self.h)
             self.h = None
 
-    def forward(self, boards, legal_moves):
+    def forward(self, boards, legal_moves, fast=False):
+        """fast=True: the blocked / FMA forward that bench.py's cpu_baseline times (net_fast.c)."""
         boards = np.ascontiguousarray(boards, np.int32)
         lm = np.ascontiguousarray(legal_moves, np.int32)
         B, K = lm.shape
         value = np.zeros(B, np.float32)
         logprob = np.zeros((B, K), np.float32)
-        lib().onet_forward(self.h, B, K, _i32p(boards), _i32p(lm), _f32p(value), _f32p(logprob))
+        fn = lib().onet_forward_fast if fast else lib().onet_forward
+        fn(self.h, B, K, _i32p(boards), _i32p(lm), _f32p(value), _f32p(logprob))
         return value, logprob
 
 

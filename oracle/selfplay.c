@@ -1,6 +1,6 @@
 /* oracle/selfplay.c -- whole-game self-play loop over the CPU restatement, one game per thread.
  * TEST INFRASTRUCTURE ONLY (see oracle.h): this is the timed host-core baseline of bench.py
- * ("cpu_baseline", kind "port").  The loop restates azalea/play_game.py:44-67 around
+ * ("cpu_baseline", kind "port"; the network forward is net_fast.c's blocked one).  The loop restates azalea/play_game.py:44-67 around
  * azalea/policy.py:132-176; the RNG is a local xoshiro256** (the reference's numpy RandomState
  * is only reproduced in parity tests, where the host draws the noise and the move). */
 #include "oracle.h"
@@ -100,7 +100,7 @@ static void *worker(void *arg) {
             osearch_cfg_t sc = {cfg->simulations, cfg->batch_size, cfg->c_puct, cfg->noise_scale,
                                 noise, sel_per_move};
             osearch_stats_t st;
-            int rc = cfg->use_net ? osearch(tree, &game, oeval_net, (void *)w->net, &sc, &st)
+            int rc = cfg->use_net ? osearch(tree, &game, oeval_net_fast, (void *)w->net, &sc, &st)
                                   : osearch(tree, &game, oeval_uniform, &uctx, &sc, &st);
             if (rc) break;                             /* SearchTreeFull: game skipped */
             w->selects += st.n_select;

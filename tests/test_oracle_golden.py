@@ -253,3 +253,28 @@ def test_g5r_oracle_network_on_the_game_s_own_leaves():
     for j, r in enumerate(rows):
         a, b = int(tape.off[r]), int(tape.off[r + 1])
         assert np.abs(lp[j, :b - a] - tape.logprob[a:b]).max() <= 1e-4
+
+
+def test_timed_network_path_matches_the_parity_path():
+    """bench.py's cpu_baseline times net_fast.c (blocked convolutions, FMA); it must be the same network as the
+    pinned parity path net.c: value and legal log-probabilities within 1e-5 on 11x11 / 6x64, 13x13 / 2x256 (the
+    configs[4] width), a 7x7 and an odd-sized net whose channel count is not a multiple of the register block."""
+    import torch
+    from azalea_amd.network import HexNetwork
+    for n, blocks, chans, B in ((11, 6, 64, 6), (13, 2, 256, 2), (7, 1, 64, 3), (5, 2, 8, 3), (9, 2, 40, 2)):
+        torch.manual_seed(n)
+        net = HexNetwork(board_size=n, num_blocks=blocks, base_chans=chans).eval()
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.6, 1.4)
+        N = orc.Net(n, blocks, chans, {k: v.detach().numpy() for k, v in net.state_dict().items()})
+        rng = np.random.RandomState(n)
+        boards = rng.randint(0, 3, (B, n, n)).astype(np.int32)
+        lm = np.zeros((B, n * n), np.int32)
+        for i in range(B):
+            e = np.flatnonzero(boards[i].ravel() == 0) + 1
+            lm[i, :len(e)] = e
+        v, lp = N.forward(boards, lm)
+        vf, lpf = N.forward(boards, lm, fast=True)
+        assert np.abs(v - vf).max() <= 1e-5 and np.abs(lp - lpf)[lm > 0].max() <= 1e-5, (n, blocks, chans)
