@@ -376,14 +376,21 @@ def resnet_roofline(st, args, steps, warmup):
     return roof
 
 
-def replay_exchange(E, dist, torch, local_rank):
+def replay_exchange(E, dist, torch, local_rank, exchange_plies=0):
     """One replay refill the way a DeviceReplayBuffer shared by all ranks takes it: the rows this
     rank harvested are packed into fixed-size records on the device, all-gathered over RCCL and appended to
     the rank's HBM ring.  The bench's harvest queue wraps around, so the most recent rows are used."""
     import numpy as np
     world = dist.get_world_size() if dist is not None else 1
     dev = torch.device("cuda", local_rank)
-    rows, _ = E.play_device(1, max_plies=40)    # a short top-up through the Player.read path: whole games, queued
+    if exchange_plies > 0:
+        # exactly `exchange_plies` more moves of every slot (at most 2N - 1: a slot then finishes at most one game,
+        # the queue bound below is never reached early), so the set of games handed over is a function of the
+        # pool alone -- the same for any number of ranks (tests/test_gpu_distributed.py)
+        assert exchange_plies <= 2 * E.n - 1
+        rows, _ = E.play_device(E.G * E.cells, max_plies=exchange_plies)
+    else:
+        rows, _ = E.play_device(1, max_plies=40)    # a short top-up through the Player.read path: whole games, queued
     rb = E.record_bytes
     E.replay_create(max(1, rows) * world + 1)
     torch.cuda.synchronize(dev)
@@ -406,7 +413,11 @@ def replay_exchange(E, dist, torch, local_rank):
             E.replay_put_records(c, p.data_ptr())
     t_put = time.perf_counter() - t2
     total = int(np.sum(counts))
+    uids = [p[:, :8].contiguous().view(torch.int64).flatten() for p, c in zip(parts, counts) if c]
+    uids = torch.cat(uids).unique().cpu().numpy() if uids else np.zeros(0, np.int64)
     return {"ranks": world, "rows_per_rank": counts, "record_bytes": rb, "bytes_gathered": total * rb,
+            "games": int(len(uids)), "game_uid_sum": int(uids.sum()), "game_uid_xor": int(np.bitwise_xor.reduce(uids)) if len(uids) else 0,
+            "game_uids": uids.tolist() if len(uids) <= 256 else None,
             "pack_seconds": t_pack, "allgather_seconds": t_gather, "ring_put_seconds": t_put,
             "path": "k_rows_pack -> all_gather(counts) + all_gather(records, device tensors) -> k_records_put"}
 
@@ -442,6 +453,9 @@ def main():
                     help="engine moves the nested product-surface leg (Player.read) is driven for; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-replay-exchange", action="store_true")
+    ap.add_argument("--exchange-plies", type=int, default=0,
+                    help="replay exchange after exactly this many further moves of every slot (default: a short top-up "
+                         "until the first game finishes)")
     args = ap.parse_args()
     headline = "tree" if args.workload == "tree" else "resnet"
     if args.steps is None:
@@ -489,7 +503,7 @@ def main():
     E = ex["engine"]
     exchange = None
     if headline == "resnet" and not args.no_replay_exchange:
-        exchange = replay_exchange(E, dist, torch, local_rank)
+        exchange = replay_exchange(E, dist, torch, local_rank, args.exchange_plies)
     E.close()
 
     selects_per_search = (args.sims // args.batch + 1) * args.batch
@@ -509,6 +523,8 @@ def main():
         line.update(throughput_fields(sums, elapsed, args.steps))
         line["world"] = {"ranks": world, "backend": (dist.get_backend() if dist is not None else None),
                          "games_per_rank": args.games}
+        if exchange is not None:
+            line["world"]["rows_per_rank"] = exchange["rows_per_rank"]
         line["kernels"] = ex["kernels"]
         if headline == "tree":
             wl = ("BASELINE configs[1]: %d concurrent %dx%d Hex games per GPU, HIP movegen+MCTS kernels only, "

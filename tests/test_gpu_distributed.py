@@ -93,3 +93,40 @@ def test_two_ranks_with_engines_share_reads_and_the_device_ring():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: [], 1: []}      # numbers of the checks that failed, per rank
+
+
+def _bench(args, world):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AZX_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable]
+    if world > 1:      # the driver's launch line; the launcher is a fresh child process (nothing here re-execs)
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())]
+    cmd += [os.path.join(root, "bench.py"), "--gpus", str(world)] + args
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_play_the_same_games_as_one():
+    """bench.py --gpus 2 the way the driver launches it (torch.distributed.run, one process per rank; gloo here
+    because both ranks share the box's one GPU): the ranks shard the pool by global game index, so two ranks with
+    32 slots each play exactly the games one rank with 64 slots plays -- the replay exchange after the same number
+    of moves hands over the same set of game uids -- and the whole-job sims are the sum over ranks."""
+    common = ["--steps", "3", "--warmup", "1", "--sims", "40", "--board", "7", "--blocks", "1", "--workload", "resnet",
+              "--no-cpu-baseline", "--exchange-plies", "12", "--settle", "40"]
+    one = _bench(common + ["--games", "64"], 1)
+    two = _bench(common + ["--games", "32"], 2)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["world"]["backend"] == "gloo"
+    x1, x2 = one["replay_allgather"], two["replay_allgather"]
+    assert x1["ranks"] == 1 and x2["ranks"] == 2 and len(x2["rows_per_rank"]) == 2 and min(x2["rows_per_rank"]) >= 1
+    assert two["world"]["rows_per_rank"] == x2["rows_per_rank"]
+    assert x1["games"] >= 4 and x1["game_uids"] == x2["game_uids"]          # the same games, whoever played them
+    assert sum(x1["rows_per_rank"]) == sum(x2["rows_per_rank"])
+    # 64 games x 3 moves x 50 select_leaf calls in both jobs: value = whole-job sims / max-over-ranks time
+    assert round(one["value"] * one["elapsed_s"]) == 64 * 3 * 50 == round(two["value"] * two["elapsed_s"])
+    assert one["plies"] == two["plies"] == 64 * 3 and one["games_finished"] == two["games_finished"]

@@ -10,7 +10,7 @@ the hand-over (k_rows_export + D2H copies, or k_replay_put), and the host frame 
 state the way bench.py does it (uniform-prior self-play, positions transplanted), so every engine move
 finishes ~1 % of the games.  One JSON object on stdout.
 
-    python tools/bench_player.py [--reads 6] [--size 4000] [--games 4096]
+    python tools/bench_player.py [--reads 6] [--size 4000] [--games 4096] [--moves 190]
 """
 import argparse
 import json
@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--sims", type=int, default=400)
     ap.add_argument("--blocks", type=int, default=6)
     ap.add_argument("--chans", type=int, default=64)
+    ap.add_argument("--moves", type=int, default=190,
+                    help="engine moves of the full-game-length legs (rows/s over the last 60); 0 = skip them")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -58,7 +60,8 @@ def main():
                                settle=2 * n * n)
     T = bench.make_engine("tree", bargs, 0, 1, 0)
     bench.settle_pool(T, bargs, 0, 1, 0)
-    E.reset(moves=bench.pool_positions(T))
+    start_positions = bench.pool_positions(T)
+    E.reset(moves=start_positions)
     T.close()
 
     # instrument the three stages
@@ -134,7 +137,64 @@ def main():
         "engine_device_seconds": dev_s, "host_overhead_frac": (wall2 - dev_s) / wall2,
         "collate_1024_seconds": t_sample, "batch_keys": sorted(batch)}
     player.stop()
+
+    # ---- a whole game length after the transplant (round 3): rows/s over the last 60 moves ---------------------
+    # Transplanted games only carry the rows played since the transplant, so the short runs above under-count;
+    # after > 121 moves every game handed over is a whole one and rows/s must equal the engine's plies/s.
+    if args.moves > 0:
+        out["player_read_full_length"] = bench.run_api(argparse.Namespace(**dict(vars(bargs), api_moves=args.moves)), 0, 1, 0,
+                                                       start_positions, torch)
+        out["device_replay_consume_full_length"] = consume_full_length(args, bargs, start_positions, torch)
     print(json.dumps(out))
+
+
+def consume_full_length(args, bargs, start, torch):
+    """DeviceReplayBuffer.consume (rows never leave HBM) driven for `--moves` engine moves after the transplant."""
+    from azalea_amd import AzaleaAgent, HexGame, Player, Policy
+    from azalea_amd.device_replay import DeviceReplayBuffer
+    n = args.board
+    cfg = dict(device="cuda", network="HexNetwork", board_size=n, num_blocks=args.blocks, base_chans=args.chans,
+               simulations=args.sims, search_batch_size=10, exploration_coef=0.5, exploration_depth=15,
+               exploration_noise_alpha=0.03, exploration_noise_scale=0.25, exploration_temperature=1.0, seed=1)
+    torch.manual_seed(0)
+    policy = Policy()
+    policy.initialize(cfg)
+    policy.settings.update(move_sampling=True, move_exploration=True)
+    agent = AzaleaAgent(lambda: HexGame(n), policy=policy, device="cuda")
+    player = Player(None, [agent], n_games=args.games, gather=False)
+    E = player.device_engine()
+    player.prepare_device_engine(E)
+    E.reset(moves=start)
+    buf = DeviceReplayBuffer(E, capacity=1 << 20, shared=False)
+    tot = {"plies": 0, "dev": 0.0, "rows": 0}
+    real_fill = E.replay_fill
+
+    def fill(*a, **k):
+        r, st = real_fill(*a, **k)
+        tot["plies"] += st["plies"]
+        tot["dev"] += st["seconds"]
+        tot["rows"] += r
+        return r, st
+    E.replay_fill = fill
+    chunk = float(8 * args.games)
+    t0 = time.perf_counter()
+    log = [(0.0, 0, 0)]
+    while tot["plies"] < args.moves * args.games:
+        buf.fresh_counter = 0
+        buf.consume(chunk, player)
+        log.append((time.perf_counter() - t0, tot["rows"], tot["plies"]))
+    player.stop()
+    lo = next(i for i, r in enumerate(log) if r[2] >= max(0, args.moves - 60) * args.games or i == len(log) - 1)
+    lo = min(lo, len(log) - 2)
+    w0, w1 = log[lo], log[-1]
+    dt = w1[0] - w0[0]
+    wall = log[-1][0]
+    return {"surface": "DeviceReplayBuffer.consume (replay_buffer.py:121-132 on the HBM ring)", "consumes": len(log) - 1,
+            "moves_since_transplant": tot["plies"] / args.games, "rows": tot["rows"], "seconds": wall,
+            "rows_per_sec": (w1[1] - w0[1]) / dt, "plies_per_sec": (w1[2] - w0[2]) / dt,
+            "rows_over_plies": (w1[1] - w0[1]) / max(1, w1[2] - w0[2]),
+            "window": "moves %.0f..%.0f after the transplant" % (w0[2] / args.games, w1[2] / args.games),
+            "host_overhead_frac": (wall - tot["dev"]) / wall}
 
 
 if __name__ == "__main__":
