@@ -368,6 +368,8 @@ def resnet_roofline(st, args, steps, warmup):
     key = [args.games, args.board, args.sims, args.batch, args.blocks, args.chans, steps, warmup,
            args.noise_scale, args.desync, args.settle]
     wide = args.chans % 128 == 0
+    if wide:      # per-forward counters of the wide tower depend on the batch and the network only (tools/prof_r3.sh)
+        key = [args.games, args.board, args.batch, args.blocks, args.chans, "per forward"]
     roof["traffic"], src = pmc_traffic(PMC_FILES["config5" if wide else "resnet"], key)
     if src:
         roof["traffic_source"] = src

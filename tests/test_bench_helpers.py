@@ -44,7 +44,7 @@ def test_committed_pmc_traffic_is_keyed_to_the_drivers_command():
     assert (a5.board, a5.blocks, a5.chans, a5.sims, a5.games, a5.desync, a5.settle) == (13, 19, 256, 800, 512, 128, 338)
     key_r = [a.games, a.board, a.sims, a.batch, a.blocks, a.chans, 20, 5, a.noise_scale, a.desync, a.settle]
     key_t = [a.games, a.board, a.sims, a.batch, 130, 20, a.noise_scale, a.desync, a.settle]
-    key_5 = [a5.games, a5.board, a5.sims, a5.batch, a5.blocks, a5.chans, 1, 1, a5.noise_scale, a5.desync, a5.settle]
+    key_5 = [a5.games, a5.board, a5.batch, a5.blocks, a5.chans, "per forward"]
     for leg, key in (("resnet", key_r), ("tree", key_t), ("config5", key_5)):
         name = bench.PMC_FILES[leg]
         path = os.path.join(ROOT, "profiles", name)

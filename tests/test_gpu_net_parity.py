@@ -145,6 +145,45 @@ def test_wide_tower_forward(eng, orc, n, blocks, chans, count, use_oracle):
     E.close()
 
 
+@pytest.mark.parametrize("n,blocks,chans,count", [(13, 2, 256, 27), (11, 2, 128, 35)])
+def test_wide_tower_batch_split_over_streams(eng, orc, n, blocks, chans, count):
+    """A wide-tower batch of more than 16 boards is cut into parts that run their layer launches on separate
+    streams (fork / join events, e_base > 0, an XCD-remapped grid per part).  A board count that is not a multiple
+    of 8, against the torch module (<= 1e-4) and bit for bit against engines created with the batch on one
+    stream and on three (AZX_WIDE_STREAMS is read once per engine, at azx_create)."""
+    import torch
+    from azalea_amd.network import HexNetwork
+    torch.manual_seed(n * 77 + chans)
+    net = HexNetwork(board_size=n, num_blocks=blocks, base_chans=chans).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.3, 1.7)
+    state = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    rng = np.random.RandomState(count)
+    boards, lm = _random_positions(orc, n, count, rng)
+    outs = {}
+    for streams in ("2", "1", "3"):
+        os.environ["AZX_WIDE_STREAMS"] = streams
+        try:
+            E = eng.Engine(board_size=n, n_games=4, simulations=10, search_batch_size=10,
+                           evaluator=eng.EVAL_RESNET, num_blocks=blocks, base_chans=chans)
+        finally:
+            os.environ.pop("AZX_WIDE_STREAMS", None)
+        assert "AZX_WIDE_STREAMS=%s" % streams in E.kernel_info()
+        E.set_weights(state)
+        outs[streams] = E.forward(boards, lm)
+        E.close()
+    value, logprob = outs["2"]
+    legal = lm > 0
+    with torch.no_grad():
+        t = net(torch.tensor(boards), torch.tensor(lm))
+    assert np.abs(value - t["value"].numpy()).max() <= TOL
+    assert np.abs(logprob - t["moves_logprob"].numpy())[legal].max() <= TOL
+    for streams in ("1", "3"):
+        assert np.array_equal(outs[streams][0], value) and np.array_equal(outs[streams][1], logprob), streams
+
+
 def test_resnet_search_replayed_by_oracle(eng, orc):
     """Search with the device network; feed the SAME (value, prior) stream to the CPU oracle:
     trees must be identical bit for bit (visit counts, values, priors, topology), and the

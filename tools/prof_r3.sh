@@ -14,18 +14,29 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$1; shift
 mkdir -p $OUT
 PASSES=${@:-stats fetch write sq1 sq2}
-# rocprofv3's counter collection falls over (SIGSEGV inside the dispatch intercept) when an engine launches on a
-# second HIP stream, which the wide tower does (two halves of a batch on two streams): the counter
-# passes run it on one stream -- same kernels, same bytes and cycles per forward; the timing pass keeps two.
-PMCENV="AZX_WIDE_STREAMS=1"
+# The timing pass is the driver's command itself.  rocprofv3's counter collection, however, falls over on this pool
+# (SIGSEGV in the dispatch intercept / its worker thread, all output lost) (a) when an engine launches on a second
+# HIP stream, which the wide tower does (two halves of a batch on two streams), and (b) somewhere
+# past ~10 k dispatches in one process -- the configs[4]-shape leg alone is 12.8 k.  So every counter pass is two
+# runs: the headline + nested tree run (--no-config5), and the configs[4]-shape leg on its own with the wide tower
+# on ONE stream and 200 instead of 800 sims per move (21 instead of 81 leaf batches per move: the same kernels
+# on the same 512-game batches, so the same bytes and cycles per forward, which is what the summary reports).
+export TMPDIR=/tmp
 ARGS="--steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --api-moves 0 ${EXTRA:-}"
+C5="--workload resnet --board 13 --blocks 19 --chans 256 --sims 200 --games ${C5GAMES:-512} --steps 1 --warmup 0 --no-cpu-baseline --no-replay-exchange"
+pmc() {   # name, counters...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py $ARGS --no-config5 > $OUT/$name.json 2> $OUT/$name.err
+  AZX_WIDE_STREAMS=1 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/${name}_c5 -- python3 $R/bench.py $C5 > $OUT/${name}_c5.json 2> $OUT/${name}_c5.err
+  echo "$name: segv $(grep -c SIGSEGV $OUT/$name.err) / $(grep -c SIGSEGV $OUT/${name}_c5.err)"
+}
 for p in $PASSES; do
   case $p in
     stats) rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/stats.json 2> $OUT/stats.err ;;
-    fetch) export $PMCENV; rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/fetch -- python3 $R/bench.py $ARGS > $OUT/fetch.json 2> $OUT/fetch.err ;;
-    write) export $PMCENV; rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py $ARGS > $OUT/write.json 2> $OUT/write.err ;;
-    sq1)   export $PMCENV; rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/sq1 -- python3 $R/bench.py $ARGS > $OUT/sq1.json 2> $OUT/sq1.err ;;
-    sq2)   export $PMCENV; rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/sq2 -- python3 $R/bench.py $ARGS > $OUT/sq2.json 2> $OUT/sq2.err ;;
+    fetch) pmc fetch FETCH_SIZE GRBM_GUI_ACTIVE ;;
+    write) pmc write WRITE_SIZE ;;
+    sq1)   pmc sq1 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU ;;
+    sq2)   pmc sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR ;;
   esac
 done
 python3 $R/tools/prof_r3_summarise.py $OUT ${STEPS:-20} ${WARMUP:-5}

@@ -169,43 +169,44 @@ if tree:
     json.dump({"kernel": "k_play<2>, the nested tree run's timed launch", "counters": tree},
               open(os.path.join(summ, "tree_pmc_counters.json"), "w"), indent=1)
 
-# ---- nested configs[4]-shape leg: k_stem_wide + 38 x k_conv_wide per leaf-batch forward -----------
+# ---- configs[4]-shape leg: k_stem_wide + 38 x k_conv_wide per leaf-batch forward ------------------
+# counters from the leg's own runs (<pass>_c5: 200 sims per move, one stream); timing from the driver's command
 c5 = line.get("config5")
-if c5:
-    sums, n_conv, n_fwd = {}, {}, {}
-    for name in ("fetch", "write", "sq1", "sq2"):
+c5line = bench_line("fetch_c5") or bench_line("write_c5") or {}
+if c5 or c5line:
+    sums, n_fwd = {}, {}
+    for name in ("fetch_c5", "write_c5", "sq1_c5", "sq2_c5"):
         rows = [r for r in rows_of(name, "counter_collection.csv") if is_wide_any(r["Kernel_Name"])]
         fw = len({r["Dispatch_Id"] for r in rows if "k_stem_wide" in r["Kernel_Name"]})
         for r in rows:
             cn = r["Counter_Name"]
             sums[cn] = sums.get(cn, 0.0) + float(r["Counter_Value"])
             n_fwd[cn] = fw
-            if is_wide(r["Kernel_Name"]):
-                n_conv[cn] = n_conv.get(cn, 0) + 1
     per_fwd = {cn: v / max(1, n_fwd[cn]) for cn, v in sums.items()}
-    cc = c5["config"]
-    key5 = [cc["games_per_gpu"], 13, cc["simulations"], cc["search_batch_size"], 19, 256, 1, 1, 0.25]
-    m5 = re.search(r"0\.\.(\d+) plies, (\d+) settle", cc.get("start", ""))
-    key5 += [int(m5.group(1)), int(m5.group(2))] if m5 else [0, 0]
+    cc = (c5 or c5line)["config"]
+    key5 = [cc["games_per_gpu"], 13, cc["search_batch_size"], 19, 256, "per forward"]
+    pos = (c5line.get("roofline") or (c5 or {}).get("roofline") or {}).get("positions_per_launch")
     if "FETCH_SIZE" in per_fwd and "WRITE_SIZE" in per_fwd:
         t5 = traffic(per_fwd["FETCH_SIZE"], per_fwd["WRITE_SIZE"])
         t5["bench_key"] = key5
-        t5["kernel"] = ("k_stem_wide_f16x3 + 38 x k_conv_wide_f16x3_s16 per leaf-batch forward: mean over the leg's %d forwards "
-                        "(warm-up and timed move alike; k_heads not included)" % n_fwd["FETCH_SIZE"])
-        t5["positions_per_forward"] = c5["roofline"]["positions_per_launch"]
-        t5["algorithmic_bytes_per_forward"] = ("activations [169][256 hi | 256 lo] f16 = 173 KB per position read + written by "
-                                                "each of 38 layers, + residual reads by 19: ~16.4 MB per position")
+        t5["kernel"] = ("k_stem_wide_f16x3 + 38 x k_conv_wide_f16x3_s16 per leaf-batch forward: mean over %d forwards of the "
+                        "configs[4]-shape leg run on its own under the counters (200 sims per move, wide tower on one "
+                        "stream: rocprofv3 --pmc falls over on the second stream and past ~10 k dispatches; same kernels, "
+                        "same 512-game batches; k_heads not included)" % n_fwd["FETCH_SIZE"])
+        t5["positions_per_forward"] = pos
+        t5["algorithmic_bytes_per_forward"] = ("activations [169][256 hi | 256 lo] f16 = 173 KB per position, read and written "
+                                                "by each of 38 layers + read as residual by 19: ~16.4 MB per position")
         json.dump(t5, open(os.path.join(summ, "config5_pmc_traffic.json"), "w"), indent=1)
     if per_fwd:
-        d5 = {"kernel": "k_stem_wide_f16x3 + 38 x k_conv_wide_f16x3_s16, per leaf-batch forward (mean over all forwards of the leg)",
-              "counters": per_fwd, "forwards": n_fwd}
+        d5 = {"kernel": "k_stem_wide_f16x3 + 38 x k_conv_wide_f16x3_s16, per leaf-batch forward (mean over the forwards of the leg's own counter runs)",
+              "counters": per_fwd, "forwards": n_fwd, "positions_per_forward": pos}
 
         def fwd_ms(name):
             rows = [r for r in rows_of(name, "kernel_trace.csv") if is_wide_any(r["Kernel_Name"])]
             fw = sum(1 for r in rows if "k_stem_wide" in r["Kernel_Name"])
             return sum(dur_ms(r) for r in rows) / max(1, fw) if rows else None
-        d5["forward_ms_kernel_trace (sum of the wide kernels' durations; two streams overlap, so >= wall)"] = fwd_ms("stats")
-        pipe(d5, per_fwd, fwd_ms("fetch"), fwd_ms("sq1"))
+        d5["forward_ms_kernel_trace_two_streams (sum of kernel durations in the driver's command; the streams overlap, so >= wall)"] = fwd_ms("stats")
+        pipe(d5, per_fwd, fwd_ms("fetch_c5"), fwd_ms("sq1_c5"))
         json.dump(d5, open(os.path.join(summ, "config5_pmc_counters.json"), "w"), indent=1)
 
 for f in ("resnet_pmc_counters.json", "resnet_pmc_traffic.json", "tree_pmc_traffic.json", "config5_pmc_traffic.json",
