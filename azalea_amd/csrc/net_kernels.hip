@@ -602,7 +602,9 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
     const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
     const int e0 = blockIdx.x * F16X3_BPB;
     if (e0 >= n_eval) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index is uniform over a wave: as a scalar, everything derived from it (channel / position base, the
+    // 64-bit part of the weight-fragment addresses) is computed on the scalar unit instead of per lane
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wb = wave >> 1, wh = wave & 1;             // board within the block, which half of its positions
     const int N = P.N, ncells = P.ncells;
     const int e = e0 + wb;
@@ -1043,6 +1045,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3(NetDev P, int layer,
 // block, wave (wm, wn): 96 positions x 64 channels = 6 x 4 tiles of 16 x 16), same HBM layout and
 // LDS staging; a k-step is one tap x 32 channels of the staged 64-channel chunk (18 per chunk):
 // 72 MFMAs, 8 weight + 12 activation fragment loads, one register set each, two channel halves.
+#ifndef WIDE_ZROW0
+#define WIDE_ZROW0 1
+#endif
 #ifndef WIDE_STAGE_GROUP
 #define WIDE_STAGE_GROUP 6
 #endif
@@ -1093,8 +1098,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     const int zero_off = 2 * BUFB;
 #elif defined(AZX_WIDE_DMA)
     const int zero_off = ((ncells * ROWB + 4095) / 4096) * 4096;
+#elif WIDE_ZROW0
+    const int zero_off = 0;                              // the all-zero row comes first: a padding tap is LDS offset 0
 #else
     const int zero_off = ncells * ROWB;
+#endif
+#if WIDE_ZROW0 && !defined(AZX_WIDE_DB) && !defined(AZX_WIDE_DMA)
+    constexpr int IMG0 = ROWB;                           // the staged image starts behind the zero row
+#else
+    constexpr int IMG0 = 0;
 #endif
 
     unsigned long long tapok = 0ull;                     // bit tap*6 + m (54 bits)
@@ -1103,7 +1115,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     for (int m = 0; m < MT; ++m) {
         const int r = row0 + 16 * m + li;
         const int ry = r / N, rx = r - ry * N;
-        rbase[m] = r * ROWB + 16 * lh;
+        rbase[m] = IMG0 + r * ROWB + 16 * lh;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int yy = ry + tap / 3 - 1, xx = rx + tap % 3 - 1;
@@ -1119,7 +1131,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
         const int delta = ((tap / 3 - 1) * N + (tap % 3 - 1)) * ROWB;
         const uint32_t word = tap < 5 ? tapok_lo : tapok_hi;
         const int bit = (tap < 5 ? tap : tap - 5) * 6 + m;
+#if WIDE_ZROW0 && !defined(AZX_WIDE_DB) && !defined(AZX_WIDE_DMA)
+        const int mask = (int)(word << (31 - bit)) >> 31;                    // v_bfe_i32: 0 or -1
+        return mask & (rbase[m] + delta);
+#else
         return ((word >> bit) & 1u) ? rbase[m] + delta : zbase;
+#endif
     };
     if (tid < ROWB / 4) reinterpret_cast<uint32_t *>(smem + zero_off)[tid] = 0u;
 
@@ -1175,7 +1192,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     }
 
     const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.Wh16);
-    const int nt0 = co_base / 16 + 4 * wn;               // this wave's first 16-channel tile
+    // this wave's first 16-channel tile: uniform over the wave, so as a scalar the 64-bit part of the weight-fragment
+    // addresses is formed on the scalar unit (per lane it was a v_mad_i64_i32 + two 64-bit shifts/adds per load)
+    const int nt0 = __builtin_amdgcn_readfirstlane(co_base / 16 + 4 * wn);
     // weights of k-step q (global index over layer, tap, chunk, half): [q][ntile][part][lane]
     auto wptr = [&](int q, int n, int part) -> const uint4 * {
         return wsrc + ((size_t)q * (NT16 * 2) + (size_t)((nt0 + n) * 2 + part)) * 64 + lane;
@@ -1314,7 +1333,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
                 for (int j = 0; j < GRP; ++j) {
                     const int idx = min(tid_o + 256 * (j0 + j), last);
                     const int row = idx >> 4, piece = idx & 15;
-                    const int dst = row * ROWB + (piece < 8 ? piece * 16 : 128 + (piece - 8) * 16);
+                    const int dst = IMG0 + row * ROWB + (piece < 8 ? piece * 16 : 128 + (piece - 8) * 16);
                     if (j0 + j < NST) *reinterpret_cast<uint4 *>(smem + dst) = stg[j];
                 }
             }
