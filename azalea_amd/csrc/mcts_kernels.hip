@@ -1805,10 +1805,14 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_play(DevEngine E, int num_
         // scalar registers) from the kernel-argument segment again, through a pointer the compiler cannot see
         // through: loaded at kernel entry they stay live -- spilled to VGPR lanes and reloaded -- across the
         // whole search.
+#ifdef AZX_PLAY_EARLY_ARGS     // diagnostic build (A/B): every engine field loaded at kernel entry, as before round 3
+        const DevEngine *Ec = &E;
+#else
         uint32_t koff = 0;
         asm volatile("" : "+s"(koff));
         const DevEngine *Ec = (const DevEngine *)((const __attribute__((address_space(4))) char *)
                                                   __builtin_amdgcn_kernarg_segment_ptr() + koff);
+#endif
         choose_body<SLOTS>(*Ec);
         wave_mem_sync();
         advance_body<SLOTS>(*Ec, nullptr, 1);

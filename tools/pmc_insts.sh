@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmci_$1
 mkdir -p $OUT
 export AZX_MCTS_GENERIC=${3:-0}
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_VALU_TRANS_F32 --output-format csv -d $OUT/sq1 -- python3 $R/tools/lib_bench.py $2 --steps 12 --warmup 3 --no-cpu-baseline > $OUT/sq1.json 2> $OUT/sq1.err
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_VALU_TRANS_F32 --output-format csv -d $OUT/sq1 -- python3 $R/tools/lib_bench.py $2 --workload tree --steps 12 --warmup 3 --no-cpu-baseline > $OUT/sq1.json 2> $OUT/sq1.err
 python3 - $OUT $1 <<'PY'
 import csv, glob, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
