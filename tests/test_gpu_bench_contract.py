@@ -41,7 +41,8 @@ def test_default_line_is_the_selfplay_headline_with_the_tree_numbers_nested():
     assert a["moves_since_transplant"] >= 70 and a["rows"] > 0 and d["rows_per_sec"] == a["rows_per_sec"] > 0
     assert 0.5 < a["rows_over_plies"] < 1.5 and 0 <= a["host_overhead_frac"] < 1
     assert {"search_root_visits", "search_root_children", "search_tree_nodes", "games"} <= set(a["metric_keys"])
-    assert d["world"] == {"ranks": 1, "backend": None, "games_per_rank": 64}
+    w = d["world"]
+    assert (w["ranks"], w["backend"], w["games_per_rank"]) == (1, None, 64) and w["rows_per_rank"] == d["replay_allgather"]["rows_per_rank"]
     assert "k_mcts<2" in d["kernels"] and "k_heads" in d["kernels"] and "AZX_MCTS_GENERIC=0" in d["kernels"]
     assert d["config"]["workload"].startswith("resnet self-play") and "de-synchronised" in d["config"]["start"]
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["unit"] == "TFLOP/s"
