@@ -57,6 +57,9 @@ struct NetDev {
     const float *fc2T, *fc2b;   // [2*ncells][64], [64]
     const float *fc3w, *fc3b;   // [64], [1]
     const float *mfcT, *mfcb;   // [4*ncells][AZX_CELL_STRIDE], [AZX_CELL_STRIDE]
+    // the two FC weight matrices as fp32-MFMA B operands (k_heads_mfma): [n tile][k group of 8][64 lanes][4]
+    const float *hmP, *hmV;
+    int hm_lda;                 // LDS row stride (floats) of k_heads_mfma's feature tile
 };
 
 // ============================================================================================
@@ -1123,6 +1126,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
         }
     }
     const int zbase = zero_off + 16 * lh;
+    (void)zbase;
     // The 54 (tap, tile) fragment offsets are invariant over the chunks; hoisted out of the chunk loop they hold
     // 54 VGPRs and the kernel spills.  The mask words and row bases pass through an opaque asm at the top of
     // every chunk, so an offset is formed where it is used and lives for its two k-steps only.
@@ -1605,6 +1609,206 @@ __global__ void k_conv_generic(NetDev P, int layer, const float *in, const float
 // masked softmax over the legal (= empty) cells, written by ORIGINAL cell index.
 // One 192-thread block per board.
 // ============================================================================================
+// ============================================================================================
+// k_heads_mfma: the heads' fully connected layers as fp32 MFMA GEMMs over a tile of boards.
+// value_fc2 (2 n^2 -> 64) and move_fc (4 n^2 -> n^2) (network.py:79, :146) are 148 kFLOP per board -- 6 GFLOP per
+// leaf batch of 40 960 -- which k_heads runs as scalar FMA chains (0.23 ms per batch, 2.9 % of a configs[2]
+// move).  Here a 256-thread block takes 32 boards: their six head planes (from the fused tower, `hfeat`) are
+// staged in LDS as the A operand ([board][k], row stride = 4 mod 64 floats: conflict-free ds_read_b128), the
+// weights come from L2 pre-packed in B-fragment order, wave w owns output tile w of move_fc (v_mfma_f32_32x32x2_f32,
+// exact fp32 products) and a quarter of value_fc2 (tile w & 1, half w >> 1 of its inputs; the halves are added
+// through LDS).  A row of the product depends on its own board only, so a board's outputs do not depend on what
+// else is in the tile.  Then value_fc3 + tanh and the masked softmax exactly as in k_heads.
+// ============================================================================================
+#define HM_MB 32
+__global__ __launch_bounds__(256) void k_heads_mfma(NetDev P, const float *__restrict__ hfeat,
+                                                    const uint8_t *__restrict__ ev_board,
+                                                    const int32_t *__restrict__ ev_flip,
+                                                    const int32_t *__restrict__ n_eval_ptr, int n_eval_host,
+                                                    float *__restrict__ logit_out, float *__restrict__ value_out,
+                                                    float *__restrict__ prior_out) {
+    extern __shared__ __align__(16) float hsm[];
+    const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
+    const int e0 = blockIdx.x * HM_MB;
+    if (e0 >= n_eval) return;
+    const int nb = min(HM_MB, n_eval - e0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int N = P.N, ncells = P.ncells, LDA = P.hm_lda;
+    const int KV = 2 * ncells, KP = 4 * ncells, KVp = (KV + 7) & ~7, KPp = (KP + 7) & ~7;
+    const int QV = KVp / 8, QP = KPp / 8, nf = 6 * ncells;
+    float *A = hsm;                                   // [32][LDA]: value inputs at 0, policy inputs at KVp
+    // what the softmax at the end needs from HBM -- the boards' empties and flip flags of this wave's eight
+    // boards -- is requested now: at one block per CU nothing else would hide those round trips later
+    uint8_t cellv[HM_MB / 4][2];
+    int flipv[HM_MB / 4];
+#pragma unroll
+    for (int bi = 0; bi < HM_MB / 4; ++bi) {
+        const int b = wave + 4 * bi, e = e0 + (b < nb ? b : 0);
+        cellv[bi][0] = ev_board[(size_t)e * AZX_CELL_STRIDE + lane];
+        cellv[bi][1] = ev_board[(size_t)e * AZX_CELL_STRIDE + 64 + lane];
+        flipv[bi] = ev_flip[e];
+    }
+    // ---- stage the tile: the 32 boards' 6 n^2 floats are one contiguous run of float2 (a board is 3 n^2 of them: 8-byte
+    // aligned whatever n); twenty-four loads in flight per thread before the first LDS write (as a load-store loop the
+    // kernel spent most of its time in ~100 dependent HBM round trips per wave).  Padding columns and missing
+    // boards are zero.
+    {
+        const int nf2 = 3 * ncells, total = nb * nf2;
+        const float2 *src = reinterpret_cast<const float2 *>(hfeat + (size_t)e0 * nf);
+        constexpr int INFL = 24;
+        for (int f0 = 0; f0 < total; f0 += 256 * INFL) {
+            float2 v[INFL];
+#pragma unroll
+            for (int j = 0; j < INFL; ++j) {
+                const int f = f0 + tid + 256 * j;
+                v[j] = src[f < total ? f : total - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < INFL; ++j) {
+                const int f = f0 + tid + 256 * j;
+                if (f < total) {
+                    const int b = f / nf2, i = 2 * (f - b * nf2);
+                    *reinterpret_cast<float2 *>(A + (size_t)b * LDA + (i < KV ? i : KVp + (i - KV))) = v[j];
+                }
+            }
+        }
+        for (int b = wave; b < HM_MB; b += 4) {
+            float *row = A + (size_t)b * LDA;
+            if (b < nb) {
+                if (lane < KVp - KV) row[KV + lane] = 0.0f;
+                if (lane < KPp - KP) row[KVp + KP + lane] = 0.0f;
+            } else {
+                for (int i = lane; i < KVp + KPp; i += 64) row[i] = 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- move_fc: output tile = wave (32 logits), K = 4 n^2 --------------------------------------------------
+    const int NTP = (ncells + 31) / 32;               // <= 4 (n <= 11)
+    f32x16 accp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[r] = 0.0f;
+    if (wave < NTP) {
+        const float4 *wp = reinterpret_cast<const float4 *>(P.hmP) + (size_t)wave * QP * 64 + lane;
+        const float *ap = A + (size_t)li * LDA + KVp + 4 * lh;
+        // weight fragments eight groups ahead (one wave per SIMD: nothing else hides an L2 round trip)
+        constexpr int AH = 8;
+        float4 bq[AH];
+#pragma unroll
+        for (int u = 0; u < AH; ++u) bq[u] = wp[(size_t)min(u, QP - 1) * 64];
+        for (int q0 = 0; q0 < QP; q0 += AH) {
+#pragma unroll
+            for (int u = 0; u < AH; ++u) {
+                const int q = q0 + u;
+                const float4 b4 = bq[u];
+                bq[u] = wp[(size_t)min(q + AH, QP - 1) * 64];
+                if (q < QP) {
+                    const float4 a4 = *reinterpret_cast<const float4 *>(ap + 8 * q);
+                    accp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, accp, 0, 0, 0);
+                    accp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, accp, 0, 0, 0);
+                    accp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, accp, 0, 0, 0);
+                    accp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, accp, 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- value_fc2: output tile = wave & 1 (32 of the 64 units), input half = wave >> 1 ----------------------
+    f32x16 accv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accv[r] = 0.0f;
+    {
+        const int vt = wave & 1, half = wave >> 1;
+        const int q0 = half ? QV / 2 : 0, q1 = half ? QV : QV / 2;
+        const float4 *wv = reinterpret_cast<const float4 *>(P.hmV) + (size_t)vt * QV * 64 + lane;
+        const float *ap = A + (size_t)li * LDA + 4 * lh;
+        constexpr int AH = 8;
+        float4 bq[AH];
+#pragma unroll
+        for (int u = 0; u < AH; ++u) bq[u] = wv[(size_t)min(q0 + u, q1 - 1) * 64];
+        for (int qb = q0; qb < q1; qb += AH) {
+#pragma unroll
+            for (int u = 0; u < AH; ++u) {
+                const int q = qb + u;
+                const float4 b4 = bq[u];
+                bq[u] = wv[(size_t)min(q + AH, q1 - 1) * 64];
+                if (q < q1) {
+                    const float4 a4 = *reinterpret_cast<const float4 *>(ap + 8 * q);
+                    accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, accv, 0, 0, 0);
+                    accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, accv, 0, 0, 0);
+                    accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, accv, 0, 0, 0);
+                    accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, accv, 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();                                  // every wave is done reading the feature tile: its memory is reused
+    float (*lg)[AZX_CELL_STRIDE] = reinterpret_cast<float (*)[AZX_CELL_STRIDE]>(hsm);            // [32][192] logits
+    float (*pv)[HM_MB][64] = reinterpret_cast<float (*)[HM_MB][64]>(hsm + HM_MB * AZX_CELL_STRIDE);   // [2 halves][32][64]
+    // C/D layout of 32x32x2: col = lane & 31 (output unit), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (board)
+    if (wave < NTP) {
+        const int j = 32 * wave + li;
+        if (j < ncells) {
+            const float bias = P.mfcb[j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float logit = accp[r] + bias;
+                lg[b][j] = logit;
+                if (b < nb) logit_out[(size_t)(e0 + b) * AZX_CELL_STRIDE + j] = logit;
+            }
+        }
+    }
+    {
+        const int j = 32 * (wave & 1) + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pv[wave >> 1][(r & 3) + 8 * (r >> 2) + 4 * lh][j] = accv[r];
+    }
+    __syncthreads();
+    if (tid < nb) {                                   // + bias, ReLU, value_fc3 + tanh (network.py:79-81)
+        float acc = 0.f;
+        for (int i = 0; i < 64; ++i) acc += fmaxf(pv[0][tid][i] + pv[1][tid][i] + P.fc2b[i], 0.f) * P.fc3w[i];
+        value_out[e0 + tid] = tanhf(acc + P.fc3b[0]);
+    }
+    if (!prior_out) return;
+    // masked softmax over the legal cells of the network-frame board (network.py:147-151), prior =
+    // exp(log_softmax) (mcts.py:210): one wavefront per board, cells lane, lane + 64 (n <= 11)
+#pragma unroll
+    for (int bi = 0; bi < HM_MB / 4; ++bi) {
+        const int b = wave + 4 * bi;
+        if (b >= nb) break;
+        const int e = e0 + b;
+        float x[2];
+        bool legal[2];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int cell = s2 * 64 + lane;
+            legal[s2] = cell < ncells && cellv[bi][s2] == 0;
+            x[s2] = legal[s2] ? lg[b][cell] : -INFINITY;
+            mx = fmaxf(mx, x[s2]);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) sum += legal[s2] ? expf(x[s2] - mx) : 0.f;
+        const float lse = mx + logf(wave_sum(sum));
+        const int flip = flipv[bi];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int cell = s2 * 64 + lane;
+            if (cell < ncells) {
+                int oc = cell;
+                if (flip) {                            // back to the mover's frame (hex.py:107-111)
+                    const int i = cell / N, j = cell - i * N;
+                    oc = (N - 1 - j) * N + (N - 1 - i);
+                }
+                prior_out[(size_t)e * AZX_CELL_STRIDE + oc] = legal[s2] ? expf(x[s2] - lse) : 0.f;
+            }
+        }
+    }
+}
+
 #ifndef HEADS_BPB
 #define HEADS_BPB 8
 #endif
@@ -1832,6 +2036,7 @@ struct AzxNet {
     bool opt_split_m = true;    // AZX_TOWER_SPLIT=0: the 6x64 tower without the fused head convs / position split
     int opt_shape = 16;         // AZX_TOWER_SHAPE=32: the 32x32x16 MFMA kernels
     int opt_wsplit = 2;         // AZX_WIDE_STREAMS: streams the wide tower's layer launches are spread over
+    bool opt_heads_mfma = true; // AZX_HEADS=valu: the scalar-FMA k_heads behind the fused tower too
     std::string info;
 };
 
@@ -1869,6 +2074,7 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     { const char *v = getenv("AZX_TOWER_SPLIT"); net->opt_split_m = v ? atoi(v) != 0 : true; }
     { const char *v = getenv("AZX_TOWER_SHAPE"); net->opt_shape = v ? atoi(v) : 16; }
     { const char *v = getenv("AZX_WIDE_STREAMS"); net->opt_wsplit = std::min(4, std::max(1, v ? atoi(v) : 2)); }
+    { const char *v = getenv("AZX_HEADS"); net->opt_heads_mfma = !(v && !strcmp(v, "valu")); }
     {
         char b[200];
         const char *tower = "k_stem_generic + k_conv_generic (VALU)";
@@ -1878,8 +2084,10 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
         else if (net->tower_variant == 1) tower = "k_tower_mfma<64,4,2,1,2> (fp32 MFMA)";
         else if (net->tower_variant == 2) tower = "k_tower_mfma<64,6,1,2,2> (fp32 MFMA)";
         else if (net->tower_variant == 3) tower = "k_tower_mfma<32,6,2,2,1> (fp32 MFMA)";
-        snprintf(b, sizeof b, "%s + k_heads (%dx%d on %dx%d; AZX_TOWER=%s AZX_TOWER_SHAPE=%d AZX_TOWER_SPLIT=%d AZX_WIDE_STREAMS=%d)",
-                 tower, blocks, chans, N, N, want_fp32 ? "fp32" : "default", net->opt_shape, (int)net->opt_split_m, net->opt_wsplit);
+        const bool hm = net->tower_variant == 4 && net->opt_split_m && net->opt_heads_mfma && ncells <= 128;
+        snprintf(b, sizeof b, "%s + %s (%dx%d on %dx%d; AZX_TOWER=%s AZX_TOWER_SHAPE=%d AZX_TOWER_SPLIT=%d AZX_WIDE_STREAMS=%d AZX_HEADS=%s)",
+                 tower, hm ? "k_heads_mfma" : "k_heads", blocks, chans, N, N, want_fp32 ? "fp32" : "default", net->opt_shape,
+                 (int)net->opt_split_m, net->opt_wsplit, net->opt_heads_mfma ? "mfma" : "valu");
         net->info = b;
     }
     const size_t E = max_evals;
@@ -2200,6 +2408,24 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
         for (int i = 0; i < 4 * n2; ++i) mfcT[(size_t)i * AZX_CELL_STRIDE + t] = (*mfw)[(size_t)t * 4 * n2 + i];
         mfcb[t] = (*mfb)[t];
     }
+    // k_heads_mfma's B operands: [n tile][k group q][lane][s] = W[k = 8 q + 4 (lane >> 5) + s][unit 32 tile + (lane & 31)]
+    const int KVp = (2 * n2 + 7) & ~7, KPp = (4 * n2 + 7) & ~7, NTP = (n2 + 31) / 32;
+    std::vector<float> hmP((size_t)NTP * (KPp / 8) * 64 * 4, 0.f), hmV((size_t)2 * (KVp / 8) * 64 * 4, 0.f);
+    for (int t = 0; t < NTP; ++t)
+        for (int q = 0; q < KPp / 8; ++q)
+            for (int l = 0; l < 64; ++l)
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int k = 8 * q + 4 * (l >> 5) + sidx, unit = 32 * t + (l & 31);
+                    if (k < 4 * n2 && unit < n2)
+                        hmP[(((size_t)t * (KPp / 8) + q) * 64 + l) * 4 + sidx] = (*mfw)[(size_t)unit * 4 * n2 + k];
+                }
+    for (int t = 0; t < 2; ++t)
+        for (int q = 0; q < KVp / 8; ++q)
+            for (int l = 0; l < 64; ++l)
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int k = 8 * q + 4 * (l >> 5) + sidx, unit = 32 * t + (l & 31);
+                    if (k < 2 * n2) hmV[(((size_t)t * (KVp / 8) + q) * 64 + l) * 4 + sidx] = (*fc2w)[(size_t)unit * 2 * n2 + k];
+                }
 #undef NEED
     (void)hipStreamSynchronize(net->stream);
     // the previous weight set is no longer referenced by any queued kernel: release it (the
@@ -2238,8 +2464,10 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
     d.fc2T = upload(net, fc2T); d.fc2b = upload(net, *fc2b);
     d.fc3w = upload(net, *fc3w); d.fc3b = upload(net, *fc3b);
     d.mfcT = upload(net, mfcT); d.mfcb = upload(net, mfcb);
+    d.hmP = upload(net, hmP); d.hmV = upload(net, hmV);
+    d.hm_lda = ((KVp + KPp - 4 + 63) / 64) * 64 + 4;        // smallest stride = 4 (mod 64) that holds a row
     if (!d.stemT || !d.stem_b || !d.Wg || !d.bias || !d.wv || !d.bv || !d.wp || !d.bp || !d.fc2T ||
-        !d.fc2b || !d.fc3w || !d.fc3b || !d.mfcT || !d.mfcb || (net->use_mfma && net->tower_variant < 4 && !d.Wp))
+        !d.fc2b || !d.fc3w || !d.fc3b || !d.mfcT || !d.mfcb || !d.hmP || !d.hmV || (net->use_mfma && net->tower_variant < 4 && !d.Wp))
         return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
     (void)hipDeviceSynchronize();
     net->ready = true;
@@ -2358,7 +2586,13 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
         if (x != net->act)   // heads read net->act
             (void)hipMemcpyAsync(net->act, x, (size_t)max_n * d.ncells * d.C * sizeof(float), hipMemcpyDeviceToDevice, st);
     }
-    {
+    if (hfeat != nullptr && net->opt_heads_mfma && d.ncells <= 128) {
+        // the fused tower left the six head planes: the FC layers run as fp32 MFMA GEMMs over tiles of 32 boards
+        const size_t hl = std::max((size_t)HM_MB * d.hm_lda, (size_t)HM_MB * AZX_CELL_STRIDE + (size_t)2 * HM_MB * 64) * sizeof(float);
+        static size_t hm_set = 0;
+        if (hl > hm_set) { (void)hipFuncSetAttribute((const void *)k_heads_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl); hm_set = hl; }
+        hipLaunchKernelGGL(k_heads_mfma, dim3((max_n + HM_MB - 1) / HM_MB), dim3(256), hl, st, d, hfeat, boards, flip, n_eval_ptr, n_host, logit, value, prior);
+    } else {
         const size_t hl = ((size_t)(6 * d.ncells + 64) * HEADS_BPB + (size_t)HEADS_BPB * AZX_CELL_STRIDE +
                            (size_t)(HEADS_KSPLIT - 1) * (64 + 192) * HEADS_BPB) * sizeof(float);
         static size_t hl_set = 0;

@@ -293,13 +293,45 @@ def test_forward_config5_shape_13x13_256ch_vs_oracle(eng, orc):
 
 
 def test_tower_variants_selected_by_environment():
-    """The alternative tower kernels (32x32x16 MFMA shape, unsplit wave tiling, exact-fp32 MFMA) are
-    chosen by environment variables read once per process: run the golden forward tests under each."""
+    """The alternative tower kernels (32x32x16 MFMA shape, unsplit wave tiling, exact-fp32 MFMA) and the scalar-FMA
+    heads kernel are chosen by environment variables read once per engine: run the golden forward tests under each."""
     import subprocess
     import sys
     here = os.path.abspath(__file__)
-    for env in ({"AZX_TOWER_SHAPE": "32"}, {"AZX_TOWER_SPLIT": "0"}, {"AZX_TOWER": "fp32"}):
+    for env in ({"AZX_TOWER_SHAPE": "32"}, {"AZX_TOWER_SPLIT": "0"}, {"AZX_TOWER": "fp32"}, {"AZX_HEADS": "valu"}):
         r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-k", "g3_forward or shipped_checkpoint"],
                            env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (env, r.stdout[-2000:], r.stderr[-2000:])
 
+
+
+def test_heads_mfma_matches_the_scalar_heads_and_does_not_depend_on_the_batch(eng, orc):
+    """k_heads_mfma (FC layers as fp32 MFMA GEMMs over tiles of 32 boards) against the scalar-FMA k_heads on the
+    same tower output: value and legal log-probabilities within 2e-6; a board's outputs are bit-identical
+    whatever else is in its tile (alone, first, last, in a ragged tail tile), which the global-game-index and
+    tournament tests rely on."""
+    z = np.load(os.path.join(GOLDEN, "g3_forward_11_6x64.npz"))
+    state = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
+    rng = np.random.RandomState(3)
+    boards, lm = _random_positions(orc, 11, 70, rng)
+    outs = {}
+    for heads in ("mfma", "valu"):
+        os.environ["AZX_HEADS"] = heads
+        try:
+            E = eng.Engine(board_size=11, n_games=8, simulations=10, search_batch_size=10,
+                           evaluator=eng.EVAL_RESNET, num_blocks=6, base_chans=64)
+        finally:
+            os.environ.pop("AZX_HEADS", None)
+        assert ("k_heads_mfma" in E.kernel_info()) == (heads == "mfma")
+        E.set_weights(state)
+        outs[heads] = E.forward(boards, lm)
+        if heads == "mfma":
+            solo = [E.forward(boards[i:i + 1], lm[i:i + 1]) for i in (0, 31, 32, 69)]
+            rev = E.forward(boards[::-1].copy(), lm[::-1].copy())
+        E.close()
+    legal = lm > 0
+    v, lp = outs["mfma"]
+    assert np.abs(v - outs["valu"][0]).max() <= 2e-6 and np.abs(lp - outs["valu"][1])[legal].max() <= 2e-6
+    for (sv, slp), i in zip(solo, (0, 31, 32, 69)):
+        assert np.array_equal(sv[0], v[i]) and np.array_equal(slp[0][legal[i]], lp[i][legal[i]]), i
+    assert np.array_equal(rev[0][::-1], v) and np.array_equal(rev[1][::-1][legal], lp[legal])
