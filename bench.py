@@ -576,10 +576,17 @@ def main():
     # ---- nested configs[4]-shape leg: 13x13, 19x256, 810 selects, one warm-up + one timed move --------------
     if args.workload == "selfplay" and not args.no_config5 and (args.board, args.blocks, args.chans) == (11, 6, 64):
         a5 = config5_args(args)
-        st5, el5, ex5 = run_workload("resnet", a5, rank, world, local_rank, 1, 1, sync, torch)
-        el5, sums5 = reduce_over_ranks(dist, torch, el5, [float(st5[k]) for k in SUM_KEYS])
-        ex5["engine"].close()
-        if rank == 0:
+        try:
+            st5, el5, ex5 = run_workload("resnet", a5, rank, world, local_rank, 1, 1, sync, torch)
+        except Exception as exc:      # a nested leg must not take the headline down (one process: no peer is left waiting)
+            if world > 1:
+                raise
+            st5 = None
+            line["config5"] = {"error": repr(exc)}
+        if st5 is not None:
+            el5, sums5 = reduce_over_ranks(dist, torch, el5, [float(st5[k]) for k in SUM_KEYS])
+            ex5["engine"].close()
+        if rank == 0 and st5 is not None:
             c5 = {"metric": "mcts_sims_per_sec", "steps": 1, "warmup": 1,
                   "dtype": "f16x3 (fp32 operands split hi+lo f16, fp32 accumulate)"}
             c5.update(throughput_fields(sums5, el5, 1))
@@ -601,10 +608,12 @@ def main():
 
     # ---- nested product-surface leg: Player.read for a whole game length -----------------------------------
     if args.workload == "selfplay" and args.api_moves > 0 and world == 1:
-        api = run_api(args, rank, world, local_rank, ex.get("start"), torch)
-        if rank == 0:
+        try:
+            api = run_api(args, rank, world, local_rank, ex.get("start"), torch)
             line["api"] = api
             line["rows_per_sec"] = api["rows_per_sec"]
+        except Exception as exc:
+            line["api"] = {"error": repr(exc)}
 
     if rank == 0:
         print(json.dumps(line))
