@@ -248,7 +248,6 @@ def run_api(args, rank, world, local_rank, start, torch):
     player.prepare_device_engine(E)
     if start is not None:
         E.reset(moves=start)
-    log = []                 # (wall at the end of the call, plies played so far, device seconds so far)
     tot = {"plies": 0, "dev": 0.0}
     real_play = E.play
 
