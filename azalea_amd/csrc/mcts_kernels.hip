@@ -415,7 +415,7 @@ __device__ __forceinline__ void compact_tree(const DevEngine &E, int g, TreeHdr 
 #define AZX_MCTS_ATTR
 #endif
 template <int SLOTS, bool FAST>
-__device__ __forceinline__ void mcts_body(const DevEngine &E, int mode_arg, int num_batches) {
+__device__ __forceinline__ void mcts_body(const DevEngine &E, int mode_arg, int num_batches, bool stage_tables = true) {
     const int mode = FAST ? (MODE_BEGIN | MODE_INLINE) : mode_arg;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int lane = threadIdx.x;
@@ -464,7 +464,8 @@ __device__ __forceinline__ void mcts_body(const DevEngine &E, int mode_arg, int 
     const float keep32 = (float)(1.0 - E.noise_scale);   // python float -> f32 (weak scalar)
     const Philox ph = game_rng(E, gh->uid);
     // the device sampler's table goes to LDS (two dependent lookups per cell and select)
-    if (E.noise_scale != 0.0 && (FAST || E.device_noise)) {
+    // (k_play stages it once per LAUNCH: the area is this table's alone, nothing between two moves writes it)
+    if (stage_tables && E.noise_scale != 0.0 && (FAST || E.device_noise)) {
         for (int i = lane; i < AZX_GAMMA_TAB + 1; i += 64) L.gtab[i] = E.gamma_tab[i];
         lds_sync();
     }
@@ -1799,7 +1800,7 @@ __global__ __launch_bounds__(64) void k_choose(DevEngine E) {
 template <int SLOTS>
 __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_play(DevEngine E, int num_batches, int steps) {
     for (int s = 0; s < steps; ++s) {
-        mcts_body<SLOTS, true>(E, MODE_BEGIN | MODE_INLINE, num_batches);
+        mcts_body<SLOTS, true>(E, MODE_BEGIN | MODE_INLINE, num_batches, s == 0);
         wave_mem_sync();
         // The move draw and the game step read their engine fields (queue, row and statistics pointers: ~50
         // scalar registers) from the kernel-argument segment again, through a pointer the compiler cannot see
