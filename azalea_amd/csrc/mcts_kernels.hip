@@ -1799,8 +1799,14 @@ __global__ __launch_bounds__(64) void k_choose(DevEngine E) {
 // and the harvest copies and arena compactions of some games overlap the searches of the others.
 template <int SLOTS>
 __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_play(DevEngine E, int num_batches, int steps) {
+#ifdef AZX_STAMP_PLAY     // diagnostic build: per-wave cycles in the search, the move draw and the game step (slots 10-12)
+    unsigned long long tp_[3] = {0, 0, 0};
+#define TP(i, stmt) { const unsigned long long a_ = __builtin_amdgcn_s_memtime(); stmt; tp_[i] += __builtin_amdgcn_s_memtime() - a_; }
+#else
+#define TP(i, stmt) stmt;
+#endif
     for (int s = 0; s < steps; ++s) {
-        mcts_body<SLOTS, true>(E, MODE_BEGIN | MODE_INLINE, num_batches, s == 0);
+        TP(0, (mcts_body<SLOTS, true>(E, MODE_BEGIN | MODE_INLINE, num_batches, s == 0)))
         wave_mem_sync();
         // The move draw and the game step read their engine fields (queue, row and statistics pointers: ~50
         // scalar registers) from the kernel-argument segment again, through a pointer the compiler cannot see
@@ -1814,11 +1820,16 @@ __global__ __launch_bounds__(64) AZX_MCTS_ATTR void k_play(DevEngine E, int num_
         const DevEngine *Ec = (const DevEngine *)((const __attribute__((address_space(4))) char *)
                                                   __builtin_amdgcn_kernarg_segment_ptr() + koff);
 #endif
-        choose_body<SLOTS>(*Ec);
+        TP(1, choose_body<SLOTS>(*Ec))
         wave_mem_sync();
-        advance_body<SLOTS>(*Ec, nullptr, 1);
+        TP(2, advance_body<SLOTS>(*Ec, nullptr, 1))
         wave_mem_sync();
     }
+#ifdef AZX_STAMP_PLAY
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 3; ++i) E.counters[(size_t)blockIdx.x * CTR_COUNT + 10 + i] += tp_[i];
+#endif
+#undef TP
 }
 
 template <int SLOTS>
