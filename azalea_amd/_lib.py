@@ -128,6 +128,16 @@ def lib():
                 "azalea_amd/libazx_hip.so is missing: build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C azalea_amd/csrc`. "
                 "The engine is HIP-only; there is no CPU fallback.")
+        # PyTorch-ROCm ships its own HIP / HSA runtime.  If this library (linked against /opt/rocm's) brings the GPU up
+        # first, a later first use of torch.cuda in the same process fails with "No HIP GPUs are available" -- and
+        # every Policy holds its weights in torch tensors.  So where torch is installed and sees a GPU, its runtime is
+        # initialised before ours is loaded; the order then no longer depends on what the caller touched first.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:      # no torch / no GPU: the engine itself reports AZX_ENODEV where it matters
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)   # AttributeError if the library lacks a declared symbol

@@ -576,3 +576,21 @@ def test_throughput_and_parity_mode_report_the_same_metric_keys(eng):
     # per-game means are of the same magnitude in both modes (same search settings, same network)
     for key in ("search_root_children", "search_root_visits", "search_tree_nodes", "search_root_width"):
         assert 0.3 * parity[key] < thru[key] / g < 3.0 * parity[key], (key, thru[key] / g, parity[key])
+
+
+def test_engine_first_then_torch_cuda_in_one_process():
+    """Loading the engine library and running a search BEFORE anything touched torch.cuda used to leave torch unable
+    to bring the GPU up afterwards ("No HIP GPUs are available": two HIP runtimes, ours first).  _lib.lib() now
+    initialises torch's runtime first; a fresh process that uses the engine and only then torch must work."""
+    import subprocess
+    import sys
+    code = ("import numpy as np\n"
+            "from azalea_amd import engine as e\n"
+            "E = e.Engine(board_size=5, n_games=2, simulations=10, evaluator=e.EVAL_UNIFORM)\n"
+            "E.search(); k = int(E.get_root()['k'][0]); E.close()\n"
+            "import torch\n"
+            "x = torch.arange(4, device='cuda', dtype=torch.float32)\n"
+            "print('OK', k, float(x.sum()))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK 25 6.0" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
