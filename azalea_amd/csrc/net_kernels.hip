@@ -1290,6 +1290,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
         {
         NT_MARK(chunk == 0 ? 0 : 2)
         __syncthreads();                                 // the previous chunk has been consumed
+        NT_MARK(4)                                       // (stamp builds: the wait at this barrier = the waves' skew)
         {
             // all of a thread's pieces are requested before the first one is written to LDS (as a plain
             // loop the compiler waited for each 16-byte load in turn: eleven memory round trips per
@@ -1342,6 +1343,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
                 }
             }
         }
+        NT_MARK(5)                                       // (stamp builds: requests, their round trips, LDS writes)
         __syncthreads();
         NT_MARK(1)
         }
@@ -2140,13 +2142,14 @@ void azx_net_destroy(AzxNet *net) {
     {
         unsigned long long h[10] = {0};
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wide_stamp), sizeof h) == hipSuccess && h[7]) {
-            static const char *nm[4] = {"prologue (bias + residual, setup)", "staging + barriers", "k-loops (MFMA)", "epilogue (stores acknowledged)"};
+            static const char *nm[6] = {"prologue (bias + residual, setup)", "barrier after staging", "k-loops (MFMA)", "epilogue (stores acknowledged)",
+                                        "barrier before staging (skew)", "staging: requests, round trips, LDS writes"};
             unsigned long long tot = 0;
-            for (int r = 0; r < 4; ++r) tot += h[r];
+            for (int r = 0; r < 6; ++r) tot += h[r];
             fprintf(stderr, "k_conv_wide_f16x3_s16 stamps over %llu waves: %.0f cycles/wave, shader clock %.0f MHz during the kernel\n",
                     h[7], (double)tot / h[7], h[8] ? 100.0 * (double)tot / (double)h[8] : 0.0);
-            for (int r = 0; r < 4; ++r)
-                fprintf(stderr, "  %-36s %6.1f%%  %9.0f cycles/wave\n", nm[r], 100.0 * h[r] / tot, (double)h[r] / h[7]);
+            for (int r = 0; r < 6; ++r)
+                fprintf(stderr, "  %-44s %6.1f%%  %9.0f cycles/wave\n", nm[r], 100.0 * h[r] / tot, (double)h[r] / h[7]);
             unsigned long long z[10] = {0};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wide_stamp), z, sizeof z);
         }
