@@ -46,6 +46,8 @@ struct NetDev {
     const float *stem_b;   // [C]
     const unsigned short *Ws;  // f16x3 pack of stemT as an MFMA A operand: [2 kk][2 ntile][hi,lo][64 lanes][8] f16 bits
     const unsigned short *Ws16, *Wh16;   // the same weights in 16x16x32 fragment order (k_tower_f16x3_s16)
+    const unsigned short *Whd16;         // the heads' six 1x1 conv filters as one 16-row A tile: [kstep 2][hi,lo][lane][8]
+    const float *hbias16;                // their folded-BN biases, padded to 16
     // tower (network.py:17-39, :50-52): BN folded into the conv weights
     const float *Wp;       // MFMA pack [layers][9][C/8][C/32][64][4]
     const unsigned short *Wh;  // f16x3 pack [layers*18 stages][2 kk][2 ntile][hi,lo][64 lanes][8] f16 bits
@@ -621,6 +623,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
     // the wave index is uniform over a wave: as a scalar, everything derived from it (channel / position base, the
     // 64-bit part of the weight-fragment addresses) is computed on the scalar unit instead of per lane
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    NT_DECL
     const int wb = wave >> 1, wh = wave & 1;             // board within the block, which half of its positions
     const int N = P.N, ncells = P.ncells;
     const int e = e0 + wb;
@@ -664,12 +667,19 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
     };
 
     f32x4 res[MT][NT];
-    auto epilogue = [&](f32x4 (&acc)[MT][NT], const float *bias, auto kind_tag) {
+    // the layer's folded-BN bias of this lane's 16 channels: requested BEFORE the barrier that ends the k-loop (the
+    // weight fragments' registers are free by then), so its L2 round trip passes while the wave waits for its
+    // partner instead of at the top of every epilogue
+    auto load_bias = [&](const float *bias, float4 (&b4)[NT]) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b4[n] = *reinterpret_cast<const float4 *>(bias + 16 * n + 4 * lh);
+    };
+    auto epilogue = [&](f32x4 (&acc)[MT][NT], const float4 (&bias4)[NT], auto kind_tag) {
         constexpr int kind = decltype(kind_tag)::value;  // 0 conv1, 1 conv2 (+ residual), 2 stem
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int cb = 16 * n + 4 * lh;
-            const float4 b4 = *reinterpret_cast<const float4 *>(bias + cb);
+            const float4 b4 = bias4[n];
             const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -742,13 +752,28 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
                 acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfl[n], xf, acc[m][n], 0, 0, 0);
             }
         }
+        float4 sb4[NT];
+        load_bias(P.stem_b, sb4);
         __syncthreads();   // every wave has read the staged cells: the tail rows are free again
-        epilogue(acc, P.stem_b, std::integral_constant<int, 2>{});
+        epilogue(acc, sb4, std::integral_constant<int, 2>{});
     }
     __syncthreads();
+    NT_MARK(0)
 
     const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.Wh16);     // 512 uint4 per stage: [ntile 4][hi,lo][lane]
     int stage = 0;
+    // The weight register set lives across layers: the fragments of a layer's FIRST k-step (channel tiles {0,1})
+    // are requested during the LAST k-step of the layer before -- they do not depend on the activations -- so their
+    // L2 round trip passes under the epilogue instead of in front of every layer's first MFMA.
+    const int last_stage = P.layers * 18 - 1;
+    f16x8 wh_[NT], wl_[NT];
+    auto load_w = [&](int st, int nn, int part) {
+        const uint4 qq = wsrc[(size_t)min(st, last_stage) * 512 + (nn * 2 + part) * 64 + lane];
+        if (part) wl_[nn] = *reinterpret_cast<const f16x8 *>(&qq);
+        else wh_[nn] = *reinterpret_cast<const f16x8 *>(&qq);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_w(0, i >> 1, i & 1);
     auto conv_layer = [&](int layer, auto residual_tag) {
         constexpr bool residual = decltype(residual_tag)::value;
         asm volatile("" : "+v"(tapok_lo), "+v"(tapok_hi), "+v"(rbase[0]), "+v"(rbase[1]), "+v"(rbase[2]), "+v"(rbase[3]));
@@ -763,20 +788,12 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
         // during the first half, weights {0,1} of the next step during the second; position tile
         // m's activations are refilled for the next step once its second-half MFMAs have issued
         // (the last tile's during the next step's first half).
-        f16x8 wh_[NT], wl_[NT];
         f16x8 xh[MT], xl[MT];
-        auto load_w = [&](int st, int nn, int part) {
-            const uint4 qq = wsrc[(size_t)st * 512 + (nn * 2 + part) * 64 + lane];
-            if (part) wl_[nn] = *reinterpret_cast<const f16x8 *>(&qq);
-            else wh_[nn] = *reinterpret_cast<const f16x8 *>(&qq);
-        };
         auto load_x = [&](int tt, int mm, int part) {
             const unsigned char *pa = smem + act_offset(tt >> 1, mm) + (tt & 1) * 64 + part * 128;
             if (part) xl[mm] = *reinterpret_cast<const f16x8 *>(pa);
             else xh[mm] = *reinterpret_cast<const f16x8 *>(pa);
         };
-#pragma unroll
-        for (int i = 0; i < 4; ++i) load_w(stage, i >> 1, i & 1);
 #pragma unroll
         for (int m = 0; m < MT - 1; ++m) { load_x(0, m, 0); load_x(0, m, 1); }
         // k-step t = 0..17: tap t/2, channels 32 (t%2) .. +31: 2 x 24 MFMAs, 16 loads
@@ -790,7 +807,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
                     if (q == 1 || q == 4 || q == 7 || q == 10) {
                         const int idx = (q - 1) / 3;                       // 0..3: tile, part
                         if (h == 0) load_w(stage + t, 2 + (idx >> 1), idx & 1);
-                        else if (t + 1 < 18) load_w(stage + t + 1, idx >> 1, idx & 1);
+                        else load_w(stage + t + 1, idx >> 1, idx & 1);      // t = 17: the next layer's first k-step
                     } else if (h == 0 && (q == 13 || q == 16)) {
                         load_x(t, MT - 1, q == 16);                        // the lagging last tile
                     } else if (h == 1 && q >= 8 && (q % 6 == 2 || q % 6 == 5)) {
@@ -812,39 +829,55 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
             }
         }
         stage += 18;
+        float4 lb4[NT];
+        load_bias(P.bias + layer * C, lb4);
+        NT_MARK(2)
         __syncthreads();   // both waves of the board finished reading it
-        epilogue(acc, P.bias + layer * C, std::integral_constant<int, residual ? 1 : 0>{});
+        NT_MARK(3)
+        epilogue(acc, lb4, std::integral_constant<int, residual ? 1 : 0>{});
+        NT_MARK(4)
         __syncthreads();   // the partner wave wrote the other rows of this board
+        NT_MARK(5)
     };
     for (int blk = 0; blk < P.blocks; ++blk) {
         conv_layer(2 * blk, std::false_type{});
         conv_layer(2 * blk + 1, std::true_type{});
     }
 
-    // heads' 1x1 convs + folded BN + ReLU (network.py:77, :83) from the registers, as in
-    // k_tower_f16x3: a cell's 64 channels sit in the four lanes li + 16 h
+    // heads' 1x1 convs + folded BN + ReLU (network.py:77, :83) as one more (tiny) MFMA layer: the last epilogue left
+    // the final activations in LDS as hi/lo f16 like every layer's; the six filters are one 16-row A tile (rows 6..15
+    // zero), the centre tap's fragments the B operand: 2 k-steps x 3 products per position tile, D[filter 4 lh +
+    // reg][position li].  (As fp32 FMAs over the registers with two cross-lane sums per output it was 3 % of the
+    // kernel: 48 LDS-crossbar shuffles per wave.)
     if (hfeat != nullptr) {
+        const uint4 *whd = reinterpret_cast<const uint4 *>(P.Whd16);
+        f16x8 ah[2], al[2];
 #pragma unroll
-        for (int o = 0; o < 6; ++o) {
-            const float *w = o < 2 ? P.wv + o * C : P.wp + (o - 2) * C;
-            float part[MT];
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 qh = whd[(ks * 2) * 64 + lane], ql = whd[(ks * 2 + 1) * 64 + lane];
+            ah[ks] = *reinterpret_cast<const f16x8 *>(&qh);
+            al[ks] = *reinterpret_cast<const f16x8 *>(&ql);
+        }
+        const float4 hb = *reinterpret_cast<const float4 *>(P.hbias16 + 4 * lh);
+        const float hbv[4] = {hb.x, hb.y, hb.z, hb.w};
 #pragma unroll
-            for (int m = 0; m < MT; ++m) part[m] = 0.0f;
+        for (int m = 0; m < MT; ++m) {
+            f32x4 hacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const float4 w4 = *reinterpret_cast<const float4 *>(w + 16 * n + 4 * lh);
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    part[m] += res[m][n][0] * w4.x + res[m][n][1] * w4.y + res[m][n][2] * w4.z + res[m][n][3] * w4.w;
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned char *pa = smem + rbase[m] + ks * 64;
+                const f16x8 xh = *reinterpret_cast<const f16x8 *>(pa), xl = *reinterpret_cast<const f16x8 *>(pa + 128);
+                hacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], xh, hacc, 0, 0, 0);
+                hacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], xh, hacc, 0, 0, 0);
+                hacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], xl, hacc, 0, 0, 0);
             }
-            const float b = o < 2 ? P.bv[o] : P.bp[o - 2];
+            const int row = 64 * wh + 16 * m + li;
+            if (live && row < ncells) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                float tot = part[m] + __shfl_xor(part[m], 16);
-                tot += __shfl_xor(tot, 32);
-                const int row = 64 * wh + 16 * m + li;
-                if (live && row < ncells && lh == (o & 3))
-                    hfeat[((size_t)e * 6 + o) * ncells + row] = fmaxf(tot + b, 0.0f);
+                for (int r = 0; r < 4; ++r) {
+                    const int o = 4 * lh + r;
+                    if (o < 6) hfeat[((size_t)e * 6 + o) * ncells + row] = fmaxf(hacc[r] + hbv[r], 0.0f);
+                }
             }
         }
     }
@@ -861,6 +894,8 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
             }
         }
     }
+    NT_MARK(6)
+    NT_FLUSH
 }
 
 // ============================================================================================
@@ -2410,6 +2445,29 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
         for (int c = 0; c < C; ++c) wp[(size_t)o * C + c] = (float)((double)(*wpc)[(size_t)o * C + c] * scp[o]);
         bp[o] = (float)shp[o];
     }
+    std::vector<unsigned short> Whd16;
+    std::vector<float> hbias16(16, 0.f);
+    if (net->tower_variant == 4 && C == 64) {
+        auto f16bits = [](float w, int part) -> unsigned short {
+            const _Float16 hi = (_Float16)w;
+            const _Float16 lo = (_Float16)(w - (float)hi);
+            const _Float16 v = part ? lo : hi;
+            unsigned short bits;
+            memcpy(&bits, &v, 2);
+            return bits;
+        };
+        Whd16.resize((size_t)2 * 2 * 64 * 8);
+        size_t oh = 0;
+        for (int ks = 0; ks < 2; ++ks)
+            for (int part = 0; part < 2; ++part)
+                for (int ln = 0; ln < 64; ++ln)
+                    for (int t = 0; t < 8; ++t) {
+                        const int o = ln & 15, ci = 32 * ks + 8 * (ln >> 4) + t;
+                        const float w = o < 2 ? wv[(size_t)o * C + ci] : o < 6 ? wp[(size_t)(o - 2) * C + ci] : 0.0f;
+                        Whd16[oh++] = f16bits(w, part);
+                    }
+        for (int o = 0; o < 6; ++o) hbias16[o] = o < 2 ? bv[o] : bp[o - 2];
+    }
     auto fc2w = get("value_fc2.weight", (size_t)64 * 2 * n2), fc2b = get("value_fc2.bias", 64);
     auto fc3w = get("value_fc3.weight", 64), fc3b = get("value_fc3.bias", 1);
     auto mfw = get("move_fc.weight", (size_t)n2 * 4 * n2), mfb = get("move_fc.bias", n2);
@@ -2470,6 +2528,16 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
         (void)hipMemcpy(b, Wh16.data(), Wh16.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
         d.Ws16 = a;
         d.Wh16 = b;
+    }
+    d.Whd16 = nullptr;
+    d.hbias16 = nullptr;
+    if (!Whd16.empty()) {
+        unsigned short *hw = nalloc<unsigned short>(net, Whd16.size());
+        if (!hw) return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
+        (void)hipMemcpy(hw, Whd16.data(), Whd16.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+        d.Whd16 = hw;
+        d.hbias16 = upload(net, hbias16);
+        if (!d.hbias16) return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
     }
     d.bias = upload(net, bias);
     d.wv = upload(net, wv); d.bv = upload(net, bv);
