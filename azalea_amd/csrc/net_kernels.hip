@@ -1660,33 +1660,34 @@ __global__ void k_conv_generic(NetDev P, int layer, const float *in, const float
 // k_heads_mfma: the heads' fully connected layers as fp32 MFMA GEMMs over a tile of boards.
 // value_fc2 (2 n^2 -> 64) and move_fc (4 n^2 -> n^2) (network.py:79, :146) are 148 kFLOP per board -- 6 GFLOP per
 // leaf batch of 40 960 -- which k_heads runs as scalar FMA chains (0.23 ms per batch, 2.9 % of a configs[2]
-// move).  Here a 256-thread block takes 32 boards: their six head planes (from the fused tower, `hfeat`) are
-// staged in LDS as the A operand ([board][k], row stride = 4 mod 64 floats: conflict-free ds_read_b128), the
-// weights come from L2 pre-packed in B-fragment order, wave w owns output tile w of move_fc (v_mfma_f32_32x32x2_f32,
-// exact fp32 products) and a quarter of value_fc2 (tile w & 1, half w >> 1 of its inputs; the halves are added
-// through LDS).  A row of the product depends on its own board only, so a board's outputs do not depend on what
-// else is in the tile.  Then value_fc3 + tanh and the masked softmax exactly as in k_heads.
+// move).  Here a 256-thread block takes 16 boards: their six head planes (from the fused tower, `hfeat`) are
+// staged in LDS as the A operand ([board][k], row stride = 4 mod 64 floats: conflict-free ds_read_b128; 49 KB, so
+// three blocks share a CU and hide each other's staging and softmax), the weights come from L2 pre-packed in
+// B-fragment order, wave w owns output tiles 2w, 2w + 1 of move_fc and tile w of value_fc2
+// (v_mfma_f32_16x16x4_f32: exact fp32 products).  A row of the product depends on its own board only, so a
+// board's outputs do not depend on what else is in the tile.  Then value_fc3 + tanh and the masked softmax
+// exactly as in k_heads.
 // ============================================================================================
-#define HM_MB 32
-__global__ __launch_bounds__(256) void k_heads_mfma(NetDev P, const float *__restrict__ hfeat,
-                                                    const uint8_t *__restrict__ ev_board,
-                                                    const int32_t *__restrict__ ev_flip,
-                                                    const int32_t *__restrict__ n_eval_ptr, int n_eval_host,
-                                                    float *__restrict__ logit_out, float *__restrict__ value_out,
-                                                    float *__restrict__ prior_out) {
+#define HM_MB 16
+__global__ __launch_bounds__(256, 3) void k_heads_mfma(NetDev P, const float *__restrict__ hfeat,
+                                                       const uint8_t *__restrict__ ev_board,
+                                                       const int32_t *__restrict__ ev_flip,
+                                                       const int32_t *__restrict__ n_eval_ptr, int n_eval_host,
+                                                       float *__restrict__ logit_out, float *__restrict__ value_out,
+                                                       float *__restrict__ prior_out) {
     extern __shared__ __align__(16) float hsm[];
     const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
     const int e0 = blockIdx.x * HM_MB;
     if (e0 >= n_eval) return;
     const int nb = min(HM_MB, n_eval - e0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
+    const int li = lane & 15, lk = lane >> 4;
     const int N = P.N, ncells = P.ncells, LDA = P.hm_lda;
-    const int KV = 2 * ncells, KP = 4 * ncells, KVp = (KV + 7) & ~7, KPp = (KP + 7) & ~7;
-    const int QV = KVp / 8, QP = KPp / 8, nf = 6 * ncells;
-    float *A = hsm;                                   // [32][LDA]: value inputs at 0, policy inputs at KVp
-    // what the softmax at the end needs from HBM -- the boards' empties and flip flags of this wave's eight
-    // boards -- is requested now: at one block per CU nothing else would hide those round trips later
+    const int KV = 2 * ncells, KP = 4 * ncells, KVp = (KV + 15) & ~15, KPp = (KP + 15) & ~15;
+    const int QV = KVp / 16, QP = KPp / 16, nf = 6 * ncells;
+    float *A = hsm;                                   // [16][LDA]: value inputs at 0, policy inputs at KVp
+    // what the softmax at the end needs from HBM -- the boards' empties and flip flags of this wave's four
+    // boards -- is requested now, far ahead of its use
     uint8_t cellv[HM_MB / 4][2];
     int flipv[HM_MB / 4];
 #pragma unroll
@@ -1696,10 +1697,9 @@ __global__ __launch_bounds__(256) void k_heads_mfma(NetDev P, const float *__res
         cellv[bi][1] = ev_board[(size_t)e * AZX_CELL_STRIDE + 64 + lane];
         flipv[bi] = ev_flip[e];
     }
-    // ---- stage the tile: the 32 boards' 6 n^2 floats are one contiguous run of float2 (a board is 3 n^2 of them: 8-byte
-    // aligned whatever n); twenty-four loads in flight per thread before the first LDS write (as a load-store loop the
-    // kernel spent most of its time in ~100 dependent HBM round trips per wave).  Padding columns and missing
-    // boards are zero.
+    // ---- stage the tile: the boards' 6 n^2 floats are one contiguous run of float2 (a board is 3 n^2 of them: 8-byte
+    // aligned whatever n); all of a thread's loads in flight before the first LDS write.  Padding columns and
+    // missing boards are zero.
     {
         const int nf2 = 3 * ncells, total = nb * nf2;
         const float2 *src = reinterpret_cast<const float2 *>(hfeat + (size_t)e0 * nf);
@@ -1731,90 +1731,89 @@ __global__ __launch_bounds__(256) void k_heads_mfma(NetDev P, const float *__res
         }
     }
     __syncthreads();
-    // ---- move_fc: output tile = wave (32 logits), K = 4 n^2 --------------------------------------------------
-    const int NTP = (ncells + 31) / 32;               // <= 4 (n <= 11)
-    f32x16 accp;
+    // ---- move_fc: output tiles 2 wave, 2 wave + 1 (16 logits each), K = 4 n^2; k = 16 t + 4 lk + s of group t ----
+    const int NTP = (ncells + 15) / 16;               // <= 8 (n <= 11)
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    f32x4_ accp[2] = {f32x4_{0.f, 0.f, 0.f, 0.f}, f32x4_{0.f, 0.f, 0.f, 0.f}};
+    constexpr int AH = 6;                             // weight fragments this many groups ahead
+    {
+        const int t0 = min(2 * wave, NTP - 1), t1 = min(2 * wave + 1, NTP - 1);
+        const float4 *w0 = reinterpret_cast<const float4 *>(P.hmP) + (size_t)t0 * QP * 64 + lane;
+        const float4 *w1 = reinterpret_cast<const float4 *>(P.hmP) + (size_t)t1 * QP * 64 + lane;
+        const float *ap = A + (size_t)li * LDA + KVp + 4 * lk;
+        float4 bq0[AH], bq1[AH];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accp[r] = 0.0f;
-    if (wave < NTP) {
-        const float4 *wp = reinterpret_cast<const float4 *>(P.hmP) + (size_t)wave * QP * 64 + lane;
-        const float *ap = A + (size_t)li * LDA + KVp + 4 * lh;
-        // weight fragments eight groups ahead (one wave per SIMD: nothing else hides an L2 round trip)
-        constexpr int AH = 8;
-        float4 bq[AH];
-#pragma unroll
-        for (int u = 0; u < AH; ++u) bq[u] = wp[(size_t)min(u, QP - 1) * 64];
+        for (int u = 0; u < AH; ++u) { bq0[u] = w0[(size_t)min(u, QP - 1) * 64]; bq1[u] = w1[(size_t)min(u, QP - 1) * 64]; }
+        if (2 * wave < NTP)
         for (int q0 = 0; q0 < QP; q0 += AH) {
 #pragma unroll
             for (int u = 0; u < AH; ++u) {
                 const int q = q0 + u;
-                const float4 b4 = bq[u];
-                bq[u] = wp[(size_t)min(q + AH, QP - 1) * 64];
+                const float4 b0 = bq0[u], b1 = bq1[u];
+                bq0[u] = w0[(size_t)min(q + AH, QP - 1) * 64];
+                bq1[u] = w1[(size_t)min(q + AH, QP - 1) * 64];
                 if (q < QP) {
-                    const float4 a4 = *reinterpret_cast<const float4 *>(ap + 8 * q);
-                    accp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, accp, 0, 0, 0);
-                    accp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, accp, 0, 0, 0);
-                    accp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, accp, 0, 0, 0);
-                    accp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, accp, 0, 0, 0);
+                    const float4 a4 = *reinterpret_cast<const float4 *>(ap + 16 * q);
+                    accp[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b0.x, accp[0], 0, 0, 0);
+                    accp[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b1.x, accp[1], 0, 0, 0);
+                    accp[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b0.y, accp[0], 0, 0, 0);
+                    accp[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b1.y, accp[1], 0, 0, 0);
+                    accp[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b0.z, accp[0], 0, 0, 0);
+                    accp[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b1.z, accp[1], 0, 0, 0);
+                    accp[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b0.w, accp[0], 0, 0, 0);
+                    accp[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b1.w, accp[1], 0, 0, 0);
                 }
             }
         }
     }
-    // ---- value_fc2: output tile = wave & 1 (32 of the 64 units), input half = wave >> 1 ----------------------
-    f32x16 accv;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accv[r] = 0.0f;
+    // ---- value_fc2: output tile = wave (16 of the 64 units), K = 2 n^2 ---------------------------------------
+    f32x4_ accv = f32x4_{0.f, 0.f, 0.f, 0.f};
     {
-        const int vt = wave & 1, half = wave >> 1;
-        const int q0 = half ? QV / 2 : 0, q1 = half ? QV : QV / 2;
-        const float4 *wv = reinterpret_cast<const float4 *>(P.hmV) + (size_t)vt * QV * 64 + lane;
-        const float *ap = A + (size_t)li * LDA + 4 * lh;
-        constexpr int AH = 8;
+        const float4 *wv = reinterpret_cast<const float4 *>(P.hmV) + (size_t)wave * QV * 64 + lane;
+        const float *ap = A + (size_t)li * LDA + 4 * lk;
         float4 bq[AH];
 #pragma unroll
-        for (int u = 0; u < AH; ++u) bq[u] = wv[(size_t)min(q0 + u, q1 - 1) * 64];
-        for (int qb = q0; qb < q1; qb += AH) {
+        for (int u = 0; u < AH; ++u) bq[u] = wv[(size_t)min(u, QV - 1) * 64];
+        for (int qb = 0; qb < QV; qb += AH) {
 #pragma unroll
             for (int u = 0; u < AH; ++u) {
                 const int q = qb + u;
                 const float4 b4 = bq[u];
-                bq[u] = wv[(size_t)min(q + AH, q1 - 1) * 64];
-                if (q < q1) {
-                    const float4 a4 = *reinterpret_cast<const float4 *>(ap + 8 * q);
-                    accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, accv, 0, 0, 0);
-                    accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, accv, 0, 0, 0);
-                    accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, accv, 0, 0, 0);
-                    accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, accv, 0, 0, 0);
+                bq[u] = wv[(size_t)min(q + AH, QV - 1) * 64];
+                if (q < QV) {
+                    const float4 a4 = *reinterpret_cast<const float4 *>(ap + 16 * q);
+                    accv = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, accv, 0, 0, 0);
+                    accv = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, accv, 0, 0, 0);
+                    accv = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, accv, 0, 0, 0);
+                    accv = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, accv, 0, 0, 0);
                 }
             }
         }
     }
     __syncthreads();                                  // every wave is done reading the feature tile: its memory is reused
-    float (*lg)[AZX_CELL_STRIDE] = reinterpret_cast<float (*)[AZX_CELL_STRIDE]>(hsm);            // [32][192] logits
-    float (*pv)[HM_MB][64] = reinterpret_cast<float (*)[HM_MB][64]>(hsm + HM_MB * AZX_CELL_STRIDE);   // [2 halves][32][64]
-    // C/D layout of 32x32x2: col = lane & 31 (output unit), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (board)
-    if (wave < NTP) {
-        const int j = 32 * wave + li;
-        if (j < ncells) {
+    float (*lg)[AZX_CELL_STRIDE] = reinterpret_cast<float (*)[AZX_CELL_STRIDE]>(hsm);            // [16][192] logits
+    float (*h2)[64] = reinterpret_cast<float (*)[64]>(hsm + HM_MB * AZX_CELL_STRIDE);            // [16][64] fc2 sums
+    // C/D layout of 16x16x4: col = lane & 15 (output unit), row = 4 (lane >> 4) + reg (board)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int j = 16 * (2 * wave + tt) + li;
+        if (2 * wave + tt < NTP && j < ncells) {
             const float bias = P.mfcb[j];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int b = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float logit = accp[r] + bias;
+            for (int r = 0; r < 4; ++r) {
+                const int b = 4 * lk + r;
+                const float logit = accp[tt][r] + bias;
                 lg[b][j] = logit;
                 if (b < nb) logit_out[(size_t)(e0 + b) * AZX_CELL_STRIDE + j] = logit;
             }
         }
     }
-    {
-        const int j = 32 * (wave & 1) + li;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pv[wave >> 1][(r & 3) + 8 * (r >> 2) + 4 * lh][j] = accv[r];
-    }
+    for (int r = 0; r < 4; ++r) h2[4 * lk + r][16 * wave + li] = accv[r];
     __syncthreads();
     if (tid < nb) {                                   // + bias, ReLU, value_fc3 + tanh (network.py:79-81)
         float acc = 0.f;
-        for (int i = 0; i < 64; ++i) acc += fmaxf(pv[0][tid][i] + pv[1][tid][i] + P.fc2b[i], 0.f) * P.fc3w[i];
+        for (int i = 0; i < 64; ++i) acc += fmaxf(h2[tid][i] + P.fc2b[i], 0.f) * P.fc3w[i];
         value_out[e0 + tid] = tanhf(acc + P.fc3b[0]);
     }
     if (!prior_out) return;
@@ -2479,23 +2478,23 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
         for (int i = 0; i < 4 * n2; ++i) mfcT[(size_t)i * AZX_CELL_STRIDE + t] = (*mfw)[(size_t)t * 4 * n2 + i];
         mfcb[t] = (*mfb)[t];
     }
-    // k_heads_mfma's B operands: [n tile][k group q][lane][s] = W[k = 8 q + 4 (lane >> 5) + s][unit 32 tile + (lane & 31)]
-    const int KVp = (2 * n2 + 7) & ~7, KPp = (4 * n2 + 7) & ~7, NTP = (n2 + 31) / 32;
-    std::vector<float> hmP((size_t)NTP * (KPp / 8) * 64 * 4, 0.f), hmV((size_t)2 * (KVp / 8) * 64 * 4, 0.f);
+    // k_heads_mfma's B operands: [n tile of 16][k group t of 16][lane][s] = W[k = 16 t + 4 (lane >> 4) + s][unit 16 tile + (lane & 15)]
+    const int KVp = (2 * n2 + 15) & ~15, KPp = (4 * n2 + 15) & ~15, NTP = (n2 + 15) / 16;
+    std::vector<float> hmP((size_t)NTP * (KPp / 16) * 64 * 4, 0.f), hmV((size_t)4 * (KVp / 16) * 64 * 4, 0.f);
     for (int t = 0; t < NTP; ++t)
-        for (int q = 0; q < KPp / 8; ++q)
+        for (int q = 0; q < KPp / 16; ++q)
             for (int l = 0; l < 64; ++l)
                 for (int sidx = 0; sidx < 4; ++sidx) {
-                    const int k = 8 * q + 4 * (l >> 5) + sidx, unit = 32 * t + (l & 31);
+                    const int k = 16 * q + 4 * (l >> 4) + sidx, unit = 16 * t + (l & 15);
                     if (k < 4 * n2 && unit < n2)
-                        hmP[(((size_t)t * (KPp / 8) + q) * 64 + l) * 4 + sidx] = (*mfw)[(size_t)unit * 4 * n2 + k];
+                        hmP[(((size_t)t * (KPp / 16) + q) * 64 + l) * 4 + sidx] = (*mfw)[(size_t)unit * 4 * n2 + k];
                 }
-    for (int t = 0; t < 2; ++t)
-        for (int q = 0; q < KVp / 8; ++q)
+    for (int t = 0; t < 4; ++t)
+        for (int q = 0; q < KVp / 16; ++q)
             for (int l = 0; l < 64; ++l)
                 for (int sidx = 0; sidx < 4; ++sidx) {
-                    const int k = 8 * q + 4 * (l >> 5) + sidx, unit = 32 * t + (l & 31);
-                    if (k < 2 * n2) hmV[(((size_t)t * (KVp / 8) + q) * 64 + l) * 4 + sidx] = (*fc2w)[(size_t)unit * 2 * n2 + k];
+                    const int k = 16 * q + 4 * (l >> 4) + sidx, unit = 16 * t + (l & 15);
+                    if (k < 2 * n2) hmV[(((size_t)t * (KVp / 16) + q) * 64 + l) * 4 + sidx] = (*fc2w)[(size_t)unit * 2 * n2 + k];
                 }
 #undef NEED
     (void)hipStreamSynchronize(net->stream);
@@ -2669,7 +2668,7 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
     }
     if (hfeat != nullptr && net->opt_heads_mfma && d.ncells <= 128) {
         // the fused tower left the six head planes: the FC layers run as fp32 MFMA GEMMs over tiles of 32 boards
-        const size_t hl = std::max((size_t)HM_MB * d.hm_lda, (size_t)HM_MB * AZX_CELL_STRIDE + (size_t)2 * HM_MB * 64) * sizeof(float);
+        const size_t hl = std::max((size_t)HM_MB * d.hm_lda, (size_t)HM_MB * AZX_CELL_STRIDE + (size_t)HM_MB * 64) * sizeof(float);
         static size_t hm_set = 0;
         if (hl > hm_set) { (void)hipFuncSetAttribute((const void *)k_heads_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl); hm_set = hl; }
         hipLaunchKernelGGL(k_heads_mfma, dim3((max_n + HM_MB - 1) / HM_MB), dim3(256), hl, st, d, hfeat, boards, flip, n_eval_ptr, n_host, logit, value, prior);

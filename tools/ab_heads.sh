@@ -1,7 +1,7 @@
 #!/bin/bash
 # Diagnostic (tools only): configs[2] with the MFMA heads and with the scalar-FMA heads (AZX_HEADS=valu), alternating.
 mkdir -p gpurun_out
-for h in mfma valu mfma valu; do
+for h in mfma valu mfma valu; do  # (libazx_hip.so)
   AZX_HEADS=$h python bench.py --workload resnet --steps 6 --warmup 2 --no-cpu-baseline --no-replay-exchange > gpurun_out/abh_tmp.json 2> gpurun_out/abh_tmp.err || { echo "$h FAILED"; tail -3 gpurun_out/abh_tmp.err; continue; }
   python - "$h" <<'P'
 import json, sys
