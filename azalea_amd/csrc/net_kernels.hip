@@ -227,6 +227,22 @@ __global__ __launch_bounds__(256) void k_tower_mfma(NetDev P, const uint8_t *__r
 // ============================================================================================
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// DIAGNOSTIC, off by default (AZX_LO_BITS = 10 compiles to nothing).  Operand sparsity buys clock: the tower is
+// power-limited (1 280 W), and zeroing low mantissa bits of the lo halves -- the operands of two of the
+// three products, hi*lo and lo*hi, 2^-11 of the result -- lowers the multipliers' switching, so the power manager
+// raises the clock: with lo rounded to 7 / 6 / 5 / 4 mantissa bits the same launch runs 1.2 / 2.0 / 3.0 / 4.1 %
+// faster (all of lo zero: 11 %).  NOT shipped: on the reference's trained checkpoint (golden G8, peaked policies) the
+// full-precision error is already 3.8e-5 of the 1e-4 tolerance and 7 bits gives 2.0e-4 (seeded nets G3 / G5r: 1e-6
+// -> 5e-6), tools/net_err_lib.py.  AZX_LO_BITS = explicit mantissa bits kept in every lo half, activations
+// (split2_f16) and weights (f16bits at pack time) alike, rounded to nearest.
+#ifndef AZX_LO_BITS
+#define AZX_LO_BITS 10
+#endif
+#define LO_MASK ((0xFFFFu << (10 - AZX_LO_BITS)) & 0xFFFFu)
+#define LO_RND (AZX_LO_BITS < 10 ? (1u << (9 - AZX_LO_BITS)) : 0u)
+static inline unsigned short lo_round_bits(unsigned short bits) {
+    return (unsigned short)((bits + LO_RND) & LO_MASK);
+}
 __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
@@ -243,6 +259,9 @@ __device__ __forceinline__ void split2_f16(float a, float b, uint32_t &hpk, uint
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la) : "v"(hpk), "v"(a));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hpk), "v"(b));
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lpk) : "v"(la), "v"(lb));
+#if AZX_LO_BITS < 10
+    lpk = (lpk + LO_RND * 0x10001u) & (LO_MASK * 0x10001u);     // round the lo halves to AZX_LO_BITS mantissa bits
+#endif
 }
 
 // Diagnostic build only (-DAZX_NET_STAMP): per-region s_memtime sums of k_tower_f16x3 (wave 0 of
@@ -2350,7 +2369,7 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
             const _Float16 v = part ? lo : hi;
             unsigned short bits;
             memcpy(&bits, &v, 2);
-            return bits;
+            return part ? lo_round_bits(bits) : bits;
         };
         // stem table as K = 27 (tap*3 + colour, padded to 32) x C weights:
         // [kk][ntile][part hi/lo][lane j + 32 h][t] = split(stemT[k = 16 kk + 8 h + t][cout 32 ntile + j])
@@ -2393,7 +2412,7 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
             const _Float16 v = part ? lo : hi;
             unsigned short bits;
             memcpy(&bits, &v, 2);
-            return bits;
+            return part ? lo_round_bits(bits) : bits;
         };
         // 16x16x32 A-operand order: lane (j = lane & 15: output channel in the tile, h = lane >> 4: k-group)
         // holds 8 consecutive k.  Stem: [ntile][hi,lo][lane][t] = split(stemT[k = 8 h + t][cout 16 ntile + j])
@@ -2453,7 +2472,7 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
             const _Float16 v = part ? lo : hi;
             unsigned short bits;
             memcpy(&bits, &v, 2);
-            return bits;
+            return part ? lo_round_bits(bits) : bits;
         };
         Whd16.resize((size_t)2 * 2 * 64 * 8);
         size_t oh = 0;
