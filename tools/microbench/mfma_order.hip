@@ -150,6 +150,141 @@ static void run2(const uint4 *d, float *o, int iters) {
     printf("run of %d on one accumulator: mean %.3f ms  best %.3f ms  %.1f TFLOP/s issued (mean)\n", 3 * NK, tot / 40, best, fl / (tot / 40 * 1e-3) / 1e12);
 }
 
+// the tower's operand paths: weight fragments (slots 0-7) from global memory (L1 / L2 resident, a 6x64 tower's
+// 1.77 MB walked in order), activation fragments (slots 8-15) from LDS; WSRC = 0: everything from LDS
+template <int WSRC>
+__global__ __launch_bounds__(256, 2) void k3(const uint4 *src, const uint4 *wsrc, float *out, int iters, unsigned long long *clk) {
+    extern __shared__ uint4 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 4096; i += 256) lds[i] = src[i];
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    f32x4 acc[4][4];
+    for (int m = 0; m < 4; ++m) for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int wq = 0;
+    f16x8 fw[8];                                        // the weight fragments are requested one step ahead
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const uint4 q = WSRC ? wsrc[(size_t)j * 64 + lane] : lds[(j * 64 + lane) & 4095]; fw[j] = *reinterpret_cast<const f16x8 *>(&q); }
+    for (int it = 0; it < iters; ++it) {
+        f16x8 f[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fw[j];
+        wq = wq + 1 == 216 ? 0 : wq + 1;
+#pragma unroll
+        for (int j = 8; j < 16; ++j) { const uint4 q = lds[((it * 16 + j) * 64 + lane) & 4095]; f[j] = *reinterpret_cast<const f16x8 *>(&q); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 2 * h; n < 2 * h + 2; ++n)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        MF(m, n, p);
+                        const int q = ((h * 4 + m) * 2 + (n & 1)) * 3 + p;      // one request in the shadow of each of the first MFMAs
+                        if (q % 3 == 1 && q / 3 < 8) {
+                            const int j = q / 3;
+                            const uint4 qq = WSRC ? wsrc[(size_t)(wq * 8 + j) * 64 + lane] : lds[(((it + 1) * 16 + j) * 64 + lane) & 4095];
+                            fw[j] = *reinterpret_cast<const f16x8 *>(&qq);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+    }
+    float sum = 0.f;
+    for (int m = 0; m < 4; ++m) for (int n = 0; n < 4; ++n) for (int r = 0; r < 4; ++r) sum += acc[m][n][r];
+    out[blockIdx.x * 256 + tid] = sum;
+    if (tid == 0 && blockIdx.x == 0) { clk[0] = __builtin_amdgcn_s_memtime() - t0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+}
+
+// the other wave tile: 128 positions x 32 channels (8 x 2 tiles).  Per k-step 4 weight fragments from global memory
+// (half of k3's) and 16 activation fragments from LDS (twice k3's), in two halves of four position tiles.
+template <int WSRC>
+__global__ __launch_bounds__(256, 2) void k5(const uint4 *src, const uint4 *wsrc, float *out, int iters, unsigned long long *clk) {
+    extern __shared__ uint4 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 4096; i += 256) lds[i] = src[i];
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    f32x4 acc[8][2];
+    for (int m = 0; m < 8; ++m) for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int wq = 0;
+    f16x8 fw[4];                                        // wh[0], wh[1], wl[0], wl[1]: requested one step ahead
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint4 q = WSRC ? wsrc[(size_t)j * 64 + lane] : lds[(j * 64 + lane) & 4095]; fw[j] = *reinterpret_cast<const f16x8 *>(&q); }
+    for (int it = 0; it < iters; ++it) {
+        f16x8 w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = fw[j];
+        wq = wq + 1 == 432 ? 0 : wq + 1;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f16x8 x[8];                                 // xh[0..3], xl[0..3] of this half (activation slots 8-15 of the image)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const uint4 q = lds[(((it * 2 + half) * 16 + 8 + j) * 64 + lane) & 4095]; x[j] = *reinterpret_cast<const f16x8 *>(&q); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        acc[4 * half + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[n + 2 * (p == 1)], x[m + 4 * (p == 2)], acc[4 * half + m][n], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int q = (m * 2 + n) * 3 + p;
+                        if (half == 0 && q % 3 == 1 && q / 3 < 4) {
+                            const int j = q / 3;
+                            const uint4 qq = WSRC ? wsrc[(size_t)(wq * 4 + j) * 64 + lane] : lds[(((it + 1) * 16 + j) * 64 + lane) & 4095];
+                            fw[j] = *reinterpret_cast<const f16x8 *>(&qq);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+        }
+    }
+    float sum = 0.f;
+    for (int m = 0; m < 8; ++m) for (int n = 0; n < 2; ++n) for (int r = 0; r < 4; ++r) sum += acc[m][n][r];
+    out[blockIdx.x * 256 + tid] = sum;
+    if (tid == 0 && blockIdx.x == 0) { clk[0] = __builtin_amdgcn_s_memtime() - t0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+}
+
+template <int WSRC>
+static void run5(const uint4 *d, const uint4 *w, float *o, int iters) {
+    static unsigned long long *clk = nullptr;
+    if (!clk) hipMalloc(&clk, 16);
+    hipFuncSetAttribute((const void *)k5<WSRC>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f, ms = 0.f, tot = 0.f;
+    for (int rep = 0; rep < 42; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k5<WSRC>, dim3(512), dim3(256), 72 * 1024, 0, d, w, o, iters, clk);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep >= 2) { tot += ms; if (ms < best) best = ms; }
+    }
+    const double fl = 512.0 * 4 * iters * 48 * 16384.0;
+    unsigned long long hc[2]; hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
+    printf("8 x 2 tile, weights from %s: mean %.3f ms  best %.3f ms  %.1f TFLOP/s issued (mean)  shader clock %.2f GHz\n", WSRC ? "global (L1/L2)" : "LDS", tot / 40, best, fl / (tot / 40 * 1e-3) / 1e12, hc[0] / (hc[1] * 10.0));
+}
+
+template <int WSRC>
+static void run3(const uint4 *d, const uint4 *w, float *o, int iters) {
+    static unsigned long long *clk = nullptr;
+    if (!clk) hipMalloc(&clk, 16);
+    hipFuncSetAttribute((const void *)k3<WSRC>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f, ms = 0.f, tot = 0.f;
+    for (int rep = 0; rep < 42; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k3<WSRC>, dim3(512), dim3(256), 72 * 1024, 0, d, w, o, iters, clk);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep >= 2) { tot += ms; if (ms < best) best = ms; }
+    }
+    const double fl = 512.0 * 4 * iters * 48 * 16384.0;
+    unsigned long long hc[2]; hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
+    printf("weights from %s: mean %.3f ms  best %.3f ms  %.1f TFLOP/s issued (mean)  shader clock %.2f GHz (block 0, last launch)\n", WSRC ? "global (L1/L2)" : "LDS", tot / 40, best, fl / (tot / 40 * 1e-3) / 1e12, hc[0] / (hc[1] * 10.0));
+}
+
 static float gauss() { float u = (rand() + 1.0f) / (RAND_MAX + 2.0f), v = (rand() + 1.0f) / (RAND_MAX + 2.0f); return sqrtf(-2.f * logf(u)) * cosf(6.2831853f * v); }
 
 template <int ORDER>
@@ -184,6 +319,15 @@ int main(int argc, char **argv) {
     uint4 *d; float *o;
     hipMalloc(&d, 4096 * 16); hipMalloc(&o, 512 * 256 * 4);
     hipMemcpy(d, h.data(), 4096 * 16, hipMemcpyHostToDevice);
+    std::vector<_Float16> hw((size_t)216 * 8 * 64 * 8);
+    for (size_t i = 0; i < hw.size(); ++i) {
+        const float v = 0.05f * gauss();
+        const _Float16 hi = (_Float16)v;
+        hw[i] = ((i / 512 / 4) & 1) ? (_Float16)(v - (float)hi) : hi;
+    }
+    uint4 *w; hipMalloc(&w, hw.size() * 2); hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+    for (int round = 0; round < 3; ++round) { run3<0>(d, w, o, iters); run3<1>(d, w, o, iters); run5<0>(d, w, o, iters); run5<1>(d, w, o, iters); }
+    if (argc > 2) return 0;
     for (int round = 0; round < 3; ++round) {
         run<0>(d, o, iters); run<1>(d, o, iters); run<2>(d, o, iters); run<3>(d, o, iters); run<4>(d, o, iters); run<5>(d, o, iters); run<6>(d, o, iters); run<7>(d, o, iters); run<8>(d, o, iters); run2<1>(d, o, iters); run2<2>(d, o, iters); run2<3>(d, o, iters);
     }
