@@ -710,7 +710,6 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
         constexpr int kind = decltype(kind_tag)::value;  // 0 conv1, 1 conv2 (+ residual), 2 stem
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const int cb = 16 * n + 4 * lh;
             const float4 b4 = bias4[n];
             const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
@@ -2008,9 +2007,25 @@ static T *nalloc(AzxNet *net, size_t count) {
     return reinterpret_cast<T *>(p);
 }
 
+// Every tower kernel takes its LDS image as dynamic shared memory above the 64 KB default: the limit is raised to
+// the CU's 160 KB for all of them whenever a network is created (per device and idempotent; a process-wide "done"
+// flag would leave a second device, or a later network with a larger image, on the first one's setting).
+static int raise_lds_limits() {
+    const int cap = 160 * 1024;
+    const void *fns[] = {(const void *)k_tower_f16x3<false>, (const void *)k_tower_f16x3<true>, (const void *)k_tower_f16x3_s16,
+                         (const void *)k_conv_wide_f16x3, (const void *)k_conv_wide_f16x3_s16,
+                         (const void *)k_tower_mfma<64, 4, 2, 1, 2>, (const void *)k_tower_mfma<64, 6, 1, 2, 2>,
+                         (const void *)k_tower_mfma<32, 6, 2, 2, 1>};
+    for (const void *f : fns)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess)
+            return nfail(AZX_EHIP, "net: raising a tower kernel's dynamic LDS limit failed");
+    return AZX_OK;
+}
+
 int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hipStream_t st) {
     if (N < 2 || N > AZX_MAX_BOARD) return nfail(AZX_EINVAL, "net: board size out of range");
     if (blocks < 0 || chans < 1) return nfail(AZX_EINVAL, "net: bad num_blocks/base_chans");
+    if (int rc = raise_lds_limits()) return rc;
     AzxNet *net = new AzxNet();
     memset(&net->d, 0, sizeof net->d);
     net->d.N = N;
@@ -2472,13 +2487,6 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
         if (net->tower_variant == 4) {
             const bool split_m = net->opt_split_m;
             const int shape = net->opt_shape;
-            static bool attr4 = false;
-            if (!attr4) {
-                (void)hipFuncSetAttribute((const void *)k_tower_f16x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                (void)hipFuncSetAttribute((const void *)k_tower_f16x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                (void)hipFuncSetAttribute((const void *)k_tower_f16x3_s16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr4 = true;
-            }
             const dim3 grid((max_n + F16X3_BPB - 1) / F16X3_BPB), block(F16X3_BPB * 128);
             if (shape == 16 && split_m) {
                 hipLaunchKernelGGL(k_tower_f16x3_s16, grid, block, lds, st, d, boards, n_eval_ptr, n_host,
@@ -2490,13 +2498,7 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
                 hfeat = net->hfeat;
             } else hipLaunchKernelGGL(k_tower_f16x3<false>, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act, (float *)nullptr);
         } else if (net->tower_variant == 5) {
-            static bool attr5 = false;
             const int wshape = net->opt_shape;
-            if (!attr5) {
-                (void)hipFuncSetAttribute((const void *)k_conv_wide_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                (void)hipFuncSetAttribute((const void *)k_conv_wide_f16x3_s16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr5 = true;
-            }
             const dim3 grid(max_n, d.C / 128), block(256);
             hipLaunchKernelGGL(k_stem_wide_f16x3, grid, block, 0, st, d, boards, net->wideX,
                                d.blocks == 0 ? net->act : (float *)nullptr, n_eval_ptr, n_host);
@@ -2549,16 +2551,10 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
                                    (const unsigned short *)net->wideX, b == d.blocks - 1 ? net->act : (float *)nullptr, n_eval_ptr, n_host);
             }
         } else if (net->tower_variant == 1) {
-            static bool attr1 = false;
-            if (!attr1) { (void)hipFuncSetAttribute((const void *)k_tower_mfma<64, 4, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
             hipLaunchKernelGGL((k_tower_mfma<64, 4, 2, 1, 2>), dim3((max_n + 1) / 2), dim3(256), lds, st, d, boards, n_eval_ptr, n_host, net->act);
         } else if (net->tower_variant == 2) {
-            static bool attr2 = false;
-            if (!attr2) { (void)hipFuncSetAttribute((const void *)k_tower_mfma<64, 6, 1, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
             hipLaunchKernelGGL((k_tower_mfma<64, 6, 1, 2, 2>), dim3(max_n), dim3(256), lds, st, d, boards, n_eval_ptr, n_host, net->act);
         } else {
-            static bool attr3 = false;
-            if (!attr3) { (void)hipFuncSetAttribute((const void *)k_tower_mfma<32, 6, 2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr3 = true; }
             hipLaunchKernelGGL((k_tower_mfma<32, 6, 2, 2, 1>), dim3((max_n + 1) / 2), dim3(256), lds, st, d, boards, n_eval_ptr, n_host, net->act);
         }
     } else {
