@@ -2194,7 +2194,7 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
         T[names[i]] = std::move(h);
     }
     const int C = net->d.C, N = net->d.N, n2 = N * N, L = net->d.layers;
-    static std::string missing;
+    std::string missing;
     auto get = [&](const std::string &name, size_t want) -> const std::vector<float> * {
         auto it = T.find(name);
         if (it == T.end() || it->second.size() != want) {
