@@ -2009,7 +2009,8 @@ static T *nalloc(AzxNet *net, size_t count) {
 
 // Every tower kernel takes its LDS image as dynamic shared memory above the 64 KB default: the limit is raised to
 // the CU's 160 KB for all of them whenever a network is created (per device and idempotent; a process-wide "done"
-// flag would leave a second device, or a later network with a larger image, on the first one's setting).
+// flag would leave a second device, or a later network with a larger image, on the first one's setting -- which
+// ROCm 7.2 happens not to enforce, but the contract is the opt-in).
 static int raise_lds_limits() {
     const int cap = 160 * 1024;
     const void *fns[] = {(const void *)k_tower_f16x3<false>, (const void *)k_tower_f16x3<true>, (const void *)k_tower_f16x3_s16,

@@ -304,6 +304,34 @@ def test_tower_variants_selected_by_environment():
         assert r.returncode == 0, (env, r.stdout[-2000:], r.stderr[-2000:])
 
 
+def test_second_network_with_a_larger_lds_image_in_one_process(eng, orc):
+    """The tower kernels take their LDS image as dynamic shared memory above the 64 KB default, and the opt-in limit
+    (hipFuncAttributeMaxDynamicSharedMemorySize) is raised for all of them at every network creation.  A later
+    network with a larger image than the first (here the exact-fp32 tower: 29 KB on 5x5, 133 KB on 11x11) must run
+    and match the oracle.  (ROCm 7.2 launches the second one even with the limit left at the first size; the test
+    pins the behaviour rather than that leniency.)"""
+    os.environ["AZX_TOWER"] = "fp32"
+    try:
+        for n in (5, 11):
+            rng = np.random.RandomState(n)
+            from azalea_amd.network import HexNetwork
+            import torch
+            torch.manual_seed(n)
+            m = HexNetwork(board_size=n, num_blocks=1, base_chans=64).eval()
+            state = {k: v.detach().numpy() for k, v in m.state_dict().items() if v.dtype == torch.float32}
+            boards, lm = _random_positions(orc, n, 6, rng)
+            E = eng.Engine(board_size=n, n_games=2, simulations=10, search_batch_size=10,
+                           evaluator=eng.EVAL_RESNET, num_blocks=1, base_chans=64)
+            assert "fp32 MFMA" in E.kernel_info()
+            E.set_weights(state)
+            value, logprob = E.forward(boards, lm)
+            E.close()
+            ov, olp = orc.Net(n, 1, 64, state).forward(boards, lm)
+            legal = lm > 0
+            assert np.abs(value - ov).max() <= TOL and np.abs(logprob - olp)[legal].max() <= TOL
+    finally:
+        os.environ.pop("AZX_TOWER", None)
+
 
 def test_heads_mfma_matches_the_scalar_heads_and_does_not_depend_on_the_batch(eng, orc):
     """k_heads_mfma (FC layers as fp32 MFMA GEMMs over tiles of 32 boards) against the scalar-FMA k_heads on the
