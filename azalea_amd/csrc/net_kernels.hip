@@ -745,7 +745,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
                 cells[i] = (y >= 0 && y < N && x >= 0 && x < N) ? bd[y * N + x] : (uint8_t)3;
             }
         }
-        if (tid < 2 * ROWB / 4) reinterpret_cast<uint32_t *>(smem + zero_off)[tid] = 0u;
+        for (int i = tid; i < 2 * ROWB / 4; i += F16X3_BPB * 128) reinterpret_cast<uint32_t *>(smem + zero_off)[i] = 0u;
         __syncthreads();
         f32x4 acc[MT][NT];
 #pragma unroll
