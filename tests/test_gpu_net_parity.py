@@ -292,6 +292,40 @@ def test_forward_config5_shape_13x13_256ch_vs_oracle(eng, orc):
     E.close()
 
 
+def test_full_size_leaf_batch_sampled_against_the_oracle(eng, orc):
+    """BASELINE configs[2] at full size: one leaf batch of the 4096-game pool (~40 k positions, the tower's real grid of
+    ~20 k blocks, the heads' ~2.5 k tiles) evaluated by the device network inside a search; 160 of its rows -- the first
+    and last rows of the batch and a seeded sample in between -- against the CPU oracle's fp32 forward of the same
+    boards: value and every legal move's prior within 1e-4.  (The small forward tests never launch more than 5 k
+    positions.)"""
+    z = np.load(os.path.join(GOLDEN, "g3_forward_11_6x64.npz"))
+    state = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
+    G = 4096
+    E = eng.Engine(board_size=11, n_games=G, simulations=400, search_batch_size=10, evaluator=eng.EVAL_RESNET,
+                   num_blocks=6, base_chans=64, noise_scale=0.25)
+    E.set_weights(state)
+    E.reset(moves=eng.random_prefixes(11, np.arange(G), 60, 1234))      # de-synchronised mid-game positions
+    n = E.search_begin()
+    assert n == G                                                       # the roots
+    n, done = E.search_step()                                           # first select batch
+    assert not done and 0.8 * G * 10 <= n <= G * 10
+    boards, lm, slot, k = E.get_leaves()
+    value, prior = E.get_evals()
+    assert len(boards) == len(value) == n
+    rng = np.random.RandomState(5)
+    rows = np.unique(np.r_[np.arange(16), np.arange(n - 16, n), rng.randint(0, n, 128)])
+    ov, olp = orc.Net(11, 6, 64, state).forward(boards[rows], lm[rows])
+    assert np.abs(value[rows] - ov).max() <= TOL
+    for i, r in enumerate(rows):
+        kk = int(k[r])
+        assert kk == int((lm[r] > 0).sum()) and kk > 0
+        assert np.abs(prior[r, :kk] - np.exp(olp[i, :kk])).max() <= TOL
+        assert abs(float(prior[r, :kk].sum()) - 1.0) <= 1e-4
+    while not done:
+        n, done = E.search_step()
+    E.close()
+
+
 def test_tower_variants_selected_by_environment():
     """The alternative tower kernels (32x32x16 MFMA shape, unsplit wave tiling, exact-fp32 MFMA) and the scalar-FMA
     heads kernel are chosen by environment variables read once per engine: run the golden forward tests under each."""
