@@ -363,6 +363,41 @@ def test_config5_workload_properties(eng):
     E.close()
 
 
+def test_config5_full_leaf_batch_sampled_against_the_oracle(eng, orc):
+    """BASELINE configs[4]'s shape at the bench leg's size (512 concurrent 13x13 games, 19x256): one leaf batch of
+    ~4.9 k positions through the wide tower as the search launches it (38 layer launches, the batch split over two
+    streams), ten of its rows -- first, last, either side of the split, a seeded sample -- against the oracle's fp32
+    forward: value and every legal prior within 1e-4."""
+    import torch
+    from azalea_amd.network import HexNetwork
+    n, G = 13, 512
+    torch.manual_seed(7)
+    net = HexNetwork(board_size=n, num_blocks=19, base_chans=256).eval()
+    state = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    E = eng.Engine(board_size=n, n_games=G, simulations=800, search_batch_size=10, evaluator=eng.EVAL_RESNET,
+                   num_blocks=19, base_chans=256)
+    assert "k_conv_wide_f16x3_s16" in E.kernel_info() and "AZX_WIDE_STREAMS=2" in E.kernel_info()
+    E.set_weights({k: v for k, v in state.items() if v.dtype == np.float32})
+    E.reset(moves=eng.random_prefixes(n, np.arange(G), 100, 4321))
+    assert E.search_begin() == G
+    cnt, done = E.search_step()
+    assert not done and 0.8 * G * 10 <= cnt <= G * 10
+    boards, lm, slot, k = E.get_leaves()
+    value, prior = E.get_evals()
+    rng = np.random.RandomState(2)
+    half = cnt // 2
+    rows = np.unique(np.r_[0, cnt - 1, half - 1, half, half + 1, rng.randint(0, cnt, 5)])
+    fv, flp = orc.Net(n, 19, 256, state).forward(boards[rows], lm[rows], fast=True)
+    assert np.abs(value[rows] - fv).max() <= 1e-4
+    for i, r in enumerate(rows):
+        kk = int(k[r])
+        assert kk == int((lm[r] > 0).sum()) and kk > 0
+        assert np.abs(prior[r, :kk] - np.exp(flp[i, :kk])).max() <= 1e-4
+    while not done:
+        cnt, done = E.search_step()
+    E.close()
+
+
 # ---- multi-GPU sharding by global game index (SURVEY 8(e)) ---------------------------------------------
 def _games_by_uid(rows):
     uid = rows["game_uid"]
