@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""SURVEY 8(f).4 measured: the reference's training step (policy_trainer.py:123-142: forward + loss of
+network.py:92-102, backward, SGD with momentum and weight decay) on stock PyTorch-ROCm at the reference's
+hyper-parameters (config/hex11_train_config.yml: 6x64 on 11x11, batch 128, 10x oversampling), fed from the HBM replay
+ring (engine self-play -> azx_replay_fill -> azx_replay_collate -> device tensors).  Reports steps/s, the share of a
+step spent collating, and the fresh rows per second the trainer consumes (batch / oversampling per step) beside what
+one GPU's self-play produces -- i.e. who waits for whom when both share a GPU.
+    python tools/bench_train_step.py [--batch 128 1024 4096] [--steps 200]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from torch import optim
+
+from azalea_amd import engine as eng
+from azalea_amd.device_replay import DeviceReplayBuffer
+from azalea_amd.network import HexNetwork
+from azalea_amd.policy_trainer import supervised_step
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, nargs="+", default=[128, 1024, 4096])
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=100000)
+    ap.add_argument("--oversampling", type=float, default=10.0)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    # the ring is filled by uniform-prior self-play (the row format does not depend on the evaluator)
+    E = eng.Engine(board_size=11, n_games=2048, simulations=50, search_batch_size=10, evaluator=eng.EVAL_UNIFORM,
+                   noise_scale=0.25)
+    buf = DeviceReplayBuffer(E, args.rows, shared=False)
+    t0 = time.perf_counter()
+    rows, st = E.replay_fill(args.rows)
+    fill_s = time.perf_counter() - t0
+    torch.manual_seed(0)
+    out = {"ring_rows": len(buf), "fill_rows_per_sec": rows / fill_s, "lines": []}
+    for B in args.batch:
+        net = HexNetwork(board_size=11, num_blocks=6, base_chans=64).to(dev)
+        opt = optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+        order = buf.epoch_indices()
+        need = (args.steps + args.warmup) * B
+        order = np.resize(order, need)
+        collate = step = 0.0
+        loss = 0.0
+        for i in range(args.steps + args.warmup):
+            if i == args.warmup:
+                torch.cuda.synchronize()
+                collate = step = 0.0
+                t_all = time.perf_counter()
+            a = time.perf_counter()
+            batch = buf.sample(order[i * B:(i + 1) * B])
+            torch.cuda.synchronize()
+            b = time.perf_counter()
+            _, loss = supervised_step(net, batch, train=True, optimizer=opt, device=dev)   # loss.item() syncs
+            c = time.perf_counter()
+            collate += b - a
+            step += c - b
+        total = time.perf_counter() - t_all
+        out["lines"].append({"batch": B, "steps_per_sec": args.steps / total, "positions_per_sec": args.steps * B / total,
+                             "ms_per_step": 1e3 * total / args.steps, "collate_share": collate / total,
+                             "fresh_rows_per_sec_consumed": args.steps * B / args.oversampling / total,
+                             "last_loss": float(loss)})
+    E.close()
+    out["note"] = ("stock PyTorch-ROCm fp32 (MIOpen / rocBLAS), one stream, loss.item() per step as the reference; "
+                   "self-play on one MI355X produces ~1.2e4 rows/s (bench.py 'api' leg)")
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
