@@ -68,6 +68,31 @@ def main():
                              "ms_per_step": 1e3 * total / args.steps, "collate_share": collate / total,
                              "fresh_rows_per_sec_consumed": args.steps * B / args.oversampling / total,
                              "last_loss": float(loss)})
+    # the same step without its three host syncs (run()'s two .item() calls and supervised_step's): the losses stay
+    # on the device and are read once at the end, as a trainer that logs every log_interval steps would
+    import torch.nn.functional as F
+    for B in args.batch:
+        net = HexNetwork(board_size=11, num_blocks=6, base_chans=64).to(dev).train()
+        opt = optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+        order = np.resize(buf.epoch_indices(), (args.steps + args.warmup) * B)
+        acc = torch.zeros((), dtype=torch.float32, device=dev)
+        for i in range(args.steps + args.warmup):
+            if i == args.warmup:
+                torch.cuda.synchronize()
+                t_all = time.perf_counter()
+            batch = buf.sample(order[i * B:(i + 1) * B])
+            opt.zero_grad()
+            o = net.forward(batch["board"], batch["legal_moves"])
+            loss = F.mse_loss(o["value"], batch["reward"]) - (batch["moves_prob"] * o["moves_logprob"]).sum() / B
+            loss.backward()
+            opt.step()
+            acc += loss.detach()
+        torch.cuda.synchronize()
+        total = time.perf_counter() - t_all
+        out["lines"].append({"batch": B, "mode": "no per-step host sync", "steps_per_sec": args.steps / total,
+                             "positions_per_sec": args.steps * B / total, "ms_per_step": 1e3 * total / args.steps,
+                             "fresh_rows_per_sec_consumed": args.steps * B / args.oversampling / total,
+                             "mean_loss": float(acc.item()) / (args.steps + args.warmup)})
     E.close()
     out["note"] = ("stock PyTorch-ROCm fp32 (MIOpen / rocBLAS), one stream, loss.item() per step as the reference; "
                    "self-play on one MI355X produces ~1.2e4 rows/s (bench.py 'api' leg)")
