@@ -60,6 +60,10 @@ class HexNetwork(nn.Module):
     def forward(self, board, legal_moves):
         """board [B,N,N] in {0,1,2}; legal_moves [B,K] 1-based tiles, 0 = padding."""
         x = self.encoder(board.long()).permute(0, 3, 1, 2).contiguous()
+        return self.forward_embedded(x, legal_moves)
+
+    def forward_embedded(self, x, legal_moves):
+        """forward() behind the embedding: x [B,4,N,N] (policy_trainer.GraphedTrainStep embeds by masks)."""
         x = F.relu(self.bn1(self.conv1(x)))
         x = self.resblocks(x)
         v = F.relu(self.value_bn1(self.value_conv1(x))).flatten(1)     # (c, h, w) order

@@ -40,6 +40,106 @@ def supervised_step(model, batch, *, train=False, optimizer=None, device="cpu"):
     return output, loss.item()
 
 
+class GraphedTrainStep:
+    """`supervised_step(model, batch, train=True, optimizer=...)` captured once as a HIP graph and replayed.
+
+    At the reference's batch of 128 the step is a chain of a few hundred small dependent kernels (3.6 ms eager on an
+    MI355X, of which the GPU is busy a fraction); one graph launch per step runs the same kernels back to back
+    (`tools/bench_train_step.py`).  Same arithmetic as the eager step with two differences that capture needs:
+    * static shapes: `legal_moves` / `moves_prob` are padded with zeros to all N*N cells instead of the batch's widest
+      row (padding logits are masked to -99 either way: exp(-99 - max) is below fp32's resolution of the softmax sum);
+    * the 3 -> 4 embedding is applied as (board == v) masks times the embedding matrix: the same forward values bit
+      for bit, and a backward that is a plain reduction instead of `embedding_dense_backward`, whose sort-based kernels
+      size their work from the indices seen at capture time (replaying them on other boards reads out of bounds).
+    The learning rate is baked into the captured optimizer kernels, so the step is re-captured when the scheduler
+    changes it.  Losses stay on the device: `step()` returns the three loss tensors of the last replay; read them
+    (`.item()`) only when logging.  CUDA only; the batch size is fixed at construction."""
+
+    def __init__(self, model, optimizer, batch_size: int, device):
+        if torch.device(device).type != "cuda":
+            raise ValueError("GraphedTrainStep needs a CUDA (ROCm) device")
+        self.model, self.optimizer, self.B = model, optimizer, int(batch_size)
+        self.device = torch.device(device)
+        n = model.board_size
+        self.cells = n * n
+        dev = self.device
+        self.board = torch.zeros((self.B, n, n), dtype=torch.int32, device=dev)
+        self.legal_moves = torch.zeros((self.B, self.cells), dtype=torch.int32, device=dev)
+        self.moves_prob = torch.zeros((self.B, self.cells), dtype=torch.float32, device=dev)
+        self.reward = torch.zeros(self.B, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros(3, dtype=torch.float32, device=dev)       # total, value, moves
+        self.out_value = torch.zeros(self.B, dtype=torch.float32, device=dev)
+        self.out_logprob = torch.zeros((self.B, self.cells), dtype=torch.float32, device=dev)
+        self.graph = None
+        self.captured_lr = None
+        self.captures = 0
+
+    def _forward(self):
+        m = self.model
+        w = m.encoder.weight
+        x = sum((self.board == v).unsqueeze(-1).to(w.dtype) * w[v] for v in range(w.shape[0]))
+        x = x.permute(0, 3, 1, 2).contiguous()
+        return m.forward_embedded(x, self.legal_moves)
+
+    def _step(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        out = self._forward()
+        value_loss = torch.nn.functional.mse_loss(out["value"], self.reward)
+        moves_loss = -(self.moves_prob * out["moves_logprob"]).sum() / self.B
+        loss = value_loss + moves_loss
+        loss.backward()
+        self.optimizer.step()
+        self.loss.copy_(torch.stack([loss.detach(), value_loss.detach(), moves_loss.detach()]))
+        self.out_value.copy_(out["value"].detach())
+        self.out_logprob.copy_(out["moves_logprob"].detach())
+
+    def _load(self, batch):
+        k = batch["legal_moves"].shape[1]
+        if len(batch["reward"]) != self.B:
+            raise ValueError("GraphedTrainStep was built for batches of %d rows, got %d" % (self.B, len(batch["reward"])))
+        self.board.copy_(batch["board"].reshape(self.board.shape))
+        self.reward.copy_(batch["reward"])
+        self.legal_moves.zero_()
+        self.moves_prob.zero_()
+        self.legal_moves[:, :k].copy_(batch["legal_moves"])
+        self.moves_prob[:, :k].copy_(batch["moves_prob"])
+
+    def _capture(self):
+        self.model.train(True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._step()
+        self.captured_lr = [g["lr"] for g in self.optimizer.param_groups]
+        self.captures += 1
+
+    def step(self, batch):
+        """One training step on `batch` (the dict `torch_batch_replays` / `DeviceReplayBuffer.sample` produce).
+        The first three calls run eagerly on a side stream (optimizer state and allocator warm-up, as
+        torch.cuda.graphs asks), the fourth captures."""
+        self._load(batch)
+        lr = [g["lr"] for g in self.optimizer.param_groups]
+        if self.graph is not None and lr != self.captured_lr:
+            self.graph = None                                   # the scheduler moved: capture again with the new rate
+        if self.graph is None:
+            self.model.train(True)
+            if self.captures == 0 and getattr(self, "_warm", 0) < 3:
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    self._step()
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                self._warm = getattr(self, "_warm", 0) + 1
+                return self.loss
+            torch.cuda.synchronize(self.device)
+            self._capture()        # capturing RUNS nothing: the captured step is this batch's, replayed below
+        self.graph.replay()
+        return self.loss
+
+    def outputs(self, k: int):
+        """(value, moves_logprob[:, :k]) of the last step, as `Network.run` returns them."""
+        return {"value": self.out_value, "moves_logprob": self.out_logprob[:, :k]}
+
+
 def initialize_replay_buffer(pool, game_factory, size: int) -> ReplayBuffer:
     """Fill a buffer with random-mover games (policy_trainer.py:145-158)."""
     player = Player(pool, [AzaleaAgent(game_factory)])
@@ -99,6 +199,11 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
         loader = DataLoader(replaybuf, batch_size=batch_size, shuffle=True, pin_memory=(device.type == "cuda"),
                             num_workers=config.get("num_dataloader_workers", 0), collate_fn=torch_batch_replays)
         batches = lambda: iter(loader)
+    # config["train_step_graph"]: full batches go through the captured step (GraphedTrainStep); their losses stay on
+    # the device until the next log line.  The epoch's ragged last batch takes the eager step.
+    gstep = (GraphedTrainStep(policy.net, optimizer, batch_size, device)
+             if config.get("train_step_graph") and device.type == "cuda" else None)
+    loss_dev = None
     loss, step, start_time = 0.0, 0, time.time()
     for epoch in range(1, config["total_epochs"] + 1):
         # The reference calls scheduler.step() at the top of every epoch (policy_trainer.py:81) under the torch
@@ -111,10 +216,16 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
             history.setdefault("lr", []).append(optimizer.param_groups[0]["lr"])
         for batch in batches():
             batch = game_class.random_reflect(batch)
-            output, loss_ = supervised_step(policy.net, batch, train=True, optimizer=optimizer, device=device)
-            loss += loss_
+            if gstep is not None and len(batch["reward"]) == batch_size:
+                l3 = gstep.step({k: v.to(device) for k, v in batch.items()})
+                loss_dev = l3[0].clone() if loss_dev is None else loss_dev + l3[0]
+            else:
+                output, loss_ = supervised_step(policy.net, batch, train=True, optimizer=optimizer, device=device)
+                loss += loss_
             replaybuf.consume(batch_size / oversampling, player)
             if config.get("log_interval") and step % config["log_interval"] == 0:
+                if loss_dev is not None:
+                    loss, loss_dev = loss + float(loss_dev.item()), None
                 sps = config["log_interval"] / max(1e-9, time.time() - start_time)
                 logging.info("step %d loss %.4f steps/sec %.2f", step, loss / config["log_interval"], sps)
                 loss, start_time = 0.0, time.time()

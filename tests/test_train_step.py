@@ -54,9 +54,60 @@ def test_supervised_step_matches_reference_gpu():
 
 
 @pytest.mark.gpu
-def test_train_loop_with_device_replay(tmp_path):
+def test_graphed_train_step_matches_the_eager_step():
+    """GraphedTrainStep (the step captured as a HIP graph, inputs padded to all cells, embedding by masks) against
+    supervised_step on the same batches: the three G9 batches cycled four times from G9's initial weights, the learning
+    rate changed after the eighth step (the graph is captured at step 4 and again at step 9).  Per-step losses and
+    outputs, then every updated tensor."""
+    from azalea_amd.network import HexNetwork
+    from azalea_amd.policy_trainer import GraphedTrainStep, supervised_step
+    from azalea_amd.prep import torch_batch_replays
+    z = np.load(os.path.join(GOLDEN, "g9_train_step.npz"))
+    frame = source_frame(load_g7())
+    dev = "cuda:0"
+    nets, opts = [], []
+    for _ in range(2):
+        net = HexNetwork(board_size=11, num_blocks=2, base_chans=16)
+        net.load_state_dict({k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith("w0:")})
+        net.to(dev)
+        nets.append(net)
+        opts.append(torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4))
+    B = len(z["batch_idx"][0])
+    TOLG = 1e-4      # graphed vs eager on the same device: same kernels but for the embedding and the padding
+    gstep = GraphedTrainStep(nets[1], opts[1], B, dev)
+    worst = 0.0
+    for step in range(12):
+        if step == 8:
+            for o in opts:
+                o.param_groups[0]["lr"] = 0.03
+        ids = z["batch_idx"][step % 3]
+        batch = torch_batch_replays([frame[int(i)] for i in ids])
+        o, loss = supervised_step(nets[0], dict(batch), train=True, optimizer=opts[0], device=dev)
+        gl = gstep.step({k: v.to(dev) for k, v in batch.items()}).cpu().numpy()
+        k = batch["legal_moves"].shape[1]
+        go = gstep.outputs(k)
+        assert abs(float(gl[0]) - loss) <= TOLG and abs(float(gl[1]) - o["value_loss"]) <= TOLG and abs(float(gl[2]) - o["moves_loss"]) <= TOLG
+        legal = batch["legal_moves"].numpy() > 0
+        worst = max(worst, float(np.abs(go["value"].cpu().numpy() - o["value"].cpu().numpy()).max()),
+                    float(np.abs(go["moves_logprob"].cpu().numpy() - o["moves_logprob"].cpu().numpy())[legal].max()))
+        if step < 3:      # the first three are also the reference's recorded steps
+            assert abs(float(gl[0]) - float(z["step%d_loss" % step])) <= 2e-3  # the GPU tolerance of the golden itself (2e-4 x 10)
+    assert gstep.captures == 2
+    assert worst <= TOLG, worst
+    a, b = nets[0].state_dict(), nets[1].state_dict()
+    for name, v in a.items():
+        if v.dtype.is_floating_point:
+            assert float((v - b[name]).abs().max()) <= TOLG, name
+        else:
+            assert torch.equal(v, b[name]), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graphed", [False, True])
+def test_train_loop_with_device_replay(tmp_path, graphed):
     """policy_trainer.train end to end on the GPU: engine self-play -> HBM replay ring -> GPU collate
-    -> supervised_step; the checkpoint it writes loads back through Policy.load."""
+    -> supervised_step (or, with config["train_step_graph"], the captured step); the checkpoint it writes loads back
+    through Policy.load."""
     from azalea_amd.policy import Policy
     from azalea_amd.policy_trainer import initialize_replay_buffer, train
     from azalea_amd.game.hex import HexGame
@@ -65,7 +116,7 @@ def test_train_loop_with_device_replay(tmp_path):
                   lr_decay_epochs=2, lr_decay=0.5, total_epochs=4, network="HexNetwork", num_blocks=1, base_chans=8,
                   simulations=20, search_batch_size=10, exploration_coef=0.5, exploration_depth=4,
                   exploration_noise_alpha=0.3, exploration_noise_scale=0.25, exploration_temperature=1.0,
-                  log_interval=2, model_checkpoint_interval=0, selfplay_games=16)
+                  log_interval=2, model_checkpoint_interval=0, selfplay_games=16, train_step_graph=graphed)
     policy = Policy()
     policy.initialize(config)
     before = {k: v.clone() for k, v in policy.net.state_dict().items()}

@@ -93,6 +93,24 @@ def main():
                              "positions_per_sec": args.steps * B / total, "ms_per_step": 1e3 * total / args.steps,
                              "fresh_rows_per_sec_consumed": args.steps * B / args.oversampling / total,
                              "mean_loss": float(acc.item()) / (args.steps + args.warmup)})
+    # the step captured as a HIP graph (policy_trainer.GraphedTrainStep): one graph launch per step
+    from azalea_amd.policy_trainer import GraphedTrainStep
+    for B in args.batch:
+        net = HexNetwork(board_size=11, num_blocks=6, base_chans=64).to(dev).train()
+        opt = optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+        gs = GraphedTrainStep(net, opt, B, dev)
+        order = np.resize(buf.epoch_indices(), (args.steps + args.warmup) * B)
+        for i in range(args.steps + args.warmup):
+            if i == args.warmup:
+                torch.cuda.synchronize()
+                t_all = time.perf_counter()
+            l3 = gs.step(buf.sample(order[i * B:(i + 1) * B]))
+        torch.cuda.synchronize()
+        total = time.perf_counter() - t_all
+        out["lines"].append({"batch": B, "mode": "hip graph (GraphedTrainStep)", "steps_per_sec": args.steps / total,
+                             "positions_per_sec": args.steps * B / total, "ms_per_step": 1e3 * total / args.steps,
+                             "fresh_rows_per_sec_consumed": args.steps * B / args.oversampling / total,
+                             "last_loss": float(l3[0].item())})
     E.close()
     out["note"] = ("stock PyTorch-ROCm fp32 (MIOpen / rocBLAS), one stream, loss.item() per step as the reference; "
                    "self-play on one MI355X produces ~1.2e4 rows/s (bench.py 'api' leg)")
