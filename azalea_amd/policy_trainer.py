@@ -40,6 +40,14 @@ def supervised_step(model, batch, *, train=False, optimizer=None, device="cpu"):
     return output, loss.item()
 
 
+def embed_by_masks(model, board):
+    """`model.encoder(board.long())` as (board == v) masks times the embedding matrix: [B,N,N] -> [B,4,N,N], the same
+    values bit for bit (1*w + 0*w' + 0*w'' = w), with a backward that is a plain reduction."""
+    w = model.encoder.weight
+    x = sum((board == v).unsqueeze(-1).to(w.dtype) * w[v] for v in range(w.shape[0]))
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
 class GraphedTrainStep:
     """`supervised_step(model, batch, train=True, optimizer=...)` captured once as a HIP graph and replayed.
 
@@ -75,11 +83,7 @@ class GraphedTrainStep:
         self.captures = 0
 
     def _forward(self):
-        m = self.model
-        w = m.encoder.weight
-        x = sum((self.board == v).unsqueeze(-1).to(w.dtype) * w[v] for v in range(w.shape[0]))
-        x = x.permute(0, 3, 1, 2).contiguous()
-        return m.forward_embedded(x, self.legal_moves)
+        return self.model.forward_embedded(embed_by_masks(self.model, self.board), self.legal_moves)
 
     def _step(self):
         self.optimizer.zero_grad(set_to_none=True)

@@ -44,6 +44,37 @@ def run_steps(device, tol_w):
     assert np.abs(o["value"].cpu().numpy() - z["eval_value"]).max() <= tol_w * 10
 
 
+def test_graphed_step_forward_is_the_eager_forward():
+    """The two things GraphedTrainStep changes about the forward pass, checked on the CPU: the embedding applied as
+    masks times the embedding matrix equals nn.Embedding bit for bit, and padding legal_moves / moves_prob to all
+    cells leaves every legal log-probability and both losses where they were (the padded logits are -99)."""
+    from azalea_amd.network import HexNetwork
+    from azalea_amd.policy_trainer import embed_by_masks
+    from azalea_amd.prep import torch_batch_replays
+    import torch.nn.functional as F
+    z = np.load(os.path.join(GOLDEN, "g9_train_step.npz"))
+    frame = source_frame(load_g7())
+    net = HexNetwork(board_size=11, num_blocks=2, base_chans=16).eval()
+    net.load_state_dict({k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith("w0:")})
+    batch = torch_batch_replays([frame[int(i)] for i in z["batch_idx"][0]])
+    with torch.no_grad():
+        want = net.encoder(batch["board"].long()).permute(0, 3, 1, 2).contiguous()
+        got = embed_by_masks(net, batch["board"])
+        assert torch.equal(want, got)
+        B, k = batch["legal_moves"].shape
+        lm = torch.zeros((B, 121), dtype=batch["legal_moves"].dtype)
+        mp = torch.zeros((B, 121), dtype=batch["moves_prob"].dtype)
+        lm[:, :k], mp[:, :k] = batch["legal_moves"], batch["moves_prob"]
+        a = net.forward(batch["board"], batch["legal_moves"])
+        b = net.forward_embedded(got, lm)
+        legal = batch["legal_moves"] > 0
+        assert torch.equal(a["value"], b["value"])
+        assert float((a["moves_logprob"] - b["moves_logprob"][:, :k])[legal].abs().max()) <= 1e-6
+        la = -(batch["moves_prob"] * a["moves_logprob"]).sum() / B
+        lb = -(mp * b["moves_logprob"]).sum() / B
+        assert abs(float(la) - float(lb)) <= 1e-6
+
+
 def test_supervised_step_matches_reference_cpu():
     run_steps("cpu", 2e-6)
 
