@@ -81,6 +81,7 @@ class GraphedTrainStep:
         self.graph = None
         self.captured_lr = None
         self.captures = 0
+        self._warm = 0                   # eager steps run so far (optimizer state / allocator warm-up before capture)
 
     def _forward(self):
         return self.model.forward_embedded(embed_by_masks(self.model, self.board), self.legal_moves)
@@ -126,13 +127,13 @@ class GraphedTrainStep:
             self.graph = None                                   # the scheduler moved: capture again with the new rate
         if self.graph is None:
             self.model.train(True)
-            if self.captures == 0 and getattr(self, "_warm", 0) < 3:
+            if self.captures == 0 and self._warm < 3:
                 side = torch.cuda.Stream(device=self.device)
                 side.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(side):
                     self._step()
                 torch.cuda.current_stream(self.device).wait_stream(side)
-                self._warm = getattr(self, "_warm", 0) + 1
+                self._warm += 1
                 return self.loss
             torch.cuda.synchronize(self.device)
             self._capture()        # capturing RUNS nothing: the captured step is this batch's, replayed below
