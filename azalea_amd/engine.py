@@ -54,7 +54,13 @@ class Engine:
         check(self.L.azx_set_prior_table(self.h, _p(t, C.c_float), t.size))
 
     def set_weights(self, tensors, on_device=False):
-        """tensors: {state_dict name: contiguous fp32 numpy array} or {name: (ptr, count)}."""
+        """tensors: {state_dict name: contiguous fp32 numpy array} or {name: (ptr, count)}.
+        `on_device`: the pointers are device memory of this GPU (torch tensors).  The engine copies them through its
+        own HIP runtime, which knows nothing of torch's streams, so whatever last wrote them -- an optimizer step
+        still in flight, a graph replay -- is waited for here."""
+        if on_device:
+            import torch
+            torch.cuda.synchronize(self.cfg.device)
         names, ptrs, counts, keep = [], [], [], []
         for name, t in tensors.items():
             if name.endswith("num_batches_tracked"):

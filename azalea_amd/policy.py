@@ -169,7 +169,8 @@ class Policy:
         if not self._uses_device_net():
             return
         sd = self._net.state_dict()
-        version = tuple(int(t._version) for t in sd.values()) + (id(self._net),)
+        version = tuple(int(t._version) for t in sd.values()) + (id(self._net),
+                                                                 getattr(self._net, "weight_updates_outside_autograd", 0))
         if version == self._weights_version:
             return
         tensors = {k: v for k, v in sd.items() if v.dtype == torch.float32}

@@ -138,6 +138,9 @@ class GraphedTrainStep:
             torch.cuda.synchronize(self.device)
             self._capture()        # capturing RUNS nothing: the captured step is this batch's, replayed below
         self.graph.replay()
+        # a replay updates the parameters without going through the dispatcher, so their autograd version counters --
+        # which Policy._sync_weights watches to know when to re-pack the engine's weights -- do not move: say so here
+        self.model.weight_updates_outside_autograd = getattr(self.model, "weight_updates_outside_autograd", 0) + 1
         return self.loss
 
     def outputs(self, k: int):

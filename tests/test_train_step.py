@@ -134,6 +134,53 @@ def test_graphed_train_step_matches_the_eager_step():
 
 
 @pytest.mark.gpu
+def test_policy_engine_sees_weights_updated_by_graph_replays():
+    """A graph replay updates the parameters without moving their autograd version counters, which is what
+    Policy._sync_weights watches: after graphed training steps the Policy's own engine (parity mode: choose_action,
+    evaluate) must evaluate with the NEW weights."""
+    from azalea_amd.policy import Policy
+    from azalea_amd.policy_trainer import GraphedTrainStep
+    from azalea_amd.prep import torch_batch_replays
+    dev = "cuda:0"
+    p = Policy()
+    p.initialize(dict(device=dev, network="HexNetwork", board_size=11, num_blocks=2, base_chans=64, simulations=20,
+                      search_batch_size=10, exploration_coef=0.5, exploration_depth=4, exploration_noise_alpha=0.3,
+                      exploration_noise_scale=0.25, exploration_temperature=1.0))
+    p.net.to(dev)
+    eng_ = p._get_engine(11)
+    board = np.zeros((1, 11, 11), np.int32)
+    lm = np.arange(1, 122, dtype=np.int32)[None]
+
+    def engine_value():
+        p._sync_weights(eng_)
+        return float(eng_.forward(board, lm)[0][0])
+
+    def torch_value():
+        p.net.eval()
+        with torch.no_grad():
+            return float(p.net(torch.tensor(board, device=dev), torch.tensor(lm, device=dev))["value"][0])
+
+    v0 = engine_value()
+    assert abs(v0 - torch_value()) <= 1e-4
+    z = np.load(os.path.join(GOLDEN, "g9_train_step.npz"))
+    frame = source_frame(load_g7())
+    opt = torch.optim.SGD(p.net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    B = len(z["batch_idx"][0])
+    gs = GraphedTrainStep(p.net, opt, B, dev)
+    for step in range(5):                                  # three eager warm-up steps, then capture + replay
+        batch = torch_batch_replays([frame[int(i)] for i in z["batch_idx"][step % 3]])
+        gs.step({k: v.to(dev) for k, v in batch.items()})
+    v1 = engine_value()                                    # synced after the capture: versions as they will stay
+    assert abs(v1 - torch_value()) <= 1e-4
+    for step in range(5, 9):                               # replays only
+        batch = torch_batch_replays([frame[int(i)] for i in z["batch_idx"][step % 3]])
+        gs.step({k: v.to(dev) for k, v in batch.items()})
+    tv = torch_value()
+    assert abs(tv - v1) > 1e-3                             # the weights did move
+    assert abs(engine_value() - tv) <= 1e-4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("graphed", [False, True])
 def test_train_loop_with_device_replay(tmp_path, graphed):
     """policy_trainer.train end to end on the GPU: engine self-play -> HBM replay ring -> GPU collate
