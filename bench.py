@@ -18,7 +18,9 @@ default line: "config5" -- BASELINE configs[4]'s shape on this one GPU (13x13, 1
 `--c5-games` games, one warm-up and one timed move) with its own `roofline` (the wide tower's per-layer MFMA
 kernel) and `cpu_baseline` -- and "api": the product surface the trainer calls (Player.read, parallel_player.py:
 24-28) driven for `--api-moves` engine moves after the pool transplant, rows/s over the last 60 of them beside
-the plies/s the engine played in the same window.
+the plies/s the engine played in the same window.  A last nested leg stands beside the path, not on it:
+"train_step" -- the reference's training step at its own batch size on the HBM replay ring, eager and captured as a
+HIP graph (`--no-train-step` skips it).
 
 Steady state: a pool that restarts finished games in place is, after its first game, spread over
 all plies.  Starting every slot from the empty board would time the opening only (no game can end
@@ -223,6 +225,48 @@ def config5_args(args):
     a.settle = 2 * a.board * a.board
     a.nodes_per_game = 0
     return a
+
+
+def run_train_step(args, local_rank, torch):
+    """SURVEY 8(f).4 beside the path: the reference's training step (policy_trainer.py:123-142) at its own batch of 128
+    (config/hex11_train_config.yml), fed from the HBM replay ring, as the reference runs it (eager, a host sync per
+    step) and captured as a HIP graph (policy_trainer.GraphedTrainStep).  Stock PyTorch-ROCm kernels either way."""
+    import numpy as np
+    from torch import optim
+    from azalea_amd import engine as eng
+    from azalea_amd.device_replay import DeviceReplayBuffer
+    from azalea_amd.network import HexNetwork
+    from azalea_amd.policy_trainer import GraphedTrainStep, supervised_step
+    dev = torch.device("cuda", local_rank)
+    B, steps, warm = 128, 60, 10
+    E = eng.Engine(board_size=args.board, n_games=1024, simulations=50, search_batch_size=10,
+                   evaluator=eng.EVAL_UNIFORM, noise_scale=0.25, device=local_rank)
+    buf = DeviceReplayBuffer(E, 20000, shared=False)
+    E.replay_fill(20000)
+    out = {"what": "policy_trainer.supervised_step(train=True): %dx%d on %dx%d, SGD(momentum 0.9, weight decay 1e-4), "
+                   "batch %d collated from a %d-row HBM ring; stock PyTorch-ROCm fp32"
+                   % (args.blocks, args.chans, args.board, args.board, B, len(buf)), "batch": B, "steps": steps}
+    torch.manual_seed(0)
+    order = np.resize(buf.epoch_indices(), (steps + warm) * B)
+    for mode in ("eager", "hip_graph"):
+        net = HexNetwork(board_size=args.board, num_blocks=args.blocks, base_chans=args.chans).to(dev)
+        opt = optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+        gs = GraphedTrainStep(net, opt, B, dev) if mode == "hip_graph" else None
+        for i in range(steps + warm):
+            if i == warm:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            batch = buf.sample(order[i * B:(i + 1) * B])
+            if gs is None:
+                supervised_step(net, batch, train=True, optimizer=opt, device=dev)
+            else:
+                gs.step(batch)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        out[mode] = {"steps_per_sec": steps / dt, "ms_per_step": 1e3 * dt / steps, "positions_per_sec": steps * B / dt}
+    E.close()
+    out["speedup"] = out["hip_graph"]["steps_per_sec"] / out["eager"]["steps_per_sec"]
+    return out
 
 
 def run_api(args, rank, world, local_rank, start, torch):
@@ -452,6 +496,7 @@ def main():
     ap.add_argument("--no-config5", action="store_true", help="skip the nested configs[4]-shape leg")
     ap.add_argument("--api-moves", type=int, default=190,
                     help="engine moves the nested product-surface leg (Player.read) is driven for; 0 = skip")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the nested training-step leg (SURVEY 8(f).4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-replay-exchange", action="store_true")
     ap.add_argument("--exchange-plies", type=int, default=0,
@@ -613,6 +658,13 @@ def main():
             line["rows_per_sec"] = api["rows_per_sec"]
         except Exception as exc:
             line["api"] = {"error": repr(exc)}
+
+    # ---- nested leg beside the path: the reference's training step on the replay ring, eager and captured ----
+    if args.workload == "selfplay" and not args.no_train_step and world == 1 and (args.board, args.blocks, args.chans) == (11, 6, 64):
+        try:
+            line["train_step"] = run_train_step(args, local_rank, torch)
+        except Exception as exc:
+            line["train_step"] = {"error": repr(exc)}
 
     if rank == 0:
         print(json.dumps(line))

@@ -36,7 +36,7 @@ def test_default_line_is_the_selfplay_headline_with_the_tree_numbers_nested():
     d = _run("--steps", "2", "--warmup", "1", "--games", "64", "--sims", "40", "--tree-steps", "6",
              "--tree-warmup", "2", "--board", "7", "--blocks", "1", "--api-moves", "70")
     _check_common(d, 2, 1)
-    assert "config5" not in d                                  # only nested under the 11x11 / 6x64 headline
+    assert "config5" not in d and "train_step" not in d        # only nested under the 11x11 / 6x64 headline
     a = d["api"]                                               # the product surface, a game length after the transplant
     assert a["moves_since_transplant"] >= 70 and a["rows"] > 0 and d["rows_per_sec"] == a["rows_per_sec"] > 0
     assert 0.5 < a["rows_over_plies"] < 1.5 and 0 <= a["host_overhead_frac"] < 1
@@ -83,6 +83,9 @@ def test_default_line_nests_the_config5_shape_with_roofline_and_cpu_baseline():
     b = c5["cpu_baseline"]
     assert b["kind"] == "port" and b["value"] > 0 and "bounded sample" in b["sample"] and "19x256" in b["sample"]
     assert "k_conv_wide_f16x3_s16" in c5["kernels"]
+    ts = d["train_step"]                                      # beside the path: SURVEY 8(f).4, eager and captured
+    assert ts["batch"] == 128 and ts["eager"]["steps_per_sec"] > 0 and ts["hip_graph"]["steps_per_sec"] > 0
+    assert abs(ts["speedup"] - ts["hip_graph"]["steps_per_sec"] / ts["eager"]["steps_per_sec"]) < 1e-9
 
 
 def test_tree_bench_line():
