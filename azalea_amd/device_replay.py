@@ -149,6 +149,22 @@ class DeviceReplayBuffer:
         out["board"] = out["board"].view(B, n, n)
         return out
 
+    def collate_into(self, indices, out: Dict[str, torch.Tensor]) -> int:
+        """`sample` without allocations: the six batch tensors are the caller's (full width: legal_moves /
+        moves_prob / board [B, cells], contiguous, the dtypes `sample` uses) and are written in place, zero padded to
+        all cells; returns the batch's widest row.  For a consumer with static input buffers (GraphedTrainStep)."""
+        idx = np.asarray(indices, np.int64).reshape(-1)
+        B, cells = len(idx), self.engine.n * self.engine.n
+        want = dict(color=((B,), torch.int64), legal_moves=((B, cells), torch.int32), result=((B,), torch.int64),
+                    board=((B, cells), torch.int32), moves_prob=((B, cells), torch.float32), reward=((B,), torch.float32))
+        for name, (shape, dtype) in want.items():
+            t = out[name]
+            if t.dtype != dtype or t.numel() != int(np.prod(shape)) or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("collate_into: '%s' must be a contiguous %s tensor of %s elements on %s"
+                                 % (name, dtype, shape, self.device))
+        torch.cuda.synchronize(self.device)      # whatever still reads the buffers (a graph replay) has finished
+        return int(self.engine.replay_collate(idx, {name: out[name].data_ptr() for name in want}))
+
     def epoch_indices(self) -> np.ndarray:
         """The order a fresh `iter(DataLoader(..., shuffle=True))` visits the rows in: the loader
         draws its worker base seed from the global RNG first, then RandomSampler seeds a private

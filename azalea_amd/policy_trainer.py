@@ -78,6 +78,8 @@ class GraphedTrainStep:
         self.loss = torch.zeros(3, dtype=torch.float32, device=dev)       # total, value, moves
         self.out_value = torch.zeros(self.B, dtype=torch.float32, device=dev)
         self.out_logprob = torch.zeros((self.B, self.cells), dtype=torch.float32, device=dev)
+        self._color = torch.zeros(self.B, dtype=torch.int64, device=dev)      # collate_into's other two outputs
+        self._result = torch.zeros(self.B, dtype=torch.int64, device=dev)
         self.graph = None
         self.captured_lr = None
         self.captures = 0
@@ -117,11 +119,22 @@ class GraphedTrainStep:
         self.captured_lr = [g["lr"] for g in self.optimizer.param_groups]
         self.captures += 1
 
+    def step_from_ring(self, replaybuf, indices):
+        """One training step on the rows `indices` of a DeviceReplayBuffer: azx_replay_collate writes them straight
+        into the step's static input tensors (no batch tensors allocated, nothing copied).  Returns (loss tensors,
+        widest row of the batch)."""
+        k = replaybuf.collate_into(indices, dict(color=self._color, legal_moves=self.legal_moves, result=self._result,
+                                                  board=self.board, moves_prob=self.moves_prob, reward=self.reward))
+        return self._run(), k
+
     def step(self, batch):
         """One training step on `batch` (the dict `torch_batch_replays` / `DeviceReplayBuffer.sample` produce).
         The first three calls run eagerly on a side stream (optimizer state and allocator warm-up, as
         torch.cuda.graphs asks), the fourth captures."""
         self._load(batch)
+        return self._run()
+
+    def _run(self):
         lr = [g["lr"] for g in self.optimizer.param_groups]
         if self.graph is not None and lr != self.captured_lr:
             self.graph = None                                   # the scheduler moved: capture again with the new rate
@@ -198,11 +211,20 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
     policy.settings["move_sampling"] = True
     agent = AzaleaAgent(game_factory, policy=policy, device=config["device"])
     player = Player(None, [agent], n_games=config.get("selfplay_games"))
+    from_ring = False
     if device_replay:
         from .device_replay import DeviceReplayBuffer
         if not isinstance(replaybuf, DeviceReplayBuffer):
             replaybuf = DeviceReplayBuffer(player.device_engine(), len(replaybuf), replaybuf)
         batches = lambda: replaybuf.loader(batch_size)
+        if config.get("train_step_graph") and device.type == "cuda":
+            # the captured step reads its rows straight from the ring: iterate the epoch's index chunks, the same
+            # order loader() visits (random_reflect is the identity for Hex, hex.py:124-134)
+            def index_chunks():
+                order = replaybuf.epoch_indices()
+                for s in range(0, len(order), batch_size):
+                    yield order[s:s + batch_size]
+            batches, from_ring = index_chunks, True
     else:
         loader = DataLoader(replaybuf, batch_size=batch_size, shuffle=True, pin_memory=(device.type == "cuda"),
                             num_workers=config.get("num_dataloader_workers", 0), collate_fn=torch_batch_replays)
@@ -222,14 +244,23 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
             scheduler.step()
         if history is not None:
             history.setdefault("lr", []).append(optimizer.param_groups[0]["lr"])
-        for batch in batches():
-            batch = game_class.random_reflect(batch)
-            if gstep is not None and len(batch["reward"]) == batch_size:
-                l3 = gstep.step({k: v.to(device) for k, v in batch.items()})
-                loss_dev = l3[0].clone() if loss_dev is None else loss_dev + l3[0]
-            else:
-                output, loss_ = supervised_step(policy.net, batch, train=True, optimizer=optimizer, device=device)
-                loss += loss_
+        for item in batches():
+            batch = item
+            if from_ring:                                        # item: a chunk of ring row indices
+                if len(item) == batch_size:
+                    l3, _ = gstep.step_from_ring(replaybuf, item)
+                    loss_dev = l3[0].clone() if loss_dev is None else loss_dev + l3[0]
+                    batch = None
+                else:
+                    batch = replaybuf.sample(item)              # the epoch's ragged last chunk: eager step below
+            if batch is not None:
+                batch = game_class.random_reflect(batch)
+                if gstep is not None and len(batch["reward"]) == batch_size:
+                    l3 = gstep.step({k: v.to(device) for k, v in batch.items()})
+                    loss_dev = l3[0].clone() if loss_dev is None else loss_dev + l3[0]
+                else:
+                    output, loss_ = supervised_step(policy.net, batch, train=True, optimizer=optimizer, device=device)
+                    loss += loss_
             replaybuf.consume(batch_size / oversampling, player)
             if config.get("log_interval") and step % config["log_interval"] == 0:
                 if loss_dev is not None:

@@ -104,10 +104,10 @@ def main():
             if i == args.warmup:
                 torch.cuda.synchronize()
                 t_all = time.perf_counter()
-            l3 = gs.step(buf.sample(order[i * B:(i + 1) * B]))
+            l3, _ = gs.step_from_ring(buf, order[i * B:(i + 1) * B])
         torch.cuda.synchronize()
         total = time.perf_counter() - t_all
-        out["lines"].append({"batch": B, "mode": "hip graph (GraphedTrainStep)", "steps_per_sec": args.steps / total,
+        out["lines"].append({"batch": B, "mode": "hip graph fed from the ring (GraphedTrainStep.step_from_ring)", "steps_per_sec": args.steps / total,
                              "positions_per_sec": args.steps * B / total, "ms_per_step": 1e3 * total / args.steps,
                              "fresh_rows_per_sec_consumed": args.steps * B / args.oversampling / total,
                              "last_loss": float(l3[0].item())})
