@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""The trainer's loop as one GPU runs it (policy_trainer.py:82-90: a training step, then
+`replaybuf.consume(batch_size / oversampling, player)`), at the reference's hyper-parameters (6x64 on 11x11, batch 128,
+10x oversampling, 400-sim self-play on 4096 concurrent games): the captured training step fed from the HBM ring, with
+the refills played inline (DeviceReplayBuffer.consume), and the same steps without any refill.
+Reports steps/s and the rows the refills brought.  (Round 3 also measured the refills played UNDER the steps by a
+background thread on a second engine handle: 344.7 vs 339.6 steps/s, profiles/r3_train_loop_bench.json -- the tower
+fills every CU's registers and LDS, so the training kernels queue behind its blocks; that variant was removed.)
+    python tools/bench_train_loop.py [--steps 1200] [--games 4096] [--sims 400]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from torch import optim
+
+from azalea_amd import AzaleaAgent, HexGame, Player, Policy
+from azalea_amd.device_replay import DeviceReplayBuffer
+from azalea_amd.policy_trainer import GraphedTrainStep
+
+
+def run(mode, args):
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    policy = Policy()
+    policy.initialize(dict(device=dev, network="HexNetwork", board_size=11, num_blocks=6, base_chans=64,
+                           simulations=args.sims, search_batch_size=10, exploration_coef=0.5, exploration_depth=15,
+                           exploration_noise_alpha=0.03, exploration_noise_scale=0.25, exploration_temperature=1.0, seed=1))
+    policy.net.to(dev).train()
+    policy.settings.update(move_sampling=True, move_exploration=True)
+    agent = AzaleaAgent(lambda: HexGame(11), policy=policy, device=dev)
+    player = Player(None, [agent], n_games=args.games, gather=False)
+    E = player.device_engine()
+    buf = DeviceReplayBuffer(E, 100000, shared=False)
+    from azalea_amd import engine as eng
+    # the pool in steady state, as in bench.py: seeded random legal positions of 0..92 plies, then an untimed fill of
+    # two game lengths so that whole games are being handed over; the accounting starts from zero after it
+    player.prepare_device_engine(E)
+    E.reset(moves=eng.random_prefixes(11, np.arange(args.games), 92, 1))
+    buf.consume(args.fill, player)
+    buf.fresh_counter = 0
+    opt = optim.SGD(policy.net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    B = 128
+    gs = GraphedTrainStep(policy.net, opt, B, torch.device(dev))
+    refills, rows = [], 0
+    order = np.random.RandomState(0).randint(0, len(buf), (args.steps + 20, B))
+    for i in range(args.steps + 20):
+        if i == 20:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            refills, rows = [], 0
+        gs.step_from_ring(buf, order[i] % len(buf))
+        m = buf.consume(B / 10.0, player) if mode == "inline" else None
+        if m:
+            refills.append(time.perf_counter())
+            rows += int(m["moves_per_game"])
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    player.stop()
+    out = {"mode": mode, "steps": args.steps, "seconds": t1 - t0, "steps_per_sec": args.steps / (t1 - t0),
+           "refills": len(refills), "rows_refilled": rows}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=1600)
+    ap.add_argument("--games", type=int, default=4096)
+    ap.add_argument("--sims", type=int, default=400)
+    ap.add_argument("--fill", type=int, default=60000, help="rows of the untimed initial fill")
+    args = ap.parse_args()
+    res = [run("inline", args), run("steps only", args)]
+    print(json.dumps({"what": "captured training step (batch 128) + consume(12.8) per step; 6x64 resnet self-play, %d games, "
+                              "%d sims" % (args.games, args.sims), "runs": res,
+                      "selfplay_share_of_loop": 1.0 - res[0]["steps_per_sec"] / res[1]["steps_per_sec"]}))
+
+
+if __name__ == "__main__":
+    main()
