@@ -4,6 +4,7 @@ The HIP engine is the product: if the shared object is missing or no MI355X is v
 calls fail loudly -- there is deliberately no CPU fallback (and nothing here imports oracle/).
 """
 import ctypes as C
+import logging
 import os
 import subprocess
 
@@ -67,6 +68,7 @@ SYMBOLS = {
     "azx_create": (C.c_int, [C.POINTER(Config), C.POINTER(_vp)]),
     "azx_destroy": (None, [_vp]),
     "azx_set_weights": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(_vp), _i64p, C.c_int]),
+    "azx_debug_weights": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _i64p, C.c_char_p, C.c_int]),
     "azx_set_prior_table": (C.c_int, [_vp, _f32p, C.c_int]),
     "azx_reset": (C.c_int, [_vp, _i32p, C.c_int, _i32p, _i32p, C.c_int]),
     "azx_set_active": (C.c_int, [_vp, _i32p]),
@@ -132,12 +134,14 @@ def lib():
         # first, a later first use of torch.cuda in the same process fails with "No HIP GPUs are available" -- and
         # every Policy holds its weights in torch tensors.  So where torch is installed and sees a GPU, its runtime is
         # initialised before ours is loaded; the order then no longer depends on what the caller touched first.
-        try:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.init()
-        except Exception:      # no torch / no GPU: the engine itself reports AZX_ENODEV where it matters
-            pass
+        # (AZX_NO_TORCH_PREINIT=1 skips this for consumers of the bare C API that never touch torch.)
+        if not os.environ.get("AZX_NO_TORCH_PREINIT"):
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    torch.cuda.init()
+            except (ImportError, RuntimeError) as exc:      # no torch / no usable GPU: the engine reports AZX_ENODEV where it matters
+                logging.getLogger(__name__).debug("torch pre-initialisation skipped: %r", exc)
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)   # AttributeError if the library lacks a declared symbol

@@ -125,7 +125,7 @@ struct DevGuard {
     } while (0)
 
 extern "C" const char *azx_last_error(void) { return g_err.c_str(); }
-extern "C" int azx_version(void) { return 4; }   // 4: 8-float row metrics, azx_kernel_info, azx_debug_set_queue_cap
+extern "C" int azx_version(void) { return 5; }   // 5: AZX_ERANGE, azx_debug_weights, device-side weight pack
 
 extern "C" int azx_create(const azx_config *cfg, azx_engine **out) {
     if (!cfg || !out) return fail(AZX_EINVAL, "null argument");
@@ -280,6 +280,23 @@ extern "C" int azx_debug_set_queue_cap(azx_engine *e, int64_t rows) {
     if (!e || rows < 0) return fail(AZX_EINVAL, "bad argument");
     e->dbg_qcap = rows;
     return AZX_OK;
+}
+
+// AZX_ERANGE when a split-f16 tower launch of this call overflowed an activation (net_kernels.hip: NetDev::sat_flag)
+static int check_net_range(azx_engine *e) {
+    if (!e->net) return AZX_OK;
+    int rc = azx_net_check_range(e->net, e->stream);
+    if (rc) g_err = azx_net_error();
+    return rc;
+}
+
+extern "C" int azx_debug_weights(azx_engine *e, int which, void *out, int64_t cap, int64_t *nbytes, char *name, int name_cap) {
+    if (!e) return fail(AZX_EINVAL, "null engine");
+    ENGINE_GUARD(e);
+    if (!e->net) return fail(AZX_ESTATE, "engine was not created with AZX_EVAL_RESNET");
+    int rc = azx_net_debug_weights(e->net, which, out, cap, nbytes, name, name_cap);
+    if (rc) g_err = azx_net_error();
+    return rc;
 }
 
 extern "C" int azx_set_weights(azx_engine *e, int n_tensors, const char *const *names,
@@ -454,7 +471,7 @@ extern "C" int azx_search(azx_engine *e, const double *noise, int n_select, int 
     TRY(enqueue_search(e, false));
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(e->stream));
-    return AZX_OK;
+    return check_net_range(e);
 }
 
 static int read_pending(azx_engine *e, int *n_pending) {
@@ -462,7 +479,7 @@ static int read_pending(azx_engine *e, int *n_pending) {
     HIPCHECK(hipMemcpyAsync(&n, e->d.n_eval, sizeof n, hipMemcpyDeviceToHost, e->stream));
     HIPCHECK(hipStreamSynchronize(e->stream));
     *n_pending = n;
-    return AZX_OK;
+    return e->d.evaluator == AZX_EVAL_RESNET ? check_net_range(e) : AZX_OK;
 }
 
 extern "C" int azx_search_begin(azx_engine *e, const double *noise, int n_select, int noise_stride,
@@ -736,7 +753,7 @@ extern "C" int azx_forward(azx_engine *e, int B, int K, const int32_t *boards,
     if (!e->net) return fail(AZX_ESTATE, "engine was not created with AZX_EVAL_RESNET");
     int rc = azx_net_forward_host(e->net, B, K, boards, legal_moves, value, moves_logprob, e->stream);
     if (rc) g_err = azx_net_error();
-    return rc;
+    return rc ? rc : check_net_range(e);
 }
 
 extern "C" int azx_hex_replay(int device, int board_size, int n_games, const int32_t *moves,
@@ -918,7 +935,7 @@ extern "C" int azx_play_steps(azx_engine *e, int64_t plies, azx_play_stats *stat
     stats->positions = (int64_t)(b.c[CTR_ROWS] - a.c[CTR_ROWS]);
     stats->seconds = ms * 1e-3;
     time_collect(e, stats);
-    return AZX_OK;
+    return check_net_range(e);
 }
 
 // play whole games into the harvest queue until it holds >= min_positions rows
@@ -980,7 +997,7 @@ static int play_until(azx_engine *e, int64_t min_positions, int64_t max_plies, a
     stats->seconds = ms * 1e-3;
     time_collect(e, stats);
     *rows_out = rows;
-    return AZX_OK;
+    return check_net_range(e);
 }
 
 extern "C" int azx_play(azx_engine *e, int64_t min_positions, int64_t max_plies, int64_t cap,

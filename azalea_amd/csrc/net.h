@@ -13,6 +13,10 @@ const char *azx_net_error();
 int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void *const *ptrs,
                         const int64_t *counts, int on_device);
 bool azx_net_ready(const AzxNet *net);
+// AZX_ERANGE when a split-f16 tower launch since the last check saw an activation beyond the f16 range (blocks on st)
+int azx_net_check_range(AzxNet *net, hipStream_t st);
+// packed buffer number `which` (name, bytes, contents); *nbytes = -1 past the last one
+int azx_net_debug_weights(AzxNet *net, int which, void *out, int64_t cap, int64_t *nbytes, char *name, int name_cap);
 const char *azx_net_kernel_info(const AzxNet *net);   // which tower / heads kernels this net launches
 // evaluate the packed requests ev_board[0 .. *d.n_eval) -> ev_value, ev_prior (by original cell)
 void azx_net_eval(AzxNet *net, const DevEngine &d, hipStream_t st);

@@ -12,7 +12,7 @@
 // order so every lane fetches its 4 k-steps with one coalesced 16-byte load from L2.
 // k_heads: value/policy heads + masked softmax, one block per board.
 // k_*_generic: plain VALU fallback for channel counts the MFMA tiling does not cover.
-#include "net.h"
+#include "net_priv.h"
 
 // Diagnostic builds only (-DAZX_NET_ABLATE=bits): time the f16x3 tower without its A-fragment LDS
 // reads (1), MFMAs (2) or weight loads (4).  Outputs are garbage; the shipped build uses 0.
@@ -34,35 +34,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static thread_local std::string g_net_err;
 const char *azx_net_error() { return g_net_err.c_str(); }
 
-static int nfail(int code, const char *msg) {
+int azx_net_fail(int code, const char *msg) {
     g_net_err = msg;
     return code;
 }
+static int nfail(int code, const char *msg) { return azx_net_fail(code, msg); }
 
-struct NetDev {
-    int N, ncells, C, blocks, layers;     // layers = 2*blocks
-    // stem: embedding folded through conv1+bn1 (network.py:125,:141-142,:47-48,:73)
-    const float *stemT;    // [9][3][C]   table[tap][cell value][cout], then one all-zero row
-    const float *stem_b;   // [C]
-    const unsigned short *Ws;  // f16x3 pack of stemT as an MFMA A operand: [2 kk][2 ntile][hi,lo][64 lanes][8] f16 bits
-    const unsigned short *Ws16, *Wh16;   // the same weights in 16x16x32 fragment order (k_tower_f16x3_s16)
-    const unsigned short *Whd16;         // the heads' six 1x1 conv filters as one 16-row A tile: [kstep 2][hi,lo][lane][8]
-    const float *hbias16;                // their folded-BN biases, padded to 16
-    // tower (network.py:17-39, :50-52): BN folded into the conv weights
-    const float *Wp;       // MFMA pack [layers][9][C/8][C/32][64][4]
-    const unsigned short *Wh;  // f16x3 pack [layers*18 stages][2 kk][2 ntile][hi,lo][64 lanes][8] f16 bits
-    const float *Wg;       // generic   [layers][9][C][C]  (tap, cin, cout)
-    const float *bias;     // [layers][C]
-    // heads (network.py:54-60, :77-84, :127-128, :146)
-    const float *wv, *bv;  // [2][C], [2]
-    const float *wp, *bp;  // [4][C], [4]
-    const float *fc2T, *fc2b;   // [2*ncells][64], [64]
-    const float *fc3w, *fc3b;   // [64], [1]
-    const float *mfcT, *mfcb;   // [4*ncells][AZX_CELL_STRIDE], [AZX_CELL_STRIDE]
-    // the two FC weight matrices as fp32-MFMA B operands (k_heads_mfma): [n tile][k group of 8][64 lanes][4]
-    const float *hmP, *hmV;
-    int hm_lda;                 // LDS row stride (floats) of k_heads_mfma's feature tile
-};
 
 // ============================================================================================
 // fused residual tower on MFMA
@@ -235,14 +212,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // full-precision error is already 3.8e-5 of the 1e-4 tolerance and 7 bits gives 2.0e-4 (seeded nets G3 / G5r: 1e-6
 // -> 5e-6), tools/net_err_lib.py.  AZX_LO_BITS = explicit mantissa bits kept in every lo half, activations
 // (split2_f16) and weights (f16bits at pack time) alike, rounded to nearest.
-#ifndef AZX_LO_BITS
-#define AZX_LO_BITS 10
-#endif
-#define LO_MASK ((0xFFFFu << (10 - AZX_LO_BITS)) & 0xFFFFu)
-#define LO_RND (AZX_LO_BITS < 10 ? (1u << (9 - AZX_LO_BITS)) : 0u)
-static inline unsigned short lo_round_bits(unsigned short bits) {
-    return (unsigned short)((bits + LO_RND) & LO_MASK);
-}
 __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
@@ -351,6 +320,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
     // kind 0: conv1 of a Resblock; 1: conv2, y += x (network.py:37), the sum is the next block's
     // input; 2: stem, its output is the first block's input.  The block input stays in registers.
     f32x16 res[MW][NW];
+    float satmax = 0.f;                              // largest activation this lane has split into hi + lo halves
     auto epilogue = [&](f32x16 (&acc)[MW][NW], const float *bias, auto kind_tag) {
         constexpr int kind = decltype(kind_tag)::value;
 #pragma unroll
@@ -374,6 +344,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
                         if (kind == 1) v += res[m][n][r];
                         v = fmaxf(v, 0.0f);
                         if (kind != 0) res[m][n][r] = v;
+                        satmax = fmaxf(satmax, v);
                         _Float16 hi, lo;
                         split_f16(v, hi, lo);
                         h4[j] = hi;
@@ -610,6 +581,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
             }
         }
     }
+    if (satmax > 65504.0f) atomicOr(P.sat_flag, 1u);     // an activation left the f16 range: its hi half is +inf (NetDev::sat_flag)
     NT_MARK(6)
     NT_FLUSH
 }
@@ -706,6 +678,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
 #pragma unroll
         for (int n = 0; n < NT; ++n) b4[n] = *reinterpret_cast<const float4 *>(bias + 16 * n + 4 * lh);
     };
+    float satmax = 0.f;                              // largest activation this lane has split into hi + lo halves
     auto epilogue = [&](f32x4 (&acc)[MT][NT], const float4 (&bias4)[NT], auto kind_tag) {
         constexpr int kind = decltype(kind_tag)::value;  // 0 conv1, 1 conv2 (+ residual), 2 stem
 #pragma unroll
@@ -723,6 +696,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
                     if (kind != 0) res[m][n][j] = v;
                     v4[j] = v;
                 }
+                satmax = fmaxf(fmaxf(satmax, v4[0]), fmaxf(v4[1], fmaxf(v4[2], v4[3])));
                 uint2 h4, l4;
                 split2_f16(v4[0], v4[1], h4.x, l4.x);
                 split2_f16(v4[2], v4[3], h4.y, l4.y);
@@ -926,6 +900,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
             }
         }
     }
+    if (satmax > 65504.0f) atomicOr(P.sat_flag, 1u);     // an activation left the f16 range: its hi half is +inf (NetDev::sat_flag)
     NT_MARK(6)
     NT_FLUSH
 }
@@ -956,6 +931,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3(NetDev P, int layer,
                                                             float *__restrict__ out32,
                                                             const int32_t *__restrict__ n_eval_ptr, int n_eval_host) {
     constexpr int MW = WIDE_MW, NW = WIDE_NW, ROWB = WIDE_ROWB;
+    float satmax = 0.f;
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
     const int e = blockIdx.x;
@@ -1107,6 +1083,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3(NetDev P, int layer,
                         v += rv[j];
                         v = fmaxf(v, 0.0f);
                         vv[j] = v;
+                        satmax = fmaxf(satmax, v);
                         _Float16 hi, lo;
                         split_f16(v, hi, lo);
                         h4[j] = hi;
@@ -1121,6 +1098,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3(NetDev P, int layer,
             }
         }
     }
+    if (satmax > 65504.0f) atomicOr(P.sat_flag, 1u);     // an activation left the f16 range: its hi half is +inf (NetDev::sat_flag)
 }
 
 // ---- the wide tower on v_mfma_f32_16x16x32_f16 (see k_tower_f16x3_s16 for why) ----------------
@@ -1145,6 +1123,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
                                                                 const int32_t *__restrict__ n_eval_ptr, int n_eval_host,
                                                                 int e_base, int e_end) {
     constexpr int MT = WIDE16_MT, NT = WIDE16_NT, ROWB = WIDE_ROWB;
+    float satmax = 0.f;
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
     const int C = P.C, N = P.N, ncells = P.ncells;
@@ -1380,6 +1359,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
                 float vv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) vv[j] = fmaxf(acc[m][2 * np + (j >> 2)][j & 3], 0.0f);
+                satmax = fmaxf(fmaxf(fmaxf(satmax, vv[0]), fmaxf(vv[1], vv[2])), fmaxf(fmaxf(vv[3], vv[4]), fmaxf(vv[5], fmaxf(vv[6], vv[7]))));
                 uint4 h8, l8;
                 split2_f16(vv[0], vv[1], h8.x, l8.x);
                 split2_f16(vv[2], vv[3], h8.y, l8.y);
@@ -1399,6 +1379,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
 #ifdef AZX_NET_STAMP
     __builtin_amdgcn_s_waitcnt(0);      // the stores have been acknowledged: their time belongs to the epilogue
 #endif
+    if (satmax > 65504.0f) atomicOr(P.sat_flag, 1u);     // an activation left the f16 range: its hi half is +inf (NetDev::sat_flag)
     NT_MARK(3)
     WT_FLUSH
 }
@@ -1409,6 +1390,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_wide_f16x3(NetDev P, const uint
                                                             unsigned short *out, float *__restrict__ out32,
                                                             const int32_t *__restrict__ n_eval_ptr, int n_eval_host) {
     constexpr int MW = WIDE_MW, NW = WIDE_NW;
+    float satmax = 0.f;
     __shared__ unsigned char cells[(AZX_MAX_BOARD + 2) * (AZX_MAX_BOARD + 2) + 15];
     const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
     const int e = blockIdx.x;
@@ -1495,6 +1477,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_wide_f16x3(NetDev P, const uint
                     for (int j = 0; j < 4; ++j) {
                         const float v = fmaxf(acc[m][n][4 * g4 + j] + bv[j], 0.0f);
                         vv[j] = v;
+                        satmax = fmaxf(satmax, v);
                         _Float16 hi, lo;
                         split_f16(v, hi, lo);
                         h4[j] = hi;
@@ -1509,6 +1492,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_wide_f16x3(NetDev P, const uint
             }
         }
     }
+    if (satmax > 65504.0f) atomicOr(P.sat_flag, 1u);     // an activation left the f16 range: its hi half is +inf (NetDev::sat_flag)
 }
 
 // ============================================================================================
@@ -1968,44 +1952,7 @@ __global__ __launch_bounds__(192 * HEADS_KSPLIT) void k_heads(NetDev P, const fl
 // ============================================================================================
 // host side
 // ============================================================================================
-struct AzxNet {
-    NetDev d;
-    int max_evals = 0;
-    bool ready = false;
-    bool use_mfma = false;
-    hipStream_t stream = nullptr;
-    std::vector<void *> allocs;
-    size_t persistent_allocs = 0;    // allocs[0..persistent) live as long as the net; the rest are the current weights
-    float *act = nullptr, *act2 = nullptr, *act3 = nullptr;   // [E][ncells][C]
-    unsigned short *wideX = nullptr, *wideY = nullptr;        // wide tower: [E][ncells][C hi | C lo] f16
-    float *logit = nullptr;                                     // [E][AZX_CELL_STRIDE]
-    float *hfeat = nullptr;                                     // [E][6][ncells] head features from the fused tower
-    // host-forward staging
-    uint8_t *hb_board = nullptr;
-    int32_t *hb_flip = nullptr;
-    float *hb_value = nullptr;
-    size_t lds_bytes = 0;
-    int tower_variant = 0;
-    // wide tower: the second half of a batch's boards runs its layer launches on a second stream
-    hipStream_t stream2[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-    bool streams_ok = false;
-    // diagnostic switches, read once per engine by azx_net_create (azx_net_kernel_info reports the outcome)
-    bool opt_split_m = true;    // AZX_TOWER_SPLIT=0: the 6x64 tower without the fused head convs / position split
-    int opt_shape = 16;         // AZX_TOWER_SHAPE=32: the 32x32x16 MFMA kernels
-    int opt_wsplit = 2;         // AZX_WIDE_STREAMS: streams the wide tower's layer launches are spread over
-    bool opt_heads_mfma = true; // AZX_HEADS=valu: the scalar-FMA k_heads behind the fused tower too
-    std::string info;
-};
 
-template <typename T>
-static T *nalloc(AzxNet *net, size_t count) {
-    void *p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)) != hipSuccess) return nullptr;
-    (void)hipMemset(p, 0, std::max<size_t>(count * sizeof(T), 16));
-    net->allocs.push_back(p);
-    return reinterpret_cast<T *>(p);
-}
 
 // Every tower kernel takes its LDS image as dynamic shared memory above the 64 KB default: the limit is raised to
 // the CU's 160 KB for all of them whenever a network is created (per device and idempotent; a process-wide "done"
@@ -2050,8 +1997,9 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     { const char *v = getenv("AZX_TOWER_SHAPE"); net->opt_shape = v ? atoi(v) : 16; }
     { const char *v = getenv("AZX_WIDE_STREAMS"); net->opt_wsplit = std::min(4, std::max(1, v ? atoi(v) : 2)); }
     { const char *v = getenv("AZX_HEADS"); net->opt_heads_mfma = !(v && !strcmp(v, "valu")); }
+    { const char *v = getenv("AZX_PACK"); net->pack_on_host = v && !strcmp(v, "host"); }
     {
-        char b[200];
+        char b[260];
         const char *tower = "k_stem_generic + k_conv_generic (VALU)";
         if (net->tower_variant == 4)
             tower = net->opt_shape == 16 && net->opt_split_m ? "k_tower_f16x3_s16" : net->opt_split_m ? "k_tower_f16x3<true>" : "k_tower_f16x3<false>";
@@ -2060,9 +2008,9 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
         else if (net->tower_variant == 2) tower = "k_tower_mfma<64,6,1,2,2> (fp32 MFMA)";
         else if (net->tower_variant == 3) tower = "k_tower_mfma<32,6,2,2,1> (fp32 MFMA)";
         const bool hm = net->tower_variant == 4 && net->opt_split_m && net->opt_heads_mfma && ncells <= 128;
-        snprintf(b, sizeof b, "%s + %s (%dx%d on %dx%d; AZX_TOWER=%s AZX_TOWER_SHAPE=%d AZX_TOWER_SPLIT=%d AZX_WIDE_STREAMS=%d AZX_HEADS=%s)",
+        snprintf(b, sizeof b, "%s + %s (%dx%d on %dx%d; AZX_TOWER=%s AZX_TOWER_SHAPE=%d AZX_TOWER_SPLIT=%d AZX_WIDE_STREAMS=%d AZX_HEADS=%s AZX_PACK=%s)",
                  tower, hm ? "k_heads_mfma" : "k_heads", blocks, chans, N, N, want_fp32 ? "fp32" : "default", net->opt_shape,
-                 (int)net->opt_split_m, net->opt_wsplit, net->opt_heads_mfma ? "mfma" : "valu");
+                 (int)net->opt_split_m, net->opt_wsplit, net->opt_heads_mfma ? "mfma" : "valu", net->pack_on_host ? "host" : "device");
         net->info = b;
     }
     const size_t E = max_evals;
@@ -2089,7 +2037,11 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     net->lds_bytes = (size_t)bpb * 2 * (ncells + 1) * (chans + 4) * sizeof(float);
     if (net->tower_variant == 4) net->lds_bytes = (size_t)F16X3_BPB * 128 * 272 + 2 * 272;   // boards + the zero rows (two in k_tower_f16x3_s16)
     if (net->tower_variant == 5) net->lds_bytes = (size_t)(ncells + 2) * WIDE_ROWB;   // two zero rows + the chunk image
-    net->persistent_allocs = net->allocs.size();
+    net->d.sat_flag = nalloc<uint32_t>(net, 4);
+    if (!net->d.sat_flag) {
+        azx_net_destroy(net);
+        return nfail(AZX_ENOMEM, "net: hipMalloc failed");
+    }
     *out = net;
     return AZX_OK;
 }
@@ -2170,312 +2122,13 @@ void azx_net_destroy(AzxNet *net) {
 #endif
     if (!net) return;
     for (void *p : net->allocs) (void)hipFree(p);
+    if (net->raw_tab_host) (void)hipHostFree((void *)net->raw_tab_host);
+    if (net->wmax_host) (void)hipHostFree((void *)net->wmax_host);
     delete net;
 }
 
 bool azx_net_ready(const AzxNet *net) { return net && net->ready; }
 
-static float *upload(AzxNet *net, const std::vector<float> &h) {
-    float *p = nalloc<float>(net, h.size());
-    if (p) (void)hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
-    return p;
-}
-
-int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void *const *ptrs,
-                        const int64_t *counts, int on_device) {
-    std::map<std::string, std::vector<float>> T;
-    for (int i = 0; i < n; ++i) {
-        std::vector<float> h((size_t)counts[i]);
-        if (on_device) {
-            if (hipMemcpy(h.data(), ptrs[i], h.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
-                return nfail(AZX_EHIP, "net: copying a weight tensor from the device failed");
-        } else {
-            memcpy(h.data(), ptrs[i], h.size() * sizeof(float));
-        }
-        T[names[i]] = std::move(h);
-    }
-    const int C = net->d.C, N = net->d.N, n2 = N * N, L = net->d.layers;
-    std::string missing;
-    auto get = [&](const std::string &name, size_t want) -> const std::vector<float> * {
-        auto it = T.find(name);
-        if (it == T.end() || it->second.size() != want) {
-            missing = "net: tensor '" + name + "' missing or has the wrong size";
-            return nullptr;
-        }
-        return &it->second;
-    };
-    // eval-mode BatchNorm2d folded to scale/shift, eps 1e-5 (network.py:21,:48)
-    auto fold = [&](const std::string &pre, int c, std::vector<double> &scale, std::vector<double> &shift) -> bool {
-        auto w = get(pre + ".weight", c), b = get(pre + ".bias", c), m = get(pre + ".running_mean", c),
-             v = get(pre + ".running_var", c);
-        if (!w || !b || !m || !v) return false;
-        scale.resize(c);
-        shift.resize(c);
-        for (int i = 0; i < c; ++i) {
-            scale[i] = (double)(*w)[i] / std::sqrt((double)(*v)[i] + 1e-5);
-            shift[i] = (double)(*b)[i] - (double)(*m)[i] * scale[i];
-        }
-        return true;
-    };
-#define NEED(x) if (!(x)) return nfail(AZX_EINVAL, missing.c_str())
-    std::vector<double> sc, sh;
-    // stem table: T[tap][v][co] = scale[co] * sum_i emb[v][i] * w[co][i][tap]
-    auto emb = get("encoder.weight", 12);
-    auto w1 = get("conv1.weight", (size_t)C * 4 * 9);
-    NEED(emb && w1 && fold("bn1", C, sc, sh));
-    std::vector<float> stemT((size_t)(9 * 3 + 1) * C, 0.0f), stem_b(C);   // row 27: zeros (off-board taps)
-    for (int tap = 0; tap < 9; ++tap)
-        for (int v = 0; v < 3; ++v)
-            for (int co = 0; co < C; ++co) {
-                double s = 0;
-                for (int i = 0; i < 4; ++i) s += (double)(*emb)[v * 4 + i] * (double)(*w1)[(co * 4 + i) * 9 + tap];
-                stemT[(tap * 3 + v) * C + co] = (float)(s * sc[co]);
-            }
-    for (int co = 0; co < C; ++co) stem_b[co] = (float)sh[co];
-    // tower
-    std::vector<float> Wg((size_t)L * 9 * C * C), bias((size_t)L * C);
-    for (int l = 0; l < L; ++l) {
-        char nm[128];
-        snprintf(nm, sizeof nm, "resblocks.%d.conv%d.weight", l / 2, l % 2 + 1);
-        auto w = get(nm, (size_t)C * C * 9);
-        snprintf(nm, sizeof nm, "resblocks.%d.bn%d", l / 2, l % 2 + 1);
-        NEED(w && fold(nm, C, sc, sh));
-        for (int tap = 0; tap < 9; ++tap)
-            for (int ci = 0; ci < C; ++ci)
-                for (int co = 0; co < C; ++co)
-                    Wg[(((size_t)l * 9 + tap) * C + ci) * C + co] =
-                        (float)((double)(*w)[((size_t)co * C + ci) * 9 + tap] * sc[co]);
-        for (int co = 0; co < C; ++co) bias[(size_t)l * C + co] = (float)sh[co];
-    }
-    std::vector<float> Wp;
-    if (net->use_mfma && net->tower_variant < 4) {
-        // B-fragment order: [layer][tap][q][ntile][lane(j + 32 h)][t] = W[tap][cin 8q+4h+t][cout 32 ntile + j]
-        const int NT = C / 32, Q = C / 8;
-        Wp.resize((size_t)L * 9 * Q * NT * 64 * 4);
-        for (int l = 0; l < L; ++l)
-            for (int tap = 0; tap < 9; ++tap)
-                for (int q = 0; q < Q; ++q)
-                    for (int nt = 0; nt < NT; ++nt)
-                        for (int ln = 0; ln < 64; ++ln)
-                            for (int t = 0; t < 4; ++t) {
-                                const int j = ln & 31, h = ln >> 5;
-                                const int ci = 8 * q + 4 * h + t, co = 32 * nt + j;
-                                Wp[(((((size_t)l * 9 + tap) * Q + q) * NT + nt) * 64 + ln) * 4 + t] =
-                                    Wg[(((size_t)l * 9 + tap) * C + ci) * C + co];
-                            }
-    }
-    std::vector<unsigned short> Wh, Ws;
-    if (net->tower_variant == 4 || net->tower_variant == 5) {
-        const int NT = C / 32, NCH = C / 64;
-        auto f16bits = [](float w, int part) -> unsigned short {
-            const _Float16 hi = (_Float16)w;
-            const _Float16 lo = (_Float16)(w - (float)hi);
-            const _Float16 v = part ? lo : hi;
-            unsigned short bits;
-            memcpy(&bits, &v, 2);
-            return part ? lo_round_bits(bits) : bits;
-        };
-        // stem table as K = 27 (tap*3 + colour, padded to 32) x C weights:
-        // [kk][ntile][part hi/lo][lane j + 32 h][t] = split(stemT[k = 16 kk + 8 h + t][cout 32 ntile + j])
-        Ws.resize((size_t)2 * NT * 2 * 64 * 8);
-        size_t os = 0;
-        for (int kk = 0; kk < 2; ++kk)
-            for (int nt = 0; nt < NT; ++nt)
-                for (int part = 0; part < 2; ++part)
-                    for (int ln = 0; ln < 64; ++ln)
-                        for (int t = 0; t < 8; ++t) {
-                            const int j = ln & 31, h = ln >> 5;
-                            const int k = 16 * kk + 8 * h + t, co = 32 * nt + j;
-                            Ws[os++] = f16bits(k < 27 ? stemT[(size_t)k * C + co] : 0.0f, part);
-                        }
-        // conv weights, one 16-channel k-step after the other in the order the kernels walk them:
-        // [layer][tap][64-channel chunk][half][kk][ntile][part hi/lo][lane j + 32 h][t]
-        //   = split(W[tap][cin 64 chunk + 32 half + 16 kk + 8 h + t][cout 32 ntile + j])
-        Wh.resize((size_t)L * 9 * NCH * 2 * 2 * NT * 2 * 64 * 8);
-        size_t o = 0;
-        for (int l = 0; l < L; ++l)
-            for (int tap = 0; tap < 9; ++tap)
-                for (int ch = 0; ch < NCH; ++ch)
-                    for (int half = 0; half < 2; ++half)
-                        for (int kk = 0; kk < 2; ++kk)
-                            for (int nt = 0; nt < NT; ++nt)
-                                for (int part = 0; part < 2; ++part)
-                                    for (int ln = 0; ln < 64; ++ln)
-                                        for (int t = 0; t < 8; ++t) {
-                                            const int j = ln & 31, h = ln >> 5;
-                                            const int ci = 64 * ch + 32 * half + 16 * kk + 8 * h + t, co = 32 * nt + j;
-                                            Wh[o++] = f16bits(Wg[(((size_t)l * 9 + tap) * C + ci) * C + co], part);
-                                        }
-    }
-    std::vector<unsigned short> Wh16, Ws16;
-    if (net->tower_variant == 4 || net->tower_variant == 5) {
-        const int NT16 = C / 16, NCH = C / 64;
-        auto f16bits = [](float w, int part) -> unsigned short {
-            const _Float16 hi = (_Float16)w;
-            const _Float16 lo = (_Float16)(w - (float)hi);
-            const _Float16 v = part ? lo : hi;
-            unsigned short bits;
-            memcpy(&bits, &v, 2);
-            return part ? lo_round_bits(bits) : bits;
-        };
-        // 16x16x32 A-operand order: lane (j = lane & 15: output channel in the tile, h = lane >> 4: k-group)
-        // holds 8 consecutive k.  Stem: [ntile][hi,lo][lane][t] = split(stemT[k = 8 h + t][cout 16 ntile + j])
-        Ws16.resize((size_t)NT16 * 2 * 64 * 8);
-        size_t os = 0;
-        for (int nt = 0; nt < NT16; ++nt)
-            for (int part = 0; part < 2; ++part)
-                for (int ln = 0; ln < 64; ++ln)
-                    for (int t = 0; t < 8; ++t) {
-                        const int j = ln & 15, h = ln >> 4, k = 8 * h + t, co = 16 * nt + j;
-                        Ws16[os++] = f16bits(k < 27 ? stemT[(size_t)k * C + co] : 0.0f, part);
-                    }
-        // convs, one 32-channel k-step after the other:
-        // [layer][tap][64-channel chunk][half][ntile][hi,lo][lane][t]
-        //   = split(W[tap][cin 64 chunk + 32 half + 8 h + t][cout 16 ntile + j])
-        Wh16.resize((size_t)L * 9 * NCH * 2 * NT16 * 2 * 64 * 8);
-        size_t o = 0;
-        for (int l = 0; l < L; ++l)
-            for (int tap = 0; tap < 9; ++tap)
-                for (int ch = 0; ch < NCH; ++ch)
-                    for (int half = 0; half < 2; ++half)
-                        for (int nt = 0; nt < NT16; ++nt)
-                            for (int part = 0; part < 2; ++part)
-                                for (int ln = 0; ln < 64; ++ln)
-                                    for (int t = 0; t < 8; ++t) {
-                                        const int j = ln & 15, h = ln >> 4;
-                                        const int ci = 64 * ch + 32 * half + 8 * h + t;
-                                        int co = 16 * nt + j;
-                                        // wide tower: row j = 4 lh + r of tile n = nt % 4 of a wave's 64-channel
-                                        // group is channel 32 (n >> 1) + 8 lh + 4 (n & 1) + r of the group, so a
-                                        // lane's accumulators are 8 consecutive channels per tile pair
-                                        // (k_conv_wide_f16x3_s16's 16-byte epilogue pieces)
-                                        if (net->tower_variant == 5)
-                                            co = 64 * (nt / 4) + 32 * ((nt % 4) >> 1) + 8 * (j >> 2) + 4 * (nt & 1) + (j & 3);
-                                        Wh16[o++] = f16bits(Wg[(((size_t)l * 9 + tap) * C + ci) * C + co], part);
-                                    }
-    }
-    // heads
-    auto wvc = get("value_conv1.weight", (size_t)2 * C), wpc = get("move_conv1.weight", (size_t)4 * C);
-    std::vector<double> scv, shv, scp, shp;
-    NEED(wvc && wpc && fold("value_bn1", 2, scv, shv) && fold("move_bn1", 4, scp, shp));
-    std::vector<float> wv((size_t)2 * C), bv(2), wp((size_t)4 * C), bp(4);
-    for (int o = 0; o < 2; ++o) {
-        for (int c = 0; c < C; ++c) wv[(size_t)o * C + c] = (float)((double)(*wvc)[(size_t)o * C + c] * scv[o]);
-        bv[o] = (float)shv[o];
-    }
-    for (int o = 0; o < 4; ++o) {
-        for (int c = 0; c < C; ++c) wp[(size_t)o * C + c] = (float)((double)(*wpc)[(size_t)o * C + c] * scp[o]);
-        bp[o] = (float)shp[o];
-    }
-    std::vector<unsigned short> Whd16;
-    std::vector<float> hbias16(16, 0.f);
-    if (net->tower_variant == 4 && C == 64) {
-        auto f16bits = [](float w, int part) -> unsigned short {
-            const _Float16 hi = (_Float16)w;
-            const _Float16 lo = (_Float16)(w - (float)hi);
-            const _Float16 v = part ? lo : hi;
-            unsigned short bits;
-            memcpy(&bits, &v, 2);
-            return part ? lo_round_bits(bits) : bits;
-        };
-        Whd16.resize((size_t)2 * 2 * 64 * 8);
-        size_t oh = 0;
-        for (int ks = 0; ks < 2; ++ks)
-            for (int part = 0; part < 2; ++part)
-                for (int ln = 0; ln < 64; ++ln)
-                    for (int t = 0; t < 8; ++t) {
-                        const int o = ln & 15, ci = 32 * ks + 8 * (ln >> 4) + t;
-                        const float w = o < 2 ? wv[(size_t)o * C + ci] : o < 6 ? wp[(size_t)(o - 2) * C + ci] : 0.0f;
-                        Whd16[oh++] = f16bits(w, part);
-                    }
-        for (int o = 0; o < 6; ++o) hbias16[o] = o < 2 ? bv[o] : bp[o - 2];
-    }
-    auto fc2w = get("value_fc2.weight", (size_t)64 * 2 * n2), fc2b = get("value_fc2.bias", 64);
-    auto fc3w = get("value_fc3.weight", 64), fc3b = get("value_fc3.bias", 1);
-    auto mfw = get("move_fc.weight", (size_t)n2 * 4 * n2), mfb = get("move_fc.bias", n2);
-    NEED(fc2w && fc2b && fc3w && fc3b && mfw && mfb);
-    std::vector<float> fc2T((size_t)2 * n2 * 64), mfcT((size_t)4 * n2 * AZX_CELL_STRIDE, 0.f), mfcb(AZX_CELL_STRIDE, 0.f);
-    for (int o = 0; o < 64; ++o)
-        for (int i = 0; i < 2 * n2; ++i) fc2T[(size_t)i * 64 + o] = (*fc2w)[(size_t)o * 2 * n2 + i];
-    for (int t = 0; t < n2; ++t) {
-        for (int i = 0; i < 4 * n2; ++i) mfcT[(size_t)i * AZX_CELL_STRIDE + t] = (*mfw)[(size_t)t * 4 * n2 + i];
-        mfcb[t] = (*mfb)[t];
-    }
-    // k_heads_mfma's B operands: [n tile of 16][k group t of 16][lane][s] = W[k = 16 t + 4 (lane >> 4) + s][unit 16 tile + (lane & 15)]
-    const int KVp = (2 * n2 + 15) & ~15, KPp = (4 * n2 + 15) & ~15, NTP = (n2 + 15) / 16;
-    std::vector<float> hmP((size_t)NTP * (KPp / 16) * 64 * 4, 0.f), hmV((size_t)4 * (KVp / 16) * 64 * 4, 0.f);
-    for (int t = 0; t < NTP; ++t)
-        for (int q = 0; q < KPp / 16; ++q)
-            for (int l = 0; l < 64; ++l)
-                for (int sidx = 0; sidx < 4; ++sidx) {
-                    const int k = 16 * q + 4 * (l >> 4) + sidx, unit = 16 * t + (l & 15);
-                    if (k < 4 * n2 && unit < n2)
-                        hmP[(((size_t)t * (KPp / 16) + q) * 64 + l) * 4 + sidx] = (*mfw)[(size_t)unit * 4 * n2 + k];
-                }
-    for (int t = 0; t < 4; ++t)
-        for (int q = 0; q < KVp / 16; ++q)
-            for (int l = 0; l < 64; ++l)
-                for (int sidx = 0; sidx < 4; ++sidx) {
-                    const int k = 16 * q + 4 * (l >> 4) + sidx, unit = 16 * t + (l & 15);
-                    if (k < 2 * n2) hmV[(((size_t)t * (KVp / 16) + q) * 64 + l) * 4 + sidx] = (*fc2w)[(size_t)unit * 2 * n2 + k];
-                }
-#undef NEED
-    (void)hipStreamSynchronize(net->stream);
-    // the previous weight set is no longer referenced by any queued kernel: release it (the
-    // trainer refreshes the weights on every Player.read)
-    for (size_t i = net->persistent_allocs; i < net->allocs.size(); ++i) (void)hipFree(net->allocs[i]);
-    net->allocs.resize(net->persistent_allocs);
-    NetDev &d = net->d;
-    d.stemT = upload(net, stemT);
-    d.stem_b = upload(net, stem_b);
-    d.Wg = upload(net, Wg);
-    d.Wp = (net->use_mfma && net->tower_variant < 4) ? upload(net, Wp) : nullptr;
-    d.Wh = nullptr;
-    d.Ws = nullptr;
-    if (net->tower_variant == 4 || net->tower_variant == 5) {
-        unsigned short *wsd = nalloc<unsigned short>(net, Ws.size());
-        if (!wsd) return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
-        (void)hipMemcpy(wsd, Ws.data(), Ws.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
-        d.Ws = wsd;
-        unsigned short *wh = nalloc<unsigned short>(net, Wh.size());
-        if (!wh) return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
-        (void)hipMemcpy(wh, Wh.data(), Wh.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
-        d.Wh = wh;
-    }
-    d.Ws16 = d.Wh16 = nullptr;
-    if (net->tower_variant == 4 || net->tower_variant == 5) {
-        unsigned short *a = nalloc<unsigned short>(net, Ws16.size()), *b = nalloc<unsigned short>(net, Wh16.size());
-        if (!a || !b) return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
-        (void)hipMemcpy(a, Ws16.data(), Ws16.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
-        (void)hipMemcpy(b, Wh16.data(), Wh16.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
-        d.Ws16 = a;
-        d.Wh16 = b;
-    }
-    d.Whd16 = nullptr;
-    d.hbias16 = nullptr;
-    if (!Whd16.empty()) {
-        unsigned short *hw = nalloc<unsigned short>(net, Whd16.size());
-        if (!hw) return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
-        (void)hipMemcpy(hw, Whd16.data(), Whd16.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
-        d.Whd16 = hw;
-        d.hbias16 = upload(net, hbias16);
-        if (!d.hbias16) return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
-    }
-    d.bias = upload(net, bias);
-    d.wv = upload(net, wv); d.bv = upload(net, bv);
-    d.wp = upload(net, wp); d.bp = upload(net, bp);
-    d.fc2T = upload(net, fc2T); d.fc2b = upload(net, *fc2b);
-    d.fc3w = upload(net, *fc3w); d.fc3b = upload(net, *fc3b);
-    d.mfcT = upload(net, mfcT); d.mfcb = upload(net, mfcb);
-    d.hmP = upload(net, hmP); d.hmV = upload(net, hmV);
-    d.hm_lda = ((KVp + KPp - 4 + 63) / 64) * 64 + 4;        // smallest stride = 4 (mod 64) that holds a row
-    if (!d.stemT || !d.stem_b || !d.Wg || !d.bias || !d.wv || !d.bv || !d.wp || !d.bp || !d.fc2T ||
-        !d.fc2b || !d.fc3w || !d.fc3b || !d.mfcT || !d.mfcb || !d.hmP || !d.hmV || (net->use_mfma && net->tower_variant < 4 && !d.Wp))
-        return nfail(AZX_ENOMEM, "net: uploading packed weights failed");
-    (void)hipDeviceSynchronize();
-    net->ready = true;
-    return AZX_OK;
-}
 
 // tower + heads over boards[0 .. n) (n read from n_eval_ptr on the device when given)
 static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, const int32_t *n_eval_ptr,
@@ -2586,6 +2239,20 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
 }
 
 const char *azx_net_kernel_info(const AzxNet *net) { return net->info.c_str(); }
+
+// The split-f16 towers OR 1 into d.sat_flag when an activation left the f16 range (its `hi` half became +inf).
+// Read where the host synchronises anyway; the flag is cleared so the next call starts clean.
+int azx_net_check_range(AzxNet *net, hipStream_t st) {
+    if (!net || !net->d.sat_flag) return AZX_OK;
+    uint32_t flag = 0;
+    if (hipMemcpyAsync(&flag, net->d.sat_flag, sizeof flag, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return nfail(AZX_EHIP, "net: reading the activation range flag failed");
+    if (!flag) return AZX_OK;
+    (void)hipMemsetAsync(net->d.sat_flag, 0, sizeof flag, st);
+    return nfail(AZX_ERANGE, "net: an activation of the residual tower exceeded the f16 range (65504) of the split-f16 "
+                             "kernels -- the evaluations of this call are not valid (AZX_TOWER=fp32 runs the fp32 MFMA tower)");
+}
 
 void azx_net_eval(AzxNet *net, const DevEngine &e, hipStream_t st) {
     run_net(net, e.ev_board, e.ev_flip, e.n_eval, 0, net->max_evals, net->logit, e.ev_value, e.ev_prior, st);

@@ -65,11 +65,11 @@ class DeviceReplayBuffer:
         refill = max(0, num_examples - self.fresh_counter)
         if not refill:
             return {}
-        if player is not None and hasattr(player, "prepare_device_engine"):
-            player.prepare_device_engine(self.engine)     # push the trainer's current weights
         if self.shared and azdist.is_distributed():
-            rows, st = self._fill_shared(int(np.ceil(refill)))
+            rows, st = self.refill_shared(int(np.ceil(refill)), player)
         else:
+            if player is not None and hasattr(player, "prepare_device_engine"):
+                player.prepare_device_engine(self.engine)     # push the trainer's current weights
             rows, st = self.engine.replay_fill(int(np.ceil(refill)))
             st = dict(st, **self._game_sums(rows))
         self.fresh_counter += rows
@@ -89,6 +89,16 @@ class DeviceReplayBuffer:
         f = getattr(self.engine, "game_metric_sums", None)
         sums = f(rows) if (f is not None and rows) else {}
         return {"game_" + k: float(sums.get(k, 0.0)) for k in self._SEARCH_KEYS}
+
+    def refill_shared(self, refill: int, player=None):
+        """One refill of `refill` rows played by all ranks.  With a leader / follower Player (training: rank 0 is
+        the trainer) rank 0 announces it and broadcasts its network first; every rank then packs ITS current
+        module into its engine -- after the broadcast these are the same weights everywhere."""
+        if player is not None and hasattr(player, "announce"):
+            player.announce(azdist.OP_REFILL, refill)
+        if player is not None and hasattr(player, "prepare_device_engine"):
+            player.prepare_device_engine(self.engine)
+        return self._fill_shared(refill)
 
     def _fill_shared(self, refill: int):
         """One refill played by all ranks: each rank plays its share of whole games into its harvest

@@ -133,8 +133,40 @@ def broadcast_int(value: int, src: int = 0) -> int:
     return int(t.item())
 
 
+# ---- training-time topology: rank 0 is the trainer, every rank plays ------------------------------
+# The reference has ONE trainer whose workers always search with its live weights (parallel_player.py:36-38:
+# the agents -- and with them the network's CUDA-IPC tensors -- are handed to the worker processes).  Here rank 0
+# runs the optimizer; before every shared production it says what is to be produced (`lead`), broadcasts the
+# network (parameters AND BatchNorm statistics) and all ranks play their share.  The other ranks sit in
+# policy_trainer.serve_selfplay, doing what rank 0 announces (`follow`): their control flow never depends on
+# their own arithmetic, so replicas cannot drift apart and nobody waits in a collective the others skip.
+OP_STOP, OP_READ, OP_REFILL = 0, 1, 2
+
+
+def rank() -> int:
+    return dist.get_rank() if is_distributed() else 0
+
+
+def lead(op: int, arg: int = 0) -> None:
+    """Rank 0: announce the next collective production (OP_READ: Player.read(arg); OP_REFILL: a shared
+    DeviceReplayBuffer refill of arg rows; OP_STOP: training is over)."""
+    if is_distributed():
+        t = torch.tensor([int(op), int(arg)], dtype=torch.int64, device=_comm_device())
+        dist.broadcast(t, src=0)
+
+
+def follow() -> Tuple[int, int]:
+    """Ranks != 0: wait for rank 0's announcement."""
+    t = torch.zeros(2, dtype=torch.int64, device=_comm_device())
+    dist.broadcast(t, src=0)
+    op, arg = (int(x) for x in t.tolist())
+    return op, arg
+
+
 def broadcast_weights(net: torch.nn.Module, src: int = 0) -> None:
-    """One flat broadcast of parameters + buffers (2.1 MB for the 6x64 net)."""
+    """One flat broadcast of parameters + buffers (2.1 MB for the 6x64 net): conv / linear weights and the
+    BatchNorm affine terms AND running statistics -- self-play folds the statistics into the convolutions, so a
+    rank with stale ones would search with another network."""
     if not is_distributed():
         return
     tensors = [t for t in net.state_dict().values() if t.is_floating_point()]

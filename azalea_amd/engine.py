@@ -80,6 +80,29 @@ class Engine:
         c_counts = (C.c_int64 * n)(*counts)
         check(self.L.azx_set_weights(self.h, n, c_names, c_ptrs, c_counts, 1 if on_device else 0))
 
+    def packed_weights(self):
+        """{operand name: bytes} -- the packed weight buffers exactly as the kernels read them (azx_debug_weights)."""
+        out, which = {}, 0
+        while True:
+            nbytes = C.c_int64(0)
+            name = C.create_string_buffer(64)
+            check(self.L.azx_debug_weights(self.h, which, None, 0, C.byref(nbytes), name, 64))
+            if nbytes.value < 0:
+                return out
+            buf = np.empty(nbytes.value, np.uint8)
+            check(self.L.azx_debug_weights(self.h, which, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(nbytes), name, 64))
+            out[name.value.decode()] = buf
+            which += 1
+
+    def weights_digest(self):
+        """sha256 over the packed operands: two engines search with the same network iff their digests agree."""
+        import hashlib
+        h = hashlib.sha256()
+        for name, buf in sorted(self.packed_weights().items()):
+            h.update(name.encode())
+            h.update(buf.tobytes())
+        return h.hexdigest()
+
     def reset(self, slots=None, moves=None):
         """Reset slots (all by default); `moves` = list of move lists replayed per slot."""
         s = None if slots is None else np.ascontiguousarray(slots, np.int32)

@@ -64,10 +64,18 @@ def rows_to_frame(rows) -> ReplayDataFrame:
 class Player:
     MAX_BARREN_PRODUCTIONS = 1000     # consecutive productions without a finished game before read() gives up
 
-    def __init__(self, pool, agents: Sequence, *, n_games: int = None, gather: bool = True):
+    def __init__(self, pool, agents: Sequence, *, n_games: int = None, gather: bool = True, role: str = None):
+        """`gather`: under torch.distributed every rank plays its share of a read and all ranks get all rows.
+        `role`: None -- every rank calls read() itself, in lock-step (symmetric); "leader" / "follower" -- the
+        training-time topology (azalea_amd/distributed.py: rank 0 announces each shared production and broadcasts
+        the trainer's weights first; the followers are driven by policy_trainer.serve_selfplay)."""
+        if role not in (None, "leader", "follower"):
+            raise ValueError("Player role must be None, 'leader' or 'follower'")
         self.agents = agents
         self.running = True
         self.gather = gather
+        self.role = role if (gather and azdist.is_distributed()) else None
+        self.weight_syncs = 0          # broadcasts of the trainer's weights this player took part in
         self.n_games = n_games or int(os.environ.get("AZX_GAMES", "4096"))
         self._games = deque()          # finished games waiting to be read: (rows dict, metrics)
         self._engine = None
@@ -81,6 +89,7 @@ class Player:
         overflowed its tree (SearchTreeFull) is skipped like the reference's worker does
         (parallel_player.py:73-76) and counted in metrics['game_error']."""
         shared = self.gather and azdist.is_distributed()
+        self.announce(azdist.OP_READ, int(np.ceil(size)))
         self._agree_seed_base()       # a collective when shared: every rank passes here, whatever its quota
         quota = azdist.shard_quota(size) if shared else size
         rows_list, metrics = [], defaultdict(float)
@@ -110,6 +119,23 @@ class Player:
             rows = azdist.all_gather_rows(rows, n)
             metrics = azdist.all_reduce_metrics(dict(metrics))
         return rows_to_frame(rows), dict(metrics)
+
+    def announce(self, op: int, arg: int) -> None:
+        """Leader / follower topology only: rank 0 says what all ranks produce next, then its network --
+        the trainer's live weights and BatchNorm statistics -- is broadcast, so every rank searches with what
+        the trainer holds right now (parallel_player.py:36-38).  Collectives: called by every rank, in the
+        same place (the leader from read() / DeviceReplayBuffer.consume, the followers from serve_selfplay
+        through the same two methods)."""
+        if self.role is None:
+            return
+        if self.role == "leader":
+            azdist.lead(op, arg)
+        pol = self._device_policy()
+        if pol is not None:
+            azdist.broadcast_weights(pol.net, src=0)
+            # in-place copies into the parameters do move their version counters, graph replays do not:
+            pol.net.weight_updates_outside_autograd = getattr(pol.net, "weight_updates_outside_autograd", 0) + 1
+            self.weight_syncs += 1
 
     def stop(self) -> None:
         self.running = False
@@ -150,7 +176,12 @@ class Player:
         if pol is None:
             return
         local = int(pol.rng.randint(0, 2 ** 31 - 1))
-        self._seed_base = azdist.broadcast_int(local) if (self.gather and azdist.is_distributed()) else local
+        if self.gather and azdist.is_distributed():
+            self._seed_base = azdist.broadcast_int(local)
+        else:
+            # no shared index space: the engine counts its own games 0, 1, ... (stride 1, offset 0 in _get_engine);
+            # ranks whose policies were seeded alike must still not replay each other's games
+            self._seed_base = (local ^ (azdist.rank() * 0x9E3779B1)) & 0x7FFFFFFF
 
     def _produce(self, want: int) -> None:
         pol = self._device_policy()
@@ -186,7 +217,7 @@ class Player:
     def _get_engine(self, pol: Policy):
         n = self.agents[0].game.board_size
         rank, world = ((torch.distributed.get_rank(), torch.distributed.get_world_size())
-                       if azdist.is_distributed() else (0, 1))
+                       if (self.gather and azdist.is_distributed()) else (0, 1))
         device = (pol.net.device.index or 0) if pol.net.device.type == "cuda" else 0
         key = (n, device, pol.simulations, pol.search_batch_size, float(pol.exploration_coef),
                pol.exploration_depth, pol.exploration_noise_alpha, pol.exploration_noise_scale,

@@ -18,6 +18,7 @@ from torch import optim
 from torch.optim import lr_scheduler
 from torch.utils.data import DataLoader
 
+from . import distributed as azdist
 from .azalea_agent import AzaleaAgent
 from .parallel_player import Player
 from .prep import torch_batch_replays
@@ -171,6 +172,30 @@ def initialize_replay_buffer(pool, game_factory, size: int) -> ReplayBuffer:
     return buf
 
 
+def serve_selfplay(player, replaybuf=None) -> int:
+    """Ranks != 0 of a training job: play what rank 0 announces, with the weights rank 0 broadcasts, until it
+    says stop (azalea_amd/distributed.py).  The counterpart of the reference's worker loop
+    (parallel_player.py:55-76) -- with the trainer's live network arriving over RCCL instead of CUDA IPC.
+    Returns the number of productions served."""
+    served = 0
+    while True:
+        op, arg = azdist.follow()
+        if op == azdist.OP_STOP:
+            break
+        if op == azdist.OP_READ:
+            player.read(arg)                       # the rows are rank 0's to keep; every rank gets them anyway
+        elif op == azdist.OP_REFILL:
+            rows, _ = replaybuf.refill_shared(arg, player)
+            replaybuf.fresh_counter += rows
+        else:
+            raise RuntimeError("serve_selfplay: unknown announcement %d" % op)
+        served += 1
+    pol = player._device_policy()
+    if pol is not None:
+        azdist.broadcast_weights(pol.net, src=0)   # everyone leaves with the trained network
+    return served
+
+
 def save_checkpoint(policy, name, *, optimizer=None, replaybuf=None) -> str:
     """{'policy': ..., 'optimizer': ...} -> name.policy.pth (policy_trainer.py:161-181)."""
     state = {"policy": policy.state_dict()}
@@ -188,7 +213,12 @@ def save_checkpoint(policy, name, *, optimizer=None, replaybuf=None) -> str:
 
 def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False, history=None) -> str:
     """The reference training loop (policy_trainer.py:23-119) over this package's Player.
-    `history`: optional dict; receives the learning rate each epoch trained with under "lr"."""
+    `history`: optional dict; receives the learning rate each epoch trained with under "lr".
+
+    Under torch.distributed (one process per GPU) rank 0 is the trainer: it alone runs the optimizer and writes
+    checkpoints.  Every shared production -- a Player.read or a device-ring refill -- is announced by rank 0, which
+    broadcasts its network first; the other ranks serve self-play (`serve_selfplay`) and return when rank 0 stops,
+    holding the trained weights.  All ranks pass the same config and must call train() together."""
     os.makedirs("%s/checkpoints" % rundir, exist_ok=True)
     np.random.seed(config["seed"])
     torch.manual_seed(config["seed"])
@@ -200,7 +230,10 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
     batch_size = config["batch_size"]
     game_class = import_and_get(config["game"])
     game_factory = partial(game_class, board_size=config["board_size"])
+    shared = azdist.is_distributed()
+    leader = azdist.rank() == 0
     if replaybuf is None:
+        # symmetric under torch.distributed: every rank plays its share of the random-mover games, all get all rows
         replaybuf = initialize_replay_buffer(None, game_factory, config["replaybuf_size"])
     optimizer = optim.SGD(policy.net.parameters(), lr=config["lr_initial"], momentum=config["momentum"],
                           weight_decay=config["l2_regularization"])
@@ -210,12 +243,18 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
     policy.settings["move_exploration"] = True
     policy.settings["move_sampling"] = True
     agent = AzaleaAgent(game_factory, policy=policy, device=config["device"])
-    player = Player(None, [agent], n_games=config.get("selfplay_games"))
+    player = Player(None, [agent], n_games=config.get("selfplay_games"),
+                    role=("leader" if leader else "follower") if shared else None)
     from_ring = False
     if device_replay:
         from .device_replay import DeviceReplayBuffer
         if not isinstance(replaybuf, DeviceReplayBuffer):
             replaybuf = DeviceReplayBuffer(player.device_engine(), len(replaybuf), replaybuf)
+    if shared and not leader:
+        serve_selfplay(player, replaybuf)
+        player.stop()
+        return "%s/checkpoints/final.policy.pth" % rundir      # written by rank 0
+    if device_replay:
         batches = lambda: replaybuf.loader(batch_size)
         if config.get("train_step_graph") and device.type == "cuda":
             # the captured step reads its rows straight from the ring: iterate the epoch's index chunks, the same
@@ -271,5 +310,8 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
             if config.get("model_checkpoint_interval") and step % config["model_checkpoint_interval"] == 0:
                 save_checkpoint(policy, "%s/checkpoints/checkpoint.%d" % (rundir, step), optimizer=optimizer)
             step += 1
+    if shared:
+        azdist.lead(azdist.OP_STOP)
+        azdist.broadcast_weights(policy.net, src=0)
     player.stop()
     return save_checkpoint(policy, "%s/checkpoints/final" % rundir)

@@ -39,7 +39,10 @@ enum {
     AZX_EHIP = -2,       /* HIP runtime failure (message has the hipError string) */
     AZX_ENOMEM = -3,
     AZX_ESTATE = -4,     /* call sequence error (e.g. apply without select) */
-    AZX_ENODEV = -5      /* no MI355X visible: there is no CPU fallback */
+    AZX_ENODEV = -5,     /* no MI355X visible: there is no CPU fallback */
+    AZX_ERANGE = -6      /* a folded weight or a tower activation is outside the f16 range of the split-f16 kernels
+                            (the reference computes in fp32 throughout, network.py:68-85): azx_set_weights rejects such
+                            weights; a call whose evaluations overflowed reports it and its results are not valid */
 };
 
 /* evaluator = what plays the role of Network.run inside mcts.evaluate_batch (mcts.py:202-215) */
@@ -83,8 +86,9 @@ typedef struct {
 typedef struct azx_engine azx_engine;
 
 const char *azx_last_error(void);
-int azx_version(void);            /* ABI revision: 4 = 8-float row metrics, azx_kernel_info, azx_debug_set_queue_cap
-                                   * (3 = azx_config.game_index_*, azx_play_stats.sum_game_length) */
+int azx_version(void);            /* ABI revision: 5 = AZX_ERANGE, azx_debug_weights, weights packed on the device
+                                   * (4 = 8-float row metrics, azx_kernel_info, azx_debug_set_queue_cap;
+                                   *  3 = azx_config.game_index_*, azx_play_stats.sum_game_length) */
 
 /* Policy.initialize / Policy.reset (policy.py:36-63, :76-80): allocate device arenas. */
 int azx_create(const azx_config *cfg, azx_engine **out);
@@ -95,6 +99,15 @@ void azx_destroy(azx_engine *e);
  * on the device (torch tensor.data_ptr()) when on_device != 0, else on the host. */
 int azx_set_weights(azx_engine *e, int n_tensors, const char *const *names,
                     const void *const *ptrs, const int64_t *counts, int on_device);
+/* The trainer changes its weights every step (policy_trainer.py:85-90) and the engine is refreshed on every
+ * Player.read, so azx_set_weights folds / splits / re-orders ON THE DEVICE, reading device tensors in place
+ * (host arrays are staged first); blocking.  AZX_ERANGE: a BatchNorm-folded weight is not finite or -- for the
+ * split-f16 towers -- beyond the f16 range (65504); the message names the tensor, nothing is installed and the
+ * engine has no weights until a valid set arrives.
+ * Debug / tests: packed operand number `which` as the kernels read it -- *nbytes = its size (-1 past the last one),
+ * its name in `name`, its bytes in `out` when cap suffices.  AZX_PACK=host (read at azx_create) selects the scalar
+ * host reference packer; the two are bit-identical (tests/test_gpu_weights.py). */
+int azx_debug_weights(azx_engine *e, int which, void *out, int64_t cap, int64_t *nbytes, char *name, int name_cap);
 
 /* AZX_EVAL_UNIFORM_HASH only: prior_by_k[k] = the f32 prior a k-move position gets. */
 int azx_set_prior_table(azx_engine *e, const float *prior_by_k, int count);

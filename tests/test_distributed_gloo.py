@@ -252,3 +252,154 @@ def test_world2_gloo_all_gather_and_broadcast():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: [], 1: []}      # numbers of the checks that failed, per rank
+
+
+# ---- training-time topology: rank 0 trains, every rank plays with rank 0's live weights ---------------------------
+
+class DigestEngine(StubPlayEngine):
+    """StubPlayEngine that remembers a digest of every weight set it was handed (Player._push_weights)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.digests = []
+
+    def set_weights(self, tensors, on_device=False):
+        import hashlib
+        h = hashlib.sha256()
+        for name in sorted(tensors):
+            h.update(name.encode())
+            h.update(np.ascontiguousarray(tensors[name]).tobytes())
+        self.digests.append(h.hexdigest())
+
+
+def _train_config(rundir_seed=0):
+    return dict(seed=7, device="cpu", replaybuf_oversampling=4, batch_size=8, game="azalea_amd.game.hex.HexGame",
+                board_size=4, replaybuf_size=64, lr_initial=0.05, momentum=0.9, l2_regularization=1e-4,
+                lr_decay_epochs=100, lr_decay=0.1, total_epochs=3, selfplay_games=8, log_interval=0,
+                model_checkpoint_interval=10)
+
+
+def _train_worker(rank, world, port, rundir, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import glob
+    from azalea_amd import Policy
+    from azalea_amd import parallel_player as pp
+    from azalea_amd.policy_trainer import train
+    real, real_announce = pp._eng.Engine, pp.Player.announce
+    pp._eng.Engine = DigestEngine
+    synced = []
+
+    def announce(self, op, arg):                       # digest of the module right after every weight broadcast
+        real_announce(self, op, arg)
+        pol_ = self._device_policy()
+        if self.role is not None and pol_ is not None:
+            e = DigestEngine.__new__(DigestEngine)
+            e.digests = []
+            e.set_weights({k: v.detach().cpu().numpy() for k, v in pol_.net.state_dict().items() if v.dtype == torch.float32})
+            synced.append(e.digests[0])
+    pp.Player.announce = announce
+    fails = []
+    try:
+        cfg = dict(device="cpu", network="HexNetwork", board_size=4, num_blocks=1, base_chans=8, simulations=20,
+                   search_batch_size=10, exploration_coef=0.5, exploration_depth=3, exploration_noise_alpha=0.3,
+                   exploration_noise_scale=0.25, exploration_temperature=1.0, seed=5)
+        torch.manual_seed(100 + rank)                  # the ranks START with different networks
+        pol = Policy()
+        pol.initialize(cfg)
+        StubPlayEngine.created.clear()
+        path = train(pol, _train_config(), rundir)
+        engines = [e for e in StubPlayEngine.created if isinstance(e, DigestEngine)]
+        packed = engines[0].digests if engines else []
+        alld = [None] * world
+        dist.all_gather_object(alld, synced)
+        # every announced production found rank 0's weights of that moment on every rank (they started apart), the
+        # weights moved between productions (training happened), and an engine only ever packed synced weights
+        fails += [] if (len(synced) >= 3 and all(d == alld[0] for d in alld)) else [301]
+        fails += [] if len(set(alld[0])) >= 3 else [302]
+        fails += [] if (len(packed) >= 1 and set(packed) <= set(synced)) else [306]
+        # everyone leaves train() with the trained network; rank 0 alone wrote checkpoints
+        sd = torch.cat([t.detach().reshape(-1).double() for t in pol.net.state_dict().values() if t.is_floating_point()])
+        sums = [None] * world
+        dist.all_gather_object(sums, float(sd.sum()))
+        fails += [] if all(x == sums[0] for x in sums) else [303]
+        dist.barrier()
+        files = sorted(glob.glob(os.path.join(rundir, "checkpoints", "*.policy.pth")))
+        fails += [] if (os.path.basename(path) == "final.policy.pth" and os.path.exists(path)
+                        and len(files) == len(set(files)) and any("checkpoint.0." in f for f in files)) else [304]
+        if rank == 0:
+            state = torch.load(path, weights_only=False)["policy"]["net"]
+            same = all(torch.equal(state[k], v) for k, v in pol.net.state_dict().items())
+            fails += [] if same else [305]
+    finally:
+        pp._eng.Engine, pp.Player.announce = real, real_announce
+    out[rank] = fails
+    dist.destroy_process_group()
+
+
+def _spawn(fn, world, *args):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(fn, args=(world, _free_port()) + args + (out,), nprocs=world, join=True)
+    return dict(out)
+
+
+def test_train_rank0_trains_everyone_plays_with_its_weights(tmp_path):
+    """policy_trainer.train under torch.distributed (world 2 and 3): rank 0 runs the optimizer, announces every
+    shared Player.read and broadcasts its network first; the other ranks serve self-play.  Every production saw
+    the same weights on all ranks although they started from different networks, the weights changed between
+    refills (training happened), all ranks return with the trained network, and the checkpoint files were
+    written once."""
+    for world in (2, 3):
+        rundir = str(tmp_path / ("run%d" % world))
+        out = _spawn(_train_worker, world, rundir)
+        assert out == {r: [] for r in range(world)}
+
+
+def _world8_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from azalea_amd import distributed as azd
+    fails = []
+    # ragged all-gather with empty ranks: rank r contributes r % 3 rows
+    counts = [r % 3 for r in range(world)]
+    got = azd.all_gather_rows(_rows(rank, counts[rank]), 5)
+    want = {k: np.concatenate([_rows(r, counts[r])[k] for r in range(world)]) for k in got}
+    fails += [] if all(np.array_equal(got[k], want[k]) for k in got) else [401]
+    # quotas: 8 ranks, 5 rows wanted -> ranks 0..4 play one row's worth, 5..7 nothing, and they still join
+    fails += [] if [azd.shard_quota(5, r, world) for r in range(world)] == [1, 1, 1, 1, 1, 0, 0, 0] else [402]
+    from azalea_amd import AzaleaAgent, HexGame, Player
+    agent = AzaleaAgent(lambda: HexGame(4))
+    agent.seed(10 + rank)
+    pl = Player(None, [agent])
+    frame, m = pl.read(5)
+    pl.stop()
+    sizes = [None] * world
+    dist.all_gather_object(sizes, len(frame))
+    fails += [] if (len(set(sizes)) == 1 and m["games"] == 5 and len(frame) >= 5) else [403]
+    # the shared device-ring refill with 8 ranks, three of them idle
+    from azalea_amd.device_replay import DeviceReplayBuffer
+    E = StubEngine(4, seed=50 + rank)
+    buf = DeviceReplayBuffer(E, capacity=500)
+    buf.consume(2.5)                                    # refill = 2.5 - (-2.5) = 5 rows
+    c = buf.last_exchange["rows_per_rank"]
+    fails += [] if (len(c) == world and c[5:] == [0, 0, 0] and min(c[:5]) >= 1 and len(buf) == sum(c)) else [404]
+    dig = [None] * world
+    dist.all_gather_object(dig, int(E.ring[:E.size].astype(np.int64).sum()))
+    fails += [] if len(set(dig)) == 1 else [405]
+    # leader / follower announcements reach all 8
+    if rank == 0:
+        azd.lead(azd.OP_REFILL, 1234)
+        got = (azd.OP_REFILL, 1234)
+    else:
+        got = azd.follow()
+    fails += [] if got == (azd.OP_REFILL, 1234) else [406]
+    out[rank] = fails
+    dist.destroy_process_group()
+
+
+def test_world8_gloo_quota_zero_ranks_join_the_collectives():
+    out = _spawn(_world8_worker, 8)
+    assert out == {r: [] for r in range(8)}

@@ -1,0 +1,257 @@
+"""azx_set_weights on the device (net_pack.hip): bit-identity with the host reference packer, refresh cost, and the
+f16 range guards (weights rejected by name, activations flagged) of the split-f16 towers -- the reference computes
+in fp32 throughout (azalea/network.py:68-85), so a network the hi+lo f16 split cannot carry must fail loudly, never
+return inf / NaN logits."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from azalea_amd import engine as eng
+from azalea_amd._lib import AzxError
+from azalea_amd.network import HexNetwork
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _net(n, blocks, chans, seed=0):
+    """Random-init network with non-trivial BatchNorm statistics (a trained net's look)."""
+    torch.manual_seed(seed)
+    net = HexNetwork(board_size=n, num_blocks=blocks, base_chans=chans).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    for name, t in net.state_dict().items():
+        if name.endswith("running_mean"):
+            t.copy_(0.3 * torch.randn(t.shape, generator=g))
+        elif name.endswith("running_var"):
+            t.copy_(0.5 + torch.rand(t.shape, generator=g))
+        elif "bn" in name and name.endswith("weight"):
+            t.copy_(0.5 + torch.rand(t.shape, generator=g))
+        elif "bn" in name and name.endswith("bias"):
+            t.copy_(0.2 * torch.randn(t.shape, generator=g))
+    return net
+
+
+def _engine(n, blocks, chans, env=None):
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:       # the switches are read once, by azx_create
+        return eng.Engine(board_size=n, n_games=2, simulations=20, search_batch_size=10, evaluator=eng.EVAL_RESNET,
+                          num_blocks=blocks, base_chans=chans)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _state_np(net):
+    return {k: v.detach().cpu().numpy() for k, v in net.state_dict().items() if v.dtype == torch.float32}
+
+
+def _state_dev(net):
+    return {k: (v.data_ptr(), v.numel()) for k, v in net.state_dict().items() if v.dtype == torch.float32}
+
+
+def _positions(n, count, seed=3):
+    rng = np.random.RandomState(seed)
+    boards = rng.randint(0, 3, size=(count, n, n)).astype(np.int32)
+    lm = np.zeros((count, n * n), np.int32)
+    for i in range(count):
+        e = np.flatnonzero(boards[i].ravel() == 0) + 1
+        lm[i, :len(e)] = e
+    return boards, lm
+
+
+@pytest.mark.parametrize("n,blocks,chans,env", [
+    (11, 6, 64, {}),                              # k_tower_f16x3_s16: Ws16 / Wh16 / Whd16
+    (11, 2, 64, {"AZX_TOWER_SHAPE": "32"}),       # k_tower_f16x3: Ws / Wh
+    (13, 2, 256, {}),                             # wide tower, 16x16x32 order with the channel permutation
+    (13, 1, 128, {"AZX_TOWER_SHAPE": "32"}),      # wide tower, 32x32x16 order
+    (11, 2, 64, {"AZX_TOWER": "fp32"}),           # k_tower_mfma: Wp
+    (9, 2, 32, {}),                               # k_tower_mfma<32,...>
+    (7, 1, 48, {}),                               # generic VALU kernels: Wg
+])
+def test_device_pack_is_bit_identical_to_the_host_reference(n, blocks, chans, env):
+    net = _net(n, blocks, chans)
+    dev_net = _net(n, blocks, chans).to("cuda:0")
+    E_dev = _engine(n, blocks, chans, env)
+    E_host = _engine(n, blocks, chans, dict(env, AZX_PACK="host"))
+    assert "AZX_PACK=device" in E_dev.kernel_info() and "AZX_PACK=host" in E_host.kernel_info()
+    E_host.set_weights(_state_np(net))
+    ref = E_host.packed_weights()
+    assert len(ref) >= 15
+    # live device tensors read in place, and host arrays staged through the arena: both equal the reference
+    for source in ("device tensors", "host arrays"):
+        if source == "device tensors":
+            E_dev.set_weights(_state_dev(dev_net), on_device=True)
+        else:
+            E_dev.set_weights(_state_np(net))
+        got = E_dev.packed_weights()
+        assert sorted(got) == sorted(ref)
+        for name in ref:
+            assert np.array_equal(got[name], ref[name]), "%s differs (%s, %s)" % (name, source, env)
+    assert E_dev.weights_digest() == E_host.weights_digest()
+    # a second refresh with other weights overwrites in place (persistent buffers) and the forward follows
+    other = _net(n, blocks, chans, seed=5)
+    E_dev.set_weights(_state_np(other))
+    E_host.set_weights(_state_np(other))
+    assert E_dev.weights_digest() == E_host.weights_digest()
+    boards, lm = _positions(n, 6)
+    v1, lp1 = E_dev.forward(boards, lm)
+    v2, lp2 = E_host.forward(boards, lm)
+    assert np.array_equal(v1, v2) and np.array_equal(lp1, lp2)
+    E_dev.close()
+    E_host.close()
+
+
+def test_weight_refresh_cost_19x256():
+    """the trainer refreshes the engine on every Player.read; the 19x256 network (90 MB of filters) used
+    to make a D2H copy, O(38 * 9 * 256^2) host iterations per layout and an upload.  On the device: < 2 ms."""
+    n, blocks, chans = 13, 19, 256
+    net = _net(n, blocks, chans).to("cuda:0")
+    E = _engine(n, blocks, chans)
+    sd = _state_dev(net)
+    E.set_weights(sd, on_device=True)               # first call allocates the packed buffers
+    torch.cuda.synchronize()
+    t = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        E.set_weights(sd, on_device=True)
+        t.append(time.perf_counter() - t0)
+    ms = 1e3 * float(np.median(t))
+    E.close()
+    small = _net(11, 6, 64).to("cuda:0")
+    E = _engine(11, 6, 64)
+    sd = _state_dev(small)
+    E.set_weights(sd, on_device=True)
+    t6 = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        E.set_weights(sd, on_device=True)
+        t6.append(time.perf_counter() - t0)
+    E.close()
+    out = {"what": "Engine.set_weights(on_device=True) wall time, median of 10 (python call incl. the table upload, pack "
+                   "kernels, range readback)", "ms_19x256_13": ms, "ms_6x64_11": 1e3 * float(np.median(t6)),
+           "all_ms_19x256": [1e3 * x for x in t]}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "weight_refresh.json"), "w"), indent=1)
+    print(out)
+    assert ms < 2.0, out
+
+
+def test_folded_weight_beyond_f16_is_rejected_by_name():
+    from oracle import oracle as orc
+    n, blocks, chans = 11, 2, 64
+    net = _net(n, blocks, chans)
+    E = _engine(n, blocks, chans)
+    E.set_weights(_state_np(net))
+    boards, lm = _positions(n, 4)
+    v_ok, lp_ok = E.forward(boards, lm)
+    # (a) a 1e5-scaled convolution: the folded filter cannot be carried as hi + lo f16 halves
+    bad = _state_np(net)
+    bad["resblocks.1.conv2.weight"] = bad["resblocks.1.conv2.weight"] * 1e5
+    with pytest.raises(AzxError) as ei:
+        E.set_weights(bad)
+    assert "resblocks.1.conv2.weight" in str(ei.value) and "-6" in str(ei.value) and "65504" in str(ei.value)
+    with pytest.raises(AzxError):              # nothing was installed: the engine refuses to evaluate
+        E.forward(boards, lm)
+    # (b) a NaN anywhere in a filter
+    bad = _state_np(net)
+    bad["conv1.weight"] = bad["conv1.weight"].copy()
+    bad["conv1.weight"][3, 1, 1, 1] = np.nan
+    with pytest.raises(AzxError) as ei:
+        E.set_weights(bad)
+    assert "conv1.weight" in str(ei.value) and "not finite" in str(ei.value)
+    # (c) a collapsed running variance: scale = w / sqrt(1e-12 + 1e-5) ~ 316 w.  In range: the forward must match the
+    # fp32 oracle; out of range (a larger bn weight): rejected.  Never inf / NaN.
+    col = _state_np(net)
+    col["resblocks.0.bn1.running_var"] = np.full(chans, 1e-12, np.float32)
+    E.set_weights(col)
+    v, lp = E.forward(boards, lm)
+    ov, olp = orc.Net(n, blocks, chans, col).forward(boards, lm)
+    legal = lm > 0
+    assert np.isfinite(v).all() and np.isfinite(lp[legal]).all()
+    assert np.abs(v - ov).max() <= 1e-4 and np.abs(lp - olp)[legal].max() <= 1e-4
+    col["resblocks.0.bn1.weight"] = np.full(chans, 2e4, np.float32)           # x 316 x max |w| ~ 0.04 -> ~2.6e5
+    with pytest.raises(AzxError) as ei:
+        E.set_weights(col)
+    assert "resblocks.0.conv1.weight" in str(ei.value)
+    # the engine recovers with the next valid set
+    E.set_weights(_state_np(net))
+    v2, lp2 = E.forward(boards, lm)
+    assert np.array_equal(v2, v_ok) and np.array_equal(lp2, lp_ok)
+    # the fp32 tower has no such limit: the scaled net installs there
+    F = _engine(n, blocks, chans, {"AZX_TOWER": "fp32"})
+    bad = _state_np(net)
+    bad["resblocks.1.conv2.weight"] = bad["resblocks.1.conv2.weight"] * 1e5
+    F.set_weights(bad)
+    F.close()
+    E.close()
+
+
+def _scaled(state, s, blocks):
+    """The same function with every tower activation multiplied by s: BN affine terms of the stem and of every block
+    scale with s (ReLU is positively homogeneous) and the two head convolutions divide it out again."""
+    out = {k: v.copy() for k, v in state.items()}
+    out["bn1.weight"] *= s
+    out["bn1.bias"] *= s
+    for b in range(blocks):
+        for j in (1, 2):
+            out["resblocks.%d.bn%d.bias" % (b, j)] *= s
+            out["resblocks.%d.bn%d.running_mean" % (b, j)] *= s
+    out["value_conv1.weight"] /= s
+    out["move_conv1.weight"] /= s
+    return out
+
+
+def _max_activation(net, boards):
+    acts = []
+    hooks = [m.register_forward_hook(lambda mod, i, o: acts.append(float(o.abs().max()))) for m in
+             [net.bn1] + [b for b in net.resblocks]]
+    with torch.no_grad():
+        lm = torch.ones((len(boards), 1), dtype=torch.int32)
+        net(torch.tensor(boards), lm)
+    for h in hooks:
+        h.remove()
+    return max(acts)
+
+
+@pytest.mark.parametrize("n,blocks,chans", [(11, 6, 64), (13, 2, 128)])
+def test_large_activations_match_the_oracle_and_overflow_is_flagged(n, blocks, chans):
+    from oracle import oracle as orc
+    net = _net(n, blocks, chans)
+    state = _state_np(net)
+    boards, lm = _positions(n, 8)
+    legal = lm > 0
+    amax = _max_activation(net, boards)
+    E = _engine(n, blocks, chans)
+    # activations around 3e4 -- inside the f16 range: same function, still within 1e-4 of the fp32 oracle
+    big = _scaled(state, 3e4 / amax, blocks)
+    E.set_weights(big)
+    v, lp = E.forward(boards, lm)
+    ov, olp = orc.Net(n, blocks, chans, big).forward(boards, lm)
+    assert np.abs(v - ov).max() <= 1e-4 and np.abs(lp - olp)[legal].max() <= 1e-4
+    # activations around 3e5: every weight is representable, the residual stream is not -> the call says so
+    huge = _scaled(state, 3e5 / amax, blocks)
+    E.set_weights(huge)
+    with pytest.raises(AzxError) as ei:
+        E.forward(boards, lm)
+    assert "-6" in str(ei.value) and "activation" in str(ei.value)
+    # ... also on the self-play path, and the flag does not stick to the next, valid network
+    with pytest.raises(AzxError):
+        E.play_steps(1)
+    E.set_weights(state)
+    E.reset()
+    E.play_steps(1)
+    v, lp = E.forward(boards, lm)
+    ov, olp = orc.Net(n, blocks, chans, state).forward(boards, lm)
+    assert np.abs(v - ov).max() <= 1e-4 and np.abs(lp - olp)[legal].max() <= 1e-4
+    E.close()
