@@ -2038,7 +2038,7 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     if (net->tower_variant == 4) net->lds_bytes = (size_t)F16X3_BPB * 128 * 272 + 2 * 272;   // boards + the zero rows (two in k_tower_f16x3_s16)
     if (net->tower_variant == 5) net->lds_bytes = (size_t)(ncells + 2) * WIDE_ROWB;   // two zero rows + the chunk image
     net->d.sat_flag = nalloc<uint32_t>(net, 4);
-    if (!net->d.sat_flag) {
+    if (!net->d.sat_flag || hipDeviceSynchronize() != hipSuccess) {     // (the zero fills ran on the null stream)
         azx_net_destroy(net);
         return nfail(AZX_ENOMEM, "net: hipMalloc failed");
     }

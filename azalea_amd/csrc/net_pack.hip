@@ -137,6 +137,9 @@ static int ensure_buffers(AzxNet *net, const Plan &p) {
         hipHostMalloc((void **)&net->raw_tab_host, sizeof(const float *) * net->raw_slots) != hipSuccess ||
         hipHostMalloc((void **)&net->wmax_host, sizeof(uint32_t) * (p.L + 2)) != hipSuccess)
         return azx_net_fail(AZX_ENOMEM, "net: allocating the pack scratch failed");
+    // nalloc zero-fills with hipMemset on the null stream, which the engine's non-blocking stream does not wait for:
+    // let the fills land before anything is packed into the buffers
+    if (hipDeviceSynchronize() != hipSuccess) return azx_net_fail(AZX_EHIP, "net: device sync after allocating the packed buffers failed");
     net->packed_once = true;
     return AZX_OK;
 }
@@ -746,6 +749,7 @@ int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void
                 net->raw_arena = nalloc<float>(net, total);
                 net->raw_arena_floats = total;
                 if (!net->raw_arena) return azx_net_fail(AZX_ENOMEM, "net: allocating the weight staging arena failed");
+                if (hipDeviceSynchronize() != hipSuccess) return azx_net_fail(AZX_EHIP, "net: device sync failed");   // its zero fill (null stream)
             }
             // queued kernels of an earlier pack may still read the arena
             if (hipStreamSynchronize(net->stream) != hipSuccess) return azx_net_fail(AZX_EHIP, "net: stream sync failed");
