@@ -19,6 +19,10 @@
 #include "net.h"
 #include "replay_kernels.h"
 
+#ifndef AZX_SRC_SHA
+#define AZX_SRC_SHA "unknown"      // the Makefile passes the digest of the kernel sources (profiles are keyed to it)
+#endif
+
 static thread_local std::string g_err;
 
 static int fail(int code, const char *fmt, ...) {
@@ -271,7 +275,8 @@ extern "C" int azx_kernel_info(azx_engine *e, char *buf, int cap) {
     std::string text = std::string("tree=") + tree + "; play=" + play + "; net=" +
                        (e->net ? azx_net_kernel_info(e->net) : "none") +
                        "; switches: AZX_MCTS_GENERIC=" + (e->force_generic ? "1" : "0") +
-                       " AZX_NO_PERSISTENT=" + (e->no_persistent ? "1" : "0");
+                       " AZX_NO_PERSISTENT=" + (e->no_persistent ? "1" : "0") +
+                       "; src=" AZX_SRC_SHA;       // sha256 (16 hex digits) over the kernel sources this library was built from
     snprintf(buf, (size_t)cap, "%s", text.c_str());
     return (int)text.size();
 }

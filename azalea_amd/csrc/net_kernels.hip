@@ -19,6 +19,10 @@
 #ifndef AZX_NET_ABLATE
 #define AZX_NET_ABLATE 0
 #endif
+// -DAZX_SAT_TRACK=0: the split-f16 epilogues without the activation range tracking (A/B builds only)
+#ifndef AZX_SAT_TRACK
+#define AZX_SAT_TRACK 1
+#endif
 
 #include <cmath>
 #include <cstdio>
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, co
                         if (kind == 1) v += res[m][n][r];
                         v = fmaxf(v, 0.0f);
                         if (kind != 0) res[m][n][r] = v;
-                        satmax = fmaxf(satmax, v);
+                        if (AZX_SAT_TRACK) satmax = fmaxf(satmax, v);
                         _Float16 hi, lo;
                         split_f16(v, hi, lo);
                         h4[j] = hi;
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
                     if (kind != 0) res[m][n][j] = v;
                     v4[j] = v;
                 }
-                satmax = fmaxf(fmaxf(satmax, v4[0]), fmaxf(v4[1], fmaxf(v4[2], v4[3])));
+                if (AZX_SAT_TRACK) satmax = fmaxf(fmaxf(satmax, v4[0]), fmaxf(v4[1], fmaxf(v4[2], v4[3])));
                 uint2 h4, l4;
                 split2_f16(v4[0], v4[1], h4.x, l4.x);
                 split2_f16(v4[2], v4[3], h4.y, l4.y);
@@ -1083,7 +1087,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3(NetDev P, int layer,
                         v += rv[j];
                         v = fmaxf(v, 0.0f);
                         vv[j] = v;
-                        satmax = fmaxf(satmax, v);
+                        if (AZX_SAT_TRACK) satmax = fmaxf(satmax, v);
                         _Float16 hi, lo;
                         split_f16(v, hi, lo);
                         h4[j] = hi;
@@ -1359,7 +1363,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
                 float vv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) vv[j] = fmaxf(acc[m][2 * np + (j >> 2)][j & 3], 0.0f);
-                satmax = fmaxf(fmaxf(fmaxf(satmax, vv[0]), fmaxf(vv[1], vv[2])), fmaxf(fmaxf(vv[3], vv[4]), fmaxf(vv[5], fmaxf(vv[6], vv[7]))));
+                if (AZX_SAT_TRACK) satmax = fmaxf(fmaxf(fmaxf(satmax, vv[0]), fmaxf(vv[1], vv[2])), fmaxf(fmaxf(vv[3], vv[4]), fmaxf(vv[5], fmaxf(vv[6], vv[7]))));
                 uint4 h8, l8;
                 split2_f16(vv[0], vv[1], h8.x, l8.x);
                 split2_f16(vv[2], vv[3], h8.y, l8.y);
@@ -1477,7 +1481,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_wide_f16x3(NetDev P, const uint
                     for (int j = 0; j < 4; ++j) {
                         const float v = fmaxf(acc[m][n][4 * g4 + j] + bv[j], 0.0f);
                         vv[j] = v;
-                        satmax = fmaxf(satmax, v);
+                        if (AZX_SAT_TRACK) satmax = fmaxf(satmax, v);
                         _Float16 hi, lo;
                         split_f16(v, hi, lo);
                         h4[j] = hi;

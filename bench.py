@@ -48,9 +48,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# committed rocprofv3 --pmc summaries of this round (tools/prof_r3.sh); attached only when their bench_key matches
-PMC_FILES = {"resnet": "r3_resnet_pmc_traffic.json", "tree": "r3_tree_pmc_traffic.json",
-             "config5": "r3_config5_pmc_traffic.json"}
+# committed rocprofv3 --pmc summaries of this round (tools/prof.sh); attached only when their bench_key matches AND they
+# were recorded on the kernel sources this library was built from (src_sha, azx_kernel_info's `src=`)
+PMC_FILES = {"resnet": "r4_resnet_pmc_traffic.json", "tree": "r4_tree_pmc_traffic.json",
+             "config5": "r4_config5_pmc_traffic.json"}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TF = 157.3   # dense fp32 MFMA peak
 F16_MFMA_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline is 2:1 sparse)
@@ -127,17 +128,31 @@ def cpu_baseline(args, workload, net_state=None, sims=None, max_plies=None, game
     return base
 
 
-def pmc_traffic(name, key):
+def src_sha(kernels):
+    """`src=<digest>` of azx_kernel_info: the kernel sources the loaded library was built from."""
+    for part in (kernels or "").split(";"):
+        part = part.strip()
+        if part.startswith("src="):
+            return part[4:]
+    return None
+
+
+def pmc_traffic(name, key, kernels=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
-    command (tools/prof_r3.sh: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction of
-    MI355X_MICROARCH.md).  Only attached when the file was recorded for exactly this configuration."""
+    command (tools/prof.sh: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction of
+    MI355X_MICROARCH.md).  Only attached when the file was recorded for exactly this configuration and on exactly
+    these kernel sources; otherwise (None, why)."""
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
-        return None, None
+        return None, "no committed counter file (profiles/%s)" % name
     t = json.load(open(path))
     if t.get("bench_key") != key:
-        return None, None
-    return t.get("hbm_bytes_per_launch"), "profiles/%s (PMC, same command)" % name
+        return None, "profiles/%s was recorded for another configuration" % name
+    sha = src_sha(kernels)
+    if t.get("src_sha") != sha:
+        return None, ("profiles/%s was recorded on kernel sources %s, this library is %s: not attached"
+                      % (name, t.get("src_sha"), sha))
+    return t.get("hbm_bytes_per_launch"), "profiles/%s (PMC, same command, kernel sources %s)" % (name, sha)
 
 
 def make_engine(workload, args, rank, world, local_rank):
@@ -352,7 +367,7 @@ def throughput_fields(st_sums, elapsed, steps):
     return out
 
 
-def tree_roofline(st, args, steps, warmup):
+def tree_roofline(st, args, steps, warmup, kernels=None):
     b = model_bytes(st)
     achieved = b / st["mcts_seconds"] / 1e9 if st["mcts_seconds"] > 0 else 0.0
     kl = max(1, st.get("mcts_kernel_launches") or st["mcts_launches"])
@@ -375,13 +390,18 @@ def tree_roofline(st, args, steps, warmup):
                  "(DESIGN 3.1)"),
     }
     key = [args.games, args.board, args.sims, args.batch, steps, warmup, args.noise_scale, args.desync, args.settle]
-    roof["traffic"], src = pmc_traffic(PMC_FILES["tree"], key)
-    if src:
-        roof["traffic_source"] = src
+    roof["traffic"], src = pmc_traffic(PMC_FILES["tree"], key, kernels)
+    roof["traffic_source"] = src
+    if roof["traffic"]:
+        # what the HBM actually delivered, beside the model fraction above (the model prices the reference's
+        # six-array layout; the kernel moves fewer bytes and is issue-bound)
+        roof["achieved_hbm_gbs"] = roof["traffic"] / (1e-3 * roof["avg_launch_ms"]) / 1e9
+        roof["achieved_hbm_frac"] = roof["achieved_hbm_gbs"] / HBM_PEAK_GBS
+        roof["frac_is"] = "model bytes (SURVEY 8(d)) / time / peak; achieved_hbm_frac = counter bytes / time / peak"
     return roof
 
 
-def resnet_roofline(st, args, steps, warmup):
+def resnet_roofline(st, args, steps, warmup, kernels=None):
     # dominant kernels: the residual tower + heads, one launch pair per leaf batch, timed with HIP events on
     # the engine stream.  ALGORITHMIC flops (107 851 784 per evaluated position) over that
     # time, against the dense MFMA peak of the dtype the tower issues: f16 (the fp32 operands are carried as
@@ -411,11 +431,11 @@ def resnet_roofline(st, args, steps, warmup):
     key = [args.games, args.board, args.sims, args.batch, args.blocks, args.chans, steps, warmup,
            args.noise_scale, args.desync, args.settle]
     wide = args.chans % 128 == 0
-    if wide:      # per-forward counters of the wide tower depend on the batch and the network only (tools/prof_r3.sh)
+    if wide:      # per-forward counters of the wide tower depend on the batch and the network only (tools/prof.sh)
         key = [args.games, args.board, args.batch, args.blocks, args.chans, "per forward"]
-    roof["traffic"], src = pmc_traffic(PMC_FILES["config5" if wide else "resnet"], key)
-    if src:
-        roof["traffic_source"] = src
+    roof["traffic"], src = pmc_traffic(PMC_FILES["config5" if wide else "resnet"], key, kernels)
+    roof["traffic_source"] = src
+    if roof["traffic"]:
         roof["traffic_scope"] = ("HBM bytes of one leaf-batch forward: the stem + %d per-layer launches (k_heads not counted)"
                                  % (2 * args.blocks)) if wide else "HBM bytes of one k_tower_f16x3_s16 launch (k_heads not counted)"
     return roof
@@ -576,7 +596,7 @@ def main():
             wl = ("BASELINE configs[1]: %d concurrent %dx%d Hex games per GPU, HIP movegen+MCTS kernels only, "
                   "uniform priors (no net), %d sims/move (%d select_leaf calls)"
                   % (args.games, args.board, args.board, args.sims, selects_per_search))
-            line["roofline"] = tree_roofline(st, args, args.steps, args.warmup)
+            line["roofline"] = tree_roofline(st, args, args.steps, args.warmup, ex["kernels"])
         else:
             name = ("BASELINE configs[2]" if (args.board, args.blocks, args.chans) == (11, 6, 64) else
                     "BASELINE configs[4] shape on one GPU" if (args.board, args.blocks, args.chans) == (13, 19, 256)
@@ -585,7 +605,7 @@ def main():
                   "forward on split-f16 MFMA (fp32-accurate), random-init weights"
                   % (name, args.games, args.board, args.board, args.sims, selects_per_search, args.blocks, args.chans))
             line["dtype"] = "f16x3 (fp32 operands split hi+lo f16, fp32 accumulate)"
-            line["roofline"] = resnet_roofline(st, args, args.steps, args.warmup)
+            line["roofline"] = resnet_roofline(st, args, args.steps, args.warmup, ex["kernels"])
             if exchange is not None:
                 line["replay_allgather"] = exchange
         line["config"] = dict(workload=wl, **common_cfg)
@@ -608,7 +628,7 @@ def main():
                                            "kernels only, uniform priors (no net), %d sims/move (%d select_leaf calls)"
                                            % (args.games, args.board, args.board, args.sims, selects_per_search)),
                               "start": common_cfg["start"].replace("%d warm-up" % args.warmup, "%d warm-up" % args.tree_warmup)}
-            tree["roofline"] = tree_roofline(st_t, args, args.tree_steps, args.tree_warmup)
+            tree["roofline"] = tree_roofline(st_t, args, args.tree_steps, args.tree_warmup, ex_t["kernels"])
             tree["kernels"] = ex_t["kernels"]
             if world == 1 and not args.no_cpu_baseline:
                 try:
@@ -641,7 +661,7 @@ def main():
                             "games_per_gpu": a5.games, "board": 13, "simulations": a5.sims, "search_batch_size": a5.batch,
                             "start": "steady-state pool as the headline's (0..%d plies, %d settle moves), 1 warm-up move"
                                      % (a5.desync, a5.settle)}
-            c5["roofline"] = resnet_roofline(st5, a5, 1, 1)
+            c5["roofline"] = resnet_roofline(st5, a5, 1, 1, ex5["kernels"])
             c5["kernels"] = ex5["kernels"]
             if world == 1 and not args.no_cpu_baseline:
                 try:      # 19x256 on the host: ~0.2 s per position and thread -> one ply of a 20-sim search per thread

@@ -48,14 +48,24 @@ def test_committed_pmc_traffic_is_keyed_to_the_drivers_command():
     for leg, key in (("resnet", key_r), ("tree", key_t), ("config5", key_5)):
         name = bench.PMC_FILES[leg]
         path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):       # recorded on the GPU box once per round (tools/prof_r3.sh)
+        if not os.path.exists(path):       # recorded on the GPU box once per round (tools/prof.sh)
             continue
         t = json.load(open(path))
         assert t["bench_key"] == key, name
-        traffic, src = bench.pmc_traffic(name, key)
+        assert t.get("src_sha"), "counter files are keyed to the kernel sources they were recorded on"
+        kernels = "tree=...; net=...; src=%s" % t["src_sha"]
+        traffic, src = bench.pmc_traffic(name, key, kernels)
         assert traffic and traffic == t["hbm_bytes_per_launch"] and name in src
         assert abs(t["hbm_bytes_per_launch"] - (2 * t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024) < 1.0
-        assert bench.pmc_traffic(name, key[:-1] + [0]) == (None, None)
+        assert bench.pmc_traffic(name, key[:-1] + [0], kernels)[0] is None
+        # another library (other kernel sources) does not get these counters attached
+        other, why = bench.pmc_traffic(name, key, "tree=...; src=0000000000000000")
+        assert other is None and "not attached" in why
+
+
+def test_src_sha_is_read_from_the_kernel_description():
+    assert bench.src_sha("tree=k_play<2>; net=none; switches: A=0; src=207b9a732d64cae7") == "207b9a732d64cae7"
+    assert bench.src_sha("tree=x") is None and bench.src_sha(None) is None
 
 
 def test_cpu_baseline_carries_the_reference_shim_context():

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round-3 profile set of the command the driver runs (python3 bench.py --steps 20 --warmup 5), on the MI355X
+# Profile set of the command the driver runs (python3 bench.py --steps 20 --warmup 5), on the MI355X
 # box through gpurun.  Kernel trace + stats in one run; PMC counters in their own runs (one --pmc group per
 # pass, --kernel-trace only, the program directly after `--`).  The line's three GPU legs are all in the run:
 # the configs[2] headline (k_tower_f16x3_s16), the nested configs[1] tree run (k_play<2>) and the nested
 # configs[4]-shape leg (k_conv_wide_f16x3_s16); the product-surface leg is skipped (--api-moves 0: the same kernels
-# as the headline).  Summaries land in gpurun_out/<out>/summary/ (tools/prof_r3_summarise.py) and are copied into
+# as the headline).  Summaries land in gpurun_out/<out>/summary/ (tools/prof_summarise.py) and are copied into
 # profiles/ by hand.
-# usage: tools/prof_r3.sh <outdir under gpurun_out> [passes...]   passes: stats fetch write sq1 sq2 (default all)
+# usage: tools/prof.sh <outdir under gpurun_out> [passes...]   passes: stats fetch write sq1 sq2 (default all)
 set -u
 cd /tmp
 export TMPDIR=/tmp
@@ -39,4 +39,4 @@ for p in $PASSES; do
     sq2)   pmc sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR ;;
   esac
 done
-python3 $R/tools/prof_r3_summarise.py $OUT ${STEPS:-20} ${WARMUP:-5}
+python3 $R/tools/prof_summarise.py $OUT ${STEPS:-20} ${WARMUP:-5}

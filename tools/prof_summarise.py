@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 passes of tools/prof_r3.sh into the JSON/CSV files kept under profiles/.
+"""Summarise the rocprofv3 passes of tools/prof.sh into the JSON/CSV files kept under profiles/.
 
   <out>/summary/kernel_stats.csv          per-kernel totals of the --stats run (rocprofv3's own file)
   <out>/summary/kernel_durations.json     mean duration of the timed launches of the tower / wide-conv / heads / tree kernels
@@ -66,6 +66,7 @@ def dur_ms(r):
 
 
 line = bench_line("stats") or bench_line("fetch") or {}
+SHA = src_sha(bench_line("fetch") or line)          # the counters' own run
 evals_per_move = 42          # 41 select batches + the root evaluation (11x11, 400 sims)
 
 # ---- kernel stats ------------------------------------------------------------------------------
@@ -98,8 +99,16 @@ def counters(name, pick):
     return by
 
 
+def src_sha(ln):
+    """`src=<digest>` of the bench line's kernel description: the kernel sources the profiled library was built from."""
+    for part in ((ln or {}).get("kernels") or "").split(";"):
+        if part.strip().startswith("src="):
+            return part.strip()[4:]
+    return None
+
+
 def traffic(f, w):
-    return {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
+    return {"src_sha": SHA, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
             "read_bytes": 2.0 * f * 1024.0, "written_bytes": w * 1024.0,
             "note": "FETCH_SIZE/WRITE_SIZE in KiB, separate --pmc passes; gfx950 tallies the 128-B requests of wide "
                     "loads at 64 B, so reads are doubled (MI355X_MICROARCH.md, HBM section)"}
