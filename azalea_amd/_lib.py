@@ -109,6 +109,22 @@ SYMBOLS = {
     "azx_stream": (_vp, [_vp]),
 }
 
+class TrainConfig(C.Structure):
+    _fields_ = [("board_size", C.c_int32), ("num_blocks", C.c_int32), ("base_chans", C.c_int32),
+                ("batch_size", C.c_int32), ("device", C.c_int32)]
+
+
+_pp = C.POINTER(_vp)
+SYMBOLS.update({
+    "azx_train_create": (C.c_int, [C.POINTER(TrainConfig), C.POINTER(_vp)]),
+    "azx_train_destroy": (None, [_vp]),
+    "azx_train_bind": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), _pp, _i64p, _pp]),
+    "azx_train_inputs": (C.c_int, [_vp, _pp, _pp, _pp, _pp]),
+    "azx_train_outputs": (C.c_int, [_vp, _pp, _pp, _pp]),
+    "azx_train_step": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, _vp]),
+    "azx_train_debug": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int64, _i64p]),
+})
+
 _lib = None
 
 

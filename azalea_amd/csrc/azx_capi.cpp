@@ -17,6 +17,7 @@
 #include "azx_dev.h"
 #include "mcts_kernels.h"
 #include "net.h"
+#include "train.h"
 #include "replay_kernels.h"
 
 #ifndef AZX_SRC_SHA
@@ -1349,4 +1350,66 @@ extern "C" int azx_debug_counters(azx_engine *e, uint64_t *out16) {
     TRY(snap_counters(e, &snap));
     for (int j = 0; j < CTR_COUNT; ++j) out16[j] = snap.c[j];
     return AZX_OK;
+}
+
+// ---- native training step (train_kernels.hip) ----------------------------------------------------------------
+struct azx_trainer {
+    AzxTrain *t = nullptr;
+    int device = 0;
+};
+
+#define TRAIN_GUARD(h) DevGuard _dev_guard((h)->device)
+static int trn_rc(int rc) {
+    if (rc) g_err = azx_trn_error();
+    return rc;
+}
+
+extern "C" int azx_train_create(const azx_train_config *cfg, azx_trainer **out) {
+    if (!cfg || !out) return fail(AZX_EINVAL, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(AZX_ENODEV, "no HIP device visible: the training step is HIP-only (no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(AZX_EINVAL, "device %d out of range (%d visible)", cfg->device, ndev);
+    DevGuard guard(cfg->device);
+    azx_trainer *h = new azx_trainer();
+    h->device = cfg->device;
+    int rc = azx_trn_create(&h->t, cfg->board_size, cfg->num_blocks, cfg->base_chans, cfg->batch_size, cfg->device);
+    if (rc) { delete h; return trn_rc(rc); }
+    *out = h;
+    return AZX_OK;
+}
+
+extern "C" void azx_train_destroy(azx_trainer *h) {
+    if (!h) return;
+    { TRAIN_GUARD(h); azx_trn_destroy(h->t); }
+    delete h;
+}
+
+extern "C" int azx_train_bind(azx_trainer *h, int n, const char *const *names, void *const *tensors,
+                              const int64_t *counts, void *const *momentum) {
+    if (!h || !names || !tensors || !counts) return fail(AZX_EINVAL, "null argument");
+    TRAIN_GUARD(h);
+    return trn_rc(azx_trn_bind(h->t, n, names, tensors, counts, momentum));
+}
+
+extern "C" int azx_train_inputs(azx_trainer *h, int32_t **board, int32_t **legal_moves, float **moves_prob, float **reward) {
+    if (!h) return fail(AZX_EINVAL, "null argument");
+    return trn_rc(azx_trn_inputs(h->t, board, legal_moves, moves_prob, reward));
+}
+
+extern "C" int azx_train_outputs(azx_trainer *h, float **loss3, float **value, float **moves_logprob) {
+    if (!h) return fail(AZX_EINVAL, "null argument");
+    return trn_rc(azx_trn_outputs(h->t, loss3, value, moves_logprob));
+}
+
+extern "C" int azx_train_step(azx_trainer *h, float lr, float momentum, float weight_decay, void *hip_stream) {
+    if (!h) return fail(AZX_EINVAL, "null argument");
+    TRAIN_GUARD(h);
+    return trn_rc(azx_trn_step(h->t, lr, momentum, weight_decay, (hipStream_t)hip_stream));
+}
+
+extern "C" int azx_train_debug(azx_trainer *h, const char *name, void *out, int64_t cap, int64_t *nbytes) {
+    if (!h || !name || !nbytes) return fail(AZX_EINVAL, "null argument");
+    TRAIN_GUARD(h);
+    return trn_rc(azx_trn_debug(h->t, name, out, cap, nbytes));
 }

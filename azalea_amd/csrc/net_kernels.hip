@@ -1967,7 +1967,7 @@ static int raise_lds_limits() {
     const void *fns[] = {(const void *)k_tower_f16x3<false>, (const void *)k_tower_f16x3<true>, (const void *)k_tower_f16x3_s16,
                          (const void *)k_conv_wide_f16x3, (const void *)k_conv_wide_f16x3_s16,
                          (const void *)k_tower_mfma<64, 4, 2, 1, 2>, (const void *)k_tower_mfma<64, 6, 1, 2, 2>,
-                         (const void *)k_tower_mfma<32, 6, 2, 2, 1>};
+                         (const void *)k_tower_mfma<32, 6, 2, 2, 1>, (const void *)k_heads_mfma, (const void *)k_heads};
     for (const void *f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess)
             return nfail(AZX_EHIP, "net: raising a tower kernel's dynamic LDS limit failed");
@@ -2230,14 +2230,10 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
     if (hfeat != nullptr && net->opt_heads_mfma && d.ncells <= 128) {
         // the fused tower left the six head planes: the FC layers run as fp32 MFMA GEMMs over tiles of 32 boards
         const size_t hl = std::max((size_t)HM_MB * d.hm_lda, (size_t)HM_MB * AZX_CELL_STRIDE + (size_t)HM_MB * 64) * sizeof(float);
-        static size_t hm_set = 0;
-        if (hl > hm_set) { (void)hipFuncSetAttribute((const void *)k_heads_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl); hm_set = hl; }
         hipLaunchKernelGGL(k_heads_mfma, dim3((max_n + HM_MB - 1) / HM_MB), dim3(256), hl, st, d, hfeat, boards, flip, n_eval_ptr, n_host, logit, value, prior);
     } else {
         const size_t hl = ((size_t)(6 * d.ncells + 64) * HEADS_BPB + (size_t)HEADS_BPB * AZX_CELL_STRIDE +
                            (size_t)(HEADS_KSPLIT - 1) * (64 + 192) * HEADS_BPB) * sizeof(float);
-        static size_t hl_set = 0;
-        if (hl > hl_set) { (void)hipFuncSetAttribute((const void *)k_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl); hl_set = hl; }
         hipLaunchKernelGGL(k_heads, dim3((max_n + HEADS_BPB - 1) / HEADS_BPB), dim3(192 * HEADS_KSPLIT), hl, st, d, net->act, hfeat, boards, flip, n_eval_ptr, n_host, logit, value, prior);
     }
 }

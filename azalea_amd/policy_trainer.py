@@ -60,8 +60,8 @@ class GraphedTrainStep:
     * the 3 -> 4 embedding is applied as (board == v) masks times the embedding matrix: the same forward values bit
       for bit, and a backward that is a plain reduction instead of `embedding_dense_backward`, whose sort-based kernels
       size their work from the indices seen at capture time (replaying them on other boards reads out of bounds).
-    The learning rate is baked into the captured optimizer kernels, so the step is re-captured when the scheduler
-    changes it.  Losses stay on the device: `step()` returns the three loss tensors of the last replay; read them
+    The optimizer's hyper-parameters and buffer addresses are baked into the captured kernels, so the step is
+    re-captured when any of them changes (the scheduler's rate, momentum / weight decay edits, a reloaded state).  Losses stay on the device: `step()` returns the three loss tensors of the last replay; read them
     (`.item()`) only when logging.  CUDA only; the batch size is fixed at construction."""
 
     def __init__(self, model, optimizer, batch_size: int, device):
@@ -82,9 +82,25 @@ class GraphedTrainStep:
         self._color = torch.zeros(self.B, dtype=torch.int64, device=dev)      # collate_into's other two outputs
         self._result = torch.zeros(self.B, dtype=torch.int64, device=dev)
         self.graph = None
-        self.captured_lr = None
+        self.captured_key = None
         self.captures = 0
         self._warm = 0                   # eager steps run so far (optimizer state / allocator warm-up before capture)
+
+    def _capture_key(self):
+        """Everything the captured optimizer kernels have baked in: the hyper-parameters of every group and the
+        addresses of the parameters, their gradients' owners and their momentum buffers (optimizer.load_state_dict
+        replaces the buffers; replaying the old graph would keep updating the dead ones)."""
+        key = []
+        for g in self.optimizer.param_groups:
+            key.append(tuple(g.get(k) for k in ("lr", "momentum", "weight_decay", "dampening", "nesterov", "maximize")))
+            for p in g["params"]:
+                buf = self.optimizer.state.get(p, {}).get("momentum_buffer")
+                key.append((p.data_ptr(), None if buf is None else buf.data_ptr()))
+        return key
+
+    def invalidate(self):
+        """Force a re-capture on the next step (after anything the capture key cannot see changed)."""
+        self.graph = None
 
     def _forward(self):
         return self.model.forward_embedded(embed_by_masks(self.model, self.board), self.legal_moves)
@@ -117,7 +133,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._step()
-        self.captured_lr = [g["lr"] for g in self.optimizer.param_groups]
+        self.captured_key = self._capture_key()
         self.captures += 1
 
     def step_from_ring(self, replaybuf, indices):
@@ -136,9 +152,8 @@ class GraphedTrainStep:
         return self._run()
 
     def _run(self):
-        lr = [g["lr"] for g in self.optimizer.param_groups]
-        if self.graph is not None and lr != self.captured_lr:
-            self.graph = None                                   # the scheduler moved: capture again with the new rate
+        if self.graph is not None and self._capture_key() != self.captured_key:
+            self.graph = None          # the scheduler moved, or the optimizer was reloaded / re-configured: capture again
         if self.graph is None:
             self.model.train(True)
             if self.captures == 0 and self._warm < 3:
@@ -256,7 +271,7 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
         return "%s/checkpoints/final.policy.pth" % rundir      # written by rank 0
     if device_replay:
         batches = lambda: replaybuf.loader(batch_size)
-        if config.get("train_step_graph") and device.type == "cuda":
+        if (config.get("train_step_graph") or config.get("train_step_native")) and device.type == "cuda":
             # the captured step reads its rows straight from the ring: iterate the epoch's index chunks, the same
             # order loader() visits (random_reflect is the identity for Hex, hex.py:124-134)
             def index_chunks():
@@ -270,8 +285,13 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
         batches = lambda: iter(loader)
     # config["train_step_graph"]: full batches go through the captured step (GraphedTrainStep); their losses stay on
     # the device until the next log line.  The epoch's ragged last batch takes the eager step.
-    gstep = (GraphedTrainStep(policy.net, optimizer, batch_size, device)
-             if config.get("train_step_graph") and device.type == "cuda" else None)
+    # config["train_step_native"]: the hand-written step (native_train.NativeTrainStep: no autograd, no MIOpen).
+    gstep = None
+    if config.get("train_step_native") and device.type == "cuda":
+        from .native_train import NativeTrainStep
+        gstep = NativeTrainStep(policy.net, optimizer, batch_size, device)
+    elif config.get("train_step_graph") and device.type == "cuda":
+        gstep = GraphedTrainStep(policy.net, optimizer, batch_size, device)
     loss_dev = None
     loss, step, start_time = 0.0, 0, time.time()
     for epoch in range(1, config["total_epochs"] + 1):

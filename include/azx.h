@@ -326,6 +326,43 @@ int azx_kernel_info(azx_engine *e, char *buf, int cap);
  * games find it full and park (parallel_player.py has no counterpart: its pipes block instead). */
 int azx_debug_set_queue_cap(azx_engine *e, int64_t rows);
 
+/* ---- the training step on the device ---------------------------------------------------------
+ * Replaces policy_trainer.supervised_step(train=True) (azalea/policy_trainer.py:123-142: zero_grad, Network.run with
+ * compute_loss, backward, optimizer.step) for HexNetwork (network.py:68-102, :120-152) under torch.optim.SGD
+ * (momentum, weight decay): forward in TRAIN mode (BatchNorm on batch statistics, running statistics and
+ * num_batches_tracked updated), the reference's loss, backward, and the SGD update written IN PLACE into the caller's
+ * parameter and momentum tensors -- hand-written fp32-MFMA kernels, one captured HIP graph per step.  The trainer
+ * keeps owning its tensors (PyTorch holds them); this handle owns the activations and scratch.  11x11 boards and
+ * below, 16 / 32 / 64 channels, any batch. */
+typedef struct {
+    int32_t board_size, num_blocks, base_chans;   /* policy.py:51-53 */
+    int32_t batch_size;                           /* config batch_size (hex11_train_config.yml: 128) */
+    int32_t device;
+} azx_train_config;
+typedef struct azx_trainer azx_trainer;
+int azx_train_create(const azx_train_config *cfg, azx_trainer **out);
+void azx_train_destroy(azx_trainer *t);
+/* Every state_dict entry of the module by name (network.py:42-61, :120-132), as DEVICE pointers that stay valid and
+ * are updated in place: parameters (fp32) with their SGD momentum buffers momentum[i] (fp32, same shape, zero before
+ * the first step = torch's lazily created buffer), BatchNorm running_mean / running_var (fp32) and
+ * num_batches_tracked (int64) with momentum[i] = NULL.  Call again after the tensors were re-allocated. */
+int azx_train_bind(azx_trainer *t, int n, const char *const *names, void *const *tensors, const int64_t *counts,
+                   void *const *momentum);
+/* the step's static input buffers (device), row stride board_size^2, the layout azx_replay_collate writes:
+ * board i32[B][cells], legal_moves i32[B][cells] (ascending tile + 1, zero padded), moves_prob f32[B][cells] (by child
+ * index, zero padded), reward f32[B] */
+int azx_train_inputs(azx_trainer *t, int32_t **board, int32_t **legal_moves, float **moves_prob, float **reward);
+/* device buffers holding the last step's results: loss f32[3] = {total, value, moves} (network.py:92-102),
+ * value f32[B], moves_logprob f32[B][cells] (entry j = log-probability of legal move j; padding as the reference's
+ * -99 logits) */
+int azx_train_outputs(azx_trainer *t, float **loss3, float **value, float **moves_logprob);
+/* One optimizer step on the bound tensors with the inputs currently in the input buffers, enqueued on `hip_stream`
+ * (a hipStream_t; NULL = the default stream) and NOT synchronised: order it after whatever filled the inputs and
+ * before whatever reads the weights.  lr / momentum / weight_decay: torch.optim.SGD's (policy_trainer.py:44-49). */
+int azx_train_step(azx_trainer *t, float lr, float momentum, float weight_decay, void *hip_stream);
+/* tests: internal buffer by name ("raw<l>", "act<l>", "g<l>" [B][cells][C]; "sums"; "grad:<state_dict name>") */
+int azx_train_debug(azx_trainer *t, const char *name, void *out, int64_t cap, int64_t *nbytes);
+
 /* engine stream (hipStream_t) so callers can bracket work with HIP events */
 void *azx_stream(azx_engine *e);
 

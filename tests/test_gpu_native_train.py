@@ -1,0 +1,231 @@
+"""The hand-written training step (csrc/train_kernels.hip, azalea_amd/native_train.py) against (a) torch autograd layer
+by layer -- every intermediate the kernels keep (pre-BatchNorm outputs, activations, masked gradients, parameter
+gradients) --, (b) the reference's own recorded step (golden G9: azalea/policy_trainer.py:123-142 run by importing the
+reference; losses, outputs, updated tensors incl. BatchNorm running statistics) and (c) the eager PyTorch step over
+twelve steps at the reference's training shape (6x64, batch 128)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from replay_golden import load_g7, source_frame
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda:0"
+
+
+def _random_batch(n, B, seed):
+    rng = np.random.RandomState(seed)
+    cells = n * n
+    board = rng.randint(0, 3, (B, n, n)).astype(np.int32)
+    board[rng.rand(B, n, n) < 0.4] = 0
+    lm = np.zeros((B, cells), np.int32)
+    mp = np.zeros((B, cells), np.float32)
+    for i in range(B):
+        e = np.flatnonzero(board[i].ravel() == 0) + 1
+        lm[i, :len(e)] = e
+        p = rng.dirichlet(np.full(len(e), 0.3)).astype(np.float32)
+        mp[i, :len(e)] = p
+    reward = rng.choice([-1.0, 1.0], B).astype(np.float32)
+    k = int((lm > 0).sum(1).max())
+    return dict(board=torch.tensor(board), legal_moves=torch.tensor(lm[:, :k]), moves_prob=torch.tensor(mp[:, :k]),
+                reward=torch.tensor(reward))
+
+
+def _net(n, blocks, chans, seed=0):
+    from azalea_amd.network import HexNetwork
+    torch.manual_seed(seed)
+    net = HexNetwork(board_size=n, num_blocks=blocks, base_chans=chans)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():      # BatchNorm affine terms away from (1, 0) so that their gradients matter
+        for name, p in net.named_parameters():
+            if "bn" in name and name.endswith("weight"):
+                p.copy_(0.5 + torch.rand(p.shape, generator=g))
+            elif "bn" in name and name.endswith("bias"):
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+    return net.to(DEV)
+
+
+@pytest.mark.parametrize("n,blocks,chans,B", [(11, 2, 64, 8), (11, 1, 16, 5), (9, 2, 32, 7), (11, 6, 64, 128)])
+def test_every_intermediate_matches_autograd(n, blocks, chans, B):
+    from azalea_amd.native_train import NativeTrainStep
+    net, ref = _net(n, blocks, chans), _net(n, blocks, chans)
+    batch = {k: v.to(DEV) for k, v in _random_batch(n, B, 5).items()}
+    cells, L = n * n, 2 * blocks
+    # ---- torch: the same forward with hooks on every pre-BN output and activation ----
+    ref.train()
+    raws, acts = {}, {}
+
+    def nhwc(t):
+        return t.permute(0, 2, 3, 1).reshape(B, cells, -1)
+    x0 = ref.encoder(batch["board"].long()).permute(0, 3, 1, 2).contiguous()
+    r = ref.conv1(x0); r.retain_grad(); raws[0] = r
+    x = F.relu(ref.bn1(r)); x.retain_grad(); acts[0] = x
+    for k, blk in enumerate(ref.resblocks):
+        r1 = blk.conv1(x); r1.retain_grad(); raws[2 * k + 1] = r1
+        y = F.relu(blk.bn1(r1)); y.retain_grad(); acts[2 * k + 1] = y
+        r2 = blk.conv2(y); r2.retain_grad(); raws[2 * k + 2] = r2
+        x = F.relu(blk.bn2(r2) + x); x.retain_grad(); acts[2 * k + 2] = x
+    v = F.relu(ref.value_bn1(ref.value_conv1(x))).flatten(1)
+    v = ref.value_fc3(F.relu(ref.value_fc2(v)))
+    value = torch.tanh(v).squeeze(1)
+    p = F.relu(ref.move_bn1(ref.move_conv1(x))).flatten(1)
+    logit = ref.move_fc(p)
+    lm = batch["legal_moves"]
+    logit = torch.gather(logit, 1, (lm - 1).clamp(min=0).long()).masked_fill(lm == 0, -99)
+    logprob = F.log_softmax(logit, dim=1)
+    value_loss = F.mse_loss(value, batch["reward"])
+    moves_loss = -(batch["moves_prob"] * logprob).sum() / B
+    (value_loss + moves_loss).backward()
+    # ---- native: one step with lr = 0 (nothing moves; every buffer stays inspectable) ----
+    opt = torch.optim.SGD(net.parameters(), lr=0.0, momentum=0.9, weight_decay=0.0)
+    step = NativeTrainStep(net, opt, B, DEV)
+    loss = step.step(batch).cpu().numpy()
+    torch.cuda.synchronize()
+    C = chans
+
+    def close(a, b, tol, what):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        scale = max(1.0, float(np.abs(b).max()))
+        err = float(np.abs(a - b).max()) / scale
+        assert err <= tol, "%s: %.3g (scale %.3g)" % (what, err, scale)
+    assert abs(loss[1] - float(value_loss.detach())) <= 1e-5 and abs(loss[2] - float(moves_loss.detach())) <= 1e-5
+    for l in range(L + 1):
+        close(step.debug("raw%d" % l).reshape(B, cells, C), nhwc(raws[l].detach()).cpu().numpy(), 2e-5, "raw%d" % l)
+        close(step.debug("act%d" % l).reshape(B, cells, C), nhwc(acts[l].detach()).cpu().numpy(), 2e-5, "act%d" % l)
+    legal = (lm > 0).cpu().numpy()
+    k = lm.shape[1]
+    close(step.out_value.cpu().numpy(), value.detach().cpu().numpy(), 1e-5, "value")
+    close(step.out_logprob.cpu().numpy()[:, :k][legal], logprob.detach().cpu().numpy()[legal], 1e-5, "logprob")
+    # g_l = dL/d(activation l) masked by its ReLU; torch keeps dL/dact: mask it the same way.  Gradients are ~1e-3 ..
+    # 1e-6 in absolute terms, so they are compared relative to their own size: in the 2-norm (an activation within
+    # rounding of zero may pass the ReLU on one side and not on the other: a handful of the 10^6 entries of a layer,
+    # each a legitimate fp32 answer) and, loosely, entry by entry
+    def rel(got, want, what, tol2, tolmax):
+        got, want = np.asarray(got, np.float64).ravel(), np.asarray(want, np.float64).ravel()
+        n2, mx = float(np.linalg.norm(want)), float(np.abs(want).max())
+        assert float(np.linalg.norm(got - want)) <= tol2 * max(n2, 1e-30), "%s: |d|2 %.3g of %.3g" % (what, np.linalg.norm(got - want), n2)
+        assert float(np.abs(got - want).max()) <= tolmax * max(mx, 1e-30), "%s: max %.3g of %.3g" % (what, np.abs(got - want).max(), mx)
+    # (at batch 128 a layer has 10^6 entries and a few kink decisions do differ -- they add up down the chain; the small
+    # shapes pin the arithmetic tightly, the training shape is held to the size of that effect and, below, to fp64)
+    big = B * cells * C > 200000
+    for l in range(L, -1, -1):
+        want = (nhwc(acts[l].grad) * (nhwc(acts[l].detach()) > 0)).cpu().numpy()
+        rel(step.debug("g%d" % l), want, "g%d" % l, 2e-2 if big else 2e-4, 1.0 if big else 2e-2)
+    for name, prm in ref.named_parameters():
+        rel(step.debug("grad:" + name), prm.grad.detach().cpu().numpy(), "grad " + name, 5e-3 if big else 2e-4, 5e-2 if big else 1e-3)
+    if big:
+        # calibration against float64 autograd: both fp32 computations sit a few kink decisions (~1e-3 of the gradient's
+        # norm) away from it -- the native one within a small multiple of torch's own distance
+        ref64 = _net(n, blocks, chans).double().train()
+        o64 = ref64.forward(batch["board"], batch["legal_moves"])
+        l64 = F.mse_loss(o64["value"], batch["reward"].double()) - (batch["moves_prob"].double() * o64["moves_logprob"]).sum() / B
+        l64.backward()
+        for (name, p32), (_, p64) in zip(ref.named_parameters(), ref64.named_parameters()):
+            truth = p64.grad.cpu().numpy().ravel()
+            e_torch = float(np.linalg.norm(p32.grad.double().cpu().numpy().ravel() - truth))
+            e_native = float(np.linalg.norm(step.debug("grad:" + name).astype(np.float64) - truth))
+            assert e_native <= max(5.0 * e_torch, 5e-3 * float(np.linalg.norm(truth))), (name, e_native, e_torch)
+    # lr = 0, weight decay 0: nothing but the BatchNorm statistics moved
+    for (name, a), (_, b) in zip(net.state_dict().items(), ref.state_dict().items()):
+        if a.dtype.is_floating_point:
+            close(a.cpu().numpy(), b.cpu().numpy(), 2e-5, name)
+        else:
+            assert torch.equal(a, b), name
+    step.close()
+
+
+def test_native_step_matches_the_reference_recorded_steps():
+    """Golden G9: three supervised_step calls of the reference (SGD 0.1 / 0.9 / 1e-4, train-mode BatchNorm) from the
+    recorded initial weights -- the bounds the eager GPU step is held to (test_train_step.py: 2e-4 on the updated
+    tensors, ten times that on the per-step outputs)."""
+    from azalea_amd.native_train import NativeTrainStep
+    from azalea_amd.network import HexNetwork
+    from azalea_amd.policy_trainer import supervised_step
+    from azalea_amd.prep import torch_batch_replays
+    z = np.load(os.path.join(GOLDEN, "g9_train_step.npz"))
+    frame = source_frame(load_g7())
+    net = HexNetwork(board_size=11, num_blocks=2, base_chans=16)
+    net.load_state_dict({k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith("w0:")})
+    net.to(DEV)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    B = len(z["batch_idx"][0])
+    step = NativeTrainStep(net, opt, B, DEV)
+    tol = 2e-4
+    for s, ids in enumerate(z["batch_idx"]):
+        batch = torch_batch_replays([frame[int(i)] for i in ids])
+        loss = step.step({k: v.to(DEV) for k, v in batch.items()}).cpu().numpy()
+        assert abs(loss[0] - float(z["step%d_loss" % s])) <= tol * 10
+        assert abs(loss[1] - float(z["step%d_value_loss" % s])) <= tol * 10
+        assert abs(loss[2] - float(z["step%d_moves_loss" % s])) <= tol * 10
+        k = batch["legal_moves"].shape[1]
+        o = step.outputs(k)
+        assert np.abs(o["value"].cpu().numpy() - z["step%d_value" % s]).max() <= tol * 10
+        legal = batch["legal_moves"].numpy() > 0
+        assert np.abs(o["moves_logprob"].cpu().numpy() - z["step%d_moves_logprob" % s])[legal].max() <= tol * 10
+    for k, v in net.state_dict().items():
+        want = z["w3:" + k]
+        if want.dtype.kind == "f":
+            assert np.abs(v.cpu().numpy() - want).max() <= tol, k
+        else:
+            assert np.array_equal(v.cpu().numpy(), want), k
+    # the optimizer's own state is what the kernels used: the eval-mode pass after the three steps agrees too
+    batch = torch_batch_replays([frame[int(i)] for i in z["batch_idx"][0]])
+    o, loss = supervised_step(net, batch, train=False, device=DEV)
+    assert abs(loss - float(z["eval_loss"])) <= tol * 10
+    step.close()
+
+
+def test_native_step_tracks_the_eager_step_over_twelve_steps():
+    """6x64 on 11x11, batch 128 (config/hex11_train_config.yml), SGD 0.1 -> 0.03 after eight steps, against
+    policy_trainer.supervised_step: twelve steps of the eager trajectory, the native step taken from the SAME state
+    each time (weights, BatchNorm buffers, momentum copied over before the step -- two fp32 trajectories at lr 0.1
+    drift apart by themselves, which would measure the optimisation's sensitivity, not the step): losses, outputs,
+    then every tensor and every momentum buffer after the step."""
+    from azalea_amd.native_train import NativeTrainStep
+    from azalea_amd.policy_trainer import supervised_step
+    B, n = 128, 11
+    nets = [_net(n, 6, 64, seed=2), _net(n, 6, 64, seed=2)]
+    opts = [torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4) for m in nets]
+    step = NativeTrainStep(nets[1], opts[1], B, DEV)
+    worst = {"loss": 0.0, "out": 0.0, "tensor": 0.0, "momentum": 0.0}
+    for i in range(12):
+        if i == 8:
+            for o in opts:
+                o.param_groups[0]["lr"] = 0.03
+        with torch.no_grad():                       # same state in
+            for (_, a), (_, b) in zip(nets[0].state_dict().items(), nets[1].state_dict().items()):
+                b.copy_(a)
+            for pa, pb in zip(nets[0].parameters(), nets[1].parameters()):
+                ma = opts[0].state.get(pa, {}).get("momentum_buffer")
+                if ma is not None:
+                    opts[1].state[pb]["momentum_buffer"].copy_(ma)
+        batch = _random_batch(n, B, 100 + i % 4)
+        o, loss = supervised_step(nets[0], dict(batch), train=True, optimizer=opts[0], device=DEV)
+        nl = step.step({k: v.to(DEV) for k, v in batch.items()}).cpu().numpy()
+        worst["loss"] = max(worst["loss"], abs(float(nl[0]) - loss), abs(float(nl[1]) - o["value_loss"]), abs(float(nl[2]) - o["moves_loss"]))
+        legal = batch["legal_moves"].numpy() > 0
+        k = batch["legal_moves"].shape[1]
+        no = step.outputs(k)
+        worst["out"] = max(worst["out"], float(np.abs(no["value"].cpu().numpy() - o["value"].cpu().numpy()).max()),
+                           float(np.abs(no["moves_logprob"].cpu().numpy() - o["moves_logprob"].cpu().numpy())[legal].max()))
+        a, b = nets[0].state_dict(), nets[1].state_dict()
+        for name, v in a.items():
+            if v.dtype.is_floating_point:
+                worst["tensor"] = max(worst["tensor"], float((v - b[name]).abs().max()))
+            else:
+                assert torch.equal(v, b[name]), name
+        for pa, pb in zip(nets[0].parameters(), nets[1].parameters()):
+            ma, mb = opts[0].state[pa]["momentum_buffer"], opts[1].state[pb]["momentum_buffer"]
+            worst["momentum"] = max(worst["momentum"], float((ma - mb).abs().max()) / max(1e-6, float(ma.abs().max())))
+    assert step.steps == 12
+    assert worst["loss"] <= 1e-4 and worst["out"] <= 1e-4, worst
+    assert worst["tensor"] <= 2e-4, worst         # G9's bound on an updated tensor
+    assert worst["momentum"] <= 2e-2, worst       # relative to the buffer's largest entry (ReLU-kink decisions, see above)
+    # the momentum buffers are the optimizer's own tensors: its state_dict is a normal SGD checkpoint
+    sd = opts[1].state_dict()
+    assert len(sd["state"]) == len(list(nets[1].parameters()))
+    step.close()

@@ -229,20 +229,22 @@ def test_policy_engine_sees_weights_updated_by_graph_replays():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("graphed", [False, True])
-def test_train_loop_with_device_replay(tmp_path, graphed):
+@pytest.mark.parametrize("mode", ["eager", "graph", "native"])
+def test_train_loop_with_device_replay(tmp_path, mode):
     """policy_trainer.train end to end on the GPU: engine self-play -> HBM replay ring -> GPU collate
-    -> supervised_step (or, with config["train_step_graph"], the captured step); the checkpoint it writes loads back
-    through Policy.load."""
+    -> supervised_step (or, with config["train_step_graph"], the captured step; with config["train_step_native"], the
+    hand-written one); the checkpoint it writes loads back through Policy.load."""
     from azalea_amd.policy import Policy
     from azalea_amd.policy_trainer import initialize_replay_buffer, train
     from azalea_amd.game.hex import HexGame
     config = dict(seed=3, device="cuda:0", replaybuf_oversampling=2, batch_size=32, game="azalea_amd.game.hex.HexGame",
                   board_size=5, replaybuf_size=128, lr_initial=0.05, momentum=0.9, l2_regularization=1e-4,
-                  lr_decay_epochs=2, lr_decay=0.5, total_epochs=4, network="HexNetwork", num_blocks=1, base_chans=8,
+                  lr_decay_epochs=2, lr_decay=0.5, total_epochs=4, network="HexNetwork", num_blocks=1,
+                  base_chans=16 if mode == "native" else 8,
                   simulations=20, search_batch_size=10, exploration_coef=0.5, exploration_depth=4,
                   exploration_noise_alpha=0.3, exploration_noise_scale=0.25, exploration_temperature=1.0,
-                  log_interval=2, model_checkpoint_interval=0, selfplay_games=16, train_step_graph=graphed)
+                  log_interval=2, model_checkpoint_interval=0, selfplay_games=16, train_step_graph=mode == "graph",
+                  train_step_native=mode == "native")
     policy = Policy()
     policy.initialize(config)
     before = {k: v.clone() for k, v in policy.net.state_dict().items()}
