@@ -34,7 +34,10 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define TRN_EPS 1e-5
-#define TRN_WG_GROUPS 28          // k_trn_wgrad: board groups per tap (9 x 28 = 252 workgroups <= 256 CUs)
+#define TRN_MAXL 38               // tower conv layers (19 blocks): the per-layer pointers live IN the kernel argument struct --
+                                  // a pointer fetched from a table in memory is a generic pointer to the compiler, every
+                                  // access through it a FLAT instruction whose completion the LDS waits then also wait for
+#define TRN_WG_GROUPS 64          // k_trn_wgrad: board groups (x 4 channel-tile pairs at C = 64: 256 workgroups)
 
 static thread_local std::string g_trn_err;
 const char *azx_trn_error() { return g_trn_err.c_str(); }
@@ -52,14 +55,14 @@ struct TrnDev {
     const float *prob, *reward;    // [B][cells], [B]
     // parameters (torch tensors, updated in place)
     const float *emb, *w1;         // encoder.weight [3][4], conv1.weight [C][4][3][3]
-    const float *const *bn_w, *const *bn_b;      // [L + 1] -> [C]   (device arrays of pointers)
+    const float *bn_w[TRN_MAXL + 1], *bn_b[TRN_MAXL + 1];      // [L + 1] -> [C]
     const float *vconv, *pconv;    // [2][C], [4][C]
     const float *hbn_w[2], *hbn_b[2];            // value_bn1 (2), move_bn1 (4)
     const float *fc2w, *fc2b, *fc3w, *fc3b, *mfw, *mfb;
     // work buffers
-    float *const *raw, *const *act, *const *g;   // [L + 1] -> [B][cells][C]
-    const float *const *Wf, *const *Wb;          // [L + 1] (index 1..L) MFMA-order filters: forward / backward-data
-    const float *const *convw;                   // [L + 1] (index 1..L) the filters themselves (torch layout [co][ci][3][3])
+    float *raw[TRN_MAXL + 1], *act[TRN_MAXL + 1], *g[TRN_MAXL + 1];   // [L + 1] -> [B][cells][C]
+    float *Wf[TRN_MAXL + 1], *Wb[TRN_MAXL + 1];  // (index 1..L) MFMA-order filters: forward / backward-data
+    const float *convw[TRN_MAXL + 1];            // (index 1..L) the filters themselves (torch layout [co][ci][3][3])
     double *sums;                  // [(L + 1)][C][4]
     double *hsums;                 // [6][4]
     double *lossacc;               // [2]
@@ -70,8 +73,8 @@ struct TrnDev {
     float *value, *logprob;        // [B], [B][cells]
     float *loss3;
     float *wpart;                  // [L][G][C*C*9] weight-gradient partial sums (index l - 1)
-    float *stem_part;              // [B][27*C]
-    float *hconv_part;             // [B][6*C]
+    double *stem_dT;               // [27][C]  dL/d(stem table), summed over the boards (f64 atomics)
+    double *hconv_acc;             // [6][C]   gradient of the two 1x1 head convolutions
     float *grad;                   // flat gradient buffer (offsets in the segment table)
     const float *hp;               // lr, momentum, weight decay
 };
@@ -144,18 +147,38 @@ __global__ __launch_bounds__(256) void k_trn_stem_fwd(TrnDev P) {
 // =================================================================================================================
 enum { ROLE_FWD = 0, ROLE_BWD = 1 };
 
+// Diagnostic build only (-DAZX_TRN_STAMP): shader-clock stamps of k_trn_conv's phases (every wave's lane 0), summed per
+// role; azx_trn_destroy prints them.  The shipped kernels execute no stamp.
+#ifdef AZX_TRN_STAMP
+// every wave of the LAST launch of a role leaves its phase times in its own slot (no atomics: a stamp must not wait on
+// other waves' stamps); the host averages
+#define TS_WAVES 2048
+__device__ unsigned long long g_trn_stamp[3][TS_WAVES][8];
+#define TS_DECL unsigned long long ts_last = __builtin_amdgcn_s_memtime(), ts_acc[6] = {0, 0, 0, 0, 0, 0}; const unsigned long long ts_rt0 = __builtin_amdgcn_s_memrealtime();
+#define TS_MARK(r) { const unsigned long long ts_now = __builtin_amdgcn_s_memtime(); ts_acc[r] += ts_now - ts_last; ts_last = ts_now; }
+#define TS_END { const int ts_w = ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)); \
+    if ((threadIdx.x & 63) == 0 && ts_w < TS_WAVES) { for (int k_ = 0; k_ < 6; ++k_) g_trn_stamp[ROLE][ts_w][k_] = ts_acc[k_]; \
+        g_trn_stamp[ROLE][ts_w][6] = 1; g_trn_stamp[ROLE][ts_w][7] = __builtin_amdgcn_s_memrealtime() - ts_rt0; } }
+#else
+#define TS_DECL
+#define TS_MARK(r)
+#define TS_END
+#endif
+
 template <int C, int ROLE>
 __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
     constexpr int NT = (C + 31) / 32, LDW = C + 4, Q = C / 8, C4 = C / 4;
     extern __shared__ __align__(16) float lds[];
     float *X = lds;                                    // [(cells + 1)][LDW]
     const int N = P.N, cells = P.cells;
-    float *cA = X + (size_t)(cells + 1) * LDW;          // per input channel coefficients
+    // (the backward epilogue re-uses X as a [cells][36] output tile: the region is the larger of the two)
+    float *cA = X + (size_t)max((cells + 1) * LDW, cells * 36);      // per input channel coefficients
     float *cB = cA + C, *cM = cB + C, *cI = cM + C, *cK = cI + C;     // cK: [2][C] (BWD)
     float *pM = cK + 2 * C, *pI = pM + C;               // BWD epilogue: mean / invstd of layer l - 1
     float *red = pI + C;                                // [4][32][2]
     const int nt = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
+    TS_DECL
 
     // ---- per-channel coefficients -----------------------------------------------------------------------
     if (tid < C) {
@@ -181,36 +204,63 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
     }
     for (int i = tid; i < LDW; i += 256) X[(size_t)cells * LDW + i] = 0.f;
     __syncthreads();
+    TS_MARK(0)
 
     // ---- stage the input operand ---------------------------------------------------------------------------
+    // (every load of the block is requested before the first one is used: a dependent load -> use loop would pay
+    // the L2 / HBM latency once per iteration, eight times per block)
     {
+        constexpr int ITER = (121 * C4 + 255) / 256;
         const size_t base = (size_t)b * cells * C;
+        const int total = cells * C4;
         if (ROLE == ROLE_FWD) {
             const float4 *src = reinterpret_cast<const float4 *>(P.raw[l - 1] + base);
             const bool has_res = ((l - 1) & 1) == 0 && l - 1 >= 2;
             const float4 *res = has_res ? reinterpret_cast<const float4 *>(P.act[l - 3] + base) : nullptr;
             float4 *dst = reinterpret_cast<float4 *>(P.act[l - 1] + base);
-            for (int i = tid; i < cells * C4; i += 256) {
+            float4 va[ITER], vr[ITER];
+#pragma unroll
+            for (int k = 0; k < ITER; ++k) {
+                const int i = tid + 256 * k;
+                va[k] = i < total ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                vr[k] = (has_res && i < total) ? res[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#ifdef AZX_TRN_STAMP
+            __builtin_amdgcn_s_waitcnt(0);
+            TS_MARK(4)
+#endif
+#pragma unroll
+            for (int k = 0; k < ITER; ++k) {
+                const int i = tid + 256 * k;
+                if (i >= total) break;
                 const int pos = i / C4, c = (i - pos * C4) * 4;
-                float4 v = src[i];
-                v.x = v.x * cA[c] + cB[c];
-                v.y = v.y * cA[c + 1] + cB[c + 1];
-                v.z = v.z * cA[c + 2] + cB[c + 2];
-                v.w = v.w * cA[c + 3] + cB[c + 3];
-                if (has_res) {
-                    const float4 r = res[i];
-                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                }
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                float4 v = va[k];
+                v.x = fmaxf(v.x * cA[c] + cB[c] + vr[k].x, 0.f);
+                v.y = fmaxf(v.y * cA[c + 1] + cB[c + 1] + vr[k].y, 0.f);
+                v.z = fmaxf(v.z * cA[c + 2] + cB[c + 2] + vr[k].z, 0.f);
+                v.w = fmaxf(v.w * cA[c + 3] + cB[c + 3] + vr[k].w, 0.f);
                 *reinterpret_cast<float4 *>(X + (size_t)pos * LDW + c) = v;
                 if (NT == 1 || (c >> 5) == nt) dst[i] = v;       // each of a board's blocks writes its channel half
             }
+#ifdef AZX_TRN_STAMP
+            TS_MARK(5)
+#endif
         } else {
             const float4 *gs = reinterpret_cast<const float4 *>(P.g[l] + base);
             const float4 *rs = reinterpret_cast<const float4 *>(P.raw[l] + base);
-            for (int i = tid; i < cells * C4; i += 256) {
+            float4 vg[ITER], vr[ITER];
+#pragma unroll
+            for (int k = 0; k < ITER; ++k) {
+                const int i = tid + 256 * k;
+                vg[k] = i < total ? gs[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                vr[k] = i < total ? rs[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < ITER; ++k) {
+                const int i = tid + 256 * k;
+                if (i >= total) break;
                 const int pos = i / C4, c = (i - pos * C4) * 4;
-                const float4 gv = gs[i], rv = rs[i];
+                const float4 gv = vg[k], rv = vr[k];
                 float4 v;
                 v.x = cA[c] * (gv.x - cK[c] - (rv.x - cM[c]) * cI[c] * cK[C + c]);
                 v.y = cA[c + 1] * (gv.y - cK[c + 1] - (rv.y - cM[c + 1]) * cI[c + 1] * cK[C + c + 1]);
@@ -221,30 +271,51 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
         }
     }
     __syncthreads();
+    TS_MARK(1)
 
     // ---- k-loop: 9 taps x C / 8 steps of four 32x32x2 MFMAs ----------------------------------------------------
+    // One wave per SIMD and a dependent MFMA chain: nothing hides a load but the loop itself.  So the filter
+    // fragments of tap t + 1 (C / 8 16-byte loads from L2) are requested before tap t's MFMAs start, and a tap's
+    // activation fragments (LDS) are all requested at its top; two accumulators alternate so that consecutive
+    // MFMAs do not wait on each other's result.
     const int r = wave * 32 + li;
     const bool rvalid = r < cells;
     const int ry = r / N, rx = r - ry * N;
-    f32x16 acc;
+    f32x16 acc, acc2;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const float4 *wl = reinterpret_cast<const float4 *>(ROLE == ROLE_FWD ? P.Wf[l] : P.Wb[l]);
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
+    const float4 *wl = reinterpret_cast<const float4 *>(ROLE == ROLE_FWD ? P.Wf[l] : P.Wb[l]) + (size_t)nt * 64 + lane;
+    float4 bcur[Q], bnxt[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) bcur[q] = wl[(size_t)q * NT * 64];
+#pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
+        if (tap < 8) {
+            const float4 *wt = wl + (size_t)(tap + 1) * Q * NT * 64;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) bnxt[q] = wt[(size_t)q * NT * 64];
+        }
         const int yy = ry + tap / 3 - 1, xx = rx + tap % 3 - 1;
         const bool ok = rvalid && yy >= 0 && yy < N && xx >= 0 && xx < N;
         const float *arow = X + (size_t)(ok ? yy * N + xx : cells) * LDW + 4 * lh;
-        const float4 *wt = wl + ((size_t)tap * Q * NT + nt) * 64 + lane;
-#pragma unroll 4
+        float4 af[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) af[q] = *reinterpret_cast<const float4 *>(arow + 8 * q);
+#pragma unroll
         for (int q = 0; q < Q; ++q) {
-            const float4 bf = wt[(size_t)q * NT * 64];
-            const float4 af = *reinterpret_cast<const float4 *>(arow + 8 * q);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bcur[q].x, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, bcur[q].y, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, bcur[q].z, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, bcur[q].w, acc2, 0, 0, 0);
+        }
+        if (tap < 8) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) bcur[q] = bnxt[q];
         }
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
+    TS_MARK(2)
 
     // ---- epilogue: C/D layout col = lane & 31 (output channel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) ----
     const int co = nt * 32 + li;
@@ -264,24 +335,69 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
             }
         }
     } else {
-        float *out = P.g[l - 1] + base;
-        const float *pact = P.act[l - 1] + base, *praw = P.raw[l - 1] + base;
-        const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= P.L;
-        const float *skip = has_skip ? P.g[l + 1] + base : nullptr;
-        const float pm = cvalid ? pM[co] : 0.f, pi = cvalid ? pI[co] : 0.f;
+        // the accumulators go through LDS (the input tile is done with) so that the skip gradient, the ReLU mask's
+        // activation and the BatchNorm input are read -- and g written -- in coalesced 16-byte pieces
+        constexpr int LDO = 36, CHo = C < 32 ? C : 32, O4 = CHo / 4, ITER = (121 * O4 + 255) / 256;
+        __syncthreads();                                 // every wave has finished reading X
+        float *Y = X;                                    // [cells][LDO]: this block's 32 output channels
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-            if (row < cells && cvalid) {
-                const size_t o = (size_t)row * C + co;
-                float v = acc[i];
-                if (has_skip) v += skip[o];
-                v = pact[o] > 0.f ? v : 0.f;
-                out[o] = v;
-                s1 += v;
-                s2 += v * (praw[o] - pm) * pi;
-            }
+            if (row < cells) Y[(size_t)row * LDO + li] = acc[i];
         }
+        __syncthreads();
+        float *out = P.g[l - 1] + base + nt * 32;
+        const float *pact = P.act[l - 1] + base + nt * 32, *praw = P.raw[l - 1] + base + nt * 32;
+        const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= P.L;
+        const float *skip = has_skip ? P.g[l + 1] + base + nt * 32 : nullptr;
+        const int total = cells * O4;
+        float4 ea[ITER], er[ITER], es[ITER];
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) {
+            const int i = tid + 256 * k, pos = i / O4, c = (i - pos * O4) * 4;
+            const bool on = i < total;
+            const size_t o = (size_t)pos * C + c;
+            ea[k] = on ? *reinterpret_cast<const float4 *>(pact + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            er[k] = on ? *reinterpret_cast<const float4 *>(praw + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            es[k] = (on && has_skip) ? *reinterpret_cast<const float4 *>(skip + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // a thread's items all have the same four channels (256 is a multiple of O4): four pairs of running sums
+        float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+        const int c0 = (tid % O4) * 4;
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) {
+            const int i = tid + 256 * k;
+            if (i >= total) break;
+            const int pos = i / O4;
+            const float4 y = *reinterpret_cast<const float4 *>(Y + (size_t)pos * LDO + c0);
+            float4 v;
+            v.x = ea[k].x > 0.f ? y.x + es[k].x : 0.f;
+            v.y = ea[k].y > 0.f ? y.y + es[k].y : 0.f;
+            v.z = ea[k].z > 0.f ? y.z + es[k].z : 0.f;
+            v.w = ea[k].w > 0.f ? y.w + es[k].w : 0.f;
+            *reinterpret_cast<float4 *>(out + (size_t)pos * C + c0) = v;
+            a4[0] += v.x; a4[1] += v.y; a4[2] += v.z; a4[3] += v.w;
+            q4[0] += v.x * (er[k].x - pM[nt * 32 + c0]) * pI[nt * 32 + c0];
+            q4[1] += v.y * (er[k].y - pM[nt * 32 + c0 + 1]) * pI[nt * 32 + c0 + 1];
+            q4[2] += v.z * (er[k].z - pM[nt * 32 + c0 + 2]) * pI[nt * 32 + c0 + 2];
+            q4[3] += v.w * (er[k].w - pM[nt * 32 + c0 + 3]) * pI[nt * 32 + c0 + 3];
+        }
+        // per channel: the 256 / O4 threads that share it -> f64 atomics, one pair per channel and block
+        __syncthreads();
+        float *rs = Y;                                   // [256][8]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { rs[tid * 8 + j] = a4[j]; rs[tid * 8 + 4 + j] = q4[j]; }
+        __syncthreads();
+        if (tid < CHo) {
+            const int grp4 = tid / 4, j = tid % 4;
+            double a = 0, q = 0;
+            for (int th = grp4; th < 256; th += O4) { a += rs[th * 8 + j]; q += rs[th * 8 + 4 + j]; }
+            atomicAdd(&P.sums[((size_t)(l - 1) * C + nt * 32 + tid) * 4 + 2], a);
+            atomicAdd(&P.sums[((size_t)(l - 1) * C + nt * 32 + tid) * 4 + 3], q);
+        }
+        TS_MARK(3)
+        TS_END
+        return;
     }
     s1 += __shfl_xor(s1, 32);
     s2 += __shfl_xor(s2, 32);
@@ -298,87 +414,149 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
         atomicAdd(&P.sums[((size_t)lay * C + nt * 32 + tid) * 4 + k0], a);
         atomicAdd(&P.sums[((size_t)lay * C + nt * 32 + tid) * 4 + k0 + 1], q);
     }
+    TS_MARK(3)
+    TS_END
 }
 
 // =================================================================================================================
 // weight gradient of layer l: dW[co][ci][tap] = sum over boards and positions of draw_l[pos][co] act_{l-1}[pos + tap][ci]
-//   grid (9 taps, G board groups); a block walks its boards, M = co, N = ci, K = the board's positions (padded to
-//   an even count), A = draw^T and B = the shifted input, both staged in LDS; partial sums per group, reduced by
-//   k_trn_update (two stages, fixed order: the step is reproducible)
+//   A GEMM with a tiny output (C x 9 C) and a long reduction (B x cells positions).  Splitting the reduction over
+//   P_k blocks costs P_k partial copies of the output; splitting the output over P_o blocks costs P_o reads of both
+//   operands.  Here P_o = the (co tile, ci tile) pairs (4 for C = 64) and P_k = G board groups (64 at batch 128):
+//   grid (pairs, G) = 256 workgroups.  A block stages, per board, the 32-channel halves of draw (BatchNorm backward
+//   applied on the way in) and of the input ONCE and runs all 9 taps from them -- a tap is a row offset into the
+//   staged input, the off-board taps read a zero row; its 4 waves split the positions and are summed through LDS.
+//   Partials are reduced by k_trn_wreduce in a fixed order: the step is reproducible.
 // =================================================================================================================
 template <int C>
 __global__ __launch_bounds__(256) void k_trn_wgrad(TrnDev P, int l, int G) {
-    constexpr int NT = (C + 31) / 32, T = NT * NT, WPT = 4 / T, LDD = C + 32, C4 = C / 4;
+    constexpr int NT = (C + 31) / 32, CH = C < 32 ? C : 32, H4 = CH / 4, ITER = (121 * H4 + 255) / 256;
     extern __shared__ __align__(16) float lds[];
-    const int N = P.N, cells = P.cells, KP = (cells + 1) & ~1;
-    float *D = lds;                                     // [KP][LDD] draw
-    float *A = D + (size_t)KP * LDD;                     // [KP][LDD] shifted input
-    float *cA = A + (size_t)KP * LDD, *cM = cA + C, *cI = cM + C, *cK = cI + C;      // cK [2][C]
-    const int tap = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = P.N, cells = P.cells, KP = (cells + 1) & ~1, NP = N + 2;
+    float *D = lds;                                     // [KP][32] draw, this block's co half (rows >= cells zero)
+    float *A = D + (size_t)KP * 32;                      // [(N + 2)^2][32] input, this block's ci half, on a board with a
+                                                         //   zero border: a tap is a constant row offset, no bounds test
+    float *red = A + (size_t)NP * NP * 32;               // [3 taps][4 waves][1024] reduction rounds
+    float *cA = red + 12 * 1024, *cM = cA + 32, *cI = cM + 32, *cK = cI + 32;     // cK [2][32]
+    int *prow = reinterpret_cast<int *>(cK + 64);        // [KP] padded-board row of position k (0 for the padding k)
+    const int pair = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tm = pair / NT, tn = pair % NT;
     const int li = lane & 31, lh = lane >> 5;
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-    if (tid < C) {
-        const int c = tid;
+    constexpr int ROLE = 2;
+    (void)ROLE;
+    TS_DECL
+    if (tid < CH) {
+        const int c = tm * 32 + tid;
         float mean, inv;
         bn_coeffs(P, l, c, mean, inv);
-        cM[c] = mean;
-        cI[c] = inv;
-        cA[c] = P.bn_w[l][c] * inv;
-        cK[c] = (float)(dsum(P.sums, l, C, c, 2) * (double)P.invN);
-        cK[C + c] = (float)(dsum(P.sums, l, C, c, 3) * (double)P.invN);
+        cM[tid] = mean;
+        cI[tid] = inv;
+        cA[tid] = P.bn_w[l][c] * inv;
+        cK[tid] = (float)(dsum(P.sums, l, C, c, 2) * (double)P.invN);
+        cK[32 + tid] = (float)(dsum(P.sums, l, C, c, 3) * (double)P.invN);
     }
-    // rows beyond the board and columns beyond C are read by the MFMA lanes: keep them zero
-    for (int i = tid; i < 2 * KP * LDD; i += 256) lds[i] = 0.f;
-    __syncthreads();
-    const int tile = WPT == 1 ? wave : 0, sub = WPT == 1 ? 0 : wave;
-    const int tm = tile / NT, tn = tile % NT;
-    f32x16 acc;
+    for (int i = tid; i < KP * 32 + NP * NP * 32; i += 256) lds[i] = 0.f;
+    for (int i = tid; i < KP; i += 256) prow[i] = i < cells ? (i / N + 1) * NP + (i % N) + 1 : 0;
+    f32x16 acc[9];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    __syncthreads();
+    TS_MARK(0)
+    const int S = KP / 2;
     for (int b = grp; b < P.B; b += G) {
         const size_t base = (size_t)b * cells * C;
-        const float4 *gs = reinterpret_cast<const float4 *>(P.g[l] + base);
-        const float4 *rs = reinterpret_cast<const float4 *>(P.raw[l] + base);
-        const float4 *as = reinterpret_cast<const float4 *>(P.act[l - 1] + base);
-        for (int i = tid; i < cells * C4; i += 256) {
-            const int pos = i / C4, c = (i - pos * C4) * 4;
-            const float4 gv = gs[i], rv = rs[i];
-            float4 v;
-            v.x = cA[c] * (gv.x - cK[c] - (rv.x - cM[c]) * cI[c] * cK[C + c]);
-            v.y = cA[c + 1] * (gv.y - cK[c + 1] - (rv.y - cM[c + 1]) * cI[c + 1] * cK[C + c + 1]);
-            v.z = cA[c + 2] * (gv.z - cK[c + 2] - (rv.z - cM[c + 2]) * cI[c + 2] * cK[C + c + 2]);
-            v.w = cA[c + 3] * (gv.w - cK[c + 3] - (rv.w - cM[c + 3]) * cI[c + 3] * cK[C + c + 3]);
-            *reinterpret_cast<float4 *>(D + (size_t)pos * LDD + c) = v;
-            const int y = pos / N, x = pos - y * N, yy = y + dy, xx = x + dx;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (yy >= 0 && yy < N && xx >= 0 && xx < N) a = as[(size_t)(yy * N + xx) * C4 + (i - pos * C4)];
-            *reinterpret_cast<float4 *>(A + (size_t)pos * LDD + c) = a;
+        const float *gs = P.g[l] + base + tm * 32, *rs = P.raw[l] + base + tm * 32, *as = P.act[l - 1] + base + tn * 32;
+        {
+            float4 vg[ITER], vr[ITER], va[ITER];
+            const int total = cells * H4;
+#pragma unroll
+            for (int k = 0; k < ITER; ++k) {
+                const int i = tid + 256 * k, pos = i / H4, c = (i - pos * H4) * 4;
+                const bool on = i < total;
+                vg[k] = on ? *reinterpret_cast<const float4 *>(gs + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                vr[k] = on ? *reinterpret_cast<const float4 *>(rs + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                va[k] = on ? *reinterpret_cast<const float4 *>(as + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < ITER; ++k) {
+                const int i = tid + 256 * k;
+                if (i >= total) break;
+                const int pos = i / H4, c = (i - pos * H4) * 4;
+                const float4 gv = vg[k], rv = vr[k];
+                float4 v;
+                v.x = cA[c] * (gv.x - cK[c] - (rv.x - cM[c]) * cI[c] * cK[32 + c]);
+                v.y = cA[c + 1] * (gv.y - cK[c + 1] - (rv.y - cM[c + 1]) * cI[c + 1] * cK[32 + c + 1]);
+                v.z = cA[c + 2] * (gv.z - cK[c + 2] - (rv.z - cM[c + 2]) * cI[c + 2] * cK[32 + c + 2]);
+                v.w = cA[c + 3] * (gv.w - cK[c + 3] - (rv.w - cM[c + 3]) * cI[c + 3] * cK[32 + c + 3]);
+                *reinterpret_cast<float4 *>(D + (size_t)pos * 32 + c) = v;
+                *reinterpret_cast<float4 *>(A + (size_t)prow[pos] * 32 + c) = va[k];
+            }
         }
         __syncthreads();
-        const float *dp = D + (size_t)lh * LDD + tm * 32 + li, *ap = A + (size_t)lh * LDD + tn * 32 + li;
-        for (int s = sub; s < KP / 2; s += WPT)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[(size_t)2 * s * LDD], ap[(size_t)2 * s * LDD], acc, 0, 0, 0);
+        TS_MARK(1)
+        // this wave's k-steps s = wave, wave + 4, ...; the operands of step s + 4 are requested before step s's MFMAs
+        int s = wave < S ? wave : S - 1;
+        float a_c = D[(size_t)(2 * s + lh) * 32 + li], b_c[9];
+        {
+            const float *bp = A + (size_t)prow[2 * s + lh] * 32 + li;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) b_c[t] = bp[((t / 3 - 1) * NP + (t % 3 - 1)) * 32];
+        }
+        for (; s < S; s += 4) {
+            const int sn = s + 4 < S ? s + 4 : s;
+            const float a_n = D[(size_t)(2 * sn + lh) * 32 + li];
+            float b_n[9];
+            const float *bp = A + (size_t)prow[2 * sn + lh] * 32 + li;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) b_n[t] = bp[((t / 3 - 1) * NP + (t % 3 - 1)) * 32];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b_c[t], acc[t], 0, 0, 0);
+            a_c = a_n;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) b_c[t] = b_n[t];
+        }
         __syncthreads();
+        TS_MARK(2)
     }
+    // the four waves' shares of the nine tiles -> one, three taps per round through LDS ([3][4 waves][1024]; plain
+    // writes and reads: LDS float atomics run at a small fraction of that rate)
     float *part = P.wpart + ((size_t)(l - 1) * G + grp) * ((size_t)C * C * 9);
-    if (WPT == 1) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int co = tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh, ci = tn * 32 + li;
-            if (co < C && ci < C) part[((size_t)co * C + ci) * 9 + tap] = acc[i];
-        }
-    } else {
-        float *redt = lds;                               // [4][1024] (the operand tiles are done with)
+    for (int t0 = 0; t0 < 9; t0 += 3) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) redt[(size_t)wave * 1024 + i * 64 + lane] = acc[i];
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[(u * 4 + wave) * 1024 + i * 64 + lane] = acc[t0 + u][i];
         __syncthreads();
-        for (int e = tid; e < 1024; e += 256) {
-            const int i = e >> 6, ln = e & 63;
-            const int co = (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5), ci = ln & 31;
-            if (co < C && ci < C)
-                part[((size_t)co * C + ci) * 9 + tap] = redt[e] + redt[1024 + e] + redt[2048 + e] + redt[3072 + e];
+        for (int e = tid; e < 3 * 1024; e += 256) {
+            const int u = e >> 10, i = (e >> 6) & 15, ln = e & 63, r = e & 1023;
+            const int co = tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5), ci = tn * 32 + (ln & 31);
+            const float *q = red + (size_t)u * 4096 + r;
+            if (co < C && ci < C) part[((size_t)co * C + ci) * 9 + t0 + u] = (q[0] + q[1024]) + (q[2048] + q[3072]);
         }
+        __syncthreads();
     }
+    TS_MARK(3)
+    TS_END
+}
+
+// second stage: the G partial copies of layer l's filter gradient -> the flat gradient buffer
+__global__ __launch_bounds__(256) void k_trn_wreduce(TrnDev P, int l, int G, size_t n, size_t goff) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const float *part = P.wpart + (size_t)(l - 1) * G * n + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = 0;
+    for (; g + 4 <= G; g += 4) {
+        s0 += part[(size_t)g * n];
+        s1 += part[(size_t)(g + 1) * n];
+        s2 += part[(size_t)(g + 2) * n];
+        s3 += part[(size_t)(g + 3) * n];
+    }
+    for (; g < G; ++g) s0 += part[(size_t)g * n];
+    P.grad[goff + e] = (s0 + s1) + (s2 + s3);
 }
 
 // =================================================================================================================
@@ -478,20 +656,34 @@ __global__ __launch_bounds__(256) void k_trn_heads_fc(TrnDev P) {
     __syncthreads();
     // value_fc2 (2 cells -> 64) + ReLU: a wave per output, lanes along the input
     const int KV = 2 * cells, KPp = 4 * cells;
-    for (int o = wave; o < 64; o += 4) {
-        const float *w = P.fc2w + (size_t)o * KV;
-        float s = 0.f;
-        for (int i = lane; i < KV; i += 64) s += w[i] * ha[i];
-        s = wave_sum(s);
-        if (lane == 0) h2[o] = fmaxf(s + P.fc2b[o], 0.f);
+    // (four outputs at a time: their loads are independent, the wave reductions come after)
+    for (int o0 = wave * 4; o0 < 64; o0 += 16) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = lane; i < KV; i += 64) {
+            const float x = ha[i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += P.fc2w[(size_t)(o0 + u) * KV + i] * x;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float r = wave_sum(s[u]);
+            if (lane == 0) h2[o0 + u] = fmaxf(r + P.fc2b[o0 + u], 0.f);
+        }
     }
     // move_fc (4 cells -> cells)
-    for (int t = wave; t < cells; t += 4) {
-        const float *w = P.mfw + (size_t)t * KPp;
-        float s = 0.f;
-        for (int i = lane; i < KPp; i += 64) s += w[i] * ha[2 * cells + i];
-        s = wave_sum(s);
-        if (lane == 0) logit[t] = s + P.mfb[t];
+    for (int t0 = wave * 4; t0 < cells; t0 += 16) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = lane; i < KPp; i += 64) {
+            const float x = ha[2 * cells + i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t0 + u < cells) s[u] += P.mfw[(size_t)(t0 + u) * KPp + i] * x;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float r = wave_sum(s[u]);
+            if (lane == 0 && t0 + u < cells) logit[t0 + u] = r + P.mfb[t0 + u];
+        }
     }
     __syncthreads();
     if (wave == 0) {
@@ -537,11 +729,13 @@ __global__ __launch_bounds__(256) void k_trn_heads_fc(TrnDev P) {
     // back through the FC layers to the head planes
     for (int i = tid; i < KV; i += 256) {
         float s = 0.f;
+#pragma unroll 8
         for (int o = 0; o < 64; ++o) s += P.fc2w[(size_t)o * KV + i] * dh2s[o];
         gflat[i] = ha[i] > 0.f ? s : 0.f;
     }
     for (int i = tid; i < KPp; i += 256) {
         float s = 0.f;
+#pragma unroll 11
         for (int t = 0; t < cells; ++t) s += P.mfw[(size_t)t * KPp + i] * dlog[t];
         gflat[2 * cells + i] = ha[2 * cells + i] > 0.f ? s : 0.f;
     }
@@ -563,38 +757,65 @@ __global__ __launch_bounds__(256) void k_trn_heads_fc(TrnDev P) {
     (void)sc;
 }
 
-// gradients of the FC layers: one thread per element, the batch is the reduction (fixed order)
+// gradients of the FC layers: the batch is the reduction (fixed order).  Block roles by index:
+//   [0, nM)        move_fc.weight  [cells][4 cells]: 4 rows x 256 columns per block
+//   [nM, nM + 16)  value_fc2.weight [64][2 cells]:   4 rows x all columns per block
+//   last           the biases and value_fc3
 struct HeadGradOffs { size_t fc2w, fc2b, fc3w, fc3b, mfw, mfb; };
 __global__ __launch_bounds__(256) void k_trn_heads_wgrad(TrnDev P, HeadGradOffs O) {
-    const int cells = P.cells, B = P.B, KV = 2 * cells, KPp = 4 * cells;
-    const size_t n_mfw = (size_t)cells * KPp, n_fc2 = (size_t)64 * KV;
-    const size_t total = n_mfw + n_fc2 + cells + 64 + 64 + 1;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        float s = 0.f;
-        if (e < n_mfw) {
-            const int t = (int)(e / KPp), i = (int)(e - (size_t)t * KPp);
-            for (int b = 0; b < B; ++b) s += P.dlogit[(size_t)b * 128 + t] * P.hact[(size_t)b * 6 * cells + 2 * cells + i];
-            P.grad[O.mfw + e] = s;
-        } else if (e < n_mfw + n_fc2) {
-            const size_t k = e - n_mfw;
-            const int o = (int)(k / KV), i = (int)(k - (size_t)o * KV);
-            for (int b = 0; b < B; ++b) s += P.dh2[(size_t)b * 64 + o] * P.hact[(size_t)b * 6 * cells + i];
-            P.grad[O.fc2w + k] = s;
-        } else if (e < n_mfw + n_fc2 + cells) {
-            const int t = (int)(e - n_mfw - n_fc2);
-            for (int b = 0; b < B; ++b) s += P.dlogit[(size_t)b * 128 + t];
-            P.grad[O.mfb + t] = s;
-        } else if (e < n_mfw + n_fc2 + cells + 64) {
-            const int o = (int)(e - n_mfw - n_fc2 - cells);
-            for (int b = 0; b < B; ++b) s += P.dh2[(size_t)b * 64 + o];
-            P.grad[O.fc2b + o] = s;
-        } else if (e < n_mfw + n_fc2 + cells + 128) {
-            const int o = (int)(e - n_mfw - n_fc2 - cells - 64);
-            for (int b = 0; b < B; ++b) s += P.dv3[b] * P.h2[(size_t)b * 64 + o];
-            P.grad[O.fc3w + o] = s;
-        } else {
-            for (int b = 0; b < B; ++b) s += P.dv3[b];
-            P.grad[O.fc3b] = s;
+    __shared__ float dl[4][256];             // the block's four gradient rows over the batch (B <= 256 per pass)
+    const int cells = P.cells, B = P.B, KV = 2 * cells, KPp = 4 * cells, tid = threadIdx.x;
+    const int ichunks = (KPp + 255) / 256, tgroups = (cells + 3) / 4, nM = ichunks * tgroups;
+    const int blk = blockIdx.x;
+    if (blk < nM + 16) {
+        const bool mf = blk < nM;
+        const int r0 = mf ? (blk / ichunks) * 4 : (blk - nM) * 4;
+        const int i = mf ? (blk % ichunks) * 256 + tid : tid;
+        const int rows = mf ? cells : 64, cols = mf ? KPp : KV;
+        const float *src = mf ? P.dlogit : P.dh2;
+        const int sstride = mf ? 128 : 64;
+        const float *x = P.hact + (mf ? 2 * cells : 0);
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int b0 = 0; b0 < B; b0 += 256) {
+            const int nb = min(256, B - b0);
+            __syncthreads();
+            for (int e = tid; e < 4 * nb; e += 256) {
+                const int u = e / nb, bb = e - u * nb;
+                dl[u][bb] = r0 + u < rows ? src[(size_t)(b0 + bb) * sstride + r0 + u] : 0.f;
+            }
+            __syncthreads();
+            if (i < cols) {
+#pragma unroll 8
+                for (int bb = 0; bb < nb; ++bb) {
+                    const float xv = x[(size_t)(b0 + bb) * 6 * cells + i];
+                    s[0] += dl[0][bb] * xv; s[1] += dl[1][bb] * xv; s[2] += dl[2][bb] * xv; s[3] += dl[3][bb] * xv;
+                }
+            }
+        }
+        if (i < cols) {
+            float *gdst = P.grad + (mf ? O.mfw : O.fc2w);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r0 + u < rows) gdst[(size_t)(r0 + u) * cols + i] = s[u];
+        }
+    } else {
+        for (int e = tid; e < cells + 64 + 64 + 1; e += 256) {
+            float s = 0.f;
+            if (e < cells) {
+                for (int b = 0; b < B; ++b) s += P.dlogit[(size_t)b * 128 + e];
+                P.grad[O.mfb + e] = s;
+            } else if (e < cells + 64) {
+                const int o = e - cells;
+                for (int b = 0; b < B; ++b) s += P.dh2[(size_t)b * 64 + o];
+                P.grad[O.fc2b + o] = s;
+            } else if (e < cells + 128) {
+                const int o = e - cells - 64;
+                for (int b = 0; b < B; ++b) s += P.dv3[b] * P.h2[(size_t)b * 64 + o];
+                P.grad[O.fc3w + o] = s;
+            } else {
+                for (int b = 0; b < B; ++b) s += P.dv3[b];
+                P.grad[O.fc3b] = s;
+            }
         }
     }
 }
@@ -654,12 +875,12 @@ __global__ __launch_bounds__(256) void k_trn_heads_bwd(TrnDev P) {
         atomicAdd(&P.sums[((size_t)L * C + tid) * 4 + 3], q);
     }
     // weight gradients of the 1x1 convolutions: this board's share
-    float *part = P.hconv_part + (size_t)b * 6 * C;
     for (int i = tid; i < 6 * C; i += 256) {
         const int o = i / C, cc = i - o * C;
         float s = 0.f;
+#pragma unroll 11
         for (int pos = 0; pos < cells; ++pos) s += dh[o * 128 + pos] * act[(size_t)pos * C + cc];
-        part[i] = s;
+        atomicAdd(&P.hconv_acc[i], (double)s);
     }
 }
 
@@ -692,16 +913,28 @@ __global__ __launch_bounds__(256) void k_trn_stem_bwd(TrnDev P) {
         Dr[i] = cA[c] * (g0[i] - cK[c] - (r0[i] - cM[c]) * cI[c] * cK[C + c]);
     }
     __syncthreads();
-    float *part = P.stem_part + (size_t)b * 27 * C;
-    for (int i = tid; i < 27 * C; i += 256) {
-        const int k = i / C, co = i - k * C, tap = k / 3, v = k - tap * 3;
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        float s = 0.f;
+    // dT[tap][v][co] += draw[pos][co] over the positions whose tap-neighbour holds v: a thread per (tap, co), the
+    // three cell values in three accumulators; nbv[tap][pos] = that neighbour's value (3 = off the board)
+    __shared__ unsigned char nbv[9 * 128];
+    for (int i = tid; i < 9 * cells; i += 256) {
+        const int tap = i / cells, pos = i - tap * cells;
+        const int y = pos / N, x = pos - y * N, yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        nbv[tap * 128 + pos] = (yy >= 0 && yy < N && xx >= 0 && xx < N) ? cellv[yy * N + xx] : (unsigned char)3;
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * C; i += 256) {
+        const int tap = i / C, co = i - tap * C;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
         for (int pos = 0; pos < cells; ++pos) {
-            const int y = pos / N, x = pos - y * N, yy = y + dy, xx = x + dx;
-            if (yy >= 0 && yy < N && xx >= 0 && xx < N && cellv[yy * N + xx] == v) s += Dr[(size_t)pos * C + co];
+            const float v = Dr[(size_t)pos * C + co];
+            const int cv = nbv[tap * 128 + pos];
+            a0 += cv == 0 ? v : 0.f;
+            a1 += cv == 1 ? v : 0.f;
+            a2 += cv == 2 ? v : 0.f;
         }
-        part[i] = s;
+        atomicAdd(&P.stem_dT[(tap * 3 + 0) * C + co], (double)a0);
+        atomicAdd(&P.stem_dT[(tap * 3 + 1) * C + co], (double)a1);
+        atomicAdd(&P.stem_dT[(tap * 3 + 2) * C + co], (double)a2);
     }
 }
 
@@ -723,11 +956,7 @@ __global__ __launch_bounds__(256) void k_trn_finalize(TrnDev P, FinalizeArgs F) 
     __shared__ float dT[27 * C];
     const int tid = threadIdx.x, B = P.B, L = P.L;
     if (blockIdx.x == 0) {
-        for (int i = tid; i < 27 * C; i += 256) {
-            float s = 0.f;
-            for (int b = 0; b < B; ++b) s += P.stem_part[(size_t)b * 27 * C + i];
-            dT[i] = s;
-        }
+        for (int i = tid; i < 27 * C; i += 256) dT[i] = (float)P.stem_dT[i];
         __syncthreads();
         for (int i = tid; i < C * 36; i += 256) {       // conv1.weight [co][i4][tap]
             const int co = i / 36, r = i - co * 36, i4 = r / 9, tap = r - i4 * 9;
@@ -744,8 +973,7 @@ __global__ __launch_bounds__(256) void k_trn_finalize(TrnDev P, FinalizeArgs F) 
         }
     } else if (blockIdx.x == 1) {
         for (int i = tid; i < 6 * C; i += 256) {
-            float s = 0.f;
-            for (int b = 0; b < B; ++b) s += P.hconv_part[(size_t)b * 6 * C + i];
+            const float s = (float)P.hconv_acc[i];
             if (i < 2 * C) P.grad[F.g_vconv + i] = s;
             else P.grad[F.g_pconv + i - 2 * C] = s;
         }
@@ -777,12 +1005,12 @@ __global__ __launch_bounds__(256) void k_trn_finalize(TrnDev P, FinalizeArgs F) 
 
 // =================================================================================================================
 // SGD update of every tensor, in place (torch.optim.SGD: d = g + wd p; buf = mu buf + d; p -= lr buf).  A block
-// handles 1024 consecutive elements of one segment; conv filters take their gradient from the wgrad partial sums.
+// handles 1024 consecutive elements of one segment.
 // =================================================================================================================
 struct Segment {
     float *p, *mom;
     size_t n, goff;
-    int layer;          // >= 1: tower conv filter of that layer (gradient = sum of partials, packs refreshed); 0: plain
+    int layer;          // >= 1: tower conv filter of that layer; 0: anything else
 };
 
 template <int C>
@@ -795,15 +1023,7 @@ __global__ __launch_bounds__(256) void k_trn_update(TrnDev P, const Segment *seg
     for (int k = 0; k < 4; ++k) {
         const size_t e = e0 + (size_t)k * 256 + threadIdx.x;
         if (e >= S.n) break;
-        float gr;
-        if (S.layer >= 1) {
-            const float *part = P.wpart + (size_t)(S.layer - 1) * G * S.n + e;
-            gr = 0.f;
-            for (int g = 0; g < G; ++g) gr += part[(size_t)g * S.n];
-            P.grad[S.goff + e] = gr;
-        } else {
-            gr = P.grad[S.goff + e];
-        }
+        const float gr = P.grad[S.goff + e];
         const float p = S.p[e], d = gr + wd * p, buf = mu * S.mom[e] + d, np = p - lr * buf;
         S.mom[e] = buf;
         S.p[e] = np;
@@ -829,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_trn_pack(TrnDev P) {
     const int l = blockIdx.y + 1;
     const int tap = (int)(e % 9), ci = (int)(e / 9 % C), co = (int)(e / 9 / C);
     const float v = P.convw[l][e];
-    float *wf = const_cast<float *>(P.Wf[l]), *wb = const_cast<float *>(P.Wb[l]);
+    float *wf = P.Wf[l], *wb = P.Wb[l];
     wf[((((size_t)tap * Q + (ci >> 3)) * NT + (co >> 5)) * 64 + (co & 31) + 32 * ((ci >> 2) & 1)) * 4 + (ci & 3)] = v;
     wb[((((size_t)(8 - tap) * Q + (co >> 3)) * NT + (ci >> 5)) * 64 + (ci & 31) + 32 * ((co >> 2) & 1)) * 4 + (co & 3)] = v;
 }
@@ -858,6 +1078,7 @@ struct AzxTrain {
     int n_blocks = 0;
     FinalizeArgs fin;
     HeadGradOffs hoffs;
+    std::vector<size_t> conv_goff;
     float *hp_dev = nullptr;
     int32_t *in_board = nullptr, *in_legal = nullptr;
     float *in_prob = nullptr, *in_reward = nullptr;
@@ -869,6 +1090,7 @@ struct AzxTrain {
     hipStream_t cap = nullptr, side = nullptr;
     std::vector<hipEvent_t> events;
     bool use_graph = true;
+    bool fork = true;            // AZX_TRAIN_FORK=0: the weight-gradient passes in line with the data chain (profiling)
 };
 
 template <typename T>
@@ -891,7 +1113,7 @@ static T *upload_table(AzxTrain *t, const std::vector<T> &v) {
 int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int device) {
     if (N < 2 || N > 11) return tfail(AZX_EINVAL, "train: the native step covers boards up to 11x11 (121 cells = four 32-row MFMA tiles)");
     if (chans != 16 && chans != 32 && chans != 64) return tfail(AZX_EINVAL, "train: base_chans must be 16, 32 or 64");
-    if (blocks < 1 || batch < 1) return tfail(AZX_EINVAL, "train: num_blocks and batch must be positive");
+    if (blocks < 1 || batch < 1 || 2 * blocks > TRN_MAXL) return tfail(AZX_EINVAL, "train: num_blocks must be 1..19 and the batch positive");
     AzxTrain *t = new AzxTrain();
     memset(&t->d, 0, sizeof t->d);
     t->device = device;
@@ -911,11 +1133,12 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
         }
     }
     // sums | hsums | lossacc contiguous: one memset per step
-    const size_t nsum = (size_t)(L + 1) * C * 4 + 6 * 4 + 2;
+    const size_t nsum = (size_t)(L + 1) * C * 4 + 6 * 4 + 2 + 27 * C + 6 * C;
     double *z = ok ? talloc<double>(t, nsum) : nullptr;
     ok = ok && z;
     if (ok) {
         d.sums = z; d.hsums = z + (size_t)(L + 1) * C * 4; d.lossacc = d.hsums + 24;
+        d.stem_dT = d.lossacc + 2; d.hconv_acc = d.stem_dT + 27 * C;
         t->zero_bytes = nsum * sizeof(double);
     }
     ok = ok && (d.hraw = talloc<float>(t, (size_t)B * 6 * cells)) && (d.hact = talloc<float>(t, (size_t)B * 6 * cells)) &&
@@ -923,8 +1146,7 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
          (d.dh2 = talloc<float>(t, (size_t)B * 64)) && (d.dv3 = talloc<float>(t, B)) &&
          (d.dlogit = talloc<float>(t, (size_t)B * 128)) && (d.value = talloc<float>(t, B)) &&
          (d.logprob = talloc<float>(t, (size_t)B * cells)) && (d.loss3 = talloc<float>(t, 4)) &&
-         (d.wpart = talloc<float>(t, (size_t)L * t->G * C * C * 9)) && (d.stem_part = talloc<float>(t, (size_t)B * 27 * C)) &&
-         (d.hconv_part = talloc<float>(t, (size_t)B * 6 * C)) &&
+         (d.wpart = talloc<float>(t, (size_t)L * t->G * C * C * 9)) &&
          (t->in_board = talloc<int32_t>(t, (size_t)B * cells)) && (t->in_legal = talloc<int32_t>(t, (size_t)B * cells)) &&
          (t->in_prob = talloc<float>(t, (size_t)B * cells)) && (t->in_reward = talloc<float>(t, B)) &&
          (t->hp_dev = talloc<float>(t, 4));
@@ -933,19 +1155,8 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
         return tfail(AZX_ENOMEM, "train: hipMalloc failed");
     }
     d.board = t->in_board; d.legal = t->in_legal; d.prob = t->in_prob; d.reward = t->in_reward; d.hp = t->hp_dev;
-    {
-        std::vector<float *> v;
-        v = t->raw; d.raw = upload_table(t, v);
-        v = t->act; d.act = upload_table(t, v);
-        v = t->g; d.g = upload_table(t, v);
-        std::vector<const float *> w(t->Wf.begin(), t->Wf.end());
-        d.Wf = upload_table(t, w);
-        w.assign(t->Wb.begin(), t->Wb.end());
-        d.Wb = upload_table(t, w);
-        if (!d.raw || !d.act || !d.g || !d.Wf || !d.Wb) {
-            azx_trn_destroy(t);
-            return tfail(AZX_ENOMEM, "train: uploading the buffer tables failed");
-        }
+    for (int l = 0; l <= L; ++l) {
+        d.raw[l] = t->raw[l]; d.act[l] = t->act[l]; d.g[l] = t->g[l]; d.Wf[l] = t->Wf[l]; d.Wb[l] = t->Wb[l];
     }
     for (int l = 0; l <= L; ++l) {
         char nm[32];
@@ -960,6 +1171,7 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     t->dbg["hg"] = {d.g6, (size_t)B * 6 * cells * 4};
     t->dbg["dlogit"] = {d.dlogit, (size_t)B * 128 * 4};
     t->use_graph = !(getenv("AZX_TRAIN_GRAPH") && !strcmp(getenv("AZX_TRAIN_GRAPH"), "0"));
+    t->fork = !(getenv("AZX_TRAIN_FORK") && !strcmp(getenv("AZX_TRAIN_FORK"), "0"));
     if (hipDeviceSynchronize() != hipSuccess) {
         azx_trn_destroy(t);
         return tfail(AZX_EHIP, "train: device sync after the allocations failed");
@@ -970,6 +1182,25 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
 
 void azx_trn_destroy(AzxTrain *t) {
     if (!t) return;
+#ifdef AZX_TRN_STAMP
+    {
+        std::vector<unsigned long long> raw((size_t)3 * TS_WAVES * 8);
+        if (hipMemcpyFromSymbol(raw.data(), HIP_SYMBOL(g_trn_stamp), raw.size() * 8) == hipSuccess)
+            for (int r = 0; r < 3; ++r) {
+                double h[8] = {0};
+                for (int w = 0; w < TS_WAVES; ++w)
+                    for (int k = 0; k < 8; ++k) h[k] += (double)raw[((size_t)r * TS_WAVES + w) * 8 + k];
+                if (h[6] == 0) continue;
+                static const char *nm[6] = {"coefficients / init + barrier", "staging + barrier", "k-loop (+ barrier in wgrad)", "epilogue / reduce + write",
+                                            "(FWD) staging loads in flight", "(FWD) staging compute + writes issued"};
+                double tot = 0;
+                for (int k = 0; k < 6; ++k) tot += h[k];
+                fprintf(stderr, "k_trn_%s, last launch, %.0f waves: %.0f cycles/wave, %.2f us/wave wall, shader clock %.0f MHz\n",
+                        r == 2 ? "wgrad" : r ? "conv<BWD>" : "conv<FWD>", h[6], tot / h[6], h[7] / h[6] / 100.0, 100.0 * tot / h[7]);
+                for (int k = 0; k < 6; ++k) fprintf(stderr, "  %-40s %6.1f%%  %9.0f cycles/wave\n", nm[k], 100.0 * h[k] / tot, h[k] / h[6]);
+            }
+    }
+#endif
     if (t->exec) (void)hipGraphExecDestroy(t->exec);
     if (t->graph) (void)hipGraphDestroy(t->graph);
     for (hipEvent_t e : t->events) (void)hipEventDestroy(e);
@@ -1051,10 +1282,7 @@ int azx_trn_bind(AzxTrain *t, int n, const char *const *names, void *const *ptrs
     d.fc2w = (const float *)fc2w->ptr; d.fc2b = (const float *)fc2b->ptr; d.fc3w = (const float *)fc3w->ptr;
     d.fc3b = (const float *)fc3b->ptr; d.mfw = (const float *)mfw->ptr; d.mfb = (const float *)mfb->ptr;
     {
-        std::vector<const float *> w(L + 1), bb(L + 1);
-        for (int l = 0; l <= L; ++l) { w[l] = (const float *)bnw[l]->ptr; bb[l] = (const float *)bnb[l]->ptr; }
-        d.bn_w = upload_table(t, w);
-        d.bn_b = upload_table(t, bb);
+        for (int l = 0; l <= L; ++l) { d.bn_w[l] = (const float *)bnw[l]->ptr; d.bn_b[l] = (const float *)bnb[l]->ptr; }
         std::vector<size_t> gw(L + 3), gb(L + 3);
         std::vector<float *> rm(L + 3), rv(L + 3);
         std::vector<long long *> tk(L + 3);
@@ -1065,7 +1293,7 @@ int azx_trn_bind(AzxTrain *t, int n, const char *const *names, void *const *ptrs
         t->fin.g_emb = emb->goff; t->fin.g_w1 = w1->goff; t->fin.g_vconv = vconv->goff; t->fin.g_pconv = pconv->goff;
         t->fin.g_bnw = upload_table(t, gw); t->fin.g_bnb = upload_table(t, gb);
         t->fin.run_mean = upload_table(t, rm); t->fin.run_var = upload_table(t, rv); t->fin.tracked = upload_table(t, tk);
-        if (!d.bn_w || !d.bn_b || !t->fin.g_bnw || !t->fin.g_bnb || !t->fin.run_mean || !t->fin.run_var || !t->fin.tracked)
+        if (!t->fin.g_bnw || !t->fin.g_bnb || !t->fin.run_mean || !t->fin.run_var || !t->fin.tracked)
             return tfail(AZX_ENOMEM, "train: uploading the parameter tables failed");
     }
     t->hoffs = {fc2w->goff, fc2b->goff, fc3w->goff, fc3b->goff, mfw->goff, mfb->goff};
@@ -1077,6 +1305,7 @@ int azx_trn_bind(AzxTrain *t, int n, const char *const *names, void *const *ptrs
             Segment s;
             s.p = (float *)b->ptr; s.mom = b->mom; s.n = b->n; s.goff = b->goff; s.layer = 0;
             for (int l = 1; l <= L; ++l) if (conv[l] == b) s.layer = l;
+            if (s.layer) { t->conv_goff.resize(L + 1); t->conv_goff[s.layer] = b->goff; }
             const int si = (int)segs.size();
             segs.push_back(s);
             for (size_t e = 0; e < b->n; e += 1024) blocks.push_back(make_int2(si, (int)(e / 1024)));
@@ -1086,12 +1315,7 @@ int azx_trn_bind(AzxTrain *t, int n, const char *const *names, void *const *ptrs
         t->n_blocks = (int)blocks.size();
         if (!t->segs || !t->blocks) return tfail(AZX_ENOMEM, "train: uploading the update tables failed");
     }
-    {
-        std::vector<const float *> cw(L + 1, nullptr);
-        for (int l = 1; l <= L; ++l) cw[l] = (const float *)conv[l]->ptr;
-        d.convw = upload_table(t, cw);
-        if (!d.convw) return tfail(AZX_ENOMEM, "train: uploading the filter table failed");
-    }
+    for (int l = 1; l <= L; ++l) d.convw[l] = (const float *)conv[l]->ptr;
     if (hipDeviceSynchronize() != hipSuccess) return tfail(AZX_EHIP, "train: device sync after the bind failed");
     t->is_bound = true;
     return AZX_OK;
@@ -1121,7 +1345,7 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
     if (hipMemsetAsync(d.sums, 0, t->zero_bytes, st) != hipSuccess) return tfail(AZX_EHIP, "train: memset failed");
     hipLaunchKernelGGL(k_trn_pack<C>, dim3((C * C * 9 + 255) / 256, L), dim3(256), 0, st, d);
     hipLaunchKernelGGL(k_trn_stem_fwd<C>, dim3(B), dim3(256), 0, st, d);
-    const size_t conv_lds = ((size_t)(cells + 1) * (C + 4) + 9 * C + 256) * sizeof(float);
+    const size_t conv_lds = ((size_t)std::max((cells + 1) * (C + 4), cells * 36) + 9 * C + 256) * sizeof(float);
     for (int l = 1; l <= L; ++l)
         hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
     const size_t hc_lds = ((size_t)cells * (C + 1) + 2 * C + 6 * C + 16) * sizeof(float);
@@ -1143,14 +1367,17 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
         return e && hipEventRecord(e, st) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess;
     };
     if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
-    hipLaunchKernelGGL(k_trn_heads_wgrad, dim3(256), dim3(256), 0, ws, d, t->hoffs);
+    const int hw_blocks = ((4 * cells + 255) / 256) * ((cells + 3) / 4) + 16 + 1;
+    hipLaunchKernelGGL(k_trn_heads_wgrad, dim3(hw_blocks), dim3(256), 0, ws, d, t->hoffs);
     hipLaunchKernelGGL(k_trn_heads_bwd<C>, dim3(B), dim3(256), 0, st, d);
     const int KP = (cells + 1) & ~1;
-    const size_t wg_lds = std::max((size_t)2 * KP * (C + 32) + 5 * C, (size_t)4096) * sizeof(float);
+    const size_t wg_lds = ((size_t)KP * 32 + (size_t)(d.N + 2) * (d.N + 2) * 32 + 12 * 1024 + 5 * 32 + KP) * sizeof(float);
+    const size_t wn = (size_t)C * C * 9;
     for (int l = L; l >= 1; --l) {
         // g_l and BN_l's sums are complete here: the weight gradient of layer l runs beside the data chain
         if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
-        hipLaunchKernelGGL(k_trn_wgrad<C>, dim3(9, G), dim3(256), wg_lds, ws, d, l, G);
+        hipLaunchKernelGGL(k_trn_wgrad<C>, dim3(NT * NT, G), dim3(256), wg_lds, ws, d, l, G);
+        hipLaunchKernelGGL(k_trn_wreduce, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, ws, d, l, G, wn, t->conv_goff[l]);
         hipLaunchKernelGGL((k_trn_conv<C, ROLE_BWD>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
     }
     const size_t sb_lds = ((size_t)cells * C + 5 * C) * sizeof(float);
@@ -1202,12 +1429,12 @@ int azx_trn_step(AzxTrain *t, float lr, float momentum, float weight_decay, hipS
     hipLaunchKernelGGL(k_trn_set_hp, dim3(1), dim3(1), 0, st, t->hp_dev, lr, momentum, weight_decay);
     if (!t->use_graph) {
         // plain launches: the weight-gradient passes fork onto the side stream after an event on `st`
-        return enqueue_any(t, st, t->side, true);
+        return enqueue_any(t, st, t->side, t->fork);
     }
     if (!t->exec) {
         if (hipStreamBeginCapture(t->cap, hipStreamCaptureModeRelaxed) != hipSuccess)
             return tfail(AZX_EHIP, "train: hipStreamBeginCapture failed");
-        int rc = enqueue_any(t, t->cap, t->side, true);
+        int rc = enqueue_any(t, t->cap, t->side, t->fork);
         hipGraph_t graph = nullptr;
         const hipError_t ce = hipStreamEndCapture(t->cap, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }

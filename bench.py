@@ -242,45 +242,85 @@ def config5_args(args):
     return a
 
 
+TRAIN_FLOP_PER_BOARD_CONV = None
+
+
+def train_step_flops(n, blocks, chans, batch):
+    """Algorithmic flops of one training step (2 per MAC): forward = flop_per_position per board, backward = twice that
+    (data + weight gradients of every layer); BatchNorm, ReLU, loss and the SGD update excluded."""
+    return 3.0 * batch * flop_per_position(n, blocks, chans)
+
+
 def run_train_step(args, local_rank, torch):
     """SURVEY 8(f).4 beside the path: the reference's training step (policy_trainer.py:123-142) at its own batch of 128
-    (config/hex11_train_config.yml), fed from the HBM replay ring, as the reference runs it (eager, a host sync per
-    step) and captured as a HIP graph (policy_trainer.GraphedTrainStep).  Stock PyTorch-ROCm kernels either way."""
+    (config/hex11_train_config.yml), fed from the HBM replay ring, four ways: as the reference runs it (eager, a host
+    sync per step for loss.item()), eager without that sync, the same stock kernels captured as a HIP graph
+    (policy_trainer.GraphedTrainStep), and the hand-written step (native_train.NativeTrainStep: fp32-MFMA kernels,
+    csrc/train_kernels.hip; no autograd, no MIOpen)."""
     import numpy as np
     from torch import optim
     from azalea_amd import engine as eng
     from azalea_amd.device_replay import DeviceReplayBuffer
+    from azalea_amd.native_train import NativeTrainStep
     from azalea_amd.network import HexNetwork
     from azalea_amd.policy_trainer import GraphedTrainStep, supervised_step
     dev = torch.device("cuda", local_rank)
-    B, steps, warm = 128, 60, 10
+    B, steps, warm = 128, 200, 20
     E = eng.Engine(board_size=args.board, n_games=1024, simulations=50, search_batch_size=10,
                    evaluator=eng.EVAL_UNIFORM, noise_scale=0.25, device=local_rank)
     buf = DeviceReplayBuffer(E, 20000, shared=False)
     E.replay_fill(20000)
     out = {"what": "policy_trainer.supervised_step(train=True): %dx%d on %dx%d, SGD(momentum 0.9, weight decay 1e-4), "
-                   "batch %d collated from a %d-row HBM ring; stock PyTorch-ROCm fp32"
+                   "batch %d collated from a %d-row HBM ring, fp32"
                    % (args.blocks, args.chans, args.board, args.board, B, len(buf)), "batch": B, "steps": steps}
     torch.manual_seed(0)
     order = np.resize(buf.epoch_indices(), (steps + warm) * B)
-    for mode in ("eager", "hip_graph"):
+    for mode in ("eager", "eager_nosync", "hip_graph", "native"):
         net = HexNetwork(board_size=args.board, num_blocks=args.blocks, base_chans=args.chans).to(dev)
         opt = optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
-        gs = GraphedTrainStep(net, opt, B, dev) if mode == "hip_graph" else None
-        for i in range(steps + warm):
+        gs = (GraphedTrainStep(net, opt, B, dev) if mode == "hip_graph" else
+              NativeTrainStep(net, opt, B, dev) if mode == "native" else None)
+        n_steps = steps if gs is not None else 60
+        for i in range(n_steps + warm):
             if i == warm:
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
-            batch = buf.sample(order[i * B:(i + 1) * B])
-            if gs is None:
-                supervised_step(net, batch, train=True, optimizer=opt, device=dev)
-            else:
-                gs.step(batch)
+            idx = order[i * B:(i + 1) * B]
+            if gs is not None:
+                gs.step_from_ring(buf, idx)            # rows collated straight into the step's static inputs
+            elif mode == "eager":
+                supervised_step(net, buf.sample(idx), train=True, optimizer=opt, device=dev)
+            else:                                      # the same eager kernels, the loss left on the device
+                batch = buf.sample(idx)
+                net.train()
+                opt.zero_grad()
+                o = net.forward(batch["board"], batch["legal_moves"])
+                loss = (torch.nn.functional.mse_loss(o["value"], batch["reward"])
+                        - (batch["moves_prob"] * o["moves_logprob"]).sum() / B)
+                loss.backward()
+                opt.step()
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
-        out[mode] = {"steps_per_sec": steps / dt, "ms_per_step": 1e3 * dt / steps, "positions_per_sec": steps * B / dt}
+        out[mode] = {"steps_per_sec": n_steps / dt, "ms_per_step": 1e3 * dt / n_steps, "positions_per_sec": n_steps * B / dt}
+        if mode == "native":
+            # the step alone (inputs resident, no collate): HIP events on torch's stream around `steps` launches
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                gs._run()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / steps
+            fl = train_step_flops(args.board, args.blocks, args.chans, B)
+            out[mode].update({"step_only_ms": ms, "step_only_steps_per_sec": 1e3 / ms,
+                              "algorithmic_tflops": fl / (ms * 1e-3) / 1e12,
+                              "frac_of_fp32_mfma_peak": fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
+                              "flop_per_step": fl})
+            gs.close()
     E.close()
-    out["speedup"] = out["hip_graph"]["steps_per_sec"] / out["eager"]["steps_per_sec"]
+    out["speedup_native_vs_hip_graph"] = out["native"]["steps_per_sec"] / out["hip_graph"]["steps_per_sec"]
+    out["speedup_native_vs_reference_style_eager"] = out["native"]["steps_per_sec"] / out["eager"]["steps_per_sec"]
+    out["speedup_hip_graph_vs_eager_nosync"] = out["hip_graph"]["steps_per_sec"] / out["eager_nosync"]["steps_per_sec"]
     return out
 
 
