@@ -37,6 +37,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TRN_MAXL 38               // tower conv layers (19 blocks): the per-layer pointers live IN the kernel argument struct --
                                   // a pointer fetched from a table in memory is a generic pointer to the compiler, every
                                   // access through it a FLAT instruction whose completion the LDS waits then also wait for
+#define TRN_HP_SLOTS 256          // hyper-parameter ring: the host may run this many steps ahead of the device
+#define TRN_SMALL_THREADS 1024    // the elementwise kernels around the tower: 16 waves per CU hide their loads' latency
 #define TRN_WG_GROUPS 64          // k_trn_wgrad: board groups (x 4 channel-tile pairs at C = 64: 256 workgroups)
 
 static thread_local std::string g_trn_err;
@@ -76,7 +78,12 @@ struct TrnDev {
     double *stem_dT;               // [27][C]  dL/d(stem table), summed over the boards (f64 atomics)
     double *hconv_acc;             // [6][C]   gradient of the two 1x1 head convolutions
     float *grad;                   // flat gradient buffer (offsets in the segment table)
-    const float *hp;               // lr, momentum, weight decay
+    float *hp;                     // lr, momentum, weight decay (written by k_trn_prep from the host's ring)
+    float *stemT;                  // [27][C] embedding folded through conv1: table[tap * 3 + cell value][cout]
+    const float *hp_ring;          // pinned host memory, TRN_HP_SLOTS x 4 floats: the host writes slot (step % slots)
+    unsigned int *step_ctr;        // steps run so far (device side of the same count)
+    double *zero_base;             // the per-step accumulators (sums | hsums | lossacc | stem_dT | hconv_acc), zero_count doubles
+    int zero_count;
 };
 
 __device__ __forceinline__ double dsum(const double *s, int l, int C, int c, int k) { return s[((size_t)l * C + c) * 4 + k]; }
@@ -93,24 +100,19 @@ __device__ __forceinline__ void bn_coeffs(const TrnDev &P, int l, int c, float &
 // stem forward: embedding (3 -> 4) o conv 3x3 (4 -> C) as a [tap][cell value][cout] table built per block
 // =================================================================================================================
 template <int C>
-__global__ __launch_bounds__(256) void k_trn_stem_fwd(TrnDev P) {
-    __shared__ float T[28 * C];
+__global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_fwd(TrnDev P) {
+    constexpr int NTH = TRN_SMALL_THREADS;
+    __shared__ float T[27 * C];
     __shared__ unsigned char cellv[128];
-    __shared__ float red[2][256];
+    __shared__ float red[2][NTH];
     const int b = blockIdx.x, tid = threadIdx.x, N = P.N, cells = P.cells;
-    for (int i = tid; i < 27 * C; i += 256) {
-        const int k = i / C, co = i - k * C, tap = k / 3, v = k - tap * 3;
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s += P.emb[v * 4 + j] * P.w1[(co * 4 + j) * 9 + tap];
-        T[i] = s;
-    }
-    for (int i = tid; i < cells; i += 256) cellv[i] = (unsigned char)P.board[(size_t)b * cells + i];
+    for (int i = tid; i < 27 * C; i += NTH) T[i] = P.stemT[i];          // built once per step by k_trn_prep
+    for (int i = tid; i < cells; i += NTH) cellv[i] = (unsigned char)P.board[(size_t)b * cells + i];
     __syncthreads();
     const int co = tid % C;
     float s1 = 0.f, s2 = 0.f;
     float *out = P.raw[0] + (size_t)b * cells * C;
-    for (int pos = tid / C; pos < cells; pos += 256 / C) {
+    for (int pos = tid / C; pos < cells; pos += NTH / C) {
         const int y = pos / N, x = pos - y * N;
         float acc = 0.f;
 #pragma unroll
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void k_trn_stem_fwd(TrnDev P) {
     __syncthreads();
     if (tid < C) {
         double a = 0, q = 0;
-        for (int i = tid; i < 256; i += C) { a += red[0][i]; q += red[1][i]; }
+        for (int i = tid; i < NTH; i += C) { a += red[0][i]; q += red[1][i]; }
         atomicAdd(&P.sums[((size_t)0 * C + tid) * 4 + 0], a);
         atomicAdd(&P.sums[((size_t)0 * C + tid) * 4 + 1], q);
     }
@@ -180,6 +182,24 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
     const int li = lane & 31, lh = lane >> 5;
     TS_DECL
 
+    // ---- the block's two input tensors are requested first: they travel while the coefficients are computed ----
+    // (FWD: raw_{l-1} and the residual act_{l-3}; BWD: g_l and raw_l; every load before the first use -- a dependent
+    // load -> use loop would pay the L2 / HBM latency once per iteration, eight times per block)
+    constexpr int ITER = (121 * C4 + 255) / 256;
+    const size_t base0 = (size_t)b * cells * C;
+    const int total = cells * C4;
+    const bool has_res = ROLE == ROLE_FWD && ((l - 1) & 1) == 0 && l - 1 >= 2;
+    const float4 *src0 = reinterpret_cast<const float4 *>((ROLE == ROLE_FWD ? P.raw[l - 1] : P.g[l]) + base0);
+    const float4 *src1 = ROLE == ROLE_FWD ? (has_res ? reinterpret_cast<const float4 *>(P.act[l - 3] + base0) : nullptr)
+                                          : reinterpret_cast<const float4 *>(P.raw[l] + base0);
+    float4 v0[ITER], v1[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        const int i = tid + 256 * k;
+        v0[k] = i < total ? src0[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v1[k] = (src1 != nullptr && i < total) ? src1[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
     // ---- per-channel coefficients -----------------------------------------------------------------------
     if (tid < C) {
         const int c = tid;
@@ -207,67 +227,34 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
     TS_MARK(0)
 
     // ---- stage the input operand ---------------------------------------------------------------------------
-    // (every load of the block is requested before the first one is used: a dependent load -> use loop would pay
-    // the L2 / HBM latency once per iteration, eight times per block)
-    {
-        constexpr int ITER = (121 * C4 + 255) / 256;
-        const size_t base = (size_t)b * cells * C;
-        const int total = cells * C4;
-        if (ROLE == ROLE_FWD) {
-            const float4 *src = reinterpret_cast<const float4 *>(P.raw[l - 1] + base);
-            const bool has_res = ((l - 1) & 1) == 0 && l - 1 >= 2;
-            const float4 *res = has_res ? reinterpret_cast<const float4 *>(P.act[l - 3] + base) : nullptr;
-            float4 *dst = reinterpret_cast<float4 *>(P.act[l - 1] + base);
-            float4 va[ITER], vr[ITER];
+    if (ROLE == ROLE_FWD) {
+        float4 *dst = reinterpret_cast<float4 *>(P.act[l - 1] + base0);
 #pragma unroll
-            for (int k = 0; k < ITER; ++k) {
-                const int i = tid + 256 * k;
-                va[k] = i < total ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                vr[k] = (has_res && i < total) ? res[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#ifdef AZX_TRN_STAMP
-            __builtin_amdgcn_s_waitcnt(0);
-            TS_MARK(4)
-#endif
+        for (int k = 0; k < ITER; ++k) {
+            const int i = tid + 256 * k;
+            if (i >= total) break;
+            const int pos = i / C4, c = (i - pos * C4) * 4;
+            float4 v = v0[k];
+            v.x = fmaxf(v.x * cA[c] + cB[c] + v1[k].x, 0.f);
+            v.y = fmaxf(v.y * cA[c + 1] + cB[c + 1] + v1[k].y, 0.f);
+            v.z = fmaxf(v.z * cA[c + 2] + cB[c + 2] + v1[k].z, 0.f);
+            v.w = fmaxf(v.w * cA[c + 3] + cB[c + 3] + v1[k].w, 0.f);
+            *reinterpret_cast<float4 *>(X + (size_t)pos * LDW + c) = v;
+            if (NT == 1 || (c >> 5) == nt) dst[i] = v;       // each of a board's blocks writes its channel half
+        }
+    } else {
 #pragma unroll
-            for (int k = 0; k < ITER; ++k) {
-                const int i = tid + 256 * k;
-                if (i >= total) break;
-                const int pos = i / C4, c = (i - pos * C4) * 4;
-                float4 v = va[k];
-                v.x = fmaxf(v.x * cA[c] + cB[c] + vr[k].x, 0.f);
-                v.y = fmaxf(v.y * cA[c + 1] + cB[c + 1] + vr[k].y, 0.f);
-                v.z = fmaxf(v.z * cA[c + 2] + cB[c + 2] + vr[k].z, 0.f);
-                v.w = fmaxf(v.w * cA[c + 3] + cB[c + 3] + vr[k].w, 0.f);
-                *reinterpret_cast<float4 *>(X + (size_t)pos * LDW + c) = v;
-                if (NT == 1 || (c >> 5) == nt) dst[i] = v;       // each of a board's blocks writes its channel half
-            }
-#ifdef AZX_TRN_STAMP
-            TS_MARK(5)
-#endif
-        } else {
-            const float4 *gs = reinterpret_cast<const float4 *>(P.g[l] + base);
-            const float4 *rs = reinterpret_cast<const float4 *>(P.raw[l] + base);
-            float4 vg[ITER], vr[ITER];
-#pragma unroll
-            for (int k = 0; k < ITER; ++k) {
-                const int i = tid + 256 * k;
-                vg[k] = i < total ? gs[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                vr[k] = i < total ? rs[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int k = 0; k < ITER; ++k) {
-                const int i = tid + 256 * k;
-                if (i >= total) break;
-                const int pos = i / C4, c = (i - pos * C4) * 4;
-                const float4 gv = vg[k], rv = vr[k];
-                float4 v;
-                v.x = cA[c] * (gv.x - cK[c] - (rv.x - cM[c]) * cI[c] * cK[C + c]);
-                v.y = cA[c + 1] * (gv.y - cK[c + 1] - (rv.y - cM[c + 1]) * cI[c + 1] * cK[C + c + 1]);
-                v.z = cA[c + 2] * (gv.z - cK[c + 2] - (rv.z - cM[c + 2]) * cI[c + 2] * cK[C + c + 2]);
-                v.w = cA[c + 3] * (gv.w - cK[c + 3] - (rv.w - cM[c + 3]) * cI[c + 3] * cK[C + c + 3]);
-                *reinterpret_cast<float4 *>(X + (size_t)pos * LDW + c) = v;
-            }
+        for (int k = 0; k < ITER; ++k) {
+            const int i = tid + 256 * k;
+            if (i >= total) break;
+            const int pos = i / C4, c = (i - pos * C4) * 4;
+            const float4 gv = v0[k], rv = v1[k];
+            float4 v;
+            v.x = cA[c] * (gv.x - cK[c] - (rv.x - cM[c]) * cI[c] * cK[C + c]);
+            v.y = cA[c + 1] * (gv.y - cK[c + 1] - (rv.y - cM[c + 1]) * cI[c + 1] * cK[C + c + 1]);
+            v.z = cA[c + 2] * (gv.z - cK[c + 2] - (rv.z - cM[c + 2]) * cI[c + 2] * cK[C + c + 2]);
+            v.w = cA[c + 3] * (gv.w - cK[c + 3] - (rv.w - cM[c + 3]) * cI[c + 3] * cK[C + c + 3]);
+            *reinterpret_cast<float4 *>(X + (size_t)pos * LDW + c) = v;
         }
     }
     __syncthreads();
@@ -321,7 +308,7 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
     const int co = nt * 32 + li;
     const bool cvalid = co < C;
     float s1 = 0.f, s2 = 0.f;
-    const size_t base = (size_t)b * cells * C;
+    const size_t base = base0;
     if (ROLE == ROLE_FWD) {
         float *out = P.raw[l] + base;
 #pragma unroll
@@ -337,7 +324,7 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
     } else {
         // the accumulators go through LDS (the input tile is done with) so that the skip gradient, the ReLU mask's
         // activation and the BatchNorm input are read -- and g written -- in coalesced 16-byte pieces
-        constexpr int LDO = 36, CHo = C < 32 ? C : 32, O4 = CHo / 4, ITER = (121 * O4 + 255) / 256;
+        constexpr int LDO = 36, CHo = C < 32 ? C : 32, O4 = CHo / 4, ITERO = (121 * O4 + 255) / 256;
         __syncthreads();                                 // every wave has finished reading X
         float *Y = X;                                    // [cells][LDO]: this block's 32 output channels
 #pragma unroll
@@ -350,12 +337,12 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
         const float *pact = P.act[l - 1] + base + nt * 32, *praw = P.raw[l - 1] + base + nt * 32;
         const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= P.L;
         const float *skip = has_skip ? P.g[l + 1] + base + nt * 32 : nullptr;
-        const int total = cells * O4;
-        float4 ea[ITER], er[ITER], es[ITER];
+        const int totalo = cells * O4;
+        float4 ea[ITERO], er[ITERO], es[ITERO];
 #pragma unroll
-        for (int k = 0; k < ITER; ++k) {
+        for (int k = 0; k < ITERO; ++k) {
             const int i = tid + 256 * k, pos = i / O4, c = (i - pos * O4) * 4;
-            const bool on = i < total;
+            const bool on = i < totalo;
             const size_t o = (size_t)pos * C + c;
             ea[k] = on ? *reinterpret_cast<const float4 *>(pact + o) : make_float4(0.f, 0.f, 0.f, 0.f);
             er[k] = on ? *reinterpret_cast<const float4 *>(praw + o) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -365,9 +352,9 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
         float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
         const int c0 = (tid % O4) * 4;
 #pragma unroll
-        for (int k = 0; k < ITER; ++k) {
+        for (int k = 0; k < ITERO; ++k) {
             const int i = tid + 256 * k;
-            if (i >= total) break;
+            if (i >= totalo) break;
             const int pos = i / O4;
             const float4 y = *reinterpret_cast<const float4 *>(Y + (size_t)pos * LDO + c0);
             float4 v;
@@ -426,7 +413,7 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
 //   grid (pairs, G) = 256 workgroups.  A block stages, per board, the 32-channel halves of draw (BatchNorm backward
 //   applied on the way in) and of the input ONCE and runs all 9 taps from them -- a tap is a row offset into the
 //   staged input, the off-board taps read a zero row; its 4 waves split the positions and are summed through LDS.
-//   Partials are reduced by k_trn_wreduce in a fixed order: the step is reproducible.
+//   Partials are reduced by k_trn_update in a fixed order: the step is reproducible.
 // =================================================================================================================
 template <int C>
 __global__ __launch_bounds__(256) void k_trn_wgrad(TrnDev P, int l, int G) {
@@ -542,29 +529,12 @@ __global__ __launch_bounds__(256) void k_trn_wgrad(TrnDev P, int l, int G) {
     TS_END
 }
 
-// second stage: the G partial copies of layer l's filter gradient -> the flat gradient buffer
-__global__ __launch_bounds__(256) void k_trn_wreduce(TrnDev P, int l, int G, size_t n, size_t goff) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
-    const float *part = P.wpart + (size_t)(l - 1) * G * n + e;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int g = 0;
-    for (; g + 4 <= G; g += 4) {
-        s0 += part[(size_t)g * n];
-        s1 += part[(size_t)(g + 1) * n];
-        s2 += part[(size_t)(g + 2) * n];
-        s3 += part[(size_t)(g + 3) * n];
-    }
-    for (; g < G; ++g) s0 += part[(size_t)g * n];
-    P.grad[goff + e] = (s0 + s1) + (s2 + s3);
-}
-
 // =================================================================================================================
 // heads, forward part 1: act_L = relu(BN_L(raw_L) + act_{L-2}); the two 1x1 convolutions; their batch sums
 // =================================================================================================================
 template <int C>
-__global__ __launch_bounds__(256) void k_trn_heads_conv(TrnDev P) {
-    constexpr int C4 = C / 4, LDX = C + 1;
+__global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_conv(TrnDev P) {
+    constexpr int C4 = C / 4, LDX = C + 1, NTH = TRN_SMALL_THREADS, ITER = (121 * C4 + NTH - 1) / NTH;
     extern __shared__ __align__(16) float lds[];
     float *X = lds;                         // [cells][LDX]
     float *cA = X + (size_t)P.cells * LDX, *cB = cA + C;
@@ -578,27 +548,39 @@ __global__ __launch_bounds__(256) void k_trn_heads_conv(TrnDev P) {
         cA[tid] = a;
         cB[tid] = P.bn_b[L][tid] - mean * a;
     }
-    for (int i = tid; i < 6 * C; i += 256) W[i] = i < 2 * C ? P.vconv[i] : P.pconv[i - 2 * C];
+    for (int i = tid; i < 6 * C; i += NTH) W[i] = i < 2 * C ? P.vconv[i] : P.pconv[i - 2 * C];
     if (tid < 12) red[tid] = 0.f;
-    __syncthreads();
     const size_t base = (size_t)b * cells * C;
     const float4 *src = reinterpret_cast<const float4 *>(P.raw[L] + base);
     const bool has_res = L >= 2;
     const float4 *res = has_res ? reinterpret_cast<const float4 *>(P.act[L - 2] + base) : nullptr;
     float4 *dst = reinterpret_cast<float4 *>(P.act[L] + base);
-    for (int i = tid; i < cells * C4; i += 256) {
+    const int total = cells * C4;
+    float4 va[ITER], vr[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        const int i = tid + NTH * k;
+        va[k] = i < total ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        vr[k] = (has_res && i < total) ? res[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        const int i = tid + NTH * k;
+        if (i >= total) break;
         const int pos = i / C4, c = (i - pos * C4) * 4;
-        float4 v = src[i];
-        v.x = v.x * cA[c] + cB[c]; v.y = v.y * cA[c + 1] + cB[c + 1]; v.z = v.z * cA[c + 2] + cB[c + 2]; v.w = v.w * cA[c + 3] + cB[c + 3];
-        if (has_res) { const float4 r = res[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        float4 v = va[k];
+        v.x = fmaxf(v.x * cA[c] + cB[c] + vr[k].x, 0.f);
+        v.y = fmaxf(v.y * cA[c + 1] + cB[c + 1] + vr[k].y, 0.f);
+        v.z = fmaxf(v.z * cA[c + 2] + cB[c + 2] + vr[k].z, 0.f);
+        v.w = fmaxf(v.w * cA[c + 3] + cB[c + 3] + vr[k].w, 0.f);
         dst[i] = v;
         float *x = X + (size_t)pos * LDX + c;
         x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
     }
     __syncthreads();
     float *hraw = P.hraw + (size_t)b * 6 * cells;
-    for (int i = tid; i < 6 * cells; i += 256) {
+    for (int i = tid; i < 6 * cells; i += NTH) {
         const int o = i / cells, pos = i - o * cells;
         const float *x = X + (size_t)pos * LDX, *w = W + o * C;
         float s = 0.f;
@@ -627,12 +609,12 @@ __device__ __forceinline__ float wave_max(float v) {
 // heads, part 2 (one block per board): BN + ReLU of the head planes, the FC layers, masked log-softmax, the loss and
 // the gradient back to the head planes (network.py:77-102, :146-152)
 // =================================================================================================================
-__global__ __launch_bounds__(256) void k_trn_heads_fc(TrnDev P) {
+__global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_fc(TrnDev P) {
+    constexpr int NTH = TRN_SMALL_THREADS, NW = NTH / 64;
     __shared__ float ha[6 * 128];           // activated head planes [o][pos] (value 0..1, policy 2..5), flat = the FC inputs
     __shared__ float xh[6 * 128];           // their xhat
-    __shared__ float h2[64], dh2s[64], logit[128], dlog[128], gflat[6 * 128];
+    __shared__ float h2[64], dh2s[64], logit[128], dlog[128], gflat[6 * 128], gpart[1024];
     __shared__ float cS[6], cT[6], cMn[6], cIv[6];
-    __shared__ float sc[8];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cells = P.cells, B = P.B;
     if (tid < 6) {
         const double m = P.hsums[tid * 4] * (double)P.invN, v = P.hsums[tid * 4 + 1] * (double)P.invN - m * m;
@@ -646,7 +628,7 @@ __global__ __launch_bounds__(256) void k_trn_heads_fc(TrnDev P) {
     __syncthreads();
     const float *hraw = P.hraw + (size_t)b * 6 * cells;
     float *hact = P.hact + (size_t)b * 6 * cells;
-    for (int i = tid; i < 6 * cells; i += 256) {
+    for (int i = tid; i < 6 * cells; i += NTH) {
         const int o = i / cells;
         const float r = hraw[i], v = fmaxf(r * cS[o] + cT[o], 0.f);
         ha[i] = v;
@@ -654,35 +636,29 @@ __global__ __launch_bounds__(256) void k_trn_heads_fc(TrnDev P) {
         hact[i] = v;
     }
     __syncthreads();
-    // value_fc2 (2 cells -> 64) + ReLU: a wave per output, lanes along the input
+    // value_fc2 (2 cells -> 64) + ReLU and move_fc (4 cells -> cells): a wave per group of four outputs, lanes along
+    // the input (four independent loads per lane and step, the wave reductions after the loop)
     const int KV = 2 * cells, KPp = 4 * cells;
-    // (four outputs at a time: their loads are independent, the wave reductions come after)
-    for (int o0 = wave * 4; o0 < 64; o0 += 16) {
+    const int n_fc2 = 16, n_mf = (cells + 3) / 4;               // groups of four outputs
+    for (int grp = wave; grp < n_fc2 + n_mf; grp += NW) {
+        const bool v = grp < n_fc2;
+        const int o0 = v ? grp * 4 : (grp - n_fc2) * 4, K = v ? KV : KPp, rows = v ? 64 : cells;
+        const float *w = v ? P.fc2w : P.mfw, *x = v ? ha : ha + 2 * cells;
         float s[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = lane; i < KV; i += 64) {
-            const float x = ha[i];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) s[u] += P.fc2w[(size_t)(o0 + u) * KV + i] * x;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float r = wave_sum(s[u]);
-            if (lane == 0) h2[o0 + u] = fmaxf(r + P.fc2b[o0 + u], 0.f);
-        }
-    }
-    // move_fc (4 cells -> cells)
-    for (int t0 = wave * 4; t0 < cells; t0 += 16) {
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = lane; i < KPp; i += 64) {
-            const float x = ha[2 * cells + i];
+#pragma unroll 2
+        for (int i = lane; i < K; i += 64) {
+            const float xv = x[i];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (t0 + u < cells) s[u] += P.mfw[(size_t)(t0 + u) * KPp + i] * x;
+                if (o0 + u < rows) s[u] += w[(size_t)(o0 + u) * K + i] * xv;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float r = wave_sum(s[u]);
-            if (lane == 0 && t0 + u < cells) logit[t0 + u] = r + P.mfb[t0 + u];
+            if (lane == 0 && o0 + u < rows) {
+                if (v) h2[o0 + u] = fmaxf(r + P.fc2b[o0 + u], 0.f);
+                else logit[o0 + u] = r + P.mfb[o0 + u];
+            }
         }
     }
     __syncthreads();
@@ -726,41 +702,53 @@ __global__ __launch_bounds__(256) void k_trn_heads_fc(TrnDev P) {
     }
     __syncthreads();
     if (tid < 128) P.dlogit[(size_t)b * 128 + tid] = tid < cells ? dlog[tid] : 0.f;
-    // back through the FC layers to the head planes
-    for (int i = tid; i < KV; i += 256) {
-        float s = 0.f;
-#pragma unroll 8
-        for (int o = 0; o < 64; ++o) s += P.fc2w[(size_t)o * KV + i] * dh2s[o];
-        gflat[i] = ha[i] > 0.f ? s : 0.f;
-    }
-    for (int i = tid; i < KPp; i += 256) {
-        float s = 0.f;
-#pragma unroll 11
-        for (int t = 0; t < cells; ++t) s += P.mfw[(size_t)t * KPp + i] * dlog[t];
-        gflat[2 * cells + i] = ha[2 * cells + i] > 0.f ? s : 0.f;
+    // back through the FC layers to the head planes: thread (i, part) sums a slice of the outputs, the parts are
+    // combined through LDS.  value: 242 inputs x 4 parts of 16 outputs; policy: 484 inputs x 2 parts of ~61 tiles.
+    {
+        const int part = tid / 256, i = tid % 256;               // value plane: 4 parts
+        if (i < KV) {
+            float sv = 0.f;
+#pragma unroll
+            for (int o = part * 16; o < part * 16 + 16; ++o) sv += P.fc2w[(size_t)o * KV + i] * dh2s[o];
+            gpart[part * 256 + i] = sv;
+        }
     }
     __syncthreads();
+    if (tid < KV) gflat[tid] = ha[tid] > 0.f ? (gpart[tid] + gpart[256 + tid]) + (gpart[512 + tid] + gpart[768 + tid]) : 0.f;
+    __syncthreads();
+    {
+        const int part = tid / 512, i = tid % 512, half = (cells + 1) / 2;
+        if (i < KPp) {
+            float sp = 0.f;
+            const int t1 = min(cells, (part + 1) * half);
+#pragma unroll 8
+            for (int t = part * half; t < t1; ++t) sp += P.mfw[(size_t)t * KPp + i] * dlog[t];
+            gpart[part * 512 + i] = sp;
+        }
+    }
+    __syncthreads();
+    if (tid < KPp) gflat[2 * cells + tid] = ha[2 * cells + tid] > 0.f ? gpart[tid] + gpart[512 + tid] : 0.f;
+    __syncthreads();
     float *g6 = P.g6 + (size_t)b * 6 * cells;
-    for (int i = tid; i < 6 * cells; i += 256) g6[i] = gflat[i];
+    for (int i = tid; i < 6 * cells; i += NTH) g6[i] = gflat[i];
     // the two reductions the head BatchNorms' backward needs
     if (tid < 6 * 32) {
         const int o = tid >> 5, j = tid & 31;
         float a = 0.f, q = 0.f;
         for (int pos = j; pos < cells; pos += 32) { const float gv = gflat[o * cells + pos]; a += gv; q += gv * xh[o * cells + pos]; }
 #pragma unroll
-        for (int s = 16; s >= 1; s >>= 1) { a += __shfl_xor(a, s); q += __shfl_xor(q, s); }
+        for (int sft = 16; sft >= 1; sft >>= 1) { a += __shfl_xor(a, sft); q += __shfl_xor(q, sft); }
         if (j == 0) {
             atomicAdd(&P.hsums[o * 4 + 2], (double)a);
             atomicAdd(&P.hsums[o * 4 + 3], (double)q);
         }
     }
-    (void)sc;
 }
 
 // gradients of the FC layers: the batch is the reduction (fixed order).  Block roles by index:
 //   [0, nM)        move_fc.weight  [cells][4 cells]: 4 rows x 256 columns per block
 //   [nM, nM + 16)  value_fc2.weight [64][2 cells]:   4 rows x all columns per block
-//   last           the biases and value_fc3
+//   the rest       the biases and value_fc3, four outputs per block
 struct HeadGradOffs { size_t fc2w, fc2b, fc3w, fc3b, mfw, mfb; };
 __global__ __launch_bounds__(256) void k_trn_heads_wgrad(TrnDev P, HeadGradOffs O) {
     __shared__ float dl[4][256];             // the block's four gradient rows over the batch (B <= 256 per pass)
@@ -799,22 +787,22 @@ __global__ __launch_bounds__(256) void k_trn_heads_wgrad(TrnDev P, HeadGradOffs 
                 if (r0 + u < rows) gdst[(size_t)(r0 + u) * cols + i] = s[u];
         }
     } else {
-        for (int e = tid; e < cells + 64 + 64 + 1; e += 256) {
+        // biases and value_fc3: a wave per output, its lanes along the batch (blocks nM + 16 ..: four outputs each)
+        const int e = (blk - nM - 16) * 4 + (tid >> 6), lane = tid & 63;
+        if (e < cells + 64 + 64 + 1) {
             float s = 0.f;
-            if (e < cells) {
-                for (int b = 0; b < B; ++b) s += P.dlogit[(size_t)b * 128 + e];
-                P.grad[O.mfb + e] = s;
-            } else if (e < cells + 64) {
-                const int o = e - cells;
-                for (int b = 0; b < B; ++b) s += P.dh2[(size_t)b * 64 + o];
-                P.grad[O.fc2b + o] = s;
-            } else if (e < cells + 128) {
-                const int o = e - cells - 64;
-                for (int b = 0; b < B; ++b) s += P.dv3[b] * P.h2[(size_t)b * 64 + o];
-                P.grad[O.fc3w + o] = s;
-            } else {
-                for (int b = 0; b < B; ++b) s += P.dv3[b];
-                P.grad[O.fc3b] = s;
+            for (int b = lane; b < B; b += 64) {
+                if (e < cells) s += P.dlogit[(size_t)b * 128 + e];
+                else if (e < cells + 64) s += P.dh2[(size_t)b * 64 + e - cells];
+                else if (e < cells + 128) s += P.dv3[b] * P.h2[(size_t)b * 64 + e - cells - 64];
+                else s += P.dv3[b];
+            }
+            s = wave_sum(s);
+            if (lane == 0) {
+                if (e < cells) P.grad[O.mfb + e] = s;
+                else if (e < cells + 64) P.grad[O.fc2b + e - cells] = s;
+                else if (e < cells + 128) P.grad[O.fc3w + e - cells - 64] = s;
+                else P.grad[O.fc3b] = s;
             }
         }
     }
@@ -825,13 +813,26 @@ __global__ __launch_bounds__(256) void k_trn_heads_wgrad(TrnDev P, HeadGradOffs 
 // gradient into the tower's output with its ReLU mask and BN_L's two reductions
 // =================================================================================================================
 template <int C>
-__global__ __launch_bounds__(256) void k_trn_heads_bwd(TrnDev P) {
+__global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_bwd(TrnDev P) {
+    constexpr int C4 = C / 4, LDX = C + 1, NTH = TRN_SMALL_THREADS, ITER = (121 * C4 + NTH - 1) / NTH;
+    extern __shared__ __align__(16) float lds[];
+    float *X = lds;                          // [cells][LDX] the tower's output (for the ReLU mask and the conv gradients)
+    float *rs = X + (size_t)P.cells * LDX;   // [NTH][8] per-thread channel sums
     __shared__ float dh[6 * 128];
     __shared__ float W[6 * C];
     __shared__ float cA[6], cMn[6], cIv[6], cK1[6], cK2[6];
     __shared__ float pM[C], pI[C];
-    __shared__ float red[2][256];
     const int b = blockIdx.x, tid = threadIdx.x, cells = P.cells, L = P.L;
+    const size_t base = (size_t)b * cells * C;
+    const float4 *act4 = reinterpret_cast<const float4 *>(P.act[L] + base), *raw4 = reinterpret_cast<const float4 *>(P.raw[L] + base);
+    const int total = cells * C4;
+    float4 va[ITER], vr[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {           // requested first: they arrive while the coefficients are computed
+        const int i = tid + NTH * k;
+        va[k] = i < total ? act4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        vr[k] = i < total ? raw4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (tid < 6) {
         const double m = P.hsums[tid * 4] * (double)P.invN, v = P.hsums[tid * 4 + 1] * (double)P.invN - m * m;
         const float inv = (float)(1.0 / sqrt((v > 0 ? v : 0) + TRN_EPS));
@@ -841,46 +842,62 @@ __global__ __launch_bounds__(256) void k_trn_heads_bwd(TrnDev P) {
         cK1[tid] = (float)(P.hsums[tid * 4 + 2] * (double)P.invN);
         cK2[tid] = (float)(P.hsums[tid * 4 + 3] * (double)P.invN);
     }
-    if (tid < C) bn_coeffs(P, L, tid, pM[tid], pI[tid]);
-    for (int i = tid; i < 6 * C; i += 256) W[i] = i < 2 * C ? P.vconv[i] : P.pconv[i - 2 * C];
+    if (tid >= 64 && tid < 64 + C) bn_coeffs(P, L, tid - 64, pM[tid - 64], pI[tid - 64]);
+    for (int i = tid; i < 6 * C; i += NTH) W[i] = i < 2 * C ? P.vconv[i] : P.pconv[i - 2 * C];
     __syncthreads();
     const float *g6 = P.g6 + (size_t)b * 6 * cells, *hraw = P.hraw + (size_t)b * 6 * cells;
-    for (int i = tid; i < 6 * cells; i += 256) {
+    for (int i = tid; i < 6 * cells; i += NTH) {
         const int o = i / cells;
         dh[o * 128 + (i - o * cells)] = cA[o] * (g6[i] - cK1[o] - (hraw[i] - cMn[o]) * cIv[o] * cK2[o]);
     }
     __syncthreads();
-    const size_t base = (size_t)b * cells * C;
-    const float *act = P.act[L] + base, *raw = P.raw[L] + base;
-    float *gL = P.g[L] + base;
-    const int c = tid % C;
-    float s1 = 0.f, s2 = 0.f;
-    for (int pos = tid / C; pos < cells; pos += 256 / C) {
-        float d = 0.f;
+    float4 *gL = reinterpret_cast<float4 *>(P.g[L] + base);
+    float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+    const int c0 = (tid % C4) * 4;              // NTH is a multiple of C4: a thread's items share their four channels
 #pragma unroll
-        for (int o = 0; o < 6; ++o) d += dh[o * 128 + pos] * W[o * C + c];
-        const size_t idx = (size_t)pos * C + c;
-        const float gv = act[idx] > 0.f ? d : 0.f;
-        gL[idx] = gv;
-        s1 += gv;
-        s2 += gv * (raw[idx] - pM[c]) * pI[c];
+    for (int k = 0; k < ITER; ++k) {
+        const int i = tid + NTH * k;
+        if (i >= total) break;
+        const int pos = i / C4;
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 6; ++o) {
+            const float h = dh[o * 128 + pos];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] += h * W[o * C + c0 + j];
+        }
+        const float a[4] = {va[k].x, va[k].y, va[k].z, va[k].w}, r[4] = {vr[k].x, vr[k].y, vr[k].z, vr[k].w};
+        float gv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            gv[j] = a[j] > 0.f ? d[j] : 0.f;
+            a4[j] += gv[j];
+            q4[j] += gv[j] * (r[j] - pM[c0 + j]) * pI[c0 + j];
+            X[(size_t)pos * LDX + c0 + j] = a[j];
+        }
+        gL[i] = make_float4(gv[0], gv[1], gv[2], gv[3]);
     }
-    red[0][tid] = s1;
-    red[1][tid] = s2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { rs[tid * 8 + j] = a4[j]; rs[tid * 8 + 4 + j] = q4[j]; }
     __syncthreads();
     if (tid < C) {
+        const int grp4 = tid / 4, j = tid % 4;
         double a = 0, q = 0;
-        for (int i = tid; i < 256; i += C) { a += red[0][i]; q += red[1][i]; }
+        for (int th = grp4; th < NTH; th += C4) { a += rs[th * 8 + j]; q += rs[th * 8 + 4 + j]; }
         atomicAdd(&P.sums[((size_t)L * C + tid) * 4 + 2], a);
         atomicAdd(&P.sums[((size_t)L * C + tid) * 4 + 3], q);
     }
-    // weight gradients of the 1x1 convolutions: this board's share
-    for (int i = tid; i < 6 * C; i += 256) {
+    // weight gradients of the 1x1 convolutions: this board's share (the tower's output is in LDS now)
+    for (int i = tid; i < 6 * C; i += NTH) {
         const int o = i / C, cc = i - o * C;
-        float s = 0.f;
-#pragma unroll 11
-        for (int pos = 0; pos < cells; ++pos) s += dh[o * 128 + pos] * act[(size_t)pos * C + cc];
-        atomicAdd(&P.hconv_acc[i], (double)s);
+        float s0 = 0.f, s1 = 0.f;
+        int pos = 0;
+        for (; pos + 2 <= cells; pos += 2) {
+            s0 += dh[o * 128 + pos] * X[(size_t)pos * LDX + cc];
+            s1 += dh[o * 128 + pos + 1] * X[(size_t)(pos + 1) * LDX + cc];
+        }
+        if (pos < cells) s0 += dh[o * 128 + pos] * X[(size_t)pos * LDX + cc];
+        atomicAdd(&P.hconv_acc[i], (double)(s0 + s1));
     }
 }
 
@@ -889,12 +906,24 @@ __global__ __launch_bounds__(256) void k_trn_heads_bwd(TrnDev P) {
 // table's gradient into conv1.weight's and the embedding's
 // =================================================================================================================
 template <int C>
-__global__ __launch_bounds__(256) void k_trn_stem_bwd(TrnDev P) {
+__global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_bwd(TrnDev P) {
+    constexpr int C4 = C / 4, NTH = TRN_SMALL_THREADS, ITER = (121 * C4 + NTH - 1) / NTH;
     extern __shared__ __align__(16) float lds[];
     float *Dr = lds;                         // [cells][C]
     float *cA = Dr + (size_t)P.cells * C, *cM = cA + C, *cI = cM + C, *cK = cI + C;
     __shared__ unsigned char cellv[128];
+    __shared__ unsigned char nbv[9 * 128];
     const int b = blockIdx.x, tid = threadIdx.x, N = P.N, cells = P.cells;
+    const size_t base = (size_t)b * cells * C;
+    const float4 *g4 = reinterpret_cast<const float4 *>(P.g[0] + base), *r4 = reinterpret_cast<const float4 *>(P.raw[0] + base);
+    const int total = cells * C4;
+    float4 vg[ITER], vr[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        const int i = tid + NTH * k;
+        vg[k] = i < total ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        vr[k] = i < total ? r4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (tid < C) {
         float mean, inv;
         bn_coeffs(P, 0, tid, mean, inv);
@@ -904,25 +933,29 @@ __global__ __launch_bounds__(256) void k_trn_stem_bwd(TrnDev P) {
         cK[tid] = (float)(dsum(P.sums, 0, C, tid, 2) * (double)P.invN);
         cK[C + tid] = (float)(dsum(P.sums, 0, C, tid, 3) * (double)P.invN);
     }
-    for (int i = tid; i < cells; i += 256) cellv[i] = (unsigned char)P.board[(size_t)b * cells + i];
+    for (int i = tid; i < cells; i += NTH) cellv[i] = (unsigned char)P.board[(size_t)b * cells + i];
     __syncthreads();
-    const size_t base = (size_t)b * cells * C;
-    const float *g0 = P.g[0] + base, *r0 = P.raw[0] + base;
-    for (int i = tid; i < cells * C; i += 256) {
-        const int c = i % C;
-        Dr[i] = cA[c] * (g0[i] - cK[c] - (r0[i] - cM[c]) * cI[c] * cK[C + c]);
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        const int i = tid + NTH * k;
+        if (i >= total) break;
+        const int c = (i % C4) * 4;
+        float4 v;
+        v.x = cA[c] * (vg[k].x - cK[c] - (vr[k].x - cM[c]) * cI[c] * cK[C + c]);
+        v.y = cA[c + 1] * (vg[k].y - cK[c + 1] - (vr[k].y - cM[c + 1]) * cI[c + 1] * cK[C + c + 1]);
+        v.z = cA[c + 2] * (vg[k].z - cK[c + 2] - (vr[k].z - cM[c + 2]) * cI[c + 2] * cK[C + c + 2]);
+        v.w = cA[c + 3] * (vg[k].w - cK[c + 3] - (vr[k].w - cM[c + 3]) * cI[c + 3] * cK[C + c + 3]);
+        reinterpret_cast<float4 *>(Dr)[i] = v;
     }
-    __syncthreads();
     // dT[tap][v][co] += draw[pos][co] over the positions whose tap-neighbour holds v: a thread per (tap, co), the
     // three cell values in three accumulators; nbv[tap][pos] = that neighbour's value (3 = off the board)
-    __shared__ unsigned char nbv[9 * 128];
-    for (int i = tid; i < 9 * cells; i += 256) {
+    for (int i = tid; i < 9 * cells; i += NTH) {
         const int tap = i / cells, pos = i - tap * cells;
         const int y = pos / N, x = pos - y * N, yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
         nbv[tap * 128 + pos] = (yy >= 0 && yy < N && xx >= 0 && xx < N) ? cellv[yy * N + xx] : (unsigned char)3;
     }
     __syncthreads();
-    for (int i = tid; i < 9 * C; i += 256) {
+    for (int i = tid; i < 9 * C; i += NTH) {
         const int tap = i / C, co = i - tap * C;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
         for (int pos = 0; pos < cells; ++pos) {
@@ -964,12 +997,16 @@ __global__ __launch_bounds__(256) void k_trn_finalize(TrnDev P, FinalizeArgs F) 
             for (int v = 0; v < 3; ++v) s += P.emb[v * 4 + i4] * dT[(tap * 3 + v) * C + co];
             P.grad[F.g_w1 + i] = s;
         }
-        if (tid < 12) {                                  // encoder.weight [v][i4]
-            const int v = tid / 4, i4 = tid - v * 4;
+        if (tid < 12 * 16) {                             // encoder.weight [v][i4]: 16 threads per entry
+            const int e = tid / 16, j = tid % 16, v = e / 4, i4 = e - v * 4;
             float s = 0.f;
-            for (int tap = 0; tap < 9; ++tap)
-                for (int co = 0; co < C; ++co) s += P.w1[(co * 4 + i4) * 9 + tap] * dT[(tap * 3 + v) * C + co];
-            P.grad[F.g_emb + tid] = s;
+            for (int k = j; k < 9 * C; k += 16) {
+                const int tap = k / C, co = k - tap * C;
+                s += P.w1[(co * 4 + i4) * 9 + tap] * dT[(tap * 3 + v) * C + co];
+            }
+#pragma unroll
+            for (int sft = 8; sft >= 1; sft >>= 1) s += __shfl_xor(s, sft);
+            if (j == 0) P.grad[F.g_emb + e] = s;
         }
     } else if (blockIdx.x == 1) {
         for (int i = tid; i < 6 * C; i += 256) {
@@ -1023,28 +1060,60 @@ __global__ __launch_bounds__(256) void k_trn_update(TrnDev P, const Segment *seg
     for (int k = 0; k < 4; ++k) {
         const size_t e = e0 + (size_t)k * 256 + threadIdx.x;
         if (e >= S.n) break;
-        const float gr = P.grad[S.goff + e];
+        float gr;
+        if (S.layer >= 1) {                             // the G partial copies of k_trn_wgrad, fixed order
+            const float *part = P.wpart + (size_t)(S.layer - 1) * G * S.n + e;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int g = 0;
+            for (; g + 4 <= G; g += 4) {
+                s0 += part[(size_t)g * S.n];
+                s1 += part[(size_t)(g + 1) * S.n];
+                s2 += part[(size_t)(g + 2) * S.n];
+                s3 += part[(size_t)(g + 3) * S.n];
+            }
+            for (; g < G; ++g) s0 += part[(size_t)g * S.n];
+            gr = (s0 + s1) + (s2 + s3);
+            P.grad[S.goff + e] = gr;
+        } else {
+            gr = P.grad[S.goff + e];
+        }
         const float p = S.p[e], d = gr + wd * p, buf = mu * S.mom[e] + d, np = p - lr * buf;
         S.mom[e] = buf;
         S.p[e] = np;
     }
 }
 
-__global__ void k_trn_set_hp(float *hp, float lr, float mu, float wd) {
-    hp[0] = lr;
-    hp[1] = mu;
-    hp[2] = wd;
-}
-
-// The MFMA-order copies of every tower filter, first kernel of each step: whatever wrote the weights last -- this
-// trainer's own update, an eager optimizer step on a ragged batch, load_state_dict, a weight broadcast -- the step
-// convolves with what the tensors hold NOW.  grid (C C 9 / 256, L).
-//   forward pack        [tap][q][ntile][lane = j + 32 h][t] = W[co = 32 ntile + j][ci = 8 q + 4 h + t][tap]
-//   backward-data pack  the same order for the transposed, flipped filter W'[n = ci][k = co][8 - tap]
+// First kernel of a step, grid (C C 9 / 256, L + 1):
+//   y < L   the MFMA-order copies of tower filter y + 1: whatever wrote the weights last -- this trainer's own update,
+//           an eager optimizer step on a ragged batch, load_state_dict, a weight broadcast -- the step convolves with
+//           what the tensors hold NOW.
+//             forward pack        [tap][q][ntile][lane = j + 32 h][t] = W[co = 32 ntile + j][ci = 8 q + 4 h + t][tap]
+//             backward-data pack  the same order for the transposed, flipped filter W'[n = ci][k = co][8 - tap]
+//   y == L  the per-step accumulators zeroed, the stem table (embedding folded through conv1), and the step's
+//           hyper-parameters fetched from the host's pinned ring (slot = steps run so far)
 template <int C>
-__global__ __launch_bounds__(256) void k_trn_pack(TrnDev P) {
+__global__ __launch_bounds__(256) void k_trn_prep(TrnDev P) {
     constexpr int NT = (C + 31) / 32, Q = C / 8;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if ((int)blockIdx.y == P.L) {
+        for (size_t i = e; i < (size_t)P.zero_count; i += (size_t)gridDim.x * 256) P.zero_base[i] = 0.0;
+        if (e < (size_t)27 * C) {
+            const int k = (int)(e / C), co = (int)(e % C), tap = k / 3, v = k - tap * 3;
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += P.emb[v * 4 + j] * P.w1[(co * 4 + j) * 9 + tap];
+            P.stemT[e] = sum;
+        }
+        if (e == 0) {
+            const unsigned int step = *P.step_ctr;
+            const float *slot = P.hp_ring + (size_t)(step % TRN_HP_SLOTS) * 4;
+            P.hp[0] = slot[0];
+            P.hp[1] = slot[1];
+            P.hp[2] = slot[2];
+            *P.step_ctr = step + 1;
+        }
+        return;
+    }
     if (e >= (size_t)C * C * 9) return;
     const int l = blockIdx.y + 1;
     const int tap = (int)(e % 9), ci = (int)(e / 9 % C), co = (int)(e / 9 / C);
@@ -1079,7 +1148,9 @@ struct AzxTrain {
     FinalizeArgs fin;
     HeadGradOffs hoffs;
     std::vector<size_t> conv_goff;
-    float *hp_dev = nullptr;
+    float *hp_dev = nullptr, *hp_ring = nullptr;       // hp_ring: pinned host memory the prep kernel reads
+    unsigned long long host_steps = 0;
+    hipEvent_t ring_ev[2] = {nullptr, nullptr};         // marks of steps TRN_HP_SLOTS / 2 apart: the host never laps the device
     int32_t *in_board = nullptr, *in_legal = nullptr;
     float *in_prob = nullptr, *in_reward = nullptr;
     size_t zero_bytes = 0;       // sums + hsums + lossacc, contiguous
@@ -1089,7 +1160,7 @@ struct AzxTrain {
     hipGraphExec_t exec = nullptr;
     hipStream_t cap = nullptr, side = nullptr;
     std::vector<hipEvent_t> events;
-    bool use_graph = true;
+    bool use_graph = false;
     bool fork = true;            // AZX_TRAIN_FORK=0: the weight-gradient passes in line with the data chain (profiling)
 };
 
@@ -1140,6 +1211,8 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
         d.sums = z; d.hsums = z + (size_t)(L + 1) * C * 4; d.lossacc = d.hsums + 24;
         d.stem_dT = d.lossacc + 2; d.hconv_acc = d.stem_dT + 27 * C;
         t->zero_bytes = nsum * sizeof(double);
+        d.zero_base = z;
+        d.zero_count = (int)nsum;
     }
     ok = ok && (d.hraw = talloc<float>(t, (size_t)B * 6 * cells)) && (d.hact = talloc<float>(t, (size_t)B * 6 * cells)) &&
          (d.g6 = talloc<float>(t, (size_t)B * 6 * cells)) && (d.h2 = talloc<float>(t, (size_t)B * 64)) &&
@@ -1149,12 +1222,15 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
          (d.wpart = talloc<float>(t, (size_t)L * t->G * C * C * 9)) &&
          (t->in_board = talloc<int32_t>(t, (size_t)B * cells)) && (t->in_legal = talloc<int32_t>(t, (size_t)B * cells)) &&
          (t->in_prob = talloc<float>(t, (size_t)B * cells)) && (t->in_reward = talloc<float>(t, B)) &&
-         (t->hp_dev = talloc<float>(t, 4));
+         (t->hp_dev = talloc<float>(t, 4)) && (d.stemT = talloc<float>(t, (size_t)27 * C)) && (d.step_ctr = talloc<unsigned int>(t, 4));
+    if (ok) ok = hipHostMalloc((void **)&t->hp_ring, (size_t)TRN_HP_SLOTS * 4 * sizeof(float)) == hipSuccess &&
+                 hipEventCreateWithFlags(&t->ring_ev[0], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&t->ring_ev[1], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         azx_trn_destroy(t);
         return tfail(AZX_ENOMEM, "train: hipMalloc failed");
     }
-    d.board = t->in_board; d.legal = t->in_legal; d.prob = t->in_prob; d.reward = t->in_reward; d.hp = t->hp_dev;
+    d.board = t->in_board; d.legal = t->in_legal; d.prob = t->in_prob; d.reward = t->in_reward; d.hp = t->hp_dev; d.hp_ring = t->hp_ring;
     for (int l = 0; l <= L; ++l) {
         d.raw[l] = t->raw[l]; d.act[l] = t->act[l]; d.g[l] = t->g[l]; d.Wf[l] = t->Wf[l]; d.Wb[l] = t->Wb[l];
     }
@@ -1170,7 +1246,10 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     t->dbg["hact"] = {d.hact, (size_t)B * 6 * cells * 4};
     t->dbg["hg"] = {d.g6, (size_t)B * 6 * cells * 4};
     t->dbg["dlogit"] = {d.dlogit, (size_t)B * 128 * 4};
-    t->use_graph = !(getenv("AZX_TRAIN_GRAPH") && !strcmp(getenv("AZX_TRAIN_GRAPH"), "0"));
+    // AZX_TRAIN_GRAPH=1: the step as one captured HIP graph.  Off by default: with the weight-gradient passes on their
+    // own stream, plain launches run the step in 0.92 ms where the graph executor's placement of the two branches
+    // takes 1.01 ms (the host needs ~0.3 ms to queue a step: it stays ahead either way).
+    t->use_graph = getenv("AZX_TRAIN_GRAPH") && !strcmp(getenv("AZX_TRAIN_GRAPH"), "1");
     t->fork = !(getenv("AZX_TRAIN_FORK") && !strcmp(getenv("AZX_TRAIN_FORK"), "0"));
     if (hipDeviceSynchronize() != hipSuccess) {
         azx_trn_destroy(t);
@@ -1207,6 +1286,8 @@ void azx_trn_destroy(AzxTrain *t) {
     if (t->cap) (void)hipStreamDestroy(t->cap);
     if (t->side) (void)hipStreamDestroy(t->side);
     for (void *p : t->allocs) (void)hipFree(p);
+    if (t->hp_ring) (void)hipHostFree(t->hp_ring);
+    for (hipEvent_t e : t->ring_ev) if (e) (void)hipEventDestroy(e);
     delete t;
 }
 
@@ -1342,15 +1423,15 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
     const TrnDev &d = t->d;
     const int L = d.L, B = d.B, cells = d.cells, G = t->G;
     constexpr int NT = (C + 31) / 32;
-    if (hipMemsetAsync(d.sums, 0, t->zero_bytes, st) != hipSuccess) return tfail(AZX_EHIP, "train: memset failed");
-    hipLaunchKernelGGL(k_trn_pack<C>, dim3((C * C * 9 + 255) / 256, L), dim3(256), 0, st, d);
-    hipLaunchKernelGGL(k_trn_stem_fwd<C>, dim3(B), dim3(256), 0, st, d);
+    constexpr int SMALL = TRN_SMALL_THREADS;
+    hipLaunchKernelGGL(k_trn_prep<C>, dim3((C * C * 9 + 255) / 256, L + 1), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_trn_stem_fwd<C>, dim3(B), dim3(SMALL), 0, st, d);
     const size_t conv_lds = ((size_t)std::max((cells + 1) * (C + 4), cells * 36) + 9 * C + 256) * sizeof(float);
     for (int l = 1; l <= L; ++l)
         hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
     const size_t hc_lds = ((size_t)cells * (C + 1) + 2 * C + 6 * C + 16) * sizeof(float);
-    hipLaunchKernelGGL(k_trn_heads_conv<C>, dim3(B), dim3(256), hc_lds, st, d);
-    hipLaunchKernelGGL(k_trn_heads_fc, dim3(B), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_trn_heads_conv<C>, dim3(B), dim3(SMALL), hc_lds, st, d);
+    hipLaunchKernelGGL(k_trn_heads_fc, dim3(B), dim3(SMALL), 0, st, d);
     size_t ev = 0;
     auto next_event = [&]() -> hipEvent_t {
         if (ev == t->events.size()) {
@@ -1367,21 +1448,21 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
         return e && hipEventRecord(e, st) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess;
     };
     if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
-    const int hw_blocks = ((4 * cells + 255) / 256) * ((cells + 3) / 4) + 16 + 1;
+    const int hw_blocks = ((4 * cells + 255) / 256) * ((cells + 3) / 4) + 16 + (cells + 129 + 3) / 4;
     hipLaunchKernelGGL(k_trn_heads_wgrad, dim3(hw_blocks), dim3(256), 0, ws, d, t->hoffs);
-    hipLaunchKernelGGL(k_trn_heads_bwd<C>, dim3(B), dim3(256), 0, st, d);
+    const size_t hb_lds = ((size_t)cells * (C + 1) + (size_t)SMALL * 8) * sizeof(float);
+    hipLaunchKernelGGL(k_trn_heads_bwd<C>, dim3(B), dim3(SMALL), hb_lds, st, d);
     const int KP = (cells + 1) & ~1;
     const size_t wg_lds = ((size_t)KP * 32 + (size_t)(d.N + 2) * (d.N + 2) * 32 + 12 * 1024 + 5 * 32 + KP) * sizeof(float);
-    const size_t wn = (size_t)C * C * 9;
+
     for (int l = L; l >= 1; --l) {
         // g_l and BN_l's sums are complete here: the weight gradient of layer l runs beside the data chain
         if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
         hipLaunchKernelGGL(k_trn_wgrad<C>, dim3(NT * NT, G), dim3(256), wg_lds, ws, d, l, G);
-        hipLaunchKernelGGL(k_trn_wreduce, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, ws, d, l, G, wn, t->conv_goff[l]);
         hipLaunchKernelGGL((k_trn_conv<C, ROLE_BWD>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
     }
     const size_t sb_lds = ((size_t)cells * C + 5 * C) * sizeof(float);
-    hipLaunchKernelGGL(k_trn_stem_bwd<C>, dim3(B), dim3(256), sb_lds, st, d);
+    hipLaunchKernelGGL(k_trn_stem_bwd<C>, dim3(B), dim3(SMALL), sb_lds, st, d);
     if (fork) {
         hipEvent_t e = next_event();
         if (!e || hipEventRecord(e, side) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess)
@@ -1397,13 +1478,13 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
 static int raise_limits(int C) {
     const int cap = 128 * 1024;     // the largest user (k_trn_wgrad<64>) takes 94 KB; some kernels add static LDS on top
     const void *f64[] = {(const void *)k_trn_conv<64, ROLE_FWD>, (const void *)k_trn_conv<64, ROLE_BWD>, (const void *)k_trn_wgrad<64>,
-                         (const void *)k_trn_heads_conv<64>, (const void *)k_trn_stem_bwd<64>};
+                         (const void *)k_trn_heads_conv<64>, (const void *)k_trn_stem_bwd<64>, (const void *)k_trn_heads_bwd<64>};
     const void *f32[] = {(const void *)k_trn_conv<32, ROLE_FWD>, (const void *)k_trn_conv<32, ROLE_BWD>, (const void *)k_trn_wgrad<32>,
-                         (const void *)k_trn_heads_conv<32>, (const void *)k_trn_stem_bwd<32>};
+                         (const void *)k_trn_heads_conv<32>, (const void *)k_trn_stem_bwd<32>, (const void *)k_trn_heads_bwd<32>};
     const void *f16[] = {(const void *)k_trn_conv<16, ROLE_FWD>, (const void *)k_trn_conv<16, ROLE_BWD>, (const void *)k_trn_wgrad<16>,
-                         (const void *)k_trn_heads_conv<16>, (const void *)k_trn_stem_bwd<16>};
+                         (const void *)k_trn_heads_conv<16>, (const void *)k_trn_stem_bwd<16>, (const void *)k_trn_heads_bwd<16>};
     const void **f = C == 64 ? f64 : C == 32 ? f32 : f16;
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < 6; ++i)
         if (hipFuncSetAttribute(f[i], hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess)
             return tfail(AZX_EHIP, "train: raising a kernel's dynamic LDS limit failed");
     return AZX_OK;
@@ -1417,6 +1498,19 @@ static int enqueue_any(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork)
     }
 }
 
+// after a step has been queued: count it, and every half ring leave a mark the host can wait on before it re-uses
+// the slots (see azx_trn_step)
+static int step_done(AzxTrain *t, hipStream_t st) {
+    const unsigned long long sidx = t->host_steps % TRN_HP_SLOTS;
+    t->host_steps += 1;
+    if ((sidx + 1) % (TRN_HP_SLOTS / 2) == 0) {
+        // steps [.., sidx] are queued: when this mark fires, the half of the ring ending at sidx is free again
+        const int which = (int)(((sidx + 1) / (TRN_HP_SLOTS / 2)) & 1);
+        if (hipEventRecord(t->ring_ev[which], st) != hipSuccess) return tfail(AZX_EHIP, "train: marking the hyper-parameter ring failed");
+    }
+    return AZX_OK;
+}
+
 int azx_trn_step(AzxTrain *t, float lr, float momentum, float weight_decay, hipStream_t st) {
     if (!t->is_bound) return tfail(AZX_ESTATE, "train: azx_train_bind has not been called");
     if (!t->cap) {
@@ -1425,11 +1519,22 @@ int azx_trn_step(AzxTrain *t, float lr, float momentum, float weight_decay, hipS
             hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) != hipSuccess)
             return tfail(AZX_EHIP, "train: creating the capture streams failed");
     }
-    // the hyper-parameters travel through device memory, so one captured graph serves every learning rate
-    hipLaunchKernelGGL(k_trn_set_hp, dim3(1), dim3(1), 0, st, t->hp_dev, lr, momentum, weight_decay);
+    // The hyper-parameters travel through a ring in pinned host memory that the step's first kernel reads (slot = steps
+    // run so far, counted on both sides): one captured graph serves every learning rate and no extra node carries
+    // them.  The host may queue at most TRN_HP_SLOTS steps ahead: every half ring it waits for the mark set half a
+    // ring ago.
+    {
+        const unsigned long long sidx = t->host_steps % TRN_HP_SLOTS;
+        if (t->host_steps >= TRN_HP_SLOTS && sidx % (TRN_HP_SLOTS / 2) == 0)
+            if (hipEventSynchronize(t->ring_ev[(sidx / (TRN_HP_SLOTS / 2)) & 1]) != hipSuccess)
+                return tfail(AZX_EHIP, "train: waiting for the hyper-parameter ring failed");
+        float *slot = t->hp_ring + sidx * 4;
+        slot[0] = lr; slot[1] = momentum; slot[2] = weight_decay; slot[3] = 0.f;
+    }
     if (!t->use_graph) {
         // plain launches: the weight-gradient passes fork onto the side stream after an event on `st`
-        return enqueue_any(t, st, t->side, t->fork);
+        if (int rc = enqueue_any(t, st, t->side, t->fork)) return rc;
+        return step_done(t, st);
     }
     if (!t->exec) {
         if (hipStreamBeginCapture(t->cap, hipStreamCaptureModeRelaxed) != hipSuccess)
@@ -1444,7 +1549,7 @@ int azx_trn_step(AzxTrain *t, float lr, float momentum, float weight_decay, hipS
             return tfail(AZX_EHIP, "train: hipGraphInstantiate failed");
     }
     if (hipGraphLaunch(t->exec, st) != hipSuccess) return tfail(AZX_EHIP, "train: hipGraphLaunch failed");
-    return AZX_OK;
+    return step_done(t, st);
 }
 
 int azx_trn_debug(AzxTrain *t, const char *name, void *out, int64_t cap, int64_t *nbytes) {
