@@ -81,6 +81,12 @@ struct azx_engine {
     int64_t ring_idx_cap = 0;
     int32_t *ring_maxk = nullptr;
     std::vector<void *> ring_allocs;
+    // azx_replay_collate_async: index staging, AZX_COLLATE_SLOTS deep (pinned host + device), one event per slot
+    long long *cidx_host[8] = {nullptr}, *cidx_dev[8] = {nullptr};
+    hipEvent_t cidx_ev[8] = {nullptr};
+    int64_t cidx_cap = 0;
+    uint64_t cidx_next = 0;
+    int32_t *cidx_maxk = nullptr;
     // timing
     std::vector<hipEvent_t> ev_pool;
     std::vector<char> ev_tag;           // 0 = tree kernel, 1 = network (tower + heads)
@@ -250,6 +256,11 @@ extern "C" void azx_destroy(azx_engine *e) {
     if (e->export_board) (void)hipFree(e->export_board);
     if (e->export_prob) (void)hipFree(e->export_prob);
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+    for (int i = 0; i < 8; ++i) {
+        if (e->cidx_ev[i]) { (void)hipEventSynchronize(e->cidx_ev[i]); (void)hipEventDestroy(e->cidx_ev[i]); }
+        if (e->cidx_host[i]) (void)hipHostFree(e->cidx_host[i]);
+        if (e->cidx_dev[i]) (void)hipFree(e->cidx_dev[i]);
+    }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1241,6 +1252,49 @@ extern "C" int azx_replay_collate(azx_engine *e, int64_t batch, const int64_t *i
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(max_k_out, e->ring_maxk, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIPCHECK(hipStreamSynchronize(e->stream));
+    return AZX_OK;
+}
+
+// The same collate, enqueued on the CALLER's stream and not synchronised (no max_k: the consumer takes full-width
+// rows): for a trainer whose step runs on that stream (azx_train_step) -- the host queues collate + step and moves on.
+// The sampled indices are staged through a small ring of pinned buffers; a slot is re-used only after the collate that
+// read it has run (one event per slot).  The caller orders ring WRITES (azx_replay_fill / put, which are blocking calls
+// on the engine's stream) after these reads by synchronising its stream before a refill.
+extern "C" int azx_replay_collate_async(azx_engine *e, int64_t batch, const int64_t *indices, int64_t *color_dev,
+                                        int32_t *legal_moves_dev, int64_t *result_dev, int32_t *board_dev,
+                                        float *moves_prob_dev, float *reward_dev, void *hip_stream) {
+    if (!e || !indices || !color_dev || !legal_moves_dev || !result_dev || !board_dev || !moves_prob_dev || !reward_dev)
+        return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
+    if (e->ring_cap == 0) return fail(AZX_ESTATE, "no replay ring: call azx_replay_create first");
+    if (batch < 1 || batch > (1 << 20)) return fail(AZX_EINVAL, "batch outside [1, 2^20]");
+    for (int64_t b = 0; b < batch; ++b)
+        if (indices[b] < 0 || indices[b] >= e->ring_size)
+            return fail(AZX_EINVAL, "index %lld outside the %lld rows held", (long long)indices[b], (long long)e->ring_size);
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (batch > e->cidx_cap) {
+        for (int i = 0; i < 8; ++i) {
+            if (e->cidx_ev[i]) HIPCHECK(hipEventSynchronize(e->cidx_ev[i]));
+            if (e->cidx_host[i]) (void)hipHostFree(e->cidx_host[i]);
+            if (e->cidx_dev[i]) (void)hipFree(e->cidx_dev[i]);
+            e->cidx_host[i] = e->cidx_dev[i] = nullptr;
+            if (hipHostMalloc((void **)&e->cidx_host[i], (size_t)batch * sizeof(long long)) != hipSuccess ||
+                hipMalloc((void **)&e->cidx_dev[i], (size_t)batch * sizeof(long long)) != hipSuccess)
+                return fail(AZX_ENOMEM, "allocating the collate index ring failed");
+            if (!e->cidx_ev[i]) HIPCHECK(hipEventCreateWithFlags(&e->cidx_ev[i], hipEventDisableTiming));
+        }
+        if (!e->cidx_maxk) TRY(dev_alloc(e, &e->cidx_maxk, 4));
+        e->cidx_cap = batch;
+    }
+    const int slot = (int)(e->cidx_next++ % 8);
+    HIPCHECK(hipEventSynchronize(e->cidx_ev[slot]));          // returns at once for a slot never used
+    memcpy(e->cidx_host[slot], indices, (size_t)batch * sizeof(int64_t));
+    HIPCHECK(hipMemcpyAsync(e->cidx_dev[slot], e->cidx_host[slot], (size_t)batch * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    azx_launch_replay_collate(e->ring, e->cidx_dev[slot], (int)batch, e->d.ncells, (long long *)color_dev,
+                              legal_moves_dev, (long long *)result_dev, board_dev, moves_prob_dev, reward_dev,
+                              e->cidx_maxk, st);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipEventRecord(e->cidx_ev[slot], st));
     return AZX_OK;
 }
 

@@ -65,6 +65,9 @@ class DeviceReplayBuffer:
         refill = max(0, num_examples - self.fresh_counter)
         if not refill:
             return {}
+        if getattr(self, "_async_reads", False):       # collate_async reads queued on torch's stream come first
+            torch.cuda.synchronize(self.device)
+            self._async_reads = False
         if self.shared and azdist.is_distributed():
             rows, st = self.refill_shared(int(np.ceil(refill)), player)
         else:
@@ -174,6 +177,23 @@ class DeviceReplayBuffer:
                                  % (name, dtype, shape, self.device))
         torch.cuda.synchronize(self.device)      # whatever still reads the buffers (a graph replay) has finished
         return int(self.engine.replay_collate(idx, {name: out[name].data_ptr() for name in want}))
+
+    def collate_async(self, indices, out: Dict[str, torch.Tensor]) -> None:
+        """`collate_into` enqueued on torch's current stream and not synchronised (azx_replay_collate_async): the
+        consumer's work on that stream -- NativeTrainStep's kernels -- runs after it, the host moves on.  Full-width
+        rows, no max_k.  Ring writes wait for these reads: `consume` synchronises before a refill."""
+        idx = np.asarray(indices, np.int64).reshape(-1)
+        B, cells = len(idx), self.engine.n * self.engine.n
+        want = dict(color=((B,), torch.int64), legal_moves=((B, cells), torch.int32), result=((B,), torch.int64),
+                    board=((B, cells), torch.int32), moves_prob=((B, cells), torch.float32), reward=((B,), torch.float32))
+        for name, (shape, dtype) in want.items():
+            t = out[name]
+            if t.dtype != dtype or t.numel() != int(np.prod(shape)) or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("collate_async: '%s' must be a contiguous %s tensor of %s elements on %s"
+                                 % (name, dtype, shape, self.device))
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.engine.replay_collate_async(idx, {name: out[name].data_ptr() for name in want}, stream)
+        self._async_reads = True
 
     def epoch_indices(self) -> np.ndarray:
         """The order a fresh `iter(DataLoader(..., shuffle=True))` visits the rows in: the loader

@@ -402,6 +402,14 @@ class Engine:
                                         C.byref(mk)))
         return mk.value
 
+    def replay_collate_async(self, indices, out, stream):
+        """replay_collate enqueued on `stream` (a hipStream_t as int) without synchronising and without max_k."""
+        idx = np.ascontiguousarray(indices, np.int64)
+        check(self.L.azx_replay_collate_async(self.h, len(idx), _p(idx, C.c_int64),
+                                              *(C.c_void_p(int(out[k])) for k in
+                                                ("color", "legal_moves", "result", "board", "moves_prob", "reward")),
+                                              C.c_void_p(int(stream))))
+
     def debug_choose(self):
         """azx_debug_choose: (move_id[G], moves_prob[G, cells]) of the device move draw on the current roots."""
         mid = np.zeros(self.G, np.int32)

@@ -251,12 +251,13 @@ def train_step_flops(n, blocks, chans, batch):
     return 3.0 * batch * flop_per_position(n, blocks, chans)
 
 
-def run_train_step(args, local_rank, torch):
-    """SURVEY 8(f).4 beside the path: the reference's training step (policy_trainer.py:123-142) at its own batch of 128
-    (config/hex11_train_config.yml), fed from the HBM replay ring, four ways: as the reference runs it (eager, a host
-    sync per step for loss.item()), eager without that sync, the same stock kernels captured as a HIP graph
-    (policy_trainer.GraphedTrainStep), and the hand-written step (native_train.NativeTrainStep: fp32-MFMA kernels,
-    csrc/train_kernels.hip; no autograd, no MIOpen)."""
+TRAIN_MODES = ("eager", "eager_nosync", "hip_graph", "native")
+
+
+def train_step_mode(args, local_rank, torch, mode):
+    """One mode of the training-step leg in THIS process (the parent runs each mode in a process of its own: the modes
+    leave state behind -- torch side streams, MIOpen workspaces, allocator pools -- that costs whichever runs next
+    20-50 %)."""
     import numpy as np
     from torch import optim
     from azalea_amd import engine as eng
@@ -270,57 +271,76 @@ def run_train_step(args, local_rank, torch):
                    evaluator=eng.EVAL_UNIFORM, noise_scale=0.25, device=local_rank)
     buf = DeviceReplayBuffer(E, 20000, shared=False)
     E.replay_fill(20000)
-    out = {"what": "policy_trainer.supervised_step(train=True): %dx%d on %dx%d, SGD(momentum 0.9, weight decay 1e-4), "
-                   "batch %d collated from a %d-row HBM ring, fp32"
-                   % (args.blocks, args.chans, args.board, args.board, B, len(buf)), "batch": B, "steps": steps}
     torch.manual_seed(0)
     order = np.resize(buf.epoch_indices(), (steps + warm) * B)
-    for mode in ("eager", "eager_nosync", "hip_graph", "native"):
-        net = HexNetwork(board_size=args.board, num_blocks=args.blocks, base_chans=args.chans).to(dev)
-        opt = optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
-        gs = (GraphedTrainStep(net, opt, B, dev) if mode == "hip_graph" else
-              NativeTrainStep(net, opt, B, dev) if mode == "native" else None)
-        n_steps = steps if gs is not None else 60
-        for i in range(n_steps + warm):
-            if i == warm:
-                torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
-            idx = order[i * B:(i + 1) * B]
-            if gs is not None:
-                gs.step_from_ring(buf, idx)            # rows collated straight into the step's static inputs
-            elif mode == "eager":
-                supervised_step(net, buf.sample(idx), train=True, optimizer=opt, device=dev)
-            else:                                      # the same eager kernels, the loss left on the device
-                batch = buf.sample(idx)
-                net.train()
-                opt.zero_grad()
-                o = net.forward(batch["board"], batch["legal_moves"])
-                loss = (torch.nn.functional.mse_loss(o["value"], batch["reward"])
-                        - (batch["moves_prob"] * o["moves_logprob"]).sum() / B)
-                loss.backward()
-                opt.step()
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
-        out[mode] = {"steps_per_sec": n_steps / dt, "ms_per_step": 1e3 * dt / n_steps, "positions_per_sec": n_steps * B / dt}
-        if mode == "native":
-            # the step alone (inputs resident, no collate): HIP events on torch's stream around `steps` launches
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(steps):
-                gs._run()
-            e1.record()
+    net = HexNetwork(board_size=args.board, num_blocks=args.blocks, base_chans=args.chans).to(dev)
+    opt = optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    gs = (GraphedTrainStep(net, opt, B, dev) if mode == "hip_graph" else
+          NativeTrainStep(net, opt, B, dev) if mode == "native" else None)
+    n_steps = steps if gs is not None else 60
+    for i in range(n_steps + warm):
+        if i == warm:
             torch.cuda.synchronize(dev)
-            ms = e0.elapsed_time(e1) / steps
-            fl = train_step_flops(args.board, args.blocks, args.chans, B)
-            out[mode].update({"step_only_ms": ms, "step_only_steps_per_sec": 1e3 / ms,
-                              "algorithmic_tflops": fl / (ms * 1e-3) / 1e12,
-                              "frac_of_fp32_mfma_peak": fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
-                              "flop_per_step": fl})
-            gs.close()
+            t0 = time.perf_counter()
+        idx = order[i * B:(i + 1) * B]
+        if gs is not None:
+            gs.step_from_ring(buf, idx)            # rows collated straight into the step's static inputs
+        elif mode == "eager":
+            supervised_step(net, buf.sample(idx), train=True, optimizer=opt, device=dev)
+        else:                                      # the same eager kernels, the loss left on the device
+            batch = buf.sample(idx)
+            net.train()
+            opt.zero_grad()
+            o = net.forward(batch["board"], batch["legal_moves"])
+            loss = (torch.nn.functional.mse_loss(o["value"], batch["reward"])
+                    - (batch["moves_prob"] * o["moves_logprob"]).sum() / B)
+            loss.backward()
+            opt.step()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    out = {"steps_per_sec": n_steps / dt, "ms_per_step": 1e3 * dt / n_steps, "positions_per_sec": n_steps * B / dt,
+           "steps": n_steps, "ring_rows": len(buf)}
+    if mode == "native":
+        # the step alone (inputs resident, no collate): HIP events on torch's stream around `steps` launches
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            gs._run()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / steps
+        fl = train_step_flops(args.board, args.blocks, args.chans, B)
+        out.update({"step_only_ms": ms, "step_only_steps_per_sec": 1e3 / ms,
+                    "algorithmic_tflops": fl / (ms * 1e-3) / 1e12,
+                    "frac_of_fp32_mfma_peak": fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
+                    "flop_per_step": fl})
+        gs.close()
     E.close()
-    out["speedup_native_vs_hip_graph"] = out["native"]["steps_per_sec"] / out["hip_graph"]["steps_per_sec"]
-    out["speedup_native_vs_reference_style_eager"] = out["native"]["steps_per_sec"] / out["eager"]["steps_per_sec"]
-    out["speedup_hip_graph_vs_eager_nosync"] = out["hip_graph"]["steps_per_sec"] / out["eager_nosync"]["steps_per_sec"]
+    return out
+
+
+def run_train_step(args, local_rank, torch):
+    """SURVEY 8(f).4 beside the path: the reference's training step (policy_trainer.py:123-142) at its own batch of 128
+    (config/hex11_train_config.yml), fed from the HBM replay ring, four ways: as the reference runs it (eager, a host
+    sync per step for loss.item()), eager without that sync, the same stock kernels captured as a HIP graph
+    (policy_trainer.GraphedTrainStep), and the hand-written step (native_train.NativeTrainStep: fp32-MFMA kernels,
+    csrc/train_kernels.hip; no autograd, no MIOpen).  Each mode runs in a child process of its own."""
+    import subprocess
+    out = {"what": "policy_trainer.supervised_step(train=True): %dx%d on %dx%d, SGD(momentum 0.9, weight decay 1e-4), "
+                   "batch 128 collated from a 20000-row HBM ring, fp32; every mode in a fresh process"
+                   % (args.blocks, args.chans, args.board, args.board), "batch": 128}
+    for mode in TRAIN_MODES:
+        cmd = [sys.executable, os.path.abspath(__file__), "--train-step-only", mode, "--board", str(args.board),
+               "--blocks", str(args.blocks), "--chans", str(args.chans)]
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank)))
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        out[mode] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": (r.stderr or r.stdout)[-400:]}
+    if all("steps_per_sec" in out[m] for m in TRAIN_MODES):
+        out["speedup_native_vs_hip_graph"] = out["native"]["steps_per_sec"] / out["hip_graph"]["steps_per_sec"]
+        out["speedup_native_vs_reference_style_eager"] = out["native"]["steps_per_sec"] / out["eager"]["steps_per_sec"]
+        out["speedup_native_vs_eager_nosync"] = out["native"]["steps_per_sec"] / out["eager_nosync"]["steps_per_sec"]
+        out["speedup_hip_graph_vs_eager_nosync"] = out["hip_graph"]["steps_per_sec"] / out["eager_nosync"]["steps_per_sec"]
     return out
 
 
@@ -557,6 +577,8 @@ def main():
     ap.add_argument("--api-moves", type=int, default=190,
                     help="engine moves the nested product-surface leg (Player.read) is driven for; 0 = skip")
     ap.add_argument("--no-train-step", action="store_true", help="skip the nested training-step leg (SURVEY 8(f).4)")
+    ap.add_argument("--train-step-only", choices=list(TRAIN_MODES), default=None,
+                    help="internal: run ONE mode of the training-step leg in this process and print its JSON")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-replay-exchange", action="store_true")
     ap.add_argument("--exchange-plies", type=int, default=0,
@@ -572,6 +594,11 @@ def main():
         args.desync = int(round(0.76 * args.board * args.board))     # mean self-play game length, random-init net
     if args.settle is None:
         args.settle = 2 * args.board * args.board if args.desync else 0
+
+    if args.train_step_only:
+        import torch
+        print(json.dumps(train_step_mode(args, 0, torch, args.train_step_only)))
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -287,6 +287,15 @@ int azx_replay_collate(azx_engine *e, int64_t batch, const int64_t *indices, int
                        int32_t *legal_moves_dev, int64_t *result_dev, int32_t *board_dev,
                        float *moves_prob_dev, float *reward_dev, int32_t *max_k_out);
 
+/* azx_replay_collate enqueued on the CALLER's stream (hipStream_t; NULL = default) and NOT synchronised, without
+ * max_k (the consumer takes full-width rows): a trainer whose step runs on that stream (azx_train_step) queues collate
+ * + step and moves on.  `indices` is copied before the call returns.  Ring writes (azx_replay_fill / azx_replay_put*,
+ * blocking calls on the engine's stream) must be ordered after these reads by the caller: synchronise the stream
+ * before a refill. */
+int azx_replay_collate_async(azx_engine *e, int64_t batch, const int64_t *indices, int64_t *color_dev,
+                             int32_t *legal_moves_dev, int64_t *result_dev, int32_t *board_dev,
+                             float *moves_prob_dev, float *reward_dev, void *hip_stream);
+
 /* float32 arithmetic self-test (tests): the tree kernels need IEEE-rounded sqrt and divide and
  * no FMA contraction (mcts.py:132-135).  sq=sqrtf(a), dv=a/(1+b), mul=(0.75f*a)*b+a. */
 int azx_selftest_arith(int device, int n, const float *a, const float *b, float *sq, float *dv,

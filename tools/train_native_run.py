@@ -45,9 +45,20 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step._run()
+    t_host = time.perf_counter() - t0          # the host has queued everything
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("native step: %.3f ms (%d steps), loss %s" % (1e3 * dt / a.steps, a.steps, step.loss.cpu().numpy()))
+    print("native step: %.3f ms (%d steps; the host queued a step in %.3f ms), loss %s"
+          % (1e3 * dt / a.steps, a.steps, 1e3 * t_host / a.steps, step.loss.cpu().numpy()))
+    # what queueing ONE step costs the host when nothing is pending (no back-pressure from a full queue)
+    costs = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step._run()
+        costs.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    print("host cost of queueing one step on an idle device: %.3f ms (median of 5)" % (1e3 * sorted(costs)[2]))
 
 
 if __name__ == "__main__":
