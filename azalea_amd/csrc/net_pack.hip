@@ -83,7 +83,9 @@ static Plan make_plan(const AzxNet *net) {
     const bool f16 = v == 4 || v == 5;
     p.wg = v == 0;                                     // k_conv_generic
     p.wp = v >= 1 && v <= 3;                           // k_tower_mfma (fp32)
-    p.s32 = f16 && (net->opt_shape != 16 || v == 5);   // 32x32x16 fragment order (k_stem_wide_f16x3 reads Ws whatever the shape)
+    // 32x32x16 fragment order: the 32-shape kernels, the wide stem (k_stem_wide_f16x3 reads Ws whatever the shape), and
+    // the unsplit 6x64 tower (AZX_TOWER_SPLIT=0 runs k_tower_f16x3<false>, a 32-shape kernel, whatever the shape)
+    p.s32 = f16 && (net->opt_shape != 16 || v == 5 || (v == 4 && !net->opt_split_m));
     p.s16 = f16 && net->opt_shape == 16;               // 16x16x32 fragment order
     p.hd16 = v == 4 && p.C == 64;
     p.n_stemT = (size_t)28 * p.C;
