@@ -260,6 +260,28 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
     __syncthreads();
     TS_MARK(1)
 
+    // ---- BWD: what the epilogue reads per output element (the ReLU mask's activation, the BatchNorm input of layer
+    // l - 1 and the skip gradient, this block's 32 channels), requested when the k-loop is done.  Requesting it BEFORE
+    // the k-loop was measured: 0.884 vs 0.863 ms per step on one box -- the 12 loads sit in the same in-order vmcnt
+    // queue as the first taps' filter fragments.
+    constexpr int LDO = 36, CHo = C < 32 ? C : 32, O4 = CHo / 4, ITERO = (121 * O4 + 255) / 256;
+    const int totalo = cells * O4;
+    float4 ea[ITERO], er[ITERO], es[ITERO];
+    auto epi_loads = [&]() {
+        const float *pact = P.act[l - 1] + base0 + nt * 32, *praw = P.raw[l - 1] + base0 + nt * 32;
+        const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= P.L;
+        const float *skip = has_skip ? P.g[l + 1] + base0 + nt * 32 : nullptr;
+#pragma unroll
+        for (int k = 0; k < ITERO; ++k) {
+            const int i = tid + 256 * k, pos = i / O4, c = (i - pos * O4) * 4;
+            const bool on = i < totalo;
+            const size_t o = (size_t)pos * C + c;
+            ea[k] = on ? *reinterpret_cast<const float4 *>(pact + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            er[k] = on ? *reinterpret_cast<const float4 *>(praw + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            es[k] = (on && has_skip) ? *reinterpret_cast<const float4 *>(skip + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
     // ---- k-loop: 9 taps x C / 8 steps of four 32x32x2 MFMAs ----------------------------------------------------
     // One wave per SIMD and a dependent MFMA chain: nothing hides a load but the loop itself.  So the filter
     // fragments of tap t + 1 (C / 8 16-byte loads from L2) are requested before tap t's MFMAs start, and a tap's
@@ -324,7 +346,7 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
     } else {
         // the accumulators go through LDS (the input tile is done with) so that the skip gradient, the ReLU mask's
         // activation and the BatchNorm input are read -- and g written -- in coalesced 16-byte pieces
-        constexpr int LDO = 36, CHo = C < 32 ? C : 32, O4 = CHo / 4, ITERO = (121 * O4 + 255) / 256;
+        epi_loads();
         __syncthreads();                                 // every wave has finished reading X
         float *Y = X;                                    // [cells][LDO]: this block's 32 output channels
 #pragma unroll
@@ -334,20 +356,6 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
         }
         __syncthreads();
         float *out = P.g[l - 1] + base + nt * 32;
-        const float *pact = P.act[l - 1] + base + nt * 32, *praw = P.raw[l - 1] + base + nt * 32;
-        const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= P.L;
-        const float *skip = has_skip ? P.g[l + 1] + base + nt * 32 : nullptr;
-        const int totalo = cells * O4;
-        float4 ea[ITERO], er[ITERO], es[ITERO];
-#pragma unroll
-        for (int k = 0; k < ITERO; ++k) {
-            const int i = tid + 256 * k, pos = i / O4, c = (i - pos * O4) * 4;
-            const bool on = i < totalo;
-            const size_t o = (size_t)pos * C + c;
-            ea[k] = on ? *reinterpret_cast<const float4 *>(pact + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-            er[k] = on ? *reinterpret_cast<const float4 *>(praw + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-            es[k] = (on && has_skip) ? *reinterpret_cast<const float4 *>(skip + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
         // a thread's items all have the same four channels (256 is a multiple of O4): four pairs of running sums
         float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
         const int c0 = (tid % O4) * 4;
@@ -432,6 +440,23 @@ __global__ __launch_bounds__(256) void k_trn_wgrad(TrnDev P, int l, int G) {
     constexpr int ROLE = 2;
     (void)ROLE;
     TS_DECL
+    // a board's three tensors (this block's channel halves) as 16-byte pieces, requested a board ahead: the first
+    // board's before the LDS is initialised, the next one's before the current one's k-loop
+    const int total = cells * H4;
+    float4 vg[ITER], vr[ITER], va[ITER];
+    auto request = [&](int b) {
+        const size_t base = (size_t)b * cells * C;
+        const float *gs = P.g[l] + base + tm * 32, *rs = P.raw[l] + base + tm * 32, *as = P.act[l - 1] + base + tn * 32;
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) {
+            const int i = tid + 256 * k, pos = i / H4, c = (i - pos * H4) * 4;
+            const bool on = i < total;
+            vg[k] = on ? *reinterpret_cast<const float4 *>(gs + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vr[k] = on ? *reinterpret_cast<const float4 *>(rs + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            va[k] = on ? *reinterpret_cast<const float4 *>(as + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (grp < P.B) request(grp);
     if (tid < CH) {
         const int c = tm * 32 + tid;
         float mean, inv;
@@ -442,7 +467,10 @@ __global__ __launch_bounds__(256) void k_trn_wgrad(TrnDev P, int l, int G) {
         cK[tid] = (float)(dsum(P.sums, l, C, c, 2) * (double)P.invN);
         cK[32 + tid] = (float)(dsum(P.sums, l, C, c, 3) * (double)P.invN);
     }
-    for (int i = tid; i < KP * 32 + NP * NP * 32; i += 256) lds[i] = 0.f;
+    {   // the operand tiles start zero: the padding k-row of D and the border of the padded board stay that way
+        float4 *z = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < (KP * 32 + NP * NP * 32) / 4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     for (int i = tid; i < KP; i += 256) prow[i] = i < cells ? (i / N + 1) * NP + (i % N) + 1 : 0;
     f32x16 acc[9];
 #pragma unroll
@@ -453,35 +481,22 @@ __global__ __launch_bounds__(256) void k_trn_wgrad(TrnDev P, int l, int G) {
     TS_MARK(0)
     const int S = KP / 2;
     for (int b = grp; b < P.B; b += G) {
-        const size_t base = (size_t)b * cells * C;
-        const float *gs = P.g[l] + base + tm * 32, *rs = P.raw[l] + base + tm * 32, *as = P.act[l - 1] + base + tn * 32;
-        {
-            float4 vg[ITER], vr[ITER], va[ITER];
-            const int total = cells * H4;
 #pragma unroll
-            for (int k = 0; k < ITER; ++k) {
-                const int i = tid + 256 * k, pos = i / H4, c = (i - pos * H4) * 4;
-                const bool on = i < total;
-                vg[k] = on ? *reinterpret_cast<const float4 *>(gs + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                vr[k] = on ? *reinterpret_cast<const float4 *>(rs + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                va[k] = on ? *reinterpret_cast<const float4 *>(as + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int k = 0; k < ITER; ++k) {
-                const int i = tid + 256 * k;
-                if (i >= total) break;
-                const int pos = i / H4, c = (i - pos * H4) * 4;
-                const float4 gv = vg[k], rv = vr[k];
-                float4 v;
-                v.x = cA[c] * (gv.x - cK[c] - (rv.x - cM[c]) * cI[c] * cK[32 + c]);
-                v.y = cA[c + 1] * (gv.y - cK[c + 1] - (rv.y - cM[c + 1]) * cI[c + 1] * cK[32 + c + 1]);
-                v.z = cA[c + 2] * (gv.z - cK[c + 2] - (rv.z - cM[c + 2]) * cI[c + 2] * cK[32 + c + 2]);
-                v.w = cA[c + 3] * (gv.w - cK[c + 3] - (rv.w - cM[c + 3]) * cI[c + 3] * cK[32 + c + 3]);
-                *reinterpret_cast<float4 *>(D + (size_t)pos * 32 + c) = v;
-                *reinterpret_cast<float4 *>(A + (size_t)prow[pos] * 32 + c) = va[k];
-            }
+        for (int k = 0; k < ITER; ++k) {
+            const int i = tid + 256 * k;
+            if (i >= total) break;
+            const int pos = i / H4, c = (i - pos * H4) * 4;
+            const float4 gv = vg[k], rv = vr[k];
+            float4 v;
+            v.x = cA[c] * (gv.x - cK[c] - (rv.x - cM[c]) * cI[c] * cK[32 + c]);
+            v.y = cA[c + 1] * (gv.y - cK[c + 1] - (rv.y - cM[c + 1]) * cI[c + 1] * cK[32 + c + 1]);
+            v.z = cA[c + 2] * (gv.z - cK[c + 2] - (rv.z - cM[c + 2]) * cI[c + 2] * cK[32 + c + 2]);
+            v.w = cA[c + 3] * (gv.w - cK[c + 3] - (rv.w - cM[c + 3]) * cI[c + 3] * cK[32 + c + 3]);
+            *reinterpret_cast<float4 *>(D + (size_t)pos * 32 + c) = v;
+            *reinterpret_cast<float4 *>(A + (size_t)prow[pos] * 32 + c) = va[k];
         }
         __syncthreads();
+        if (b + G < P.B) request(b + G);                 // travels under this board's k-loop
         TS_MARK(1)
         // this wave's k-steps s = wave, wave + 4, ...; the operands of step s + 4 are requested before step s's MFMAs
         int s = wave < S ? wave : S - 1;
@@ -507,21 +522,27 @@ __global__ __launch_bounds__(256) void k_trn_wgrad(TrnDev P, int l, int G) {
         __syncthreads();
         TS_MARK(2)
     }
-    // the four waves' shares of the nine tiles -> one, three taps per round through LDS ([3][4 waves][1024]; plain
-    // writes and reads: LDS float atomics run at a small fraction of that rate)
+    // The four waves' shares of the nine tiles -> one, three taps per round through LDS (plain 16-byte writes: LDS float
+    // atomics run at a small fraction of that rate).  red[(u * 4 + wave) * 4 + (i >> 2)][lane][i & 3]; the partial copy
+    // is laid out [tap][co][ci] so that the rows leave in 128-byte pieces (k_trn_update reads it transposed).
     float *part = P.wpart + ((size_t)(l - 1) * G + grp) * ((size_t)C * C * 9);
 #pragma unroll
     for (int t0 = 0; t0 < 9; t0 += 3) {
 #pragma unroll
         for (int u = 0; u < 3; ++u)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) red[(u * 4 + wave) * 1024 + i * 64 + lane] = acc[t0 + u][i];
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4 *>(red + ((size_t)((u * 4 + wave) * 4 + q) * 64 + lane) * 4) =
+                    make_float4(acc[t0 + u][4 * q], acc[t0 + u][4 * q + 1], acc[t0 + u][4 * q + 2], acc[t0 + u][4 * q + 3]);
         __syncthreads();
         for (int e = tid; e < 3 * 1024; e += 256) {
-            const int u = e >> 10, i = (e >> 6) & 15, ln = e & 63, r = e & 1023;
-            const int co = tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5), ci = tn * 32 + (ln & 31);
-            const float *q = red + (size_t)u * 4096 + r;
-            if (co < C && ci < C) part[((size_t)co * C + ci) * 9 + t0 + u] = (q[0] + q[1024]) + (q[2048] + q[3072]);
+            const int u = e >> 10, col = (e >> 5) & 31, cil = e & 31;          // output (co = col, ci = cil) of tile u
+            const int q = col >> 3, lh_ = (col >> 2) & 1, r = col & 3;
+            const size_t o = ((size_t)q * 64 + cil + 32 * lh_) * 4 + r;
+            const float *w0 = red + (size_t)(u * 4) * 1024;
+            const int co = tm * 32 + col, ci = tn * 32 + cil;
+            if (co < C && ci < C)
+                part[((size_t)(t0 + u) * C + co) * C + ci] = (w0[o] + w0[1024 + o]) + (w0[2048 + o] + w0[3072 + o]);
         }
         __syncthreads();
     }
@@ -1058,11 +1079,16 @@ __global__ __launch_bounds__(256) void k_trn_update(TrnDev P, const Segment *seg
     const size_t e0 = (size_t)bk.y * 1024;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const size_t e = e0 + (size_t)k * 256 + threadIdx.x;
-        if (e >= S.n) break;
+        const size_t ei = e0 + (size_t)k * 256 + threadIdx.x;
+        if (ei >= S.n) break;
+        size_t e = ei;
         float gr;
-        if (S.layer >= 1) {                             // the G partial copies of k_trn_wgrad, fixed order
-            const float *part = P.wpart + (size_t)(S.layer - 1) * G * S.n + e;
+        if (S.layer >= 1) {
+            // the G partial copies of k_trn_wgrad, laid out [tap][co][ci], summed in a fixed order: threads walk THAT
+            // order (64 coalesced reads each) and touch the filter / momentum / gradient at (co C + ci) 9 + tap
+            const size_t cc9 = S.n / 9, tap = ei / cc9, cc = ei - tap * cc9;
+            e = cc * 9 + tap;
+            const float *part = P.wpart + (size_t)(S.layer - 1) * G * S.n + ei;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
             int g = 0;
             for (; g + 4 <= G; g += 4) {
