@@ -18,5 +18,5 @@ if [ "$1" = build ]; then
   done
 else
   libs="libazx_hip.so"; for v in $VARIANTS; do libs="$libs libazx_ab$v.so"; done
-  bash tools/ab_wide_lib.sh $libs
+  bash tools/ab.sh wide $libs
 fi

@@ -17,5 +17,5 @@ if [ "$mode" = build ]; then
   wait
 else
   libs="libazx_hip.so"; for n in "$@"; do libs="$libs libazx_$n.so"; done
-  bash tools/ab_wide_lib.sh $libs
+  bash tools/ab.sh wide $libs
 fi

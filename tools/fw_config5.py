@@ -1,6 +1,6 @@
 """Diagnostic: forward time of the BASELINE configs[4] network (13x13, 19x256) through azx_forward."""
-import sys, time
-sys.path.insert(0, "/root/repo")
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from azalea_amd import engine as eng
 from azalea_amd.network import HexNetwork

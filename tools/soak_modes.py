@@ -1,7 +1,7 @@
 """Diagnostic soak (tools only): whole games in several engine configurations, every harvested game
 checked for legality (one new stone per row, normalised move distributions, winner on the last row)."""
-import sys, time
-sys.path.insert(0, "/root/repo")
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from azalea_amd import engine as eng
 
