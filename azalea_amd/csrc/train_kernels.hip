@@ -168,9 +168,8 @@ __device__ unsigned long long g_trn_stamp[3][TS_WAVES][8];
 #endif
 
 template <int C, int ROLE>
-__global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
+__device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, const int nt, const int b, float *lds) {
     constexpr int NT = (C + 31) / 32, LDW = C + 4, Q = C / 8, C4 = C / 4;
-    extern __shared__ __align__(16) float lds[];
     float *X = lds;                                    // [(cells + 1)][LDW]
     const int N = P.N, cells = P.cells;
     // (the backward epilogue re-uses X as a [cells][36] output tile: the region is the larger of the two)
@@ -178,7 +177,7 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
     float *cB = cA + C, *cM = cB + C, *cI = cM + C, *cK = cI + C;     // cK: [2][C] (BWD)
     float *pM = cK + 2 * C, *pI = pM + C;               // BWD epilogue: mean / invstd of layer l - 1
     float *red = pI + C;                                // [4][32][2]
-    const int nt = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     TS_DECL
 
@@ -424,9 +423,8 @@ __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
 //   Partials are reduced by k_trn_update in a fixed order: the step is reproducible.
 // =================================================================================================================
 template <int C>
-__global__ __launch_bounds__(256) void k_trn_wgrad(TrnDev P, int l, int G) {
+__device__ __forceinline__ void trn_wgrad_body(const TrnDev &P, const int l, const int G, const int pair, const int grp, float *lds) {
     constexpr int NT = (C + 31) / 32, CH = C < 32 ? C : 32, H4 = CH / 4, ITER = (121 * H4 + 255) / 256;
-    extern __shared__ __align__(16) float lds[];
     const int N = P.N, cells = P.cells, KP = (cells + 1) & ~1, NP = N + 2;
     float *D = lds;                                     // [KP][32] draw, this block's co half (rows >= cells zero)
     float *A = D + (size_t)KP * 32;                      // [(N + 2)^2][32] input, this block's ci half, on a board with a
@@ -434,7 +432,7 @@ __global__ __launch_bounds__(256) void k_trn_wgrad(TrnDev P, int l, int G) {
     float *red = A + (size_t)NP * NP * 32;               // [3 taps][4 waves][1024] reduction rounds
     float *cA = red + 12 * 1024, *cM = cA + 32, *cI = cM + 32, *cK = cI + 32;     // cK [2][32]
     int *prow = reinterpret_cast<int *>(cK + 64);        // [KP] padded-board row of position k (0 for the padding k)
-    const int pair = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tm = pair / NT, tn = pair % NT;
     const int li = lane & 31, lh = lane >> 5;
     constexpr int ROLE = 2;
@@ -549,6 +547,24 @@ __global__ __launch_bounds__(256) void k_trn_wgrad(TrnDev P, int l, int G) {
     TS_MARK(3)
     TS_END
 }
+
+template <int C, int ROLE>
+__global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
+    extern __shared__ __align__(16) float lds[];
+    trn_conv_body<C, ROLE>(P, l, blockIdx.x, blockIdx.y, lds);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_trn_wgrad(TrnDev P, int l, int G) {
+    extern __shared__ __align__(16) float lds[];
+    trn_wgrad_body<C>(P, l, G, blockIdx.x, blockIdx.y, lds);
+}
+
+// (Measured and dropped: one launch per backward layer with both consumers of g_l -- k_trn_conv<BWD>'s workgroups and
+// k_trn_wgrad's -- in one grid, two resident per CU at 256 registers: 1.00-1.01 ms per step against 0.83 for the two
+// kernels on two streams, whichever way the roles were mapped to workgroup indices.  As separate kernels the data chain
+// runs ahead into layer l - 1 while layer l's filter gradient is still in flight; a joint launch ends with its slower
+// half and nothing of the next layer can start under it.)
 
 // =================================================================================================================
 // heads, forward part 1: act_L = relu(BN_L(raw_L) + act_{L-2}); the two 1x1 convolutions; their batch sums

@@ -2,7 +2,8 @@
 """The trainer's loop as one GPU runs it (policy_trainer.py:82-90: a training step, then
 `replaybuf.consume(batch_size / oversampling, player)`), at the reference's hyper-parameters (6x64 on 11x11, batch 128,
 10x oversampling, 400-sim self-play on 4096 concurrent games): the captured training step fed from the HBM ring, with
-the refills played inline (DeviceReplayBuffer.consume), and the same steps without any refill.
+the refills played inline (DeviceReplayBuffer.consume), and the same steps without any refill -- with the hand-written
+step (NativeTrainStep) and with the stock kernels captured as a HIP graph (GraphedTrainStep).
 Reports steps/s and the rows the refills brought.  (Round 3 also measured the refills played UNDER the steps by a
 background thread on a second engine handle: 344.7 vs 339.6 steps/s, profiles/r3_train_loop_bench.json -- the tower
 fills every CU's registers and LDS, so the training kernels queue behind its blocks; that variant was removed.)
@@ -21,10 +22,11 @@ from torch import optim
 
 from azalea_amd import AzaleaAgent, HexGame, Player, Policy
 from azalea_amd.device_replay import DeviceReplayBuffer
+from azalea_amd.native_train import NativeTrainStep
 from azalea_amd.policy_trainer import GraphedTrainStep
 
 
-def run(mode, args):
+def run(mode, args, step_kind="native"):
     dev = "cuda:0"
     torch.manual_seed(0)
     policy = Policy()
@@ -46,7 +48,7 @@ def run(mode, args):
     buf.fresh_counter = 0
     opt = optim.SGD(policy.net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
     B = 128
-    gs = GraphedTrainStep(policy.net, opt, B, torch.device(dev))
+    gs = (NativeTrainStep if step_kind == "native" else GraphedTrainStep)(policy.net, opt, B, torch.device(dev))
     refills, rows = [], 0
     order = np.random.RandomState(0).randint(0, len(buf), (args.steps + 20, B))
     for i in range(args.steps + 20):
@@ -62,7 +64,7 @@ def run(mode, args):
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     player.stop()
-    out = {"mode": mode, "steps": args.steps, "seconds": t1 - t0, "steps_per_sec": args.steps / (t1 - t0),
+    out = {"mode": mode, "step": step_kind, "steps": args.steps, "seconds": t1 - t0, "steps_per_sec": args.steps / (t1 - t0),
            "refills": len(refills), "rows_refilled": rows}
     return out
 
@@ -74,10 +76,13 @@ def main():
     ap.add_argument("--sims", type=int, default=400)
     ap.add_argument("--fill", type=int, default=60000, help="rows of the untimed initial fill")
     args = ap.parse_args()
-    res = [run("inline", args), run("steps only", args)]
-    print(json.dumps({"what": "captured training step (batch 128) + consume(12.8) per step; 6x64 resnet self-play, %d games, "
-                              "%d sims" % (args.games, args.sims), "runs": res,
-                      "selfplay_share_of_loop": 1.0 - res[0]["steps_per_sec"] / res[1]["steps_per_sec"]}))
+    res = [run("inline", args, "native"), run("steps only", args, "native"),
+           run("inline", args, "hip_graph"), run("steps only", args, "hip_graph")]
+    print(json.dumps({"what": "training step (batch 128; hand-written / stock kernels captured as a HIP graph) + consume(12.8) per "
+                              "step; 6x64 resnet self-play, %d games, %d sims" % (args.games, args.sims), "runs": res,
+                      "selfplay_share_of_loop_native": 1.0 - res[0]["steps_per_sec"] / res[1]["steps_per_sec"],
+                      "selfplay_share_of_loop_hip_graph": 1.0 - res[2]["steps_per_sec"] / res[3]["steps_per_sec"],
+                      "loop_speedup_native_vs_hip_graph": res[0]["steps_per_sec"] / res[2]["steps_per_sec"]}))
 
 
 if __name__ == "__main__":
