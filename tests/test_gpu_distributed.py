@@ -150,7 +150,7 @@ def test_bench_eight_ranks_dry_run():
     assert one["plies"] == eight["plies"] == 64 * 3 and one["games_finished"] == eight["games_finished"]
 
 
-def _train_worker(rank, world, port, rundir, out):
+def _train_worker(rank, world, port, rundir, native, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -176,7 +176,7 @@ def _train_worker(rank, world, port, rundir, out):
     tcfg = dict(seed=11, device="cuda:0", replaybuf_oversampling=2, batch_size=16, game="azalea_amd.game.hex.HexGame",
                 board_size=n, replaybuf_size=320, lr_initial=0.05, momentum=0.9, l2_regularization=1e-4,
                 lr_decay_epochs=100, lr_decay=0.1, total_epochs=1, selfplay_games=16, log_interval=0,
-                model_checkpoint_interval=8)
+                model_checkpoint_interval=8, train_step_native=native)
     try:
         path = train(policy, tcfg, rundir, device_replay=True)
     finally:
@@ -202,14 +202,16 @@ def _train_worker(rank, world, port, rundir, out):
     dist.destroy_process_group()
 
 
-def test_train_two_ranks_rank0_trains_both_play_with_its_weights(tmp_path):
+@pytest.mark.parametrize("native", [False, True])
+def test_train_two_ranks_rank0_trains_both_play_with_its_weights(tmp_path, native):
     """VERDICT r3 #1(b, c): policy_trainer.train with world 2 (gloo, both ranks on this GPU, real engines, the HBM
-    replay ring): rank 0 runs the optimizer and broadcasts its network before every shared refill, rank 1 serves
+    replay ring): rank 0 runs the optimizer -- the eager step, or the hand-written one with its rows collated
+    asynchronously on the trainer's stream -- and broadcasts its network before every shared refill, rank 1 serves
     self-play; identical engine weight digests at every refill, one set of checkpoint files."""
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path / "run"), out), nprocs=world, join=True)
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path / "run"), native, out), nprocs=world, join=True)
     assert dict(out) == {0: [], 1: []}
 
 

@@ -262,3 +262,22 @@ def test_train_loop_with_device_replay(tmp_path, mode):
     for k, v in after.items():
         assert torch.equal(v.cpu(), q.net.state_dict()[k]), k
     assert n0 >= config["replaybuf_size"]
+
+
+def test_native_train_step_refuses_what_it_does_not_cover():
+    """NativeTrainStep is HIP-only and specific: a CPU device, another optimizer or another module is a ValueError up
+    front (the eager / captured steps apply there), never a silent fallback."""
+    from azalea_amd.native_train import NativeTrainStep
+    from azalea_amd.network import HexNetwork
+    net = HexNetwork(board_size=5, num_blocks=1, base_chans=16)
+    sgd = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
+    with pytest.raises(ValueError):
+        NativeTrainStep(net, sgd, 8, "cpu")
+    with pytest.raises(ValueError):
+        NativeTrainStep(net, torch.optim.Adam(net.parameters()), 8, "cuda:0")
+    with pytest.raises(ValueError):
+        NativeTrainStep(net, torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, nesterov=True), 8, "cuda:0")
+    with pytest.raises(ValueError):
+        NativeTrainStep(torch.nn.Linear(3, 3), sgd, 8, "cuda:0")
+    with pytest.raises(ValueError):
+        NativeTrainStep(net, torch.optim.SGD(list(net.parameters())[:3], lr=0.1), 8, "cuda:0")
