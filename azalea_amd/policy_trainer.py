@@ -241,6 +241,8 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
         torch.cuda.manual_seed_all(config["seed"])          # policy_trainer.py:33
     policy.seed(config["seed"])
     device = torch.device(config["device"])
+    if device.type == "cuda":
+        torch.cuda.set_device(device)      # RCCL collectives (announcements, weights, records) run on the current device
     oversampling = config["replaybuf_oversampling"]
     batch_size = config["batch_size"]
     game_class = import_and_get(config["game"])

@@ -65,6 +65,14 @@ def dur_ms(r):
     return (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 
 
+def src_sha(ln):
+    """`src=<digest>` of the bench line's kernel description: the kernel sources the profiled library was built from."""
+    for part in ((ln or {}).get("kernels") or "").split(";"):
+        if part.strip().startswith("src="):
+            return part.strip()[4:]
+    return None
+
+
 line = bench_line("stats") or bench_line("fetch") or {}
 SHA = src_sha(bench_line("fetch") or line)          # the counters' own run
 evals_per_move = 42          # 41 select batches + the root evaluation (11x11, 400 sims)
@@ -97,14 +105,6 @@ def counters(name, pick):
         if pick(r["Kernel_Name"]):
             by[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return by
-
-
-def src_sha(ln):
-    """`src=<digest>` of the bench line's kernel description: the kernel sources the profiled library was built from."""
-    for part in ((ln or {}).get("kernels") or "").split(";"):
-        if part.strip().startswith("src="):
-            return part.strip()[4:]
-    return None
 
 
 def traffic(f, w):
