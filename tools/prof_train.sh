@@ -11,9 +11,11 @@ f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 cp $f $OUT/kernel_stats.csv
 python3 - $OUT/kernel_stats.csv <<'P'
 import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+steps = max([int(r["Calls"]) for r in rows if "k_trn_prep" in r["Name"]] or [1])      # one k_trn_prep per step
 tot = 0
-for r in csv.DictReader(open(sys.argv[1])):
-    per_step = float(r["TotalDurationNs"]) / 1e3 / 31
+for r in rows:
+    per_step = float(r["TotalDurationNs"]) / 1e3 / steps
     if "k_trn" in r["Name"] or "rocclr" in r["Name"]:
         tot += per_step
     print("%-58s calls %5s avg %8.1f us  per step %8.1f us" % (r["Name"][:58], r["Calls"], float(r["AverageNs"]) / 1e3, per_step))
