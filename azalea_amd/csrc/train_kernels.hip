@@ -10,14 +10,17 @@
 // chain of ~40 dependent layer passes: latency-bound, not throughput-bound.  So: fp32 MFMA (v_mfma_f32_32x32x2_f32,
 // exact products -- gradients span ten orders of magnitude, no f16 range games), one workgroup per (board, 32 output
 // channels) so that a layer pass fills all 256 CUs with 4 waves each, every elementwise stage fused into the
-// producer's epilogue or the consumer's prologue, and the whole step captured once as a HIP graph:
+// producer's epilogue or the consumer's prologue, the filter gradients on a stream of their own beside the data chain:
 //   forward  : k_trn_stem_fwd, L x k_trn_conv<FWD> (prologue: BN(batch stats) + residual + ReLU of the INPUT, written
 //              out once for the backward pass; epilogue: raw output + per-channel sum / sum of squares), heads
+//   prep     : k_trn_prep (MFMA-order copies of the filters from the live tensors, accumulators zeroed, stem table,
+//              hyper-parameters from a pinned ring)
 //   backward : heads, L x k_trn_conv<BWD> (prologue: BatchNorm backward of the incoming gradient; implicit GEMM with
 //              the flipped / transposed filters; epilogue: skip-connection add, ReLU mask, the next BatchNorm's two
-//              reductions), L x k_trn_wgrad (split over boards, deterministic two-stage reduction), stem
-//   update   : k_trn_finalize (BN gradients, running statistics, small reductions), k_trn_update (SGD on every
-//              tensor IN PLACE in the trainer's torch tensors + the MFMA-order copies of the filters)
+//              reductions), L x k_trn_wgrad (split over boards and channel-tile pairs, partial copies), stem
+//   update   : k_trn_finalize (BN gradients, running statistics, small reductions), k_trn_update (second stage of
+//              the filter-gradient reduction in a fixed order, then SGD on every tensor IN PLACE in the trainer's
+//              torch tensors)
 // Layouts: activations [B][cells][C] fp32; per BatchNorm layer four f64 sums per channel {x, x^2, g, g xhat}.
 #include "train.h"
 

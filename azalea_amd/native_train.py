@@ -2,8 +2,8 @@
 
 `NativeTrainStep` stands where `policy_trainer.supervised_step(model, batch, train=True, optimizer=...)` stands in the
 reference loop (azalea/policy_trainer.py:84-90, :123-142): one call = zero_grad + train-mode forward + the loss of
-network.py:92-102 + backward + torch.optim.SGD's update, as one captured HIP graph of fp32-MFMA kernels launched on
-torch's current stream.  PyTorch keeps HOLDING everything: the kernels read and write the module's parameter tensors,
+network.py:92-102 + backward + torch.optim.SGD's update, as ~40 fp32-MFMA / elementwise kernels queued on torch's
+current stream (the filter gradients on a second one; `AZX_TRAIN_GRAPH=1` captures the whole step as one HIP graph).  PyTorch keeps HOLDING everything: the kernels read and write the module's parameter tensors,
 its BatchNorm buffers and the optimizer's momentum buffers in place, so checkpoints (policy_trainer.py:161-181), the
 StepLR scheduler and Player's weight refresh see an ordinary module and optimizer.  No autograd, no MIOpen.
 """
@@ -45,6 +45,8 @@ class NativeTrainStep:
             raise ValueError("NativeTrainStep: dampening / nesterov / maximize are not implemented")
         if {id(p) for p in g["params"]} != {id(p) for p in model.parameters()}:
             raise ValueError("NativeTrainStep: the optimizer must hold exactly the module's parameters")
+        if dev.index is None:                      # "cuda" -> the current device, as torch resolves it
+            dev = torch.device("cuda", torch.cuda.current_device())
         self.model, self.optimizer, self.B, self.device = model, optimizer, int(batch_size), dev
         n = model.board_size
         self.cells = n * n

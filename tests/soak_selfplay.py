@@ -2,7 +2,7 @@
 """Soak of the product surface (test infrastructure: it uses the CPU oracle as the checker, so it lives under
 tests/): configs[2] self-play for a while --
 Player.read frames and DeviceReplayBuffer.consume refills interleaved with optimizer steps that change the
-weights -- with every returned game replayed through the CPU oracle's rules (tests' checker; never the
+weights (eager ones on the frames, hand-written ones on the HBM ring) -- with every returned game replayed through the CPU oracle's rules (tests' checker; never the
 thing measured): each row is the position reached by the moves before it, the stone a row adds is a legal
 move, the game is not over before its last row and the last mover has a winning move there.
 
@@ -73,6 +73,8 @@ def run(budget=180.0, G=4096, sims=400, read_size=3000):
     tot_games = tot_rows = reads = refills = steps = 0
     errors = 0.0
     buf = None
+    nstep = None
+    native_steps = 0
     lengths = []
     while time.time() - t0 < budget:
         frame, m = player.read(read_size)
@@ -96,6 +98,17 @@ def run(budget=180.0, G=4096, sims=400, read_size=3000):
         mm = buf.consume(float(read_size) * 2 / 3, player)
         refills += 1
         assert mm["games"] >= 1 and np.isfinite(list(mm.values())).all()
+        # the hand-written training step on the ring (collated on its stream, nothing synchronised): the next read and
+        # the next refill play with what it left in the module
+        if nstep is None:
+            from azalea_amd.native_train import NativeTrainStep
+            nstep = NativeTrainStep(policy.net, opt, 128, "cuda")
+        policy.net.train()
+        for k in range(16):
+            l3, _ = nstep.step_from_ring(buf, np.random.RandomState(1000 + native_steps).randint(0, len(buf), 128))
+            native_steps += 1
+        assert np.isfinite(l3.cpu().numpy()).all()
+        policy.net.eval()
         rows = buf.rows(np.random.RandomState(refills).randint(0, len(buf), 512))
         k = (rows["board"].reshape(512, -1) == 0).sum(1)
         assert np.array_equal(k, (rows["legal_moves"] > 0).sum(1)) and np.abs(rows["moves_prob"].sum(1) - 1).max() < 1e-5
@@ -103,7 +116,8 @@ def run(budget=180.0, G=4096, sims=400, read_size=3000):
     E = player.device_engine()
     c = E.debug_counters()
     out = {"seconds": time.time() - t0, "reads": reads, "games_checked_move_by_move": tot_games, "rows": tot_rows,
-           "device_refills": refills, "ring_rows": len(buf), "optimizer_steps": steps, "game_errors": errors,
+           "device_refills": refills, "ring_rows": len(buf), "optimizer_steps": steps, "native_train_steps": native_steps,
+           "game_errors": errors,
            "mean_game_length": float(np.mean(lengths)), "engine_games_finished": int(c[6]), "engine_plies": int(c[8]),
            "engine_selects": int(c[0])}
     assert out["engine_selects"] == out["engine_plies"] * (sims // 10 + 1) * 10

@@ -229,3 +229,33 @@ def test_native_step_tracks_the_eager_step_over_twelve_steps():
     sd = opts[1].state_dict()
     assert len(sd["state"]) == len(list(nets[1].parameters()))
     step.close()
+
+
+def test_native_and_eager_training_learn_the_same_thing():
+    """A sanity check no parity bound can give: 150 steps on a fixed set of 64 rows (5x5, 2x16) -- the hand-written step
+    and the eager one both drive the loss down, to the same level (their fp32 trajectories are not bitwise twins, the
+    optimisation is the same)."""
+    from azalea_amd.native_train import NativeTrainStep
+    from azalea_amd.policy_trainer import supervised_step
+    n, B = 5, 32
+    data = [_random_batch(n, B, 300 + i) for i in range(2)]
+    finals, firsts = [], []
+    for kind in ("eager", "native"):
+        net = _net(n, 2, 16, seed=4)
+        opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+        step = NativeTrainStep(net, opt, B, DEV) if kind == "native" else None
+        losses = []
+        for i in range(150):
+            batch = data[i % 2]
+            if step is None:
+                _, loss = supervised_step(net, dict(batch), train=True, optimizer=opt, device=DEV)
+            else:
+                loss = float(step.step({k: v.to(DEV) for k, v in batch.items()})[0].item())
+            losses.append(loss)
+        firsts.append(np.mean(losses[:4]))
+        finals.append(np.mean(losses[-10:]))
+        assert np.isfinite(losses).all()
+        if step is not None:
+            step.close()
+    assert finals[0] < 0.6 * firsts[0] and finals[1] < 0.6 * firsts[1], (firsts, finals)      # both learn (memorise) the rows
+    assert abs(finals[0] - finals[1]) <= 0.1 * max(finals), (firsts, finals)
