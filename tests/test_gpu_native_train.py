@@ -259,3 +259,40 @@ def test_native_and_eager_training_learn_the_same_thing():
             step.close()
     assert finals[0] < 0.6 * firsts[0] and finals[1] < 0.6 * firsts[1], (firsts, finals)      # both learn (memorise) the rows
     assert abs(finals[0] - finals[1]) <= 0.1 * max(finals), (firsts, finals)
+
+
+def test_c_abi_error_behaviour_of_the_trainer():
+    """azx_train_* through ctypes: shapes the kernels do not cover are AZX_EINVAL at create, a step before the bind is
+    AZX_ESTATE, a bind that lacks a tensor (or a parameter's momentum buffer) is AZX_EINVAL naming it -- never a
+    silent fallback."""
+    import ctypes as C
+    from azalea_amd import _lib
+    L = _lib.lib()
+
+    def create(n, blocks, chans, batch):
+        h = C.c_void_p()
+        cfg = _lib.TrainConfig(n, blocks, chans, batch, 0)
+        return L.azx_train_create(C.byref(cfg), C.byref(h)), h
+    for bad in ((13, 6, 64, 8), (11, 6, 48, 8), (11, 0, 64, 8), (11, 6, 64, 0), (11, 20, 64, 8)):
+        rc, _ = create(*bad)
+        assert rc == -1, bad                                      # AZX_EINVAL
+    rc, h = create(5, 1, 16, 4)
+    assert rc == 0
+    assert L.azx_train_step(h, 0.1, 0.9, 0.0, None) == -4        # AZX_ESTATE: nothing bound
+    net = _net(5, 1, 16)
+    sd = net.state_dict()
+    names = [k for k in sd if k != "resblocks.0.bn2.running_var"]
+    moms = {k: torch.zeros_like(p) for k, p in net.named_parameters()}
+
+    def bind(names, with_momentum=True):
+        n = len(names)
+        return L.azx_train_bind(h, n, (C.c_char_p * n)(*[k.encode() for k in names]),
+                                (C.c_void_p * n)(*[sd[k].data_ptr() for k in names]),
+                                (C.c_int64 * n)(*[sd[k].numel() for k in names]),
+                                (C.c_void_p * n)(*[(moms[k].data_ptr() if (k in moms and with_momentum) else None) for k in names]))
+    assert bind(names) == -1 and b"resblocks.0.bn2.running_var" in L.azx_last_error()
+    assert bind(list(sd), with_momentum=False) == -1 and b"momentum" in L.azx_last_error()
+    assert bind(list(sd)) == 0
+    assert L.azx_train_step(h, 0.0, 0.9, 0.0, None) == 0
+    torch.cuda.synchronize()
+    L.azx_train_destroy(h)
