@@ -85,6 +85,7 @@ struct TrnDev {
     float *stemT;                  // [27][C] embedding folded through conv1: table[tap * 3 + cell value][cout]
     const float *hp_ring;          // pinned host memory, TRN_HP_SLOTS x 4 floats: the host writes slot (step % slots)
     unsigned int *step_ctr;        // steps run so far (device side of the same count)
+    unsigned short *Wf16[TRN_MAXL + 1];   // (index 1..L) forward filters as hi / lo f16 MFMA fragments (ROLE_FWD16)
     double *zero_base;             // the per-step accumulators (sums | hsums | lossacc | stem_dT | hconv_acc), zero_count doubles
     int zero_count;
 };
@@ -150,7 +151,12 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_fwd(TrnDev P) {
 //   epilogue  g_{l-1} = (acc [+ g_{l+1}: the skip connection]) * (act_{l-1} > 0), and the two reductions BN_{l-1}'s
 //             backward needs: sum g_{l-1}, sum g_{l-1} xhat_{l-1}
 // =================================================================================================================
-enum { ROLE_FWD = 0, ROLE_BWD = 1 };
+// ROLE_FWD16: the forward pass on the split-f16 arithmetic of the self-play tower (every fp32 operand as hi = f16(x),
+// lo = f16(x - hi); hi hi + hi lo + lo hi accumulated in fp32: 22 significant bits, three v_mfma_f32_32x32x16_f16 per
+// 16-channel k-step at 16x the fp32 instruction's rate) -- activations behind a BatchNorm are O(1..100), the range the
+// engine's own evaluations live in.  The backward pass stays fp32: gradients span ten orders of magnitude.
+enum { ROLE_FWD = 0, ROLE_BWD = 1, ROLE_FWD16 = 2 };
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // Diagnostic build only (-DAZX_TRN_STAMP): shader-clock stamps of k_trn_conv's phases (every wave's lane 0), summed per
 // role; azx_trn_destroy prints them.  The shipped kernels execute no stamp.
@@ -162,8 +168,8 @@ __device__ unsigned long long g_trn_stamp[3][TS_WAVES][8];
 #define TS_DECL unsigned long long ts_last = __builtin_amdgcn_s_memtime(), ts_acc[6] = {0, 0, 0, 0, 0, 0}; const unsigned long long ts_rt0 = __builtin_amdgcn_s_memrealtime();
 #define TS_MARK(r) { const unsigned long long ts_now = __builtin_amdgcn_s_memtime(); ts_acc[r] += ts_now - ts_last; ts_last = ts_now; }
 #define TS_END { const int ts_w = ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)); \
-    if ((threadIdx.x & 63) == 0 && ts_w < TS_WAVES) { for (int k_ = 0; k_ < 6; ++k_) g_trn_stamp[ROLE][ts_w][k_] = ts_acc[k_]; \
-        g_trn_stamp[ROLE][ts_w][6] = 1; g_trn_stamp[ROLE][ts_w][7] = __builtin_amdgcn_s_memrealtime() - ts_rt0; } }
+    if ((threadIdx.x & 63) == 0 && ts_w < TS_WAVES) { for (int k_ = 0; k_ < 6; ++k_) g_trn_stamp[TS_SLOT][ts_w][k_] = ts_acc[k_]; \
+        g_trn_stamp[TS_SLOT][ts_w][6] = 1; g_trn_stamp[TS_SLOT][ts_w][7] = __builtin_amdgcn_s_memrealtime() - ts_rt0; } }
 #else
 #define TS_DECL
 #define TS_MARK(r)
@@ -182,6 +188,8 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     float *red = pI + C;                                // [4][32][2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
+    constexpr int TS_SLOT = ROLE == ROLE_BWD ? 1 : 0;
+    (void)TS_SLOT;
     TS_DECL
 
     // ---- the block's two input tensors are requested first: they travel while the coefficients are computed ----
@@ -190,9 +198,10 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     constexpr int ITER = (121 * C4 + 255) / 256;
     const size_t base0 = (size_t)b * cells * C;
     const int total = cells * C4;
-    const bool has_res = ROLE == ROLE_FWD && ((l - 1) & 1) == 0 && l - 1 >= 2;
-    const float4 *src0 = reinterpret_cast<const float4 *>((ROLE == ROLE_FWD ? P.raw[l - 1] : P.g[l]) + base0);
-    const float4 *src1 = ROLE == ROLE_FWD ? (has_res ? reinterpret_cast<const float4 *>(P.act[l - 3] + base0) : nullptr)
+    constexpr bool FORWARD = ROLE != ROLE_BWD;
+    const bool has_res = FORWARD && ((l - 1) & 1) == 0 && l - 1 >= 2;
+    const float4 *src0 = reinterpret_cast<const float4 *>((FORWARD ? P.raw[l - 1] : P.g[l]) + base0);
+    const float4 *src1 = FORWARD ? (has_res ? reinterpret_cast<const float4 *>(P.act[l - 3] + base0) : nullptr)
                                           : reinterpret_cast<const float4 *>(P.raw[l] + base0);
     float4 v0[ITER], v1[ITER];
 #pragma unroll
@@ -205,7 +214,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     // ---- per-channel coefficients -----------------------------------------------------------------------
     if (tid < C) {
         const int c = tid;
-        if (ROLE == ROLE_FWD) {
+        if (FORWARD) {
             float mean, inv;
             bn_coeffs(P, l - 1, c, mean, inv);
             const float a = P.bn_w[l - 1][c] * inv;
@@ -229,7 +238,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     TS_MARK(0)
 
     // ---- stage the input operand ---------------------------------------------------------------------------
-    if (ROLE == ROLE_FWD) {
+    if (FORWARD) {
         float4 *dst = reinterpret_cast<float4 *>(P.act[l - 1] + base0);
 #pragma unroll
         for (int k = 0; k < ITER; ++k) {
@@ -241,7 +250,18 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
             v.y = fmaxf(v.y * cA[c + 1] + cB[c + 1] + v1[k].y, 0.f);
             v.z = fmaxf(v.z * cA[c + 2] + cB[c + 2] + v1[k].z, 0.f);
             v.w = fmaxf(v.w * cA[c + 3] + cB[c + 3] + v1[k].w, 0.f);
-            *reinterpret_cast<float4 *>(X + (size_t)pos * LDW + c) = v;
+            if (ROLE == ROLE_FWD16) {
+                // the LDS row as [C hi halves | C lo halves | 16 B pad] (the same 4 C + 16 bytes as the fp32 row)
+                const float f[4] = {v.x, v.y, v.z, v.w};
+                _Float16 hi[4], lo[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { hi[j] = (_Float16)f[j]; lo[j] = (_Float16)(f[j] - (float)hi[j]); }
+                unsigned char *row = reinterpret_cast<unsigned char *>(X) + (size_t)pos * (LDW * 4);
+                *reinterpret_cast<uint2 *>(row + 2 * c) = *reinterpret_cast<const uint2 *>(hi);
+                *reinterpret_cast<uint2 *>(row + 2 * C + 2 * c) = *reinterpret_cast<const uint2 *>(lo);
+            } else {
+                *reinterpret_cast<float4 *>(X + (size_t)pos * LDW + c) = v;
+            }
             if (NT == 1 || (c >> 5) == nt) dst[i] = v;       // each of a board's blocks writes its channel half
         }
     } else {
@@ -295,6 +315,47 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     f32x16 acc, acc2;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
+    if (ROLE == ROLE_FWD16) {
+        // 9 taps x C / 16 k-steps x 3 MFMAs (hi hi, hi lo, lo hi) of 32 cycles; fragments: A = the positions' 8
+        // consecutive channels 16 q + 8 (lane >> 5) .. (one 16-byte LDS read per plane; 272-byte rows: conflict-free),
+        // B = the filter's, packed by k_trn_prep as [tap][q][ntile][hi, lo][lane][8]; a tap's filter fragments are
+        // requested a tap ahead
+        constexpr int Q16 = C / 16, ROWB = LDW * 4;
+        const uint4 *w16 = reinterpret_cast<const uint4 *>(P.Wf16[l]) + (size_t)nt * 128 + lane;
+        uint4 wc[Q16][2], wn[Q16][2];
+#pragma unroll
+        for (int q = 0; q < Q16; ++q) { wc[q][0] = w16[(size_t)q * NT * 128]; wc[q][1] = w16[(size_t)q * NT * 128 + 64]; }
+        const unsigned char *Xb = reinterpret_cast<const unsigned char *>(X);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 8) {
+                const uint4 *wt = w16 + (size_t)(tap + 1) * Q16 * NT * 128;
+#pragma unroll
+                for (int q = 0; q < Q16; ++q) { wn[q][0] = wt[(size_t)q * NT * 128]; wn[q][1] = wt[(size_t)q * NT * 128 + 64]; }
+            }
+            const int yy = ry + tap / 3 - 1, xx = rx + tap % 3 - 1;
+            const bool ok = rvalid && yy >= 0 && yy < N && xx >= 0 && xx < N;
+            const unsigned char *arow = Xb + (size_t)(ok ? yy * N + xx : cells) * ROWB + 16 * lh;
+            uint4 ah[Q16], al[Q16];
+#pragma unroll
+            for (int q = 0; q < Q16; ++q) {
+                ah[q] = *reinterpret_cast<const uint4 *>(arow + 32 * q);
+                al[q] = *reinterpret_cast<const uint4 *>(arow + 2 * C + 32 * q);
+            }
+#pragma unroll
+            for (int q = 0; q < Q16; ++q) {
+                const f16x8 xh = *reinterpret_cast<const f16x8 *>(&ah[q]), xl = *reinterpret_cast<const f16x8 *>(&al[q]);
+                const f16x8 wh = *reinterpret_cast<const f16x8 *>(&wc[q][0]), wlo = *reinterpret_cast<const f16x8 *>(&wc[q][1]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wlo, acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc, 0, 0, 0);
+            }
+            if (tap < 8) {
+#pragma unroll
+                for (int q = 0; q < Q16; ++q) { wc[q][0] = wn[q][0]; wc[q][1] = wn[q][1]; }
+            }
+        }
+    } else {
     const float4 *wl = reinterpret_cast<const float4 *>(ROLE == ROLE_FWD ? P.Wf[l] : P.Wb[l]) + (size_t)nt * 64 + lane;
     float4 bcur[Q], bnxt[Q];
 #pragma unroll
@@ -324,6 +385,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
             for (int q = 0; q < Q; ++q) bcur[q] = bnxt[q];
         }
     }
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
     TS_MARK(2)
@@ -333,7 +395,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     const bool cvalid = co < C;
     float s1 = 0.f, s2 = 0.f;
     const size_t base = base0;
-    if (ROLE == ROLE_FWD) {
+    if (FORWARD) {
         float *out = P.raw[l] + base;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -407,7 +469,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
         double a = 0, q = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { a += red[(w * 32 + tid) * 2]; q += red[(w * 32 + tid) * 2 + 1]; }
-        const int lay = ROLE == ROLE_FWD ? l : l - 1, k0 = ROLE == ROLE_FWD ? 0 : 2;
+        const int lay = FORWARD ? l : l - 1, k0 = FORWARD ? 0 : 2;
         atomicAdd(&P.sums[((size_t)lay * C + nt * 32 + tid) * 4 + k0], a);
         atomicAdd(&P.sums[((size_t)lay * C + nt * 32 + tid) * 4 + k0 + 1], q);
     }
@@ -438,8 +500,8 @@ __device__ __forceinline__ void trn_wgrad_body(const TrnDev &P, const int l, con
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tm = pair / NT, tn = pair % NT;
     const int li = lane & 31, lh = lane >> 5;
-    constexpr int ROLE = 2;
-    (void)ROLE;
+    constexpr int TS_SLOT = 2;
+    (void)TS_SLOT;
     TS_DECL
     // a board's three tensors (this block's channel halves) as 16-byte pieces, requested a board ahead: the first
     // board's before the LDS is initialised, the next one's before the current one's k-loop
@@ -1166,6 +1228,13 @@ __global__ __launch_bounds__(256) void k_trn_prep(TrnDev P) {
     float *wf = P.Wf[l], *wb = P.Wb[l];
     wf[((((size_t)tap * Q + (ci >> 3)) * NT + (co >> 5)) * 64 + (co & 31) + 32 * ((ci >> 2) & 1)) * 4 + (ci & 3)] = v;
     wb[((((size_t)(8 - tap) * Q + (co >> 3)) * NT + (ci >> 5)) * 64 + (ci & 31) + 32 * ((co >> 2) & 1)) * 4 + (co & 3)] = v;
+    if (P.Wf16[l]) {         // the forward filters again, as hi / lo f16 fragments of v_mfma_f32_32x32x16_f16
+        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+        _Float16 *w16 = reinterpret_cast<_Float16 *>(P.Wf16[l]) +
+                        (((((size_t)tap * (C / 16) + (ci >> 4)) * NT + (co >> 5)) * 2) * 64 + (co & 31) + 32 * ((ci >> 3) & 1)) * 8 + (ci & 7);
+        w16[0] = hi;
+        w16[64 * 8] = lo;
+    }
 }
 
 // =================================================================================================================
@@ -1206,6 +1275,7 @@ struct AzxTrain {
     hipStream_t cap = nullptr, side = nullptr;
     std::vector<hipEvent_t> events;
     bool use_graph = false;
+    bool fwd16 = true;           // AZX_TRAIN_FWD=fp32: the forward convolutions on the fp32 MFMA as well
     bool fork = true;            // AZX_TRAIN_FORK=0: the weight-gradient passes in line with the data chain (profiling)
 };
 
@@ -1233,6 +1303,7 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     AzxTrain *t = new AzxTrain();
     memset(&t->d, 0, sizeof t->d);
     t->device = device;
+    t->fwd16 = !(getenv("AZX_TRAIN_FWD") && !strcmp(getenv("AZX_TRAIN_FWD"), "fp32"));
     TrnDev &d = t->d;
     d.N = N; d.cells = N * N; d.C = chans; d.L = 2 * blocks; d.B = batch;
     d.invN = (float)(1.0 / ((double)batch * d.cells));
@@ -1246,6 +1317,7 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
         if (l >= 1) {
             const size_t wn = (size_t)9 * (C / 8) * ((C + 31) / 32) * 64 * 4;
             ok = ok && (t->Wf[l] = talloc<float>(t, wn)) && (t->Wb[l] = talloc<float>(t, wn));
+            if (t->fwd16) ok = ok && (d.Wf16[l] = talloc<unsigned short>(t, (size_t)9 * (C / 16) * ((C + 31) / 32) * 2 * 64 * 8));
         }
     }
     // sums | hsums | lossacc contiguous: one memset per step
@@ -1473,7 +1545,8 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
     hipLaunchKernelGGL(k_trn_stem_fwd<C>, dim3(B), dim3(SMALL), 0, st, d);
     const size_t conv_lds = ((size_t)std::max((cells + 1) * (C + 4), cells * 36) + 9 * C + 256) * sizeof(float);
     for (int l = 1; l <= L; ++l)
-        hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
+        if (t->fwd16) hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD16>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
+        else hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
     const size_t hc_lds = ((size_t)cells * (C + 1) + 2 * C + 6 * C + 16) * sizeof(float);
     hipLaunchKernelGGL(k_trn_heads_conv<C>, dim3(B), dim3(SMALL), hc_lds, st, d);
     hipLaunchKernelGGL(k_trn_heads_fc, dim3(B), dim3(SMALL), 0, st, d);
@@ -1522,14 +1595,14 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
 
 static int raise_limits(int C) {
     const int cap = 128 * 1024;     // the largest user (k_trn_wgrad<64>) takes 94 KB; some kernels add static LDS on top
-    const void *f64[] = {(const void *)k_trn_conv<64, ROLE_FWD>, (const void *)k_trn_conv<64, ROLE_BWD>, (const void *)k_trn_wgrad<64>,
+    const void *f64[] = {(const void *)k_trn_conv<64, ROLE_FWD>, (const void *)k_trn_conv<64, ROLE_FWD16>, (const void *)k_trn_conv<64, ROLE_BWD>, (const void *)k_trn_wgrad<64>,
                          (const void *)k_trn_heads_conv<64>, (const void *)k_trn_stem_bwd<64>, (const void *)k_trn_heads_bwd<64>};
-    const void *f32[] = {(const void *)k_trn_conv<32, ROLE_FWD>, (const void *)k_trn_conv<32, ROLE_BWD>, (const void *)k_trn_wgrad<32>,
+    const void *f32[] = {(const void *)k_trn_conv<32, ROLE_FWD>, (const void *)k_trn_conv<32, ROLE_FWD16>, (const void *)k_trn_conv<32, ROLE_BWD>, (const void *)k_trn_wgrad<32>,
                          (const void *)k_trn_heads_conv<32>, (const void *)k_trn_stem_bwd<32>, (const void *)k_trn_heads_bwd<32>};
-    const void *f16[] = {(const void *)k_trn_conv<16, ROLE_FWD>, (const void *)k_trn_conv<16, ROLE_BWD>, (const void *)k_trn_wgrad<16>,
+    const void *f16[] = {(const void *)k_trn_conv<16, ROLE_FWD>, (const void *)k_trn_conv<16, ROLE_FWD16>, (const void *)k_trn_conv<16, ROLE_BWD>, (const void *)k_trn_wgrad<16>,
                          (const void *)k_trn_heads_conv<16>, (const void *)k_trn_stem_bwd<16>, (const void *)k_trn_heads_bwd<16>};
     const void **f = C == 64 ? f64 : C == 32 ? f32 : f16;
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 7; ++i)
         if (hipFuncSetAttribute(f[i], hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess)
             return tfail(AZX_EHIP, "train: raising a kernel's dynamic LDS limit failed");
     return AZX_OK;
