@@ -86,6 +86,11 @@ struct TrnDev {
     const float *hp_ring;          // pinned host memory, TRN_HP_SLOTS x 4 floats: the host writes slot (step % slots)
     unsigned int *step_ctr;        // steps run so far (device side of the same count)
     unsigned short *Wf16[TRN_MAXL + 1];   // (index 1..L) forward filters as hi / lo f16 MFMA fragments (ROLE_FWD16)
+    unsigned short *Wb16[TRN_MAXL + 1];   // the same for the backward-data pass (transposed, taps flipped)
+    unsigned int *gmax;                   // [L + 1] bits of max |g_l| (non-negative floats order as their bits)
+    float *wpmax;                         // [L + 1][C C 9 / 256] max |filter| per k_trn_prep block
+    unsigned int *wmax;                   // [L + 1] bits of max |filter of layer l| (k_trn_stem_fwd, from wpmax)
+    unsigned int *bnb;                    // [L + 1] bits of max_c (|gamma| sqrt(n) + |beta|) of BatchNorm l: bounds its output
     double *zero_base;             // the per-step accumulators (sums | hsums | lossacc | stem_dT | hconv_acc), zero_count doubles
     int zero_count;
 };
@@ -100,6 +105,19 @@ __device__ __forceinline__ void bn_coeffs(const TrnDev &P, int l, int c, float &
     inv = (float)(1.0 / sqrt((v > 0 ? v : 0) + TRN_EPS));
 }
 
+// the power of two that brings `bound` to [2^13, 2^14) (1 for a zero or non-finite bound)
+__device__ __forceinline__ float pow2_scale(float bound) {
+    if (!(bound > 0.f) || !(bound < INFINITY)) return 1.f;
+    int e = (int)((__float_as_uint(bound) >> 23) & 0xff) - 127;           // bound = m 2^e, 1 <= m < 2 (denormals: e = -127)
+    e = 13 - e;
+    e = e > 60 ? 60 : e < -60 ? -60 : e;      // (two such scales multiply in an epilogue: 2^+-120 stays a float)
+    return __uint_as_float((unsigned int)(e + 127) << 23);
+}
+// |gamma inv| (max|g| + |mean g| + sqrt(n) |mean g xhat|): what a channel's BatchNorm-backward image cannot exceed
+__device__ __forceinline__ float draw_bound(float a, float k0, float k1, float gmax, float sqrt_n) {
+    return fabsf(a) * (gmax + fabsf(k0) + sqrt_n * fabsf(k1));
+}
+
 // =================================================================================================================
 // stem forward: embedding (3 -> 4) o conv 3x3 (4 -> C) as a [tap][cell value][cout] table built per block
 // =================================================================================================================
@@ -110,6 +128,64 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_fwd(TrnDev P) {
     __shared__ unsigned char cellv[128];
     __shared__ float red[2][NTH];
     const int b = blockIdx.x, tid = threadIdx.x, N = P.N, cells = P.cells;
+    if (P.Wf16[1] != nullptr || P.Wb16[1] != nullptr) {
+        // The tower filters as hi / lo f16 fragments of v_mfma_f32_32x32x16_f16, scaled by the layer's power of two.
+        // Every block first reduces k_trn_prep's per-block maxima (and the BatchNorm bounds) -- block 0 publishes them
+        // for the convolution kernels --, then the grid shares the fragments: an item is one lane's 8 halves of one
+        // k-step (8 gathered filter entries in, 16 bytes of hi and 16 of lo out, coalesced):
+        //   forward pack        [tap][q = ci >> 4][ntile = co >> 5][hi, lo][lane = (co & 31) + 32 ((ci >> 3) & 1)][ci & 7]
+        //   backward-data pack  the same order for the transposed, flipped filter W'[n = ci][k = co][8 - tap]
+        constexpr int NTl = (C + 31) / 32, Q16 = C / 16, NB = (C * C * 9 + 255) / 256, NW = NTH / 64;
+        __shared__ float sW[TRN_MAXL + 1];
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int l = 1 + wave; l <= P.L; l += NW) {
+            float m = 0.f;
+            for (int j = lane; j < NB; j += 64) m = fmaxf(m, P.wpmax[l * NB + j]);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if (lane == 0) {
+                sW[l] = pow2_scale(m);
+                if (b == 0) P.wmax[l] = __float_as_uint(m);
+            }
+        }
+        if (b == 0) {
+            const float sq = sqrtf((float)P.B * cells);
+            for (int l = wave; l <= P.L; l += NW) {
+                float m = lane < C ? fabsf(P.bn_w[l][lane]) * sq + fabsf(P.bn_b[l][lane]) : 0.f;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                if (lane == 0) P.bnb[l] = __float_as_uint(m);
+            }
+        }
+        __syncthreads();
+        const unsigned per = 9u * Q16 * NTl * 64u, items = per * P.L;
+        for (unsigned idx = b * NTH + tid; idx < 2 * items; idx += gridDim.x * NTH) {
+            const bool bwd = idx >= items;
+            const unsigned it = bwd ? idx - items : idx;
+            const int l = (int)(it / per) + 1;
+            unsigned r = it - (unsigned)(l - 1) * per;
+            const int ln = (int)(r & 63u); r >>= 6;
+            const int nt = (int)(r % NTl); r /= NTl;
+            const int q = (int)(r % Q16), tp = (int)(r / Q16);            // tp: the PACK's tap index
+            unsigned short *dst = bwd ? P.Wb16[l] : P.Wf16[l];
+            if (dst == nullptr) continue;
+            const int n = 32 * nt + (ln & 31), k0 = 16 * q + 8 * (ln >> 5), tap = bwd ? 8 - tp : tp;
+            const float sc = sW[l];
+            const float *w = P.convw[l];
+            _Float16 hi[8], lo[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                // forward: n = co, k = ci; backward-data: n = ci, k = co
+                const int co = bwd ? k0 + t : n, ci = bwd ? n : k0 + t;
+                const float v = n < C ? w[((size_t)co * C + ci) * 9 + tap] * sc : 0.f;
+                hi[t] = (_Float16)v;
+                lo[t] = (_Float16)(v - (float)hi[t]);
+            }
+            uint4 *o = reinterpret_cast<uint4 *>(dst) + ((((size_t)tp * Q16 + q) * NTl + nt) * 2) * 64 + ln;
+            o[0] = *reinterpret_cast<const uint4 *>(hi);
+            o[64] = *reinterpret_cast<const uint4 *>(lo);
+        }
+    }
     for (int i = tid; i < 27 * C; i += NTH) T[i] = P.stemT[i];          // built once per step by k_trn_prep
     for (int i = tid; i < cells; i += NTH) cellv[i] = (unsigned char)P.board[(size_t)b * cells + i];
     __syncthreads();
@@ -155,7 +231,13 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_fwd(TrnDev P) {
 // lo = f16(x - hi); hi hi + hi lo + lo hi accumulated in fp32: 22 significant bits, three v_mfma_f32_32x32x16_f16 per
 // 16-channel k-step at 16x the fp32 instruction's rate) -- activations behind a BatchNorm are O(1..100), the range the
 // engine's own evaluations live in.  The backward pass stays fp32: gradients span ten orders of magnitude.
-enum { ROLE_FWD = 0, ROLE_BWD = 1, ROLE_FWD16 = 2 };
+// ROLE_BWD16 / k_trn_wgrad16: the gradients the same way.  Their range is managed per layer: every kernel that writes a
+// g_l keeps max |g_l| (one atomicMax of the float's bits per block), the consumers turn it into a bound of the
+// BatchNorm-backward image they stage -- |draw| <= |gamma inv| (max|g| + |mean g| + sqrt(n) |mean g xhat|), since
+// |xhat| <= sqrt(n) for a batch's own statistics -- and scale by the power of two that puts the bound at 2^13..2^14:
+// exact, nothing can overflow, and what the split resolves (an absolute 2^-25 of the scaled values) is 2^-38 of the
+// bound: far below the fp32 accumulation's own rounding.
+enum { ROLE_FWD = 0, ROLE_BWD = 1, ROLE_FWD16 = 2, ROLE_BWD16 = 3 };
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // Diagnostic build only (-DAZX_TRN_STAMP): shader-clock stamps of k_trn_conv's phases (every wave's lane 0), summed per
@@ -176,19 +258,35 @@ __device__ unsigned long long g_trn_stamp[3][TS_WAVES][8];
 #define TS_END
 #endif
 
+// four channels of a position into the split-f16 LDS image: a row is [C hi halves | C lo halves | 16 B pad] (the same
+// 4 C + 16 bytes as the fp32 row)
+template <int C>
+__device__ __forceinline__ void split_store(float *X, int pos, int c, float4 v) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    _Float16 hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { hi[j] = (_Float16)f[j]; lo[j] = (_Float16)(f[j] - (float)hi[j]); }
+    unsigned char *row = reinterpret_cast<unsigned char *>(X) + (size_t)pos * ((C + 4) * 4);
+    *reinterpret_cast<uint2 *>(row + 2 * c) = *reinterpret_cast<const uint2 *>(hi);
+    *reinterpret_cast<uint2 *>(row + 2 * C + 2 * c) = *reinterpret_cast<const uint2 *>(lo);
+}
+
 template <int C, int ROLE>
 __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, const int nt, const int b, float *lds) {
     constexpr int NT = (C + 31) / 32, LDW = C + 4, Q = C / 8, C4 = C / 4;
     float *X = lds;                                    // [(cells + 1)][LDW]
     const int N = P.N, cells = P.cells;
-    // (the backward epilogue re-uses X as a [cells][36] output tile: the region is the larger of the two)
-    float *cA = X + (size_t)max((cells + 1) * LDW, cells * 36);      // per input channel coefficients
+    // (the backward epilogue re-uses X as a [cells][36] output tile, then as [256][8] running sums: the region is the
+    // largest of the three)
+    float *cA = X + (size_t)max(max((cells + 1) * LDW, cells * 36), 2048);      // per input channel coefficients
     float *cB = cA + C, *cM = cB + C, *cI = cM + C, *cK = cI + C;     // cK: [2][C] (BWD)
     float *pM = cK + 2 * C, *pI = pM + C;               // BWD epilogue: mean / invstd of layer l - 1
     float *red = pI + C;                                // [4][32][2]
+    float *cS = red + 256;                              // BWD16: the operand's scale and its inverse
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    constexpr int TS_SLOT = ROLE == ROLE_BWD ? 1 : 0;
+    constexpr bool FORWARD = ROLE == ROLE_FWD || ROLE == ROLE_FWD16, F16 = ROLE == ROLE_FWD16 || ROLE == ROLE_BWD16;
+    constexpr int TS_SLOT = FORWARD ? 0 : 1;
     (void)TS_SLOT;
     TS_DECL
 
@@ -198,7 +296,6 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     constexpr int ITER = (121 * C4 + 255) / 256;
     const size_t base0 = (size_t)b * cells * C;
     const int total = cells * C4;
-    constexpr bool FORWARD = ROLE != ROLE_BWD;
     const bool has_res = FORWARD && ((l - 1) & 1) == 0 && l - 1 >= 2;
     const float4 *src0 = reinterpret_cast<const float4 *>((FORWARD ? P.raw[l - 1] : P.g[l]) + base0);
     const float4 *src1 = FORWARD ? (has_res ? reinterpret_cast<const float4 *>(P.act[l - 3] + base0) : nullptr)
@@ -233,6 +330,26 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
             pI[c] = inv;
         }
     }
+    if (ROLE == ROLE_BWD16 && wave == 0) {
+        float bd = tid < C ? draw_bound(cA[tid], cK[tid], cK[C + tid], __uint_as_float(P.gmax[l]), sqrtf((float)P.B * cells)) : 0.f;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) bd = fmaxf(bd, __shfl_xor(bd, o));
+        if (tid == 0) {
+            const float sc = pow2_scale(bd);
+            cS[0] = sc;
+            cS[1] = 1.f / (sc * pow2_scale(__uint_as_float(P.wmax[l])));
+        }
+    }
+    if (ROLE == ROLE_FWD16 && tid == 0) {
+        // what the staged activation cannot exceed: its BatchNorm's bound, plus the skip's (a chain of them down to
+        // layer 0) where there is one
+        float bd = __uint_as_float(P.bnb[l - 1]);
+        if (has_res)
+            for (int j = l - 3; j >= 0; j -= 2) bd += __uint_as_float(P.bnb[j]);
+        const float sc = pow2_scale(bd);
+        cS[0] = sc;
+        cS[1] = 1.f / (sc * pow2_scale(__uint_as_float(P.wmax[l])));
+    }
     for (int i = tid; i < LDW; i += 256) X[(size_t)cells * LDW + i] = 0.f;
     __syncthreads();
     TS_MARK(0)
@@ -250,15 +367,9 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
             v.y = fmaxf(v.y * cA[c + 1] + cB[c + 1] + v1[k].y, 0.f);
             v.z = fmaxf(v.z * cA[c + 2] + cB[c + 2] + v1[k].z, 0.f);
             v.w = fmaxf(v.w * cA[c + 3] + cB[c + 3] + v1[k].w, 0.f);
-            if (ROLE == ROLE_FWD16) {
-                // the LDS row as [C hi halves | C lo halves | 16 B pad] (the same 4 C + 16 bytes as the fp32 row)
-                const float f[4] = {v.x, v.y, v.z, v.w};
-                _Float16 hi[4], lo[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { hi[j] = (_Float16)f[j]; lo[j] = (_Float16)(f[j] - (float)hi[j]); }
-                unsigned char *row = reinterpret_cast<unsigned char *>(X) + (size_t)pos * (LDW * 4);
-                *reinterpret_cast<uint2 *>(row + 2 * c) = *reinterpret_cast<const uint2 *>(hi);
-                *reinterpret_cast<uint2 *>(row + 2 * C + 2 * c) = *reinterpret_cast<const uint2 *>(lo);
+            if (F16) {
+                const float sc = cS[0];
+                split_store<C>(X, pos, c, make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc));
             } else {
                 *reinterpret_cast<float4 *>(X + (size_t)pos * LDW + c) = v;
             }
@@ -276,7 +387,12 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
             v.y = cA[c + 1] * (gv.y - cK[c + 1] - (rv.y - cM[c + 1]) * cI[c + 1] * cK[C + c + 1]);
             v.z = cA[c + 2] * (gv.z - cK[c + 2] - (rv.z - cM[c + 2]) * cI[c + 2] * cK[C + c + 2]);
             v.w = cA[c + 3] * (gv.w - cK[c + 3] - (rv.w - cM[c + 3]) * cI[c + 3] * cK[C + c + 3]);
-            *reinterpret_cast<float4 *>(X + (size_t)pos * LDW + c) = v;
+            if (F16) {
+                const float sc = cS[0];
+                split_store<C>(X, pos, c, make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc));
+            } else {
+                *reinterpret_cast<float4 *>(X + (size_t)pos * LDW + c) = v;
+            }
         }
     }
     __syncthreads();
@@ -315,13 +431,13 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     f32x16 acc, acc2;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
-    if (ROLE == ROLE_FWD16) {
+    if (F16) {
         // 9 taps x C / 16 k-steps x 3 MFMAs (hi hi, hi lo, lo hi) of 32 cycles; fragments: A = the positions' 8
         // consecutive channels 16 q + 8 (lane >> 5) .. (one 16-byte LDS read per plane; 272-byte rows: conflict-free),
         // B = the filter's, packed by k_trn_prep as [tap][q][ntile][hi, lo][lane][8]; a tap's filter fragments are
         // requested a tap ahead
         constexpr int Q16 = C / 16, ROWB = LDW * 4;
-        const uint4 *w16 = reinterpret_cast<const uint4 *>(P.Wf16[l]) + (size_t)nt * 128 + lane;
+        const uint4 *w16 = reinterpret_cast<const uint4 *>(FORWARD ? P.Wf16[l] : P.Wb16[l]) + (size_t)nt * 128 + lane;
         uint4 wc[Q16][2], wn[Q16][2];
 #pragma unroll
         for (int q = 0; q < Q16; ++q) { wc[q][0] = w16[(size_t)q * NT * 128]; wc[q][1] = w16[(size_t)q * NT * 128 + 64]; }
@@ -401,7 +517,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
         for (int i = 0; i < 16; ++i) {
             const int row = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
             if (row < cells && cvalid) {
-                const float v = acc[i];
+                const float v = F16 ? acc[i] * cS[1] : acc[i];
                 out[(size_t)row * C + co] = v;
                 s1 += v;
                 s2 += v * v;
@@ -413,15 +529,16 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
         epi_loads();
         __syncthreads();                                 // every wave has finished reading X
         float *Y = X;                                    // [cells][LDO]: this block's 32 output channels
+        const float unscale = F16 ? cS[1] : 1.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-            if (row < cells) Y[(size_t)row * LDO + li] = acc[i];
+            if (row < cells) Y[(size_t)row * LDO + li] = F16 ? acc[i] * unscale : acc[i];
         }
         __syncthreads();
         float *out = P.g[l - 1] + base + nt * 32;
         // a thread's items all have the same four channels (256 is a multiple of O4): four pairs of running sums
-        float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+        float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f}, vmax = 0.f;
         const int c0 = (tid % O4) * 4;
 #pragma unroll
         for (int k = 0; k < ITERO; ++k) {
@@ -435,6 +552,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
             v.z = ea[k].z > 0.f ? y.z + es[k].z : 0.f;
             v.w = ea[k].w > 0.f ? y.w + es[k].w : 0.f;
             *reinterpret_cast<float4 *>(out + (size_t)pos * C + c0) = v;
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             a4[0] += v.x; a4[1] += v.y; a4[2] += v.z; a4[3] += v.w;
             q4[0] += v.x * (er[k].x - pM[nt * 32 + c0]) * pI[nt * 32 + c0];
             q4[1] += v.y * (er[k].y - pM[nt * 32 + c0 + 1]) * pI[nt * 32 + c0 + 1];
@@ -446,7 +564,12 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
         float *rs = Y;                                   // [256][8]
 #pragma unroll
         for (int j = 0; j < 4; ++j) { rs[tid * 8 + j] = a4[j]; rs[tid * 8 + 4 + j] = q4[j]; }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0) red[wave] = vmax;
         __syncthreads();
+        if (tid == 64)           // (a NaN's bits are above every finite float's: the consumers then take scale 1)
+            atomicMax(&P.gmax[l - 1], __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
         if (tid < CHo) {
             const int grp4 = tid / 4, j = tid % 4;
             double a = 0, q = 0;
@@ -613,6 +736,169 @@ __device__ __forceinline__ void trn_wgrad_body(const TrnDev &P, const int l, con
     TS_END
 }
 
+
+// =================================================================================================================
+// the same filter gradient on the split-f16 arithmetic.  The reduction index is the position, so both operands are
+// wanted K-major while they arrive (and are staged) position-major: `ds_read_b64_tr_b16` reads a 4-row x 16-column
+// block of 16-bit elements and hands every lane its COLUMN -- two of them are a lane's 8 consecutive k of
+// v_mfma_f32_32x32x16_f16.  k enumerates a board 16 cells wide (k = 16 y + x; the cells x >= N are zero rows of
+// draw), so a k-step is a board row, the input image -- the same 16-wide board with a zero border, cell (y, x) in row
+// 16 (y + 1) + x + 1 -- is read at row k + 17 + 16 dy + dx for tap (dy, dx): a constant offset, 8-byte aligned
+// whatever the tap, and with 64-byte rows (32 channels) the 4 rows a 32-lane half reads are one contiguous 256 bytes:
+// conflict-free.  draw is scaled by the layer's power of two (see ROLE_BWD16), the partial sums are scaled back.
+// =================================================================================================================
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f16x8 tr_frag(const unsigned char *p) {
+    typedef s16x4 __attribute__((address_space(3))) *lds_ptr;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 256));       // four rows on
+    s16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return *reinterpret_cast<const f16x8 *>(&r);
+}
+
+template <int C>
+__device__ __forceinline__ void trn_wgrad16_body(const TrnDev &P, const int l, const int G, const int pair, const int grp, float *lds) {
+    constexpr int NT = (C + 31) / 32, CH = C < 32 ? C : 32, H4 = CH / 4, ITER = (121 * H4 + 255) / 256;
+    const int N = P.N, cells = P.cells, KR = N * 16, BR = (N + 3) * 16;
+    unsigned char *Dh = reinterpret_cast<unsigned char *>(lds), *Dl = Dh + (size_t)KR * 64;     // [KR][32] f16 draw hi / lo
+    unsigned char *Bh = Dl + (size_t)KR * 64, *Bl = Bh + (size_t)BR * 64;                       // [BR][32] f16 input hi / lo
+    float *red = reinterpret_cast<float *>(Bl + (size_t)BR * 64);     // [3 taps][4 waves][1024] reduction rounds
+    float *cA = red + 12 * 1024, *cM = cA + 32, *cI = cM + 32, *cK = cI + 32, *cS = cK + 64;    // cK [2][32], cS [2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tm = pair / NT, tn = pair % NT;
+    constexpr int TS_SLOT = 2;
+    (void)TS_SLOT;
+    TS_DECL
+    const int total = cells * H4;
+    float4 vg[ITER], vr[ITER], va[ITER];
+    auto request = [&](int b) {
+        const size_t base = (size_t)b * cells * C;
+        const float *gs = P.g[l] + base + tm * 32, *rs = P.raw[l] + base + tm * 32, *as = P.act[l - 1] + base + tn * 32;
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) {
+            const int i = tid + 256 * k, pos = i / H4, c = (i - pos * H4) * 4;
+            const bool on = i < total;
+            vg[k] = on ? *reinterpret_cast<const float4 *>(gs + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vr[k] = on ? *reinterpret_cast<const float4 *>(rs + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            va[k] = on ? *reinterpret_cast<const float4 *>(as + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (grp < P.B) request(grp);
+    if (wave == 0) {
+        float bd = 0.f;
+        if (tid < CH) {
+            const int c = tm * 32 + tid;
+            float mean, inv;
+            bn_coeffs(P, l, c, mean, inv);
+            cM[tid] = mean;
+            cI[tid] = inv;
+            const float a = P.bn_w[l][c] * inv;
+            const float k0 = (float)(dsum(P.sums, l, C, c, 2) * (double)P.invN), k1 = (float)(dsum(P.sums, l, C, c, 3) * (double)P.invN);
+            cA[tid] = a;
+            cK[tid] = k0;
+            cK[32 + tid] = k1;
+            bd = draw_bound(a, k0, k1, __uint_as_float(P.gmax[l]), sqrtf((float)P.B * cells));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) bd = fmaxf(bd, __shfl_xor(bd, o));
+        if (tid == 0) {
+            const float sc = pow2_scale(bd);
+            cS[0] = sc;
+            cS[1] = 1.f / sc;
+        }
+    }
+    {   // the operand images start zero: the rows x >= N of draw and the border of the input stay that way
+        float4 *z = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < (KR + BR) * 128 / 16; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    __syncthreads();
+    TS_MARK(0)
+    const float sc = cS[0];
+    // this lane's corner of the transposed reads: row 8 (lane >> 5) + ((lane & 15) >> 2) of the k-step, channels
+    // 16 ((lane >> 4) & 1) + 4 (lane & 3) ..
+    const int frag_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    for (int b = grp; b < P.B; b += G) {
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) {
+            const int i = tid + 256 * k;
+            if (i >= total) break;
+            const int pos = i / H4, c = (i - pos * H4) * 4;
+            const int y = pos / N, krow = y * 16 + (pos - y * N);
+            const float4 gv = vg[k], rv = vr[k];
+            float f[4], a4[4] = {va[k].x, va[k].y, va[k].z, va[k].w};
+            f[0] = sc * (cA[c] * (gv.x - cK[c] - (rv.x - cM[c]) * cI[c] * cK[32 + c]));
+            f[1] = sc * (cA[c + 1] * (gv.y - cK[c + 1] - (rv.y - cM[c + 1]) * cI[c + 1] * cK[32 + c + 1]));
+            f[2] = sc * (cA[c + 2] * (gv.z - cK[c + 2] - (rv.z - cM[c + 2]) * cI[c + 2] * cK[32 + c + 2]));
+            f[3] = sc * (cA[c + 3] * (gv.w - cK[c + 3] - (rv.w - cM[c + 3]) * cI[c + 3] * cK[32 + c + 3]));
+            _Float16 dh[4], dl[4], ah[4], al[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dh[j] = (_Float16)f[j]; dl[j] = (_Float16)(f[j] - (float)dh[j]);
+                ah[j] = (_Float16)a4[j]; al[j] = (_Float16)(a4[j] - (float)ah[j]);
+            }
+            *reinterpret_cast<uint2 *>(Dh + (size_t)krow * 64 + 2 * c) = *reinterpret_cast<const uint2 *>(dh);
+            *reinterpret_cast<uint2 *>(Dl + (size_t)krow * 64 + 2 * c) = *reinterpret_cast<const uint2 *>(dl);
+            *reinterpret_cast<uint2 *>(Bh + (size_t)(krow + 17) * 64 + 2 * c) = *reinterpret_cast<const uint2 *>(ah);
+            *reinterpret_cast<uint2 *>(Bl + (size_t)(krow + 17) * 64 + 2 * c) = *reinterpret_cast<const uint2 *>(al);
+        }
+        __syncthreads();
+        if (b + G < P.B) request(b + G);                 // travels under this board's k-loop
+        TS_MARK(1)
+        // this wave's board rows s = wave, wave + 4, ... (uniform per wave: the transposed reads need every lane)
+        for (int s = wave; s < N; s += 4) {
+            const size_t ko = (size_t)s * 16 * 64 + frag_off;
+            const f16x8 dhi = tr_frag(Dh + ko), dlo = tr_frag(Dl + ko);
+            f16x8 bhi[9], blo[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int o = (17 + (t / 3 - 1) * 16 + (t % 3 - 1)) * 64;
+                bhi[t] = tr_frag(Bh + ko + o);
+                blo[t] = tr_frag(Bl + ko + o);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, bhi[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, blo[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, bhi[t], acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+        TS_MARK(2)
+    }
+    // the four waves' shares -> one, as in trn_wgrad_body; the scale leaves here
+    const float unscale = cS[1];
+    float *part = P.wpart + ((size_t)(l - 1) * G + grp) * ((size_t)C * C * 9);
+#pragma unroll
+    for (int t0 = 0; t0 < 9; t0 += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4 *>(red + ((size_t)((u * 4 + wave) * 4 + q) * 64 + lane) * 4) =
+                    make_float4(acc[t0 + u][4 * q], acc[t0 + u][4 * q + 1], acc[t0 + u][4 * q + 2], acc[t0 + u][4 * q + 3]);
+        __syncthreads();
+        for (int e = tid; e < 3 * 1024; e += 256) {
+            const int u = e >> 10, col = (e >> 5) & 31, cil = e & 31;          // output (co = col, ci = cil) of tile u
+            const int q = col >> 3, lh_ = (col >> 2) & 1, r = col & 3;
+            const size_t o = ((size_t)q * 64 + cil + 32 * lh_) * 4 + r;
+            const float *w0 = red + (size_t)(u * 4) * 1024;
+            const int co = tm * 32 + col, ci = tn * 32 + cil;
+            if (co < C && ci < C)
+                part[((size_t)(t0 + u) * C + co) * C + ci] = ((w0[o] + w0[1024 + o]) + (w0[2048 + o] + w0[3072 + o])) * unscale;
+        }
+        __syncthreads();
+    }
+    TS_MARK(3)
+    TS_END
+}
+
 template <int C, int ROLE>
 __global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
     extern __shared__ __align__(16) float lds[];
@@ -623,6 +909,12 @@ template <int C>
 __global__ __launch_bounds__(256) void k_trn_wgrad(TrnDev P, int l, int G) {
     extern __shared__ __align__(16) float lds[];
     trn_wgrad_body<C>(P, l, G, blockIdx.x, blockIdx.y, lds);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_trn_wgrad16(TrnDev P, int l, int G) {
+    extern __shared__ __align__(16) float lds[];
+    trn_wgrad16_body<C>(P, l, G, blockIdx.x, blockIdx.y, lds);
 }
 
 // (Measured and dropped: one launch per backward layer with both consumers of g_l -- k_trn_conv<BWD>'s workgroups and
@@ -954,7 +1246,8 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_bwd(TrnDev P) {
     }
     __syncthreads();
     float4 *gL = reinterpret_cast<float4 *>(P.g[L] + base);
-    float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+    float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f}, vmax = 0.f;
+    __shared__ float wmax[NTH / 64];
     const int c0 = (tid % C4) * 4;              // NTH is a multiple of C4: a thread's items share their four channels
 #pragma unroll
     for (int k = 0; k < ITER; ++k) {
@@ -973,6 +1266,7 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_bwd(TrnDev P) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             gv[j] = a[j] > 0.f ? d[j] : 0.f;
+            vmax = fmaxf(vmax, fabsf(gv[j]));
             a4[j] += gv[j];
             q4[j] += gv[j] * (r[j] - pM[c0 + j]) * pI[c0 + j];
             X[(size_t)pos * LDX + c0 + j] = a[j];
@@ -981,7 +1275,15 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_bwd(TrnDev P) {
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { rs[tid * 8 + j] = a4[j]; rs[tid * 8 + 4 + j] = q4[j]; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if ((tid & 63) == 0) wmax[tid >> 6] = vmax;
     __syncthreads();
+    if (tid == NTH - 1) {       // max |g_L|: the range the split-f16 consumers scale by
+        float m = 0.f;
+        for (int w = 0; w < NTH / 64; ++w) m = fmaxf(m, wmax[w]);
+        atomicMax(&P.gmax[L], __float_as_uint(m));
+    }
     if (tid < C) {
         const int grp4 = tid / 4, j = tid % 4;
         double a = 0, q = 0;
@@ -1211,6 +1513,7 @@ __global__ __launch_bounds__(256) void k_trn_prep(TrnDev P) {
             for (int j = 0; j < 4; ++j) sum += P.emb[v * 4 + j] * P.w1[(co * 4 + j) * 9 + tap];
             P.stemT[e] = sum;
         }
+        if (e <= (size_t)P.L) P.gmax[e] = 0u;
         if (e == 0) {
             const unsigned int step = *P.step_ctr;
             const float *slot = P.hp_ring + (size_t)(step % TRN_HP_SLOTS) * 4;
@@ -1221,20 +1524,23 @@ __global__ __launch_bounds__(256) void k_trn_prep(TrnDev P) {
         }
         return;
     }
-    if (e >= (size_t)C * C * 9) return;
     const int l = blockIdx.y + 1;
+    const bool on = e < (size_t)C * C * 9;
+    const float v = on ? P.convw[l][e] : 0.f;
+    {   // max |filter|: the scale of the split-f16 packs (k_trn_stem_fwd writes them)
+        __shared__ float wm[4];
+        float m = fabsf(v);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) P.wpmax[(size_t)l * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    }
+    if (!on) return;
     const int tap = (int)(e % 9), ci = (int)(e / 9 % C), co = (int)(e / 9 / C);
-    const float v = P.convw[l][e];
     float *wf = P.Wf[l], *wb = P.Wb[l];
     wf[((((size_t)tap * Q + (ci >> 3)) * NT + (co >> 5)) * 64 + (co & 31) + 32 * ((ci >> 2) & 1)) * 4 + (ci & 3)] = v;
     wb[((((size_t)(8 - tap) * Q + (co >> 3)) * NT + (ci >> 5)) * 64 + (ci & 31) + 32 * ((co >> 2) & 1)) * 4 + (co & 3)] = v;
-    if (P.Wf16[l]) {         // the forward filters again, as hi / lo f16 fragments of v_mfma_f32_32x32x16_f16
-        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
-        _Float16 *w16 = reinterpret_cast<_Float16 *>(P.Wf16[l]) +
-                        (((((size_t)tap * (C / 16) + (ci >> 4)) * NT + (co >> 5)) * 2) * 64 + (co & 31) + 32 * ((ci >> 3) & 1)) * 8 + (ci & 7);
-        w16[0] = hi;
-        w16[64 * 8] = lo;
-    }
 }
 
 // =================================================================================================================
@@ -1276,6 +1582,8 @@ struct AzxTrain {
     std::vector<hipEvent_t> events;
     bool use_graph = false;
     bool fwd16 = true;           // AZX_TRAIN_FWD=fp32: the forward convolutions on the fp32 MFMA as well
+    bool bwd16 = true;           // AZX_TRAIN_BWD=fp32: the backward-data convolutions ...
+    bool wgrad16 = true;         // AZX_TRAIN_WGRAD=fp32: ... and the filter gradients
     bool fork = true;            // AZX_TRAIN_FORK=0: the weight-gradient passes in line with the data chain (profiling)
 };
 
@@ -1304,6 +1612,8 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     memset(&t->d, 0, sizeof t->d);
     t->device = device;
     t->fwd16 = !(getenv("AZX_TRAIN_FWD") && !strcmp(getenv("AZX_TRAIN_FWD"), "fp32"));
+    t->bwd16 = !(getenv("AZX_TRAIN_BWD") && !strcmp(getenv("AZX_TRAIN_BWD"), "fp32"));
+    t->wgrad16 = !(getenv("AZX_TRAIN_WGRAD") && !strcmp(getenv("AZX_TRAIN_WGRAD"), "fp32"));
     TrnDev &d = t->d;
     d.N = N; d.cells = N * N; d.C = chans; d.L = 2 * blocks; d.B = batch;
     d.invN = (float)(1.0 / ((double)batch * d.cells));
@@ -1318,6 +1628,7 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
             const size_t wn = (size_t)9 * (C / 8) * ((C + 31) / 32) * 64 * 4;
             ok = ok && (t->Wf[l] = talloc<float>(t, wn)) && (t->Wb[l] = talloc<float>(t, wn));
             if (t->fwd16) ok = ok && (d.Wf16[l] = talloc<unsigned short>(t, (size_t)9 * (C / 16) * ((C + 31) / 32) * 2 * 64 * 8));
+            if (t->bwd16) ok = ok && (d.Wb16[l] = talloc<unsigned short>(t, (size_t)9 * (C / 16) * ((C + 31) / 32) * 2 * 64 * 8));
         }
     }
     // sums | hsums | lossacc contiguous: one memset per step
@@ -1339,7 +1650,8 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
          (d.wpart = talloc<float>(t, (size_t)L * t->G * C * C * 9)) &&
          (t->in_board = talloc<int32_t>(t, (size_t)B * cells)) && (t->in_legal = talloc<int32_t>(t, (size_t)B * cells)) &&
          (t->in_prob = talloc<float>(t, (size_t)B * cells)) && (t->in_reward = talloc<float>(t, B)) &&
-         (t->hp_dev = talloc<float>(t, 4)) && (d.stemT = talloc<float>(t, (size_t)27 * C)) && (d.step_ctr = talloc<unsigned int>(t, 4));
+         (t->hp_dev = talloc<float>(t, 4)) && (d.stemT = talloc<float>(t, (size_t)27 * C)) && (d.step_ctr = talloc<unsigned int>(t, 4)) &&
+         (d.gmax = talloc<unsigned int>(t, 3 * (TRN_MAXL + 2)));
     if (ok) ok = hipHostMalloc((void **)&t->hp_ring, (size_t)TRN_HP_SLOTS * 4 * sizeof(float)) == hipSuccess &&
                  hipEventCreateWithFlags(&t->ring_ev[0], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&t->ring_ev[1], hipEventDisableTiming) == hipSuccess;
@@ -1347,6 +1659,13 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
         azx_trn_destroy(t);
         return tfail(AZX_ENOMEM, "train: hipMalloc failed");
     }
+    d.wpmax = talloc<float>(t, (size_t)(TRN_MAXL + 2) * ((C * C * 9 + 255) / 256));
+    if (!d.wpmax) {
+        azx_trn_destroy(t);
+        return tfail(AZX_ENOMEM, "train: hipMalloc failed");
+    }
+    d.wmax = d.gmax + (TRN_MAXL + 2);
+    d.bnb = d.wmax + (TRN_MAXL + 2);
     d.board = t->in_board; d.legal = t->in_legal; d.prob = t->in_prob; d.reward = t->in_reward; d.hp = t->hp_dev; d.hp_ring = t->hp_ring;
     for (int l = 0; l <= L; ++l) {
         d.raw[l] = t->raw[l]; d.act[l] = t->act[l]; d.g[l] = t->g[l]; d.Wf[l] = t->Wf[l]; d.Wb[l] = t->Wb[l];
@@ -1543,7 +1862,7 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
     constexpr int SMALL = TRN_SMALL_THREADS;
     hipLaunchKernelGGL(k_trn_prep<C>, dim3((C * C * 9 + 255) / 256, L + 1), dim3(256), 0, st, d);
     hipLaunchKernelGGL(k_trn_stem_fwd<C>, dim3(B), dim3(SMALL), 0, st, d);
-    const size_t conv_lds = ((size_t)std::max((cells + 1) * (C + 4), cells * 36) + 9 * C + 256) * sizeof(float);
+    const size_t conv_lds = ((size_t)std::max(std::max((cells + 1) * (C + 4), cells * 36), 2048) + 9 * C + 256) * sizeof(float);
     for (int l = 1; l <= L; ++l)
         if (t->fwd16) hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD16>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
         else hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
@@ -1573,11 +1892,14 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
     const int KP = (cells + 1) & ~1;
     const size_t wg_lds = ((size_t)KP * 32 + (size_t)(d.N + 2) * (d.N + 2) * 32 + 12 * 1024 + 5 * 32 + KP) * sizeof(float);
 
+    const size_t wg16_lds = (size_t)(d.N * 16 + (d.N + 3) * 16) * 128 + (12 * 1024 + 5 * 32 + 2) * sizeof(float);
     for (int l = L; l >= 1; --l) {
         // g_l and BN_l's sums are complete here: the weight gradient of layer l runs beside the data chain
         if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
-        hipLaunchKernelGGL(k_trn_wgrad<C>, dim3(NT * NT, G), dim3(256), wg_lds, ws, d, l, G);
-        hipLaunchKernelGGL((k_trn_conv<C, ROLE_BWD>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
+        if (t->wgrad16) hipLaunchKernelGGL(k_trn_wgrad16<C>, dim3(NT * NT, G), dim3(256), wg16_lds, ws, d, l, G);
+        else hipLaunchKernelGGL(k_trn_wgrad<C>, dim3(NT * NT, G), dim3(256), wg_lds, ws, d, l, G);
+        if (t->bwd16) hipLaunchKernelGGL((k_trn_conv<C, ROLE_BWD16>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
+        else hipLaunchKernelGGL((k_trn_conv<C, ROLE_BWD>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
     }
     const size_t sb_lds = ((size_t)cells * C + 5 * C) * sizeof(float);
     hipLaunchKernelGGL(k_trn_stem_bwd<C>, dim3(B), dim3(SMALL), sb_lds, st, d);
@@ -1595,14 +1917,14 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
 
 static int raise_limits(int C) {
     const int cap = 128 * 1024;     // the largest user (k_trn_wgrad<64>) takes 94 KB; some kernels add static LDS on top
-    const void *f64[] = {(const void *)k_trn_conv<64, ROLE_FWD>, (const void *)k_trn_conv<64, ROLE_FWD16>, (const void *)k_trn_conv<64, ROLE_BWD>, (const void *)k_trn_wgrad<64>,
+    const void *f64[] = {(const void *)k_trn_conv<64, ROLE_FWD>, (const void *)k_trn_conv<64, ROLE_FWD16>, (const void *)k_trn_conv<64, ROLE_BWD>, (const void *)k_trn_conv<64, ROLE_BWD16>, (const void *)k_trn_wgrad<64>, (const void *)k_trn_wgrad16<64>,
                          (const void *)k_trn_heads_conv<64>, (const void *)k_trn_stem_bwd<64>, (const void *)k_trn_heads_bwd<64>};
-    const void *f32[] = {(const void *)k_trn_conv<32, ROLE_FWD>, (const void *)k_trn_conv<32, ROLE_FWD16>, (const void *)k_trn_conv<32, ROLE_BWD>, (const void *)k_trn_wgrad<32>,
+    const void *f32[] = {(const void *)k_trn_conv<32, ROLE_FWD>, (const void *)k_trn_conv<32, ROLE_FWD16>, (const void *)k_trn_conv<32, ROLE_BWD>, (const void *)k_trn_conv<32, ROLE_BWD16>, (const void *)k_trn_wgrad<32>, (const void *)k_trn_wgrad16<32>,
                          (const void *)k_trn_heads_conv<32>, (const void *)k_trn_stem_bwd<32>, (const void *)k_trn_heads_bwd<32>};
-    const void *f16[] = {(const void *)k_trn_conv<16, ROLE_FWD>, (const void *)k_trn_conv<16, ROLE_FWD16>, (const void *)k_trn_conv<16, ROLE_BWD>, (const void *)k_trn_wgrad<16>,
+    const void *f16[] = {(const void *)k_trn_conv<16, ROLE_FWD>, (const void *)k_trn_conv<16, ROLE_FWD16>, (const void *)k_trn_conv<16, ROLE_BWD>, (const void *)k_trn_conv<16, ROLE_BWD16>, (const void *)k_trn_wgrad<16>, (const void *)k_trn_wgrad16<16>,
                          (const void *)k_trn_heads_conv<16>, (const void *)k_trn_stem_bwd<16>, (const void *)k_trn_heads_bwd<16>};
     const void **f = C == 64 ? f64 : C == 32 ? f32 : f16;
-    for (int i = 0; i < 7; ++i)
+    for (int i = 0; i < 9; ++i)
         if (hipFuncSetAttribute(f[i], hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess)
             return tfail(AZX_EHIP, "train: raising a kernel's dynamic LDS limit failed");
     return AZX_OK;

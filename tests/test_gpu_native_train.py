@@ -138,6 +138,59 @@ def test_every_intermediate_matches_autograd(n, blocks, chans, B):
     step.close()
 
 
+@pytest.mark.parametrize("kind", ["tiny", "huge"])
+@pytest.mark.parametrize("n,blocks,chans,B", [(5, 2, 16, 6), (11, 3, 64, 16)])
+def test_gradient_range_is_managed(kind, n, blocks, chans, B):
+    """The backward pass runs on split-f16 operands scaled per layer by a power of two taken from max |g_l|
+    (train_kernels.hip, ROLE_BWD16 / k_trn_wgrad16).  Two networks whose gradients sit far outside the f16 range:
+    'tiny' -- every tower filter x 1e-6 (nothing an unscaled f16 pair resolves), so each BatchNorm works in its eps
+    regime and the gradients inside the blocks are ~1e-7; 'huge' -- rewards of +-1e6, the value head's gradients ~1e6
+    times the usual (the loss is linear in them: no forward rounding is amplified).  Parameter gradients against
+    float64 autograd, no further from it than a small multiple of torch's own fp32 distance."""
+    from azalea_amd.native_train import NativeTrainStep
+
+    def make(dtype):
+        net = _net(n, blocks, chans, seed=7)
+        with torch.no_grad():
+            if kind == "tiny":
+                for blk in net.resblocks:
+                    blk.conv1.weight.mul_(1e-6)
+                    blk.conv2.weight.mul_(1e-6)
+            else:
+                pass                   # (the rewards below)
+        return net.to(dtype).train()
+    batch = {k: v.to(DEV) for k, v in _random_batch(n, B, 11).items()}
+    if kind == "huge":
+        batch["reward"] = batch["reward"] * 1e6
+    grads = {}
+    for dtype in (torch.float32, torch.float64):
+        net = make(dtype)
+        o = net.forward(batch["board"], batch["legal_moves"])
+        loss = F.mse_loss(o["value"], batch["reward"].to(dtype)) - (batch["moves_prob"].to(dtype) * o["moves_logprob"]).sum() / B
+        loss.backward()
+        grads[dtype] = {name: p.grad.double().cpu().numpy().ravel() for name, p in net.named_parameters()}
+    net = make(torch.float32)
+    step = NativeTrainStep(net, torch.optim.SGD(net.parameters(), lr=0.0, momentum=0.9), B, DEV)
+    step.step(batch)
+    torch.cuda.synchronize()
+    sizes = []
+    for name, truth in grads[torch.float64].items():
+        got = step.debug("grad:" + name).astype(np.float64)
+        assert np.isfinite(got).all(), name
+        nt = float(np.linalg.norm(truth))
+        e_torch = float(np.linalg.norm(grads[torch.float32][name] - truth))
+        e_native = float(np.linalg.norm(got - truth))
+        assert e_native <= max(5.0 * e_torch, 1e-5 * nt), (name, e_native, e_torch, nt)
+        sizes.append(nt)
+    g_last = float(np.abs(step.debug("g%d" % (2 * blocks))).max())
+    g_inner = float(np.abs(step.debug("g1")).max())
+    if kind == "tiny":
+        assert 0 < g_inner < 6e-5, g_inner          # below the f16 normal range: an unscaled split keeps no low part
+    else:
+        assert g_last > 1e3, g_last                 # and beyond it once 576 taps x channels are summed
+    step.close()
+
+
 def test_native_step_matches_the_reference_recorded_steps():
     """Golden G9: three supervised_step calls of the reference (SGD 0.1 / 0.9 / 1e-4, train-mode BatchNorm) from the
     recorded initial weights -- the bounds the eager GPU step is held to (test_train_step.py: 2e-4 on the updated
