@@ -88,6 +88,7 @@ struct TrnDev {
     unsigned short *Wf16[TRN_MAXL + 1];   // (index 1..L) forward filters as hi / lo f16 MFMA fragments (ROLE_FWD16)
     unsigned short *Wb16[TRN_MAXL + 1];   // the same for the backward-data pass (transposed, taps flipped)
     unsigned int *gmax;                   // [L + 1] bits of max |g_l| (non-negative floats order as their bits)
+    float2 *pstat, *pgsum;                // [L + 1][B][C] per-board (sum, sum of squares) of raw_l / (sum g_l, sum g_l xhat_l)
     float *wpmax;                         // [L + 1][C C 9 / 256] max |filter| per k_trn_prep block
     unsigned int *wmax;                   // [L + 1] bits of max |filter of layer l| (k_trn_stem_fwd, from wpmax)
     unsigned int *bnb;                    // [L + 1] bits of max_c (|gamma| sqrt(n) + |beta|) of BatchNorm l: bounds its output
@@ -101,6 +102,73 @@ __device__ __forceinline__ double dsum(const double *s, int l, int C, int c, int
 __device__ __forceinline__ void bn_coeffs(const TrnDev &P, int l, int c, float &mean, float &inv) {
     const double m = dsum(P.sums, l, P.C, c, 0) * (double)P.invN;
     const double v = dsum(P.sums, l, P.C, c, 1) * (double)P.invN - m * m;
+    mean = (float)m;
+    inv = (float)(1.0 / sqrt((v > 0 ? v : 0) + TRN_EPS));
+}
+
+// The batch sums of a layer are kept as per-board partial pairs (plain stores by the kernel that produces the tensor:
+// 32 K double atomics on 16 cache lines cost a convolution launch ~4.5 us of its ~17) and summed over the boards, in
+// a fixed order, by the kernels that consume them: thread (c = tid % CW, part = tid / CW) takes the boards part,
+// part + PARTS, ...; the parts meet in LDS (`sh`: NTH double2) and threads tid < CW return the totals of channel
+// c0 + tid.  The first consumer's workgroup 0 files the totals in P.sums for everything later (k_trn_finalize, the
+// backward kernels' bn_coeffs).  Contains a barrier.
+// In two halves so that a kernel can request the partials before its bulk input and add them up when it needs them.
+// The loads are unconditional (a clamped board index, the surplus multiplied away): behind a branch the compiler waits
+// for each load in turn -- 32 round trips.
+#define TRN_PS_U 16                  // loads in flight per thread
+template <int CW, int NTH>
+__device__ __forceinline__ void sum_partials_request(const float2 *ps, int Cs, int c0, int B, int tid, float2 (&v)[TRN_PS_U]) {
+    constexpr int PARTS = NTH / CW;
+    const int c = tid % CW, part = tid / CW;
+#pragma unroll
+    for (int u = 0; u < TRN_PS_U; ++u) {
+        const int b = part + u * PARTS;
+        const float2 x = ps[(size_t)min(b, B - 1) * Cs + c0 + c];
+        const float on = b < B ? 1.f : 0.f;           // (a multiplication, not a select: the compiler turns the select
+        v[u] = make_float2(x.x * on, x.y * on);       // back into a branch around the load)
+    }
+}
+template <int CW, int NTH>
+__device__ __forceinline__ void sum_partials_finish(const float2 *ps, int Cs, int c0, int B, double2 *sh, int tid, const float2 (&v)[TRN_PS_U],
+                                                    double &a, double &q) {
+    constexpr int PARTS = NTH / CW;
+    const int c = tid % CW, part = tid / CW;
+    double sa = 0, sq = 0;
+#pragma unroll
+    for (int u = 0; u < TRN_PS_U; ++u) {
+        sa += (double)v[u].x;
+        sq += (double)v[u].y;
+    }
+    for (int b0 = part + TRN_PS_U * PARTS; b0 < B; b0 += TRN_PS_U * PARTS) {       // batches beyond 16 boards per part
+        float2 w[TRN_PS_U];
+#pragma unroll
+        for (int u = 0; u < TRN_PS_U; ++u) {
+            const int b = b0 + u * PARTS;
+            const float2 x = ps[(size_t)min(b, B - 1) * Cs + c0 + c];
+            const float on = b < B ? 1.f : 0.f;
+            w[u] = make_float2(x.x * on, x.y * on);
+        }
+#pragma unroll
+        for (int u = 0; u < TRN_PS_U; ++u) {
+            sa += (double)w[u].x;
+            sq += (double)w[u].y;
+        }
+    }
+    sh[part * CW + c] = make_double2(sa, sq);
+    __syncthreads();
+    a = 0;
+    q = 0;
+    if (tid < CW)
+        for (int pp = 0; pp < PARTS; ++pp) { a += sh[pp * CW + tid].x; q += sh[pp * CW + tid].y; }
+}
+template <int CW, int NTH>
+__device__ __forceinline__ void sum_partials(const float2 *ps, int Cs, int c0, int B, double2 *sh, int tid, double &a, double &q) {
+    float2 v[TRN_PS_U];
+    sum_partials_request<CW, NTH>(ps, Cs, c0, B, tid, v);
+    sum_partials_finish<CW, NTH>(ps, Cs, c0, B, sh, tid, v, a, q);
+}
+__device__ __forceinline__ void bn_from_sums(double s0, double s1, float invN, float &mean, float &inv) {
+    const double m = s0 * (double)invN, v = s1 * (double)invN - m * m;
     mean = (float)m;
     inv = (float)(1.0 / sqrt((v > 0 ? v : 0) + TRN_EPS));
 }
@@ -210,8 +278,7 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_fwd(TrnDev P) {
     if (tid < C) {
         double a = 0, q = 0;
         for (int i = tid; i < NTH; i += C) { a += red[0][i]; q += red[1][i]; }
-        atomicAdd(&P.sums[((size_t)0 * C + tid) * 4 + 0], a);
-        atomicAdd(&P.sums[((size_t)0 * C + tid) * 4 + 1], q);
+        P.pstat[(size_t)b * C + tid] = make_float2((float)a, (float)q);
     }
 }
 
@@ -282,7 +349,8 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     float *cB = cA + C, *cM = cB + C, *cI = cM + C, *cK = cI + C;     // cK: [2][C] (BWD)
     float *pM = cK + 2 * C, *pI = pM + C;               // BWD epilogue: mean / invstd of layer l - 1
     float *red = pI + C;                                // [4][32][2]
-    float *cS = red + 256;                              // BWD16: the operand's scale and its inverse
+    float *cS = red + 256;                              // the f16 roles: the operand's scale, the epilogue's factor
+    double2 *sh = reinterpret_cast<double2 *>(red + 264);    // [256] sum_partials
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     constexpr bool FORWARD = ROLE == ROLE_FWD || ROLE == ROLE_FWD16, F16 = ROLE == ROLE_FWD16 || ROLE == ROLE_BWD16;
@@ -298,22 +366,39 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     const int total = cells * C4;
     const bool has_res = FORWARD && ((l - 1) & 1) == 0 && l - 1 >= 2;
     const float4 *src0 = reinterpret_cast<const float4 *>((FORWARD ? P.raw[l - 1] : P.g[l]) + base0);
-    const float4 *src1 = FORWARD ? (has_res ? reinterpret_cast<const float4 *>(P.act[l - 3] + base0) : nullptr)
+    // (a layer without a skip input reads its own input twice and multiplies the copy away: a null pointer would put
+    // the loads behind a branch whose join the compiler waits at)
+    const float4 *src1 = FORWARD ? (has_res ? reinterpret_cast<const float4 *>(P.act[l - 3] + base0) : src0)
                                           : reinterpret_cast<const float4 *>(P.raw[l] + base0);
+    const float res_on = has_res ? 1.f : 0.f;
+    // (the per-board partial sums this kernel is the first to need go out before them: the coefficients are computed
+    // while the bulk is still on its way)
+    const float2 *psrc = FORWARD ? P.pstat + (size_t)(l - 1) * P.B * C : P.pgsum + (size_t)l * P.B * C;
+    float2 pv[TRN_PS_U];
+    sum_partials_request<C, 256>(psrc, C, 0, P.B, tid, pv);
+    // (unconditional loads at a clamped index -- the items beyond `total` are never looked at: a load behind a per-lane
+    // branch makes the compiler wait at the join)
     float4 v0[ITER], v1[ITER];
 #pragma unroll
-    for (int k = 0; k < ITER; ++k) {
-        const int i = tid + 256 * k;
-        v0[k] = i < total ? src0[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        v1[k] = (src1 != nullptr && i < total) ? src1[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int k = 0; k < ITER; ++k) v0[k] = src0[min(tid + 256 * k, total - 1)];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) v1[k] = src1[min(tid + 256 * k, total - 1)];
 
     // ---- per-channel coefficients -----------------------------------------------------------------------
+    // the sums this kernel is the first to need -- FWD: raw_{l-1}'s (sum, sum of squares); BWD: (sum g_l, sum g_l xhat_l)
+    // -- are taken from the per-board partials
+    double t0, t1;
+    sum_partials_finish<C, 256>(psrc, C, 0, P.B, sh, tid, pv, t0, t1);
     if (tid < C) {
         const int c = tid;
+        if (nt == 0 && b == 0) {
+            double *dst = P.sums + ((size_t)(FORWARD ? l - 1 : l) * C + c) * 4 + (FORWARD ? 0 : 2);
+            dst[0] = t0;
+            dst[1] = t1;
+        }
         if (FORWARD) {
             float mean, inv;
-            bn_coeffs(P, l - 1, c, mean, inv);
+            bn_from_sums(t0, t1, P.invN, mean, inv);
             const float a = P.bn_w[l - 1][c] * inv;
             cA[c] = a;
             cB[c] = P.bn_b[l - 1][c] - mean * a;
@@ -323,8 +408,8 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
             cM[c] = mean;
             cI[c] = inv;
             cA[c] = P.bn_w[l][c] * inv;
-            cK[c] = (float)(dsum(P.sums, l, C, c, 2) * (double)P.invN);
-            cK[C + c] = (float)(dsum(P.sums, l, C, c, 3) * (double)P.invN);
+            cK[c] = (float)(t0 * (double)P.invN);
+            cK[C + c] = (float)(t1 * (double)P.invN);
             bn_coeffs(P, l - 1, c, mean, inv);
             pM[c] = mean;
             pI[c] = inv;
@@ -363,10 +448,10 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
             if (i >= total) break;
             const int pos = i / C4, c = (i - pos * C4) * 4;
             float4 v = v0[k];
-            v.x = fmaxf(v.x * cA[c] + cB[c] + v1[k].x, 0.f);
-            v.y = fmaxf(v.y * cA[c + 1] + cB[c + 1] + v1[k].y, 0.f);
-            v.z = fmaxf(v.z * cA[c + 2] + cB[c + 2] + v1[k].z, 0.f);
-            v.w = fmaxf(v.w * cA[c + 3] + cB[c + 3] + v1[k].w, 0.f);
+            v.x = fmaxf(v.x * cA[c] + cB[c] + v1[k].x * res_on, 0.f);
+            v.y = fmaxf(v.y * cA[c + 1] + cB[c + 1] + v1[k].y * res_on, 0.f);
+            v.z = fmaxf(v.z * cA[c + 2] + cB[c + 2] + v1[k].z * res_on, 0.f);
+            v.w = fmaxf(v.w * cA[c + 3] + cB[c + 3] + v1[k].w * res_on, 0.f);
             if (F16) {
                 const float sc = cS[0];
                 split_store<C>(X, pos, c, make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc));
@@ -408,15 +493,20 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     auto epi_loads = [&]() {
         const float *pact = P.act[l - 1] + base0 + nt * 32, *praw = P.raw[l - 1] + base0 + nt * 32;
         const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= P.L;
-        const float *skip = has_skip ? P.g[l + 1] + base0 + nt * 32 : nullptr;
+        const float skip_on = has_skip ? 1.f : 0.f;
+        const float *skip = has_skip ? P.g[l + 1] + base0 + nt * 32 : pact;        // (no skip: a copy that is multiplied away)
 #pragma unroll
         for (int k = 0; k < ITERO; ++k) {
-            const int i = tid + 256 * k, pos = i / O4, c = (i - pos * O4) * 4;
-            const bool on = i < totalo;
+            const int i = min(tid + 256 * k, totalo - 1), pos = i / O4, c = (i - pos * O4) * 4;
             const size_t o = (size_t)pos * C + c;
-            ea[k] = on ? *reinterpret_cast<const float4 *>(pact + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-            er[k] = on ? *reinterpret_cast<const float4 *>(praw + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-            es[k] = (on && has_skip) ? *reinterpret_cast<const float4 *>(skip + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ea[k] = *reinterpret_cast<const float4 *>(pact + o);
+            er[k] = *reinterpret_cast<const float4 *>(praw + o);
+        }
+#pragma unroll
+        for (int k = 0; k < ITERO; ++k) {
+            const int i = min(tid + 256 * k, totalo - 1), pos = i / O4, c = (i - pos * O4) * 4;
+            const float4 e = *reinterpret_cast<const float4 *>(skip + (size_t)pos * C + c);
+            es[k] = make_float4(e.x * skip_on, e.y * skip_on, e.z * skip_on, e.w * skip_on);
         }
     };
 
@@ -574,8 +664,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
             const int grp4 = tid / 4, j = tid % 4;
             double a = 0, q = 0;
             for (int th = grp4; th < 256; th += O4) { a += rs[th * 8 + j]; q += rs[th * 8 + 4 + j]; }
-            atomicAdd(&P.sums[((size_t)(l - 1) * C + nt * 32 + tid) * 4 + 2], a);
-            atomicAdd(&P.sums[((size_t)(l - 1) * C + nt * 32 + tid) * 4 + 3], q);
+            P.pgsum[((size_t)(l - 1) * P.B + b) * C + nt * 32 + tid] = make_float2((float)a, (float)q);
         }
         TS_MARK(3)
         TS_END
@@ -592,9 +681,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
         double a = 0, q = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { a += red[(w * 32 + tid) * 2]; q += red[(w * 32 + tid) * 2 + 1]; }
-        const int lay = FORWARD ? l : l - 1, k0 = FORWARD ? 0 : 2;
-        atomicAdd(&P.sums[((size_t)lay * C + nt * 32 + tid) * 4 + k0], a);
-        atomicAdd(&P.sums[((size_t)lay * C + nt * 32 + tid) * 4 + k0 + 1], q);
+        P.pstat[((size_t)l * P.B + b) * C + nt * 32 + tid] = make_float2((float)a, (float)q);
     }
     TS_MARK(3)
     TS_END
@@ -634,15 +721,16 @@ __device__ __forceinline__ void trn_wgrad_body(const TrnDev &P, const int l, con
         const size_t base = (size_t)b * cells * C;
         const float *gs = P.g[l] + base + tm * 32, *rs = P.raw[l] + base + tm * 32, *as = P.act[l - 1] + base + tn * 32;
 #pragma unroll
-        for (int k = 0; k < ITER; ++k) {
-            const int i = tid + 256 * k, pos = i / H4, c = (i - pos * H4) * 4;
-            const bool on = i < total;
-            vg[k] = on ? *reinterpret_cast<const float4 *>(gs + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            vr[k] = on ? *reinterpret_cast<const float4 *>(rs + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            va[k] = on ? *reinterpret_cast<const float4 *>(as + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < ITER; ++k) {       // (clamped, unconditional: the staging skips the items beyond `total`)
+            const int i = min(tid + 256 * k, total - 1), pos = i / H4, c = (i - pos * H4) * 4;
+            vg[k] = *reinterpret_cast<const float4 *>(gs + (size_t)pos * C + c);
+            vr[k] = *reinterpret_cast<const float4 *>(rs + (size_t)pos * C + c);
+            va[k] = *reinterpret_cast<const float4 *>(as + (size_t)pos * C + c);
         }
     };
     if (grp < P.B) request(grp);
+    double t0, t1;       // (sum g_l, sum g_l xhat_l) of this block's channels (k_trn_conv<BWD> of layer l runs beside this kernel)
+    sum_partials<CH, 256>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.B, reinterpret_cast<double2 *>(red), tid, t0, t1);
     if (tid < CH) {
         const int c = tm * 32 + tid;
         float mean, inv;
@@ -650,8 +738,8 @@ __device__ __forceinline__ void trn_wgrad_body(const TrnDev &P, const int l, con
         cM[tid] = mean;
         cI[tid] = inv;
         cA[tid] = P.bn_w[l][c] * inv;
-        cK[tid] = (float)(dsum(P.sums, l, C, c, 2) * (double)P.invN);
-        cK[32 + tid] = (float)(dsum(P.sums, l, C, c, 3) * (double)P.invN);
+        cK[tid] = (float)(t0 * (double)P.invN);
+        cK[32 + tid] = (float)(t1 * (double)P.invN);
     }
     {   // the operand tiles start zero: the padding k-row of D and the border of the padded board stay that way
         float4 *z = reinterpret_cast<float4 *>(lds);
@@ -777,15 +865,16 @@ __device__ __forceinline__ void trn_wgrad16_body(const TrnDev &P, const int l, c
         const size_t base = (size_t)b * cells * C;
         const float *gs = P.g[l] + base + tm * 32, *rs = P.raw[l] + base + tm * 32, *as = P.act[l - 1] + base + tn * 32;
 #pragma unroll
-        for (int k = 0; k < ITER; ++k) {
-            const int i = tid + 256 * k, pos = i / H4, c = (i - pos * H4) * 4;
-            const bool on = i < total;
-            vg[k] = on ? *reinterpret_cast<const float4 *>(gs + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            vr[k] = on ? *reinterpret_cast<const float4 *>(rs + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            va[k] = on ? *reinterpret_cast<const float4 *>(as + (size_t)pos * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < ITER; ++k) {       // (clamped, unconditional: the staging skips the items beyond `total`)
+            const int i = min(tid + 256 * k, total - 1), pos = i / H4, c = (i - pos * H4) * 4;
+            vg[k] = *reinterpret_cast<const float4 *>(gs + (size_t)pos * C + c);
+            vr[k] = *reinterpret_cast<const float4 *>(rs + (size_t)pos * C + c);
+            va[k] = *reinterpret_cast<const float4 *>(as + (size_t)pos * C + c);
         }
     };
     if (grp < P.B) request(grp);
+    double t0, t1;       // (sum g_l, sum g_l xhat_l) of this block's channels (k_trn_conv<BWD> of layer l runs beside this kernel)
+    sum_partials<CH, 256>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.B, reinterpret_cast<double2 *>(red), tid, t0, t1);
     if (wave == 0) {
         float bd = 0.f;
         if (tid < CH) {
@@ -795,7 +884,7 @@ __device__ __forceinline__ void trn_wgrad16_body(const TrnDev &P, const int l, c
             cM[tid] = mean;
             cI[tid] = inv;
             const float a = P.bn_w[l][c] * inv;
-            const float k0 = (float)(dsum(P.sums, l, C, c, 2) * (double)P.invN), k1 = (float)(dsum(P.sums, l, C, c, 3) * (double)P.invN);
+            const float k0 = (float)(t0 * (double)P.invN), k1 = (float)(t1 * (double)P.invN);
             cA[tid] = a;
             cK[tid] = k0;
             cK[32 + tid] = k1;
@@ -935,9 +1024,16 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_conv(TrnDev P) 
     float *W = cB + C;                      // [6][C]
     float *red = W + 6 * C;                 // [6][2]
     const int b = blockIdx.x, tid = threadIdx.x, cells = P.cells, L = P.L;
+    double t0, t1;
+    sum_partials<C, NTH>(P.pstat + (size_t)L * P.B * C, C, 0, P.B,
+                         reinterpret_cast<double2 *>(lds + ((P.cells * LDX + 8 * C + 16 + 3) & ~3)), tid, t0, t1);
     if (tid < C) {
         float mean, inv;
-        bn_coeffs(P, L, tid, mean, inv);
+        if (b == 0) {
+            P.sums[((size_t)L * C + tid) * 4] = t0;
+            P.sums[((size_t)L * C + tid) * 4 + 1] = t1;
+        }
+        bn_from_sums(t0, t1, P.invN, mean, inv);
         const float a = P.bn_w[L][tid] * inv;
         cA[tid] = a;
         cB[tid] = P.bn_b[L][tid] - mean * a;
@@ -1288,8 +1384,7 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_bwd(TrnDev P) {
         const int grp4 = tid / 4, j = tid % 4;
         double a = 0, q = 0;
         for (int th = grp4; th < NTH; th += C4) { a += rs[th * 8 + j]; q += rs[th * 8 + 4 + j]; }
-        atomicAdd(&P.sums[((size_t)L * C + tid) * 4 + 2], a);
-        atomicAdd(&P.sums[((size_t)L * C + tid) * 4 + 3], q);
+        P.pgsum[((size_t)L * P.B + b) * C + tid] = make_float2((float)a, (float)q);
     }
     // weight gradients of the 1x1 convolutions: this board's share (the tower's output is in LDS now)
     for (int i = tid; i < 6 * C; i += NTH) {
@@ -1328,14 +1423,20 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_bwd(TrnDev P) {
         vg[k] = i < total ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         vr[k] = i < total ? r4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    double t0, t1;
+    sum_partials<C, NTH>(P.pgsum, C, 0, P.B, reinterpret_cast<double2 *>(cK + 2 * C), tid, t0, t1);
     if (tid < C) {
         float mean, inv;
+        if (b == 0) {
+            P.sums[(size_t)tid * 4 + 2] = t0;
+            P.sums[(size_t)tid * 4 + 3] = t1;
+        }
         bn_coeffs(P, 0, tid, mean, inv);
         cM[tid] = mean;
         cI[tid] = inv;
         cA[tid] = P.bn_w[0][tid] * inv;
-        cK[tid] = (float)(dsum(P.sums, 0, C, tid, 2) * (double)P.invN);
-        cK[C + tid] = (float)(dsum(P.sums, 0, C, tid, 3) * (double)P.invN);
+        cK[tid] = (float)(t0 * (double)P.invN);
+        cK[C + tid] = (float)(t1 * (double)P.invN);
     }
     for (int i = tid; i < cells; i += NTH) cellv[i] = (unsigned char)P.board[(size_t)b * cells + i];
     __syncthreads();
@@ -1618,6 +1719,7 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     d.N = N; d.cells = N * N; d.C = chans; d.L = 2 * blocks; d.B = batch;
     d.invN = (float)(1.0 / ((double)batch * d.cells));
     t->G = std::min(batch, TRN_WG_GROUPS);
+    if (getenv("AZX_TRAIN_WG_GROUPS")) t->G = std::max(1, std::min(t->G, atoi(getenv("AZX_TRAIN_WG_GROUPS"))));
     const int L = d.L, C = chans, cells = d.cells, B = batch;
     const size_t A = (size_t)B * cells * C;
     t->raw.resize(L + 1); t->act.resize(L + 1); t->g.resize(L + 1); t->Wf.assign(L + 1, nullptr); t->Wb.assign(L + 1, nullptr);
@@ -1660,7 +1762,9 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
         return tfail(AZX_ENOMEM, "train: hipMalloc failed");
     }
     d.wpmax = talloc<float>(t, (size_t)(TRN_MAXL + 2) * ((C * C * 9 + 255) / 256));
-    if (!d.wpmax) {
+    d.pstat = talloc<float2>(t, (size_t)(L + 1) * B * C);
+    d.pgsum = talloc<float2>(t, (size_t)(L + 1) * B * C);
+    if (!d.wpmax || !d.pstat || !d.pgsum) {
         azx_trn_destroy(t);
         return tfail(AZX_ENOMEM, "train: hipMalloc failed");
     }
@@ -1862,11 +1966,11 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
     constexpr int SMALL = TRN_SMALL_THREADS;
     hipLaunchKernelGGL(k_trn_prep<C>, dim3((C * C * 9 + 255) / 256, L + 1), dim3(256), 0, st, d);
     hipLaunchKernelGGL(k_trn_stem_fwd<C>, dim3(B), dim3(SMALL), 0, st, d);
-    const size_t conv_lds = ((size_t)std::max(std::max((cells + 1) * (C + 4), cells * 36), 2048) + 9 * C + 256) * sizeof(float);
+    const size_t conv_lds = ((size_t)std::max(std::max((cells + 1) * (C + 4), cells * 36), 2048) + 8 * C + 264 + 1024) * sizeof(float);
     for (int l = 1; l <= L; ++l)
         if (t->fwd16) hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD16>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
         else hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
-    const size_t hc_lds = ((size_t)cells * (C + 1) + 2 * C + 6 * C + 16) * sizeof(float);
+    const size_t hc_lds = ((size_t)((cells * (C + 1) + 8 * C + 16 + 3) & ~3)) * sizeof(float) + (size_t)SMALL * 16;
     hipLaunchKernelGGL(k_trn_heads_conv<C>, dim3(B), dim3(SMALL), hc_lds, st, d);
     hipLaunchKernelGGL(k_trn_heads_fc, dim3(B), dim3(SMALL), 0, st, d);
     size_t ev = 0;
@@ -1901,7 +2005,7 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
         if (t->bwd16) hipLaunchKernelGGL((k_trn_conv<C, ROLE_BWD16>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
         else hipLaunchKernelGGL((k_trn_conv<C, ROLE_BWD>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
     }
-    const size_t sb_lds = ((size_t)cells * C + 5 * C) * sizeof(float);
+    const size_t sb_lds = ((size_t)cells * C + 5 * C) * sizeof(float) + (size_t)SMALL * 16;
     hipLaunchKernelGGL(k_trn_stem_bwd<C>, dim3(B), dim3(SMALL), sb_lds, st, d);
     if (fork) {
         hipEvent_t e = next_event();
