@@ -852,8 +852,8 @@ __device__ __forceinline__ void trn_wgrad16_body(const TrnDev &P, const int l, c
     const int N = P.N, cells = P.cells, KR = N * 16, BR = (N + 3) * 16;
     unsigned char *Dh = reinterpret_cast<unsigned char *>(lds), *Dl = Dh + (size_t)KR * 64;     // [KR][32] f16 draw hi / lo
     unsigned char *Bh = Dl + (size_t)KR * 64, *Bl = Bh + (size_t)BR * 64;                       // [BR][32] f16 input hi / lo
-    float *red = reinterpret_cast<float *>(Bl + (size_t)BR * 64);     // [3 taps][4 waves][1024] reduction rounds
-    float *cA = red + 12 * 1024, *cM = cA + 32, *cI = cM + 32, *cK = cI + 32, *cS = cK + 64;    // cK [2][32], cS [2]
+    float *red = reinterpret_cast<float *>(Bl + (size_t)BR * 64);     // [256] double2: sum_partials
+    float *cA = red + 1024, *cM = cA + 32, *cI = cM + 32, *cK = cI + 32, *cS = cK + 64;    // cK [2][32], cS [2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tm = pair / NT, tn = pair % NT;
     constexpr int TS_SLOT = 2;
@@ -872,9 +872,13 @@ __device__ __forceinline__ void trn_wgrad16_body(const TrnDev &P, const int l, c
             va[k] = *reinterpret_cast<const float4 *>(as + (size_t)pos * C + c);
         }
     };
-    if (grp < P.B) request(grp);
-    double t0, t1;       // (sum g_l, sum g_l xhat_l) of this block's channels (k_trn_conv<BWD> of layer l runs beside this kernel)
-    sum_partials<CH, 256>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.B, reinterpret_cast<double2 *>(red), tid, t0, t1);
+    // (sum g_l, sum g_l xhat_l) of this block's channels, from the per-board partials (k_trn_conv<BWD> of layer l runs
+    // beside this kernel): requested first, added up while the first board's tensors travel
+    float2 pv[TRN_PS_U];
+    sum_partials_request<CH, 256>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.B, tid, pv);
+    request(grp);
+    double t0, t1;
+    sum_partials_finish<CH, 256>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.B, reinterpret_cast<double2 *>(red), tid, pv, t0, t1);
     if (wave == 0) {
         float bd = 0.f;
         if (tid < CH) {
@@ -902,9 +906,13 @@ __device__ __forceinline__ void trn_wgrad16_body(const TrnDev &P, const int l, c
         float4 *z = reinterpret_cast<float4 *>(lds);
         for (int i = tid; i < (KR + BR) * 128 / 16; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    f32x16 acc[9];
+    // The nine taps are shared out over the waves (wave w: taps w, w + 4 and, wave 0, tap 8), every wave walks all the
+    // board rows: a tap's tile is then complete in one wave's accumulators and leaves for HBM straight from them (C/D
+    // layout: a register's lanes 0..31 are 32 consecutive ci of one co: 128-byte rows) -- no reduction over the waves.
+    const int wv = __builtin_amdgcn_readfirstlane(wave), ntap = wv == 0 ? 3 : 2;
+    f32x16 acc[3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     __syncthreads();
@@ -913,6 +921,12 @@ __device__ __forceinline__ void trn_wgrad16_body(const TrnDev &P, const int l, c
     // this lane's corner of the transposed reads: row 8 (lane >> 5) + ((lane & 15) >> 2) of the k-step, channels
     // 16 ((lane >> 4) & 1) + 4 (lane & 3) ..
     const int frag_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    int toff[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int t = wv + 4 * u < 9 ? wv + 4 * u : 8;
+        toff[u] = (17 + (t / 3 - 1) * 16 + (t % 3 - 1)) * 64 + frag_off;
+    }
     for (int b = grp; b < P.B; b += G) {
 #pragma unroll
         for (int k = 0; k < ITER; ++k) {
@@ -940,49 +954,55 @@ __device__ __forceinline__ void trn_wgrad16_body(const TrnDev &P, const int l, c
         __syncthreads();
         if (b + G < P.B) request(b + G);                 // travels under this board's k-loop
         TS_MARK(1)
-        // this wave's board rows s = wave, wave + 4, ... (uniform per wave: the transposed reads need every lane)
-        for (int s = wave; s < N; s += 4) {
-            const size_t ko = (size_t)s * 16 * 64 + frag_off;
-            const f16x8 dhi = tr_frag(Dh + ko), dlo = tr_frag(Dl + ko);
-            f16x8 bhi[9], blo[9];
+        // board row s = one k-step; the fragments of row s + 1 are requested before row s's MFMAs (every lane takes
+        // part in a transposed read: the loop bounds are uniform)
+        f16x8 dhi = tr_frag(Dh + frag_off), dlo = tr_frag(Dl + frag_off), bhi[3], blo[3];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int o = (17 + (t / 3 - 1) * 16 + (t % 3 - 1)) * 64;
-                bhi[t] = tr_frag(Bh + ko + o);
-                blo[t] = tr_frag(Bl + ko + o);
+        for (int u = 0; u < 3; ++u) {
+            bhi[u] = tr_frag(Bh + toff[u]);
+            blo[u] = tr_frag(Bl + toff[u]);
+        }
+        for (int s = 0; s < N; ++s) {
+            const int sn = s + 1 < N ? s + 1 : s;
+            const size_t ko = (size_t)sn * 16 * 64;
+            const f16x8 ndhi = tr_frag(Dh + frag_off + ko), ndlo = tr_frag(Dl + frag_off + ko);
+            f16x8 nbhi[3], nblo[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                nbhi[u] = tr_frag(Bh + toff[u] + ko);
+                nblo[u] = tr_frag(Bl + toff[u] + ko);
             }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, bhi[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, bhi[1], acc[1], 0, 0, 0);
+            if (ntap == 3) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, bhi[2], acc[2], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, blo[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, blo[1], acc[1], 0, 0, 0);
+            if (ntap == 3) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, blo[2], acc[2], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, bhi[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, bhi[1], acc[1], 0, 0, 0);
+            if (ntap == 3) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, bhi[2], acc[2], 0, 0, 0);
+            dhi = ndhi;
+            dlo = ndlo;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, bhi[t], acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, blo[t], acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, bhi[t], acc[t], 0, 0, 0);
+            for (int u = 0; u < 3; ++u) { bhi[u] = nbhi[u]; blo[u] = nblo[u]; }
         }
         __syncthreads();
         TS_MARK(2)
     }
-    // the four waves' shares -> one, as in trn_wgrad_body; the scale leaves here
+    // the scale leaves here
     const float unscale = cS[1];
     float *part = P.wpart + ((size_t)(l - 1) * G + grp) * ((size_t)C * C * 9);
+    const int li = lane & 31, lh = lane >> 5, ci = tn * 32 + li;
 #pragma unroll
-    for (int t0 = 0; t0 < 9; t0 += 3) {
+    for (int u = 0; u < 3; ++u) {
+        if (u < ntap) {
+            const int t = wv + 4 * u;
 #pragma unroll
-        for (int u = 0; u < 3; ++u)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4 *>(red + ((size_t)((u * 4 + wave) * 4 + q) * 64 + lane) * 4) =
-                    make_float4(acc[t0 + u][4 * q], acc[t0 + u][4 * q + 1], acc[t0 + u][4 * q + 2], acc[t0 + u][4 * q + 3]);
-        __syncthreads();
-        for (int e = tid; e < 3 * 1024; e += 256) {
-            const int u = e >> 10, col = (e >> 5) & 31, cil = e & 31;          // output (co = col, ci = cil) of tile u
-            const int q = col >> 3, lh_ = (col >> 2) & 1, r = col & 3;
-            const size_t o = ((size_t)q * 64 + cil + 32 * lh_) * 4 + r;
-            const float *w0 = red + (size_t)(u * 4) * 1024;
-            const int co = tm * 32 + col, ci = tn * 32 + cil;
-            if (co < C && ci < C)
-                part[((size_t)(t0 + u) * C + co) * C + ci] = ((w0[o] + w0[1024 + o]) + (w0[2048 + o] + w0[3072 + o])) * unscale;
+            for (int i = 0; i < 16; ++i) {
+                const int co = tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                if (co < C && ci < C) part[((size_t)t * C + co) * C + ci] = acc[u][i] * unscale;
+            }
         }
-        __syncthreads();
     }
     TS_MARK(3)
     TS_END
@@ -1996,7 +2016,7 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
     const int KP = (cells + 1) & ~1;
     const size_t wg_lds = ((size_t)KP * 32 + (size_t)(d.N + 2) * (d.N + 2) * 32 + 12 * 1024 + 5 * 32 + KP) * sizeof(float);
 
-    const size_t wg16_lds = (size_t)(d.N * 16 + (d.N + 3) * 16) * 128 + (12 * 1024 + 5 * 32 + 2) * sizeof(float);
+    const size_t wg16_lds = (size_t)(d.N * 16 + (d.N + 3) * 16) * 128 + (1024 + 5 * 32 + 2) * sizeof(float);
     for (int l = L; l >= 1; --l) {
         // g_l and BN_l's sums are complete here: the weight gradient of layer l runs beside the data chain
         if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
