@@ -383,6 +383,32 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     for (int k = 0; k < ITER; ++k) v0[k] = src0[min(tid + 256 * k, total - 1)];
 #pragma unroll
     for (int k = 0; k < ITER; ++k) v1[k] = src1[min(tid + 256 * k, total - 1)];
+    // ---- BWD: what the epilogue reads per output element (the ReLU mask's activation, the BatchNorm input of layer
+    // l - 1 and the skip gradient, this block's 32 channels), requested when the k-loop is done.  Requesting them earlier
+    // was measured twice and lost twice: before the fp32 k-loop (0.884 vs 0.863 ms per step: they queue ahead of the
+    // first taps' filter fragments in the in-order vmcnt) and, with the split-f16 k-loop, together with the inputs
+    // (18.3 vs 17.1 us per launch: 12 more 16-byte loads per thread ahead of the staging's).
+    constexpr int LDO = 36, CHo = C < 32 ? C : 32, O4 = CHo / 4, ITERO = (121 * O4 + 255) / 256;
+    const int totalo = cells * O4;
+    float4 ea[ITERO], er[ITERO], es[ITERO];
+    const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= P.L;
+    const float skip_on = has_skip ? 1.f : 0.f;
+    auto epi_loads = [&]() {
+        const float *pact = P.act[l - 1] + base0 + nt * 32, *praw = P.raw[l - 1] + base0 + nt * 32;
+        const float *skip = has_skip ? P.g[l + 1] + base0 + nt * 32 : pact;        // (no skip: a copy that is multiplied away)
+#pragma unroll
+        for (int k = 0; k < ITERO; ++k) {
+            const int i = min(tid + 256 * k, totalo - 1), pos = i / O4, c = (i - pos * O4) * 4;
+            const size_t o = (size_t)pos * C + c;
+            ea[k] = *reinterpret_cast<const float4 *>(pact + o);
+            er[k] = *reinterpret_cast<const float4 *>(praw + o);
+        }
+#pragma unroll
+        for (int k = 0; k < ITERO; ++k) {
+            const int i = min(tid + 256 * k, totalo - 1), pos = i / O4, c = (i - pos * O4) * 4;
+            es[k] = *reinterpret_cast<const float4 *>(skip + (size_t)pos * C + c);
+        }
+    };
 
     // ---- per-channel coefficients -----------------------------------------------------------------------
     // the sums this kernel is the first to need -- FWD: raw_{l-1}'s (sum, sum of squares); BWD: (sum g_l, sum g_l xhat_l)
@@ -483,32 +509,6 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     __syncthreads();
     TS_MARK(1)
 
-    // ---- BWD: what the epilogue reads per output element (the ReLU mask's activation, the BatchNorm input of layer
-    // l - 1 and the skip gradient, this block's 32 channels), requested when the k-loop is done.  Requesting it BEFORE
-    // the k-loop was measured: 0.884 vs 0.863 ms per step on one box -- the 12 loads sit in the same in-order vmcnt
-    // queue as the first taps' filter fragments.
-    constexpr int LDO = 36, CHo = C < 32 ? C : 32, O4 = CHo / 4, ITERO = (121 * O4 + 255) / 256;
-    const int totalo = cells * O4;
-    float4 ea[ITERO], er[ITERO], es[ITERO];
-    auto epi_loads = [&]() {
-        const float *pact = P.act[l - 1] + base0 + nt * 32, *praw = P.raw[l - 1] + base0 + nt * 32;
-        const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= P.L;
-        const float skip_on = has_skip ? 1.f : 0.f;
-        const float *skip = has_skip ? P.g[l + 1] + base0 + nt * 32 : pact;        // (no skip: a copy that is multiplied away)
-#pragma unroll
-        for (int k = 0; k < ITERO; ++k) {
-            const int i = min(tid + 256 * k, totalo - 1), pos = i / O4, c = (i - pos * O4) * 4;
-            const size_t o = (size_t)pos * C + c;
-            ea[k] = *reinterpret_cast<const float4 *>(pact + o);
-            er[k] = *reinterpret_cast<const float4 *>(praw + o);
-        }
-#pragma unroll
-        for (int k = 0; k < ITERO; ++k) {
-            const int i = min(tid + 256 * k, totalo - 1), pos = i / O4, c = (i - pos * O4) * 4;
-            const float4 e = *reinterpret_cast<const float4 *>(skip + (size_t)pos * C + c);
-            es[k] = make_float4(e.x * skip_on, e.y * skip_on, e.z * skip_on, e.w * skip_on);
-        }
-    };
 
     // ---- k-loop: 9 taps x C / 8 steps of four 32x32x2 MFMAs ----------------------------------------------------
     // One wave per SIMD and a dependent MFMA chain: nothing hides a load but the loop itself.  So the filter
@@ -637,10 +637,10 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
             const int pos = i / O4;
             const float4 y = *reinterpret_cast<const float4 *>(Y + (size_t)pos * LDO + c0);
             float4 v;
-            v.x = ea[k].x > 0.f ? y.x + es[k].x : 0.f;
-            v.y = ea[k].y > 0.f ? y.y + es[k].y : 0.f;
-            v.z = ea[k].z > 0.f ? y.z + es[k].z : 0.f;
-            v.w = ea[k].w > 0.f ? y.w + es[k].w : 0.f;
+            v.x = ea[k].x > 0.f ? y.x + es[k].x * skip_on : 0.f;
+            v.y = ea[k].y > 0.f ? y.y + es[k].y * skip_on : 0.f;
+            v.z = ea[k].z > 0.f ? y.z + es[k].z * skip_on : 0.f;
+            v.w = ea[k].w > 0.f ? y.w + es[k].w * skip_on : 0.f;
             *reinterpret_cast<float4 *>(out + (size_t)pos * C + c0) = v;
             vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             a4[0] += v.x; a4[1] += v.y; a4[2] += v.z; a4[3] += v.w;
@@ -1150,24 +1150,57 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_fc(TrnDev P) {
     // the input (four independent loads per lane and step, the wave reductions after the loop)
     const int KV = 2 * cells, KPp = 4 * cells;
     const int n_fc2 = 16, n_mf = (cells + 3) / 4;               // groups of four outputs
+    // (every load unconditional at a clamped index, the surplus multiplied away: behind a per-lane condition the
+    // compiler waits for each load in turn -- ~100 L2 round trips per wave, 25 us of this kernel's 40)
     for (int grp = wave; grp < n_fc2 + n_mf; grp += NW) {
         const bool v = grp < n_fc2;
         const int o0 = v ? grp * 4 : (grp - n_fc2) * 4, K = v ? KV : KPp, rows = v ? 64 : cells;
         const float *w = v ? P.fc2w : P.mfw, *x = v ? ha : ha + 2 * cells;
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-        for (int i = lane; i < K; i += 64) {
-            const float xv = x[i];
+        const float *wr[4], *bias = v ? P.fc2b : P.mfb;
+        float bs[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (o0 + u < rows) s[u] += w[(size_t)(o0 + u) * K + i] * xv;
+        for (int u = 0; u < 4; ++u) {
+            wr[u] = w + (size_t)min(o0 + u, rows - 1) * K;
+            bs[u] = bias[min(o0 + u, rows - 1)];
+        }
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        if (v) {
+            float wv[4][4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {          // K <= 242
+                const int ic = min(lane + 64 * it, K - 1);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wv[it][u] = wr[u][ic];
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int i = lane + 64 * it;
+                const float xv = i < K ? x[min(i, K - 1)] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s[u] += wv[it][u] * xv;
+            }
+        } else {
+            float wv[8][4];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {          // K <= 484
+                const int ic = min(lane + 64 * it, K - 1);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wv[it][u] = wr[u][ic];
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int i = lane + 64 * it;
+                const float xv = i < K ? x[min(i, K - 1)] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s[u] += wv[it][u] * xv;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float r = wave_sum(s[u]);
             if (lane == 0 && o0 + u < rows) {
-                if (v) h2[o0 + u] = fmaxf(r + P.fc2b[o0 + u], 0.f);
-                else logit[o0 + u] = r + P.mfb[o0 + u];
+                if (v) h2[o0 + u] = fmaxf(r + bs[u], 0.f);
+                else logit[o0 + u] = r + bs[u];
             }
         }
     }
