@@ -1600,7 +1600,7 @@ __global__ __launch_bounds__(256) void k_trn_finalize(TrnDev P, FinalizeArgs F) 
 
 // =================================================================================================================
 // SGD update of every tensor, in place (torch.optim.SGD: d = g + wd p; buf = mu buf + d; p -= lr buf).  A block
-// handles 1024 consecutive elements of one segment.
+// handles 256 consecutive elements of one segment.
 // =================================================================================================================
 struct Segment {
     float *p, *mom;
@@ -1613,37 +1613,32 @@ __global__ __launch_bounds__(256) void k_trn_update(TrnDev P, const Segment *seg
     const int2 bk = blocks[blockIdx.x];
     const Segment S = segs[bk.x];
     const float lr = P.hp[0], mu = P.hp[1], wd = P.hp[2];
-    const size_t e0 = (size_t)bk.y * 1024;
+    const size_t ei = (size_t)bk.y * 256 + threadIdx.x;
+    if (ei >= S.n) return;
+    size_t e = ei;
+    float gr;
+    if (S.layer >= 1) {
+        // the G partial copies of k_trn_wgrad, laid out [tap][co][ci], summed in a fixed order: threads walk THAT
+        // order (coalesced reads) and touch the filter / momentum / gradient at (co C + ci) 9 + tap.  All of a
+        // thread's reads are requested before the first is used (unconditional at a clamped copy index: in a counted
+        // loop the compiler keeps four in flight and the kernel is 16 round trips long)
+        const size_t cc9 = S.n / 9, tap = ei / cc9, cc = ei - tap * cc9;
+        e = cc * 9 + tap;
+        const float *part = P.wpart + (size_t)(S.layer - 1) * G * S.n + ei;
+        float v[TRN_WG_GROUPS];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const size_t ei = e0 + (size_t)k * 256 + threadIdx.x;
-        if (ei >= S.n) break;
-        size_t e = ei;
-        float gr;
-        if (S.layer >= 1) {
-            // the G partial copies of k_trn_wgrad, laid out [tap][co][ci], summed in a fixed order: threads walk THAT
-            // order (64 coalesced reads each) and touch the filter / momentum / gradient at (co C + ci) 9 + tap
-            const size_t cc9 = S.n / 9, tap = ei / cc9, cc = ei - tap * cc9;
-            e = cc * 9 + tap;
-            const float *part = P.wpart + (size_t)(S.layer - 1) * G * S.n + ei;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int g = 0;
-            for (; g + 4 <= G; g += 4) {
-                s0 += part[(size_t)g * S.n];
-                s1 += part[(size_t)(g + 1) * S.n];
-                s2 += part[(size_t)(g + 2) * S.n];
-                s3 += part[(size_t)(g + 3) * S.n];
-            }
-            for (; g < G; ++g) s0 += part[(size_t)g * S.n];
-            gr = (s0 + s1) + (s2 + s3);
-            P.grad[S.goff + e] = gr;
-        } else {
-            gr = P.grad[S.goff + e];
-        }
-        const float p = S.p[e], d = gr + wd * p, buf = mu * S.mom[e] + d, np = p - lr * buf;
-        S.mom[e] = buf;
-        S.p[e] = np;
+        for (int g = 0; g < TRN_WG_GROUPS; ++g) v[g] = part[(size_t)min(g, G - 1) * S.n];
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < TRN_WG_GROUPS; ++g) s4[g & 3] += g < G ? v[g] : 0.f;
+        gr = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        P.grad[S.goff + e] = gr;
+    } else {
+        gr = P.grad[S.goff + e];
     }
+    const float p = S.p[e], d = gr + wd * p, buf = mu * S.mom[e] + d, np = p - lr * buf;
+    S.mom[e] = buf;
+    S.p[e] = np;
 }
 
 // First kernel of a step, grid (C C 9 / 256, L + 1):
@@ -1982,7 +1977,7 @@ int azx_trn_bind(AzxTrain *t, int n, const char *const *names, void *const *ptrs
             if (s.layer) { t->conv_goff.resize(L + 1); t->conv_goff[s.layer] = b->goff; }
             const int si = (int)segs.size();
             segs.push_back(s);
-            for (size_t e = 0; e < b->n; e += 1024) blocks.push_back(make_int2(si, (int)(e / 1024)));
+            for (size_t e = 0; e < b->n; e += 256) blocks.push_back(make_int2(si, (int)(e / 256)));
         }
         t->segs = upload_table(t, segs);
         t->blocks = upload_table(t, blocks);
