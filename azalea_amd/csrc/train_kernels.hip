@@ -88,10 +88,10 @@ struct TrnDev {
     unsigned short *Wf16[TRN_MAXL + 1];   // (index 1..L) forward filters as hi / lo f16 MFMA fragments (ROLE_FWD16)
     unsigned short *Wb16[TRN_MAXL + 1];   // the same for the backward-data pass (transposed, taps flipped)
     unsigned int *gmax;                   // [L + 1] bits of max |g_l| (non-negative floats order as their bits)
+    float4 *fsc;                          // [L + 1] (act scale, 1 / (act scale x filter scale), filter scale, 1 / filter scale): k_trn_stem_fwd
     float2 *pstat, *pgsum;                // [L + 1][B][C] per-board (sum, sum of squares) of raw_l / (sum g_l, sum g_l xhat_l)
     float *wpmax;                         // [L + 1][C C 9 / 256] max |filter| per k_trn_prep block
     unsigned int *wmax;                   // [L + 1] bits of max |filter of layer l| (k_trn_stem_fwd, from wpmax)
-    unsigned int *bnb;                    // [L + 1] bits of max_c (|gamma| sqrt(n) + |beta|) of BatchNorm l: bounds its output
     double *zero_base;             // the per-step accumulators (sums | hsums | lossacc | stem_dT | hconv_acc), zero_count doubles
     int zero_count;
 };
@@ -114,42 +114,42 @@ __device__ __forceinline__ void bn_coeffs(const TrnDev &P, int l, int c, float &
 // backward kernels' bn_coeffs).  Contains a barrier.
 // In two halves so that a kernel can request the partials before its bulk input and add them up when it needs them.
 // The loads are unconditional (a clamped board index, the surplus multiplied away): behind a branch the compiler waits
-// for each load in turn -- 32 round trips.
-#define TRN_PS_U 16                  // loads in flight per thread
-template <int CW, int NTH>
-__device__ __forceinline__ void sum_partials_request(const float2 *ps, int Cs, int c0, int B, int tid, float2 (&v)[TRN_PS_U]) {
+// for each load in turn -- 32 round trips.  U = loads in flight per thread (a batch of 128 is one round: 32 x 4 parts at
+// 64 channels, 16 x 8 at 32).
+template <int CW, int NTH, int U>
+__device__ __forceinline__ void sum_partials_request(const float2 *ps, int Cs, int c0, int B, int tid, float2 (&v)[U]) {
     constexpr int PARTS = NTH / CW;
     const int c = tid % CW, part = tid / CW;
 #pragma unroll
-    for (int u = 0; u < TRN_PS_U; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int b = part + u * PARTS;
         const float2 x = ps[(size_t)min(b, B - 1) * Cs + c0 + c];
         const float on = b < B ? 1.f : 0.f;           // (a multiplication, not a select: the compiler turns the select
         v[u] = make_float2(x.x * on, x.y * on);       // back into a branch around the load)
     }
 }
-template <int CW, int NTH>
-__device__ __forceinline__ void sum_partials_finish(const float2 *ps, int Cs, int c0, int B, double2 *sh, int tid, const float2 (&v)[TRN_PS_U],
+template <int CW, int NTH, int U>
+__device__ __forceinline__ void sum_partials_finish(const float2 *ps, int Cs, int c0, int B, double2 *sh, int tid, const float2 (&v)[U],
                                                     double &a, double &q) {
     constexpr int PARTS = NTH / CW;
     const int c = tid % CW, part = tid / CW;
     double sa = 0, sq = 0;
 #pragma unroll
-    for (int u = 0; u < TRN_PS_U; ++u) {
+    for (int u = 0; u < U; ++u) {
         sa += (double)v[u].x;
         sq += (double)v[u].y;
     }
-    for (int b0 = part + TRN_PS_U * PARTS; b0 < B; b0 += TRN_PS_U * PARTS) {       // batches beyond 16 boards per part
-        float2 w[TRN_PS_U];
+    for (int b0 = part + U * PARTS; b0 < B; b0 += U * PARTS) {       // batches beyond U boards per part
+        float2 w[U];
 #pragma unroll
-        for (int u = 0; u < TRN_PS_U; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int b = b0 + u * PARTS;
             const float2 x = ps[(size_t)min(b, B - 1) * Cs + c0 + c];
             const float on = b < B ? 1.f : 0.f;
             w[u] = make_float2(x.x * on, x.y * on);
         }
 #pragma unroll
-        for (int u = 0; u < TRN_PS_U; ++u) {
+        for (int u = 0; u < U; ++u) {
             sa += (double)w[u].x;
             sq += (double)w[u].y;
         }
@@ -163,9 +163,9 @@ __device__ __forceinline__ void sum_partials_finish(const float2 *ps, int Cs, in
 }
 template <int CW, int NTH>
 __device__ __forceinline__ void sum_partials(const float2 *ps, int Cs, int c0, int B, double2 *sh, int tid, double &a, double &q) {
-    float2 v[TRN_PS_U];
-    sum_partials_request<CW, NTH>(ps, Cs, c0, B, tid, v);
-    sum_partials_finish<CW, NTH>(ps, Cs, c0, B, sh, tid, v, a, q);
+    float2 v[16];
+    sum_partials_request<CW, NTH, 16>(ps, Cs, c0, B, tid, v);
+    sum_partials_finish<CW, NTH, 16>(ps, Cs, c0, B, sh, tid, v, a, q);
 }
 __device__ __forceinline__ void bn_from_sums(double s0, double s1, float invN, float &mean, float &inv) {
     const double m = s0 * (double)invN, v = s1 * (double)invN - m * m;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_fwd(TrnDev P) {
         //   forward pack        [tap][q = ci >> 4][ntile = co >> 5][hi, lo][lane = (co & 31) + 32 ((ci >> 3) & 1)][ci & 7]
         //   backward-data pack  the same order for the transposed, flipped filter W'[n = ci][k = co][8 - tap]
         constexpr int NTl = (C + 31) / 32, Q16 = C / 16, NB = (C * C * 9 + 255) / 256, NW = NTH / 64;
-        __shared__ float sW[TRN_MAXL + 1];
+        __shared__ float sW[TRN_MAXL + 1], sBn[TRN_MAXL + 1];
         const int lane = tid & 63, wave = tid >> 6;
         for (int l = 1 + wave; l <= P.L; l += NW) {
             float m = 0.f;
@@ -222,10 +222,20 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_fwd(TrnDev P) {
                 float m = lane < C ? fabsf(P.bn_w[l][lane]) * sq + fabsf(P.bn_b[l][lane]) : 0.f;
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-                if (lane == 0) P.bnb[l] = __float_as_uint(m);
+                if (lane == 0) sBn[l] = m;
             }
         }
         __syncthreads();
+        if (b == 0 && tid >= 1 && tid <= P.L) {
+            // layer l = tid stages act_{l-1}: bounded by its BatchNorm's bound plus, where it has a skip input, the
+            // skip's (a chain of them down to layer 0)
+            const int l = tid;
+            float bd = sBn[l - 1];
+            if (((l - 1) & 1) == 0 && l - 1 >= 2)
+                for (int j = l - 3; j >= 0; j -= 2) bd += sBn[j];
+            const float sa = pow2_scale(bd), sw = sW[l];
+            P.fsc[l] = make_float4(sa, 1.f / (sa * sw), sw, 1.f / sw);
+        }
         const unsigned per = 9u * Q16 * NTl * 64u, items = per * P.L;
         for (unsigned idx = b * NTH + tid; idx < 2 * items; idx += gridDim.x * NTH) {
             const bool bwd = idx >= items;
@@ -373,9 +383,19 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     const float res_on = has_res ? 1.f : 0.f;
     // (the per-board partial sums this kernel is the first to need go out before them: the coefficients are computed
     // while the bulk is still on its way)
+    // Before everything, the few words the coefficient phase works with: the BatchNorm's affine pair, the finished
+    // sums of the layers this kernel is not the first to look at, the layer's scales -- requested behind the barrier
+    // they would each cost a trip to L2 with nothing to hide it.
+    const int cc = min(tid, C - 1);
+    const float e_w = P.bn_w[FORWARD ? l - 1 : l][cc], e_b = FORWARD ? P.bn_b[l - 1][cc] : 0.f;
+    const double2 e_sl = FORWARD ? make_double2(0, 0) : *reinterpret_cast<const double2 *>(P.sums + ((size_t)l * C + cc) * 4);
+    const double2 e_sp = FORWARD ? make_double2(0, 0) : *reinterpret_cast<const double2 *>(P.sums + ((size_t)(l - 1) * C + cc) * 4);
+    const float4 e_fs = F16 ? P.fsc[l] : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float e_gmax = ROLE == ROLE_BWD16 ? __uint_as_float(P.gmax[l]) : 0.f;
     const float2 *psrc = FORWARD ? P.pstat + (size_t)(l - 1) * P.B * C : P.pgsum + (size_t)l * P.B * C;
-    float2 pv[TRN_PS_U];
-    sum_partials_request<C, 256>(psrc, C, 0, P.B, tid, pv);
+    constexpr int PSU = C >= 64 ? 32 : 16;
+    float2 pv[PSU];
+    sum_partials_request<C, 256, PSU>(psrc, C, 0, P.B, tid, pv);
     // (unconditional loads at a clamped index -- the items beyond `total` are never looked at: a load behind a per-lane
     // branch makes the compiler wait at the join)
     float4 v0[ITER], v1[ITER];
@@ -414,7 +434,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     // the sums this kernel is the first to need -- FWD: raw_{l-1}'s (sum, sum of squares); BWD: (sum g_l, sum g_l xhat_l)
     // -- are taken from the per-board partials
     double t0, t1;
-    sum_partials_finish<C, 256>(psrc, C, 0, P.B, sh, tid, pv, t0, t1);
+    sum_partials_finish<C, 256, PSU>(psrc, C, 0, P.B, sh, tid, pv, t0, t1);
     if (tid < C) {
         const int c = tid;
         if (nt == 0 && b == 0) {
@@ -425,41 +445,35 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
         if (FORWARD) {
             float mean, inv;
             bn_from_sums(t0, t1, P.invN, mean, inv);
-            const float a = P.bn_w[l - 1][c] * inv;
+            const float a = e_w * inv;
             cA[c] = a;
-            cB[c] = P.bn_b[l - 1][c] - mean * a;
+            cB[c] = e_b - mean * a;
         } else {
             float mean, inv;
-            bn_coeffs(P, l, c, mean, inv);
+            bn_from_sums(e_sl.x, e_sl.y, P.invN, mean, inv);
             cM[c] = mean;
             cI[c] = inv;
-            cA[c] = P.bn_w[l][c] * inv;
+            cA[c] = e_w * inv;
             cK[c] = (float)(t0 * (double)P.invN);
             cK[C + c] = (float)(t1 * (double)P.invN);
-            bn_coeffs(P, l - 1, c, mean, inv);
+            bn_from_sums(e_sp.x, e_sp.y, P.invN, mean, inv);
             pM[c] = mean;
             pI[c] = inv;
         }
     }
     if (ROLE == ROLE_BWD16 && wave == 0) {
-        float bd = tid < C ? draw_bound(cA[tid], cK[tid], cK[C + tid], __uint_as_float(P.gmax[l]), sqrtf((float)P.B * cells)) : 0.f;
+        float bd = tid < C ? draw_bound(cA[tid], cK[tid], cK[C + tid], e_gmax, sqrtf((float)P.B * cells)) : 0.f;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) bd = fmaxf(bd, __shfl_xor(bd, o));
         if (tid == 0) {
             const float sc = pow2_scale(bd);
             cS[0] = sc;
-            cS[1] = 1.f / (sc * pow2_scale(__uint_as_float(P.wmax[l])));
+            cS[1] = e_fs.w / sc;           // (powers of two: exact)
         }
     }
     if (ROLE == ROLE_FWD16 && tid == 0) {
-        // what the staged activation cannot exceed: its BatchNorm's bound, plus the skip's (a chain of them down to
-        // layer 0) where there is one
-        float bd = __uint_as_float(P.bnb[l - 1]);
-        if (has_res)
-            for (int j = l - 3; j >= 0; j -= 2) bd += __uint_as_float(P.bnb[j]);
-        const float sc = pow2_scale(bd);
-        cS[0] = sc;
-        cS[1] = 1.f / (sc * pow2_scale(__uint_as_float(P.wmax[l])));
+        cS[0] = e_fs.x;                    // the activation's and the filter's scales: k_trn_stem_fwd made them
+        cS[1] = e_fs.y;
     }
     for (int i = tid; i < LDW; i += 256) X[(size_t)cells * LDW + i] = 0.f;
     __syncthreads();
@@ -874,25 +888,28 @@ __device__ __forceinline__ void trn_wgrad16_body(const TrnDev &P, const int l, c
     };
     // (sum g_l, sum g_l xhat_l) of this block's channels, from the per-board partials (k_trn_conv<BWD> of layer l runs
     // beside this kernel): requested first, added up while the first board's tensors travel
-    float2 pv[TRN_PS_U];
-    sum_partials_request<CH, 256>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.B, tid, pv);
+    // (and before those, the few words the coefficient phase needs -- see trn_conv_body)
+    const int cc = tm * 32 + min(tid, CH - 1);
+    const float e_w = P.bn_w[l][cc], e_gmax = __uint_as_float(P.gmax[l]);
+    const double2 e_sl = *reinterpret_cast<const double2 *>(P.sums + ((size_t)l * C + cc) * 4);
+    float2 pv[16];
+    sum_partials_request<CH, 256, 16>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.B, tid, pv);
     request(grp);
     double t0, t1;
-    sum_partials_finish<CH, 256>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.B, reinterpret_cast<double2 *>(red), tid, pv, t0, t1);
+    sum_partials_finish<CH, 256, 16>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.B, reinterpret_cast<double2 *>(red), tid, pv, t0, t1);
     if (wave == 0) {
         float bd = 0.f;
         if (tid < CH) {
-            const int c = tm * 32 + tid;
             float mean, inv;
-            bn_coeffs(P, l, c, mean, inv);
+            bn_from_sums(e_sl.x, e_sl.y, P.invN, mean, inv);
             cM[tid] = mean;
             cI[tid] = inv;
-            const float a = P.bn_w[l][c] * inv;
+            const float a = e_w * inv;
             const float k0 = (float)(t0 * (double)P.invN), k1 = (float)(t1 * (double)P.invN);
             cA[tid] = a;
             cK[tid] = k0;
             cK[32 + tid] = k1;
-            bd = draw_bound(a, k0, k1, __uint_as_float(P.gmax[l]), sqrtf((float)P.B * cells));
+            bd = draw_bound(a, k0, k1, e_gmax, sqrtf((float)P.B * cells));
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) bd = fmaxf(bd, __shfl_xor(bd, o));
@@ -1817,7 +1834,11 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
         return tfail(AZX_ENOMEM, "train: hipMalloc failed");
     }
     d.wmax = d.gmax + (TRN_MAXL + 2);
-    d.bnb = d.wmax + (TRN_MAXL + 2);
+    d.fsc = talloc<float4>(t, TRN_MAXL + 2);
+    if (!d.fsc) {
+        azx_trn_destroy(t);
+        return tfail(AZX_ENOMEM, "train: hipMalloc failed");
+    }
     d.board = t->in_board; d.legal = t->in_legal; d.prob = t->in_prob; d.reward = t->in_reward; d.hp = t->hp_dev; d.hp_ring = t->hp_ring;
     for (int l = 0; l <= L; ++l) {
         d.raw[l] = t->raw[l]; d.act[l] = t->act[l]; d.g[l] = t->g[l]; d.Wf[l] = t->Wf[l]; d.Wb[l] = t->Wb[l];
