@@ -434,7 +434,9 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     // the sums this kernel is the first to need -- FWD: raw_{l-1}'s (sum, sum of squares); BWD: (sum g_l, sum g_l xhat_l)
     // -- are taken from the per-board partials
     double t0, t1;
+    TS_MARK(5)
     sum_partials_finish<C, 256, PSU>(psrc, C, 0, P.B, sh, tid, pv, t0, t1);
+    TS_MARK(4)
     if (tid < C) {
         const int c = tid;
         if (nt == 0 && b == 0) {
@@ -538,8 +540,14 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     if (F16) {
         // 9 taps x C / 16 k-steps x 3 MFMAs (hi hi, hi lo, lo hi) of 32 cycles; fragments: A = the positions' 8
         // consecutive channels 16 q + 8 (lane >> 5) .. (one 16-byte LDS read per plane; 272-byte rows: conflict-free),
-        // B = the filter's, packed by k_trn_prep as [tap][q][ntile][hi, lo][lane][8]; a tap's filter fragments are
-        // requested a tap ahead
+        // B = the filter's, packed by k_trn_stem_fwd as [tap][q][ntile][hi, lo][lane][8]; a tap's filter fragments are
+        // requested a tap ahead.  The k-loop (6.5-8.5 K cycles per wave for 3.5 K of MFMA) is bound by operand
+        // delivery, not by latency: each of the block's four waves pulls the same 72 KB of fragments through the CU's
+        // one 64 B/clk vector-memory path (4.6 K cycles).  Measured and dropped: the fragments requested three taps
+        // ahead (k-loop 8.4 -> 6.5 K cycles, the staging that now issues them 3.8 -> 5.5 K: 12.9 vs 13.0 us per launch)
+        // and the fragments staged ONCE per block through LDS (k-loop 5.8 K, now LDS-bound -- A and B fragments are
+        // 170 B/clk of reads per CU against 128 --, same launch time, and at 116 KB of LDS the block no longer shares a
+        // CU with the filter-gradient kernel beside it: 0.590 vs 0.559 ms per step).
         constexpr int Q16 = C / 16, ROWB = LDW * 4;
         const uint4 *w16 = reinterpret_cast<const uint4 *>(FORWARD ? P.Wf16[l] : P.Wb16[l]) + (size_t)nt * 128 + lane;
         uint4 wc[Q16][2], wn[Q16][2];
@@ -1880,7 +1888,7 @@ void azx_trn_destroy(AzxTrain *t) {
                     for (int k = 0; k < 8; ++k) h[k] += (double)raw[((size_t)r * TS_WAVES + w) * 8 + k];
                 if (h[6] == 0) continue;
                 static const char *nm[6] = {"coefficients / init + barrier", "staging + barrier", "k-loop (+ barrier in wgrad)", "epilogue / reduce + write",
-                                            "(FWD) staging loads in flight", "(FWD) staging compute + writes issued"};
+                                            "(conv) the partial sums' reduction", "(conv) start -> partial sums arrived"};
                 double tot = 0;
                 for (int k = 0; k < 6; ++k) tot += h[k];
                 fprintf(stderr, "k_trn_%s, last launch, %.0f waves: %.0f cycles/wave, %.2f us/wave wall, shader clock %.0f MHz\n",
