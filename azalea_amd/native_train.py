@@ -2,10 +2,15 @@
 
 `NativeTrainStep` stands where `policy_trainer.supervised_step(model, batch, train=True, optimizer=...)` stands in the
 reference loop (azalea/policy_trainer.py:84-90, :123-142): one call = zero_grad + train-mode forward + the loss of
-network.py:92-102 + backward + torch.optim.SGD's update, as ~40 fp32-MFMA / elementwise kernels queued on torch's
-current stream (the filter gradients on a second one; `AZX_TRAIN_GRAPH=1` captures the whole step as one HIP graph).  PyTorch keeps HOLDING everything: the kernels read and write the module's parameter tensors,
-its BatchNorm buffers and the optimizer's momentum buffers in place, so checkpoints (policy_trainer.py:161-181), the
-StepLR scheduler and Player's weight refresh see an ordinary module and optimizer.  No autograd, no MIOpen.
+network.py:92-102 + backward + torch.optim.SGD's update, as ~40 kernels queued on torch's current stream (the filter
+gradients on a second one; `AZX_TRAIN_GRAPH=1` captures the whole step as one HIP graph).  The 3x3 convolutions of all
+three passes run on the split-f16 MFMA arithmetic of the self-play tower (hi + lo f16 operands, three products, fp32
+accumulate: 22 significant bits) with every operand scaled per layer by a power of two -- the gradients from max |g_l|,
+the filters from max |w|, the activations from their BatchNorm's bound -- so nothing depends on the magnitudes staying
+inside the f16 range; `AZX_TRAIN_FWD=fp32`, `AZX_TRAIN_BWD=fp32`, `AZX_TRAIN_WGRAD=fp32` select the exact-fp32 MFMA
+kernels per pass.  PyTorch keeps HOLDING everything: the kernels read and write the module's parameter tensors, its
+BatchNorm buffers and the optimizer's momentum buffers in place, so checkpoints (policy_trainer.py:161-181), the StepLR
+scheduler and Player's weight refresh see an ordinary module and optimizer.  No autograd, no MIOpen.
 """
 import ctypes as C
 

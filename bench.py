@@ -312,7 +312,12 @@ def train_step_mode(args, local_rank, torch, mode):
         fl = train_step_flops(args.board, args.blocks, args.chans, B)
         out.update({"step_only_ms": ms, "step_only_steps_per_sec": 1e3 / ms,
                     "algorithmic_tflops": fl / (ms * 1e-3) / 1e12,
-                    "frac_of_fp32_mfma_peak": fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
+                    "arithmetic": "split f16 (hi, lo) x3 on v_mfma_f32_32x32x16_f16, fp32 accumulate, operands scaled per layer "
+                                  "by powers of two; AZX_TRAIN_FWD / _BWD / _WGRAD=fp32 select the exact-fp32 MFMA kernels",
+                    "frac_of_f16_mfma_peak": fl / (ms * 1e-3) / 1e12 / 2500.0,
+                    "issued_frac_of_f16_mfma_peak": 3.0 * fl / (ms * 1e-3) / 1e12 / 2500.0,
+                    "vs_fp32_mfma_peak": fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
+                    "bound": "launch chain: ~40 dependent kernels of 13-17 us whose matrix work is ~1.5 us each (DESIGN 8.4)",
                     "flop_per_step": fl})
         gs.close()
     E.close()

@@ -340,9 +340,11 @@ int azx_debug_set_queue_cap(azx_engine *e, int64_t rows);
  * compute_loss, backward, optimizer.step) for HexNetwork (network.py:68-102, :120-152) under torch.optim.SGD
  * (momentum, weight decay): forward in TRAIN mode (BatchNorm on batch statistics, running statistics and
  * num_batches_tracked updated), the reference's loss, backward, and the SGD update written IN PLACE into the caller's
- * parameter and momentum tensors -- hand-written fp32-MFMA kernels, one captured HIP graph per step.  The trainer
- * keeps owning its tensors (PyTorch holds them); this handle owns the activations and scratch.  11x11 boards and
- * below, 16 / 32 / 64 channels, any batch. */
+ * parameter and momentum tensors -- hand-written MFMA kernels queued on the caller's stream (the convolutions on the
+ * split-f16 arithmetic of the self-play tower, fp32 accumulate, operands scaled per layer by powers of two: results
+ * at fp32 accuracy whatever the magnitudes; environment AZX_TRAIN_FWD / _BWD / _WGRAD=fp32 selects exact-fp32 MFMA
+ * kernels per pass).  The trainer keeps owning its tensors (PyTorch holds them); this handle owns the activations
+ * and scratch.  11x11 boards and below, 16 / 32 / 64 channels, any batch. */
 typedef struct {
     int32_t board_size, num_blocks, base_chans;   /* policy.py:51-53 */
     int32_t batch_size;                           /* config batch_size (hex11_train_config.yml: 128) */

@@ -88,7 +88,8 @@ def test_default_line_nests_the_config5_shape_with_roofline_and_cpu_baseline():
     assert abs(ts["speedup_native_vs_hip_graph"] - ts["native"]["steps_per_sec"] / ts["hip_graph"]["steps_per_sec"]) < 1e-9
     assert abs(ts["speedup_hip_graph_vs_eager_nosync"] - ts["hip_graph"]["steps_per_sec"] / ts["eager_nosync"]["steps_per_sec"]) < 1e-9
     n = ts["native"]
-    assert n["step_only_ms"] > 0 and abs(n["frac_of_fp32_mfma_peak"] - n["algorithmic_tflops"] / 157.3) < 1e-6
+    assert n["step_only_ms"] > 0 and abs(n["vs_fp32_mfma_peak"] - n["algorithmic_tflops"] / 157.3) < 1e-6
+    assert abs(n["frac_of_f16_mfma_peak"] - n["algorithmic_tflops"] / 2500.0) < 1e-9
     assert ts["native"]["steps_per_sec"] > 1.5 * ts["hip_graph"]["steps_per_sec"]      # measured 2.3x
 
 
