@@ -1738,7 +1738,7 @@ struct AzxTrain {
     std::vector<float *> raw, act, g, Wf, Wb;
     Segment *segs = nullptr;
     int2 *blocks = nullptr;
-    int n_blocks = 0;
+    int n_blocks = 0, n_conv_blocks = 0;
     FinalizeArgs fin;
     HeadGradOffs hoffs;
     std::vector<size_t> conv_goff;
@@ -1997,8 +1997,10 @@ int azx_trn_bind(AzxTrain *t, int n, const char *const *names, void *const *ptrs
     t->hoffs = {fc2w->goff, fc2b->goff, fc3w->goff, fc3b->goff, mfw->goff, mfb->goff};
     // update segments and the block table
     {
+        // the tower filters' blocks first: their update (which is also the second stage of the filter-gradient
+        // reduction, the step's largest read) is launched on its own behind the last filter-gradient kernel
         std::vector<Segment> segs;
-        std::vector<int2> blocks;
+        std::vector<int2> blocks, rest;
         for (Bound *b : params) {
             Segment s;
             s.p = (float *)b->ptr; s.mom = b->mom; s.n = b->n; s.goff = b->goff; s.layer = 0;
@@ -2006,8 +2008,10 @@ int azx_trn_bind(AzxTrain *t, int n, const char *const *names, void *const *ptrs
             if (s.layer) { t->conv_goff.resize(L + 1); t->conv_goff[s.layer] = b->goff; }
             const int si = (int)segs.size();
             segs.push_back(s);
-            for (size_t e = 0; e < b->n; e += 256) blocks.push_back(make_int2(si, (int)(e / 256)));
+            for (size_t e = 0; e < b->n; e += 256) (s.layer ? blocks : rest).push_back(make_int2(si, (int)(e / 256)));
         }
+        t->n_conv_blocks = (int)blocks.size();
+        blocks.insert(blocks.end(), rest.begin(), rest.end());
         t->segs = upload_table(t, segs);
         t->blocks = upload_table(t, blocks);
         t->n_blocks = (int)blocks.size();
@@ -2084,14 +2088,23 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
     }
     const size_t sb_lds = ((size_t)cells * C + 5 * C) * sizeof(float) + (size_t)SMALL * 16;
     hipLaunchKernelGGL(k_trn_stem_bwd<C>, dim3(B), dim3(SMALL), sb_lds, st, d);
-    if (fork) {
+    auto join_side = [&]() -> bool {
+        if (!fork) return true;
         hipEvent_t e = next_event();
-        if (!e || hipEventRecord(e, side) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess)
-            return tfail(AZX_EHIP, "train: joining the weight-gradient stream failed");
-    }
+        return e && hipEventRecord(e, side) == hipSuccess && hipStreamWaitEvent(st, e, 0) == hipSuccess;
+    };
+    // every gradient is complete once the filter-gradient stream has drained: the tower filters' update (113 MB of
+    // partial copies to reduce) follows the last filter-gradient kernel on that stream, under the stem's backward, the
+    // finalize and the other tensors' update on this one
+    if (!join_side()) return tfail(AZX_EHIP, "train: joining the weight-gradient stream failed");
+    if (t->n_conv_blocks > 0)
+        hipLaunchKernelGGL(k_trn_update<C>, dim3(t->n_conv_blocks), dim3(256), 0, ws, d, (const Segment *)t->segs, (const int2 *)t->blocks, G);
     const int fin_blocks = 2 + ((L + 1) * C + 6 + 255) / 256;
     hipLaunchKernelGGL(k_trn_finalize<C>, dim3(fin_blocks), dim3(256), 0, st, d, t->fin);
-    hipLaunchKernelGGL(k_trn_update<C>, dim3(t->n_blocks), dim3(256), 0, st, d, (const Segment *)t->segs, (const int2 *)t->blocks, G);
+    if (t->n_blocks > t->n_conv_blocks)
+        hipLaunchKernelGGL(k_trn_update<C>, dim3(t->n_blocks - t->n_conv_blocks), dim3(256), 0, st, d, (const Segment *)t->segs,
+                           (const int2 *)t->blocks + t->n_conv_blocks, G);
+    if (!join_side()) return tfail(AZX_EHIP, "train: joining the weight-gradient stream failed");
     if (hipGetLastError() != hipSuccess) return tfail(AZX_EHIP, "train: a kernel of the step failed to launch");
     return AZX_OK;
 }
