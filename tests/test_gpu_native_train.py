@@ -138,6 +138,17 @@ def test_every_intermediate_matches_autograd(n, blocks, chans, B):
     step.close()
 
 
+@pytest.mark.parametrize("passes", [("FWD", "BWD", "WGRAD"), ("BWD",), ("FWD", "WGRAD")])
+def test_exact_fp32_kernels_stay_green(monkeypatch, passes):
+    """AZX_TRAIN_FWD / _BWD / _WGRAD=fp32 select the exact-fp32 MFMA kernel of a pass (read when the trainer is
+    created): every combination shares the prologues, the partial sums and the epilogues with the split-f16 kernels
+    and is held to the same comparison."""
+    for name in passes:
+        monkeypatch.setenv("AZX_TRAIN_" + name, "fp32")
+    test_every_intermediate_matches_autograd(11, 2, 64, 8)
+    test_every_intermediate_matches_autograd(9, 2, 32, 7)
+
+
 @pytest.mark.parametrize("kind", ["tiny", "huge"])
 @pytest.mark.parametrize("n,blocks,chans,B", [(5, 2, 16, 6), (11, 3, 64, 16)])
 def test_gradient_range_is_managed(kind, n, blocks, chans, B):
