@@ -149,6 +149,43 @@ def test_exact_fp32_kernels_stay_green(monkeypatch, passes):
     test_every_intermediate_matches_autograd(9, 2, 32, 7)
 
 
+@pytest.mark.parametrize("n,blocks,chans,B", [(11, 1, 64, 200), (7, 2, 32, 300), (3, 1, 16, 1), (11, 2, 16, 131), (2, 1, 64, 3)])
+def test_odd_batches_and_boards(n, blocks, chans, B):
+    """Batches that are not a multiple of anything the kernels tile by -- more boards than one round of partial-sum
+    loads covers (> 128), filter-gradient groups of unequal size (B not a multiple of 64), a single board -- and the
+    smallest boards: loss, outputs and every parameter gradient against float64 autograd, within a small multiple of
+    torch's own fp32 distance."""
+    from azalea_amd.native_train import NativeTrainStep
+    batch = {k: v.to(DEV) for k, v in _random_batch(n, B, 21).items()}
+    grads, outs = {}, {}
+    for dtype in (torch.float32, torch.float64):
+        net = _net(n, blocks, chans, seed=9).to(dtype).train()
+        o = net.forward(batch["board"], batch["legal_moves"])
+        loss = F.mse_loss(o["value"], batch["reward"].to(dtype)) - (batch["moves_prob"].to(dtype) * o["moves_logprob"]).sum() / B
+        loss.backward()
+        grads[dtype] = {name: p.grad.double().cpu().numpy().ravel() for name, p in net.named_parameters()}
+        outs[dtype] = (float(loss.detach()), o["value"].detach().double().cpu().numpy(), o["moves_logprob"].detach().double().cpu().numpy())
+    net = _net(n, blocks, chans, seed=9).train()
+    step = NativeTrainStep(net, torch.optim.SGD(net.parameters(), lr=0.0, momentum=0.9), B, DEV)
+    loss = step.step(batch).cpu().numpy()
+    torch.cuda.synchronize()
+    k = batch["legal_moves"].shape[1]
+    legal = (batch["legal_moves"] > 0).cpu().numpy()
+    assert abs(float(loss[0]) - outs[torch.float64][0]) <= 2e-5 * max(1.0, abs(outs[torch.float64][0]))
+    assert np.abs(step.out_value.cpu().numpy() - outs[torch.float64][1]).max() <= 2e-5
+    assert np.abs(step.out_logprob.cpu().numpy()[:, :k][legal] - outs[torch.float64][2][legal]).max() <= 5e-5
+    for name, truth in grads[torch.float64].items():
+        got = step.debug("grad:" + name).astype(np.float64)
+        nt = float(np.linalg.norm(truth))
+        e_torch = float(np.linalg.norm(grads[torch.float32][name] - truth))
+        e_native = float(np.linalg.norm(got - truth))
+        # (past ~2e5 activations per layer a few ReLU decisions at rounding distance from zero differ between any two
+        # fp32 computations, see test_every_intermediate_matches_autograd)
+        tol = 5e-3 if B * n * n * chans > 200000 else 2e-5
+        assert e_native <= max(5.0 * e_torch, tol * nt, 1e-12), (name, e_native, e_torch, nt)
+    step.close()
+
+
 @pytest.mark.parametrize("kind", ["tiny", "huge"])
 @pytest.mark.parametrize("n,blocks,chans,B", [(5, 2, 16, 6), (11, 3, 64, 16)])
 def test_gradient_range_is_managed(kind, n, blocks, chans, B):
