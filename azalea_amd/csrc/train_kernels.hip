@@ -7,21 +7,27 @@
 // (momentum, weight decay, no dampening / nesterov: d = g + wd p; buf = mu buf + d; p -= lr buf).
 //
 // Design.  At the reference's batch of 128 boards a step is 41 GFLOP of 3x3 convolutions in a
-// chain of ~40 dependent layer passes: latency-bound, not throughput-bound.  So: fp32 MFMA (v_mfma_f32_32x32x2_f32,
-// exact products -- gradients span ten orders of magnitude, no f16 range games), one workgroup per (board, 32 output
+// chain of ~40 dependent layer passes: latency-bound, not throughput-bound.  So: one workgroup per (board, 32 output
 // channels) so that a layer pass fills all 256 CUs with 4 waves each, every elementwise stage fused into the
-// producer's epilogue or the consumer's prologue, the filter gradients on a stream of their own beside the data chain:
-//   forward  : k_trn_stem_fwd, L x k_trn_conv<FWD> (prologue: BN(batch stats) + residual + ReLU of the INPUT, written
-//              out once for the backward pass; epilogue: raw output + per-channel sum / sum of squares), heads
-//   prep     : k_trn_prep (MFMA-order copies of the filters from the live tensors, accumulators zeroed, stem table,
-//              hyper-parameters from a pinned ring)
-//   backward : heads, L x k_trn_conv<BWD> (prologue: BatchNorm backward of the incoming gradient; implicit GEMM with
+// producer's epilogue or the consumer's prologue, the filter gradients on a stream of their own beside the data chain,
+// and the convolutions of all three passes on the split-f16 arithmetic of the self-play tower (hi + lo f16 operands,
+// three v_mfma_f32_32x32x16_f16 per k-step, fp32 accumulate) with every operand scaled per layer by a power of two
+// (ROLE_FWD16 / ROLE_BWD16 / k_trn_wgrad16 below); the exact-fp32 kernels (v_mfma_f32_32x32x2_f32) stay selectable
+// per pass (AZX_TRAIN_FWD / _BWD / _WGRAD=fp32):
+//   prep     : k_trn_prep (max |filter| per layer, fp32 MFMA-order filter copies for the fp32 roles, accumulators
+//              zeroed, stem table, hyper-parameters from a pinned ring)
+//   forward  : k_trn_stem_fwd (+ the split-f16 filter fragments and the per-layer scales), L x k_trn_conv<FWD16>
+//              (prologue: BN(batch stats) + residual + ReLU of the INPUT, written out once for the backward pass;
+//              epilogue: raw output + per-board per-channel sum / sum of squares), heads
+//   backward : heads, L x k_trn_conv<BWD16> (prologue: BatchNorm backward of the incoming gradient; implicit GEMM with
 //              the flipped / transposed filters; epilogue: skip-connection add, ReLU mask, the next BatchNorm's two
-//              reductions), L x k_trn_wgrad (split over boards and channel-tile pairs, partial copies), stem
-//   update   : k_trn_finalize (BN gradients, running statistics, small reductions), k_trn_update (second stage of
-//              the filter-gradient reduction in a fixed order, then SGD on every tensor IN PLACE in the trainer's
-//              torch tensors)
-// Layouts: activations [B][cells][C] fp32; per BatchNorm layer four f64 sums per channel {x, x^2, g, g xhat}.
+//              reductions, max |g|), L x k_trn_wgrad16 (split over boards and channel-tile pairs, partial copies), stem
+//   update   : k_trn_finalize (BN gradients, running statistics, small reductions), k_trn_update twice (the tower
+//              filters -- second stage of the filter-gradient reduction in a fixed order -- behind the last
+//              filter-gradient kernel on its stream; everything else at the end of the data chain): SGD IN PLACE in the
+//              trainer's torch tensors
+// Layouts: activations [B][cells][C] fp32; per BatchNorm layer per-board partial pairs (x, x^2) and (g, g xhat), summed
+// in a fixed order by the kernels that consume them (sum_partials), the totals filed as four f64 per channel.
 #include "train.h"
 
 #include <cmath>
@@ -674,7 +680,8 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
             q4[2] += v.z * (er[k].z - pM[nt * 32 + c0 + 2]) * pI[nt * 32 + c0 + 2];
             q4[3] += v.w * (er[k].w - pM[nt * 32 + c0 + 3]) * pI[nt * 32 + c0 + 3];
         }
-        // per channel: the 256 / O4 threads that share it -> f64 atomics, one pair per channel and block
+        // per channel: the 256 / O4 threads that share it -> this board's partial pair (k_trn_conv of layer l - 1 and
+        // its filter-gradient kernel add the boards up)
         __syncthreads();
         float *rs = Y;                                   // [256][8]
 #pragma unroll
@@ -1683,9 +1690,10 @@ __global__ __launch_bounds__(256) void k_trn_update(TrnDev P, const Segment *seg
 }
 
 // First kernel of a step, grid (C C 9 / 256, L + 1):
-//   y < L   the MFMA-order copies of tower filter y + 1: whatever wrote the weights last -- this trainer's own update,
-//           an eager optimizer step on a ragged batch, load_state_dict, a weight broadcast -- the step convolves with
-//           what the tensors hold NOW.
+//   y < L   max |filter y + 1| (per-block maxima: the scale of the split-f16 fragments k_trn_stem_fwd writes) and the
+//           fp32 MFMA-order copies the exact-fp32 roles convolve with: whatever wrote the weights last -- this trainer's
+//           own update, an eager optimizer step on a ragged batch, load_state_dict, a weight broadcast -- the step
+//           convolves with what the tensors hold NOW.
 //             forward pack        [tap][q][ntile][lane = j + 32 h][t] = W[co = 32 ntile + j][ci = 8 q + 4 h + t][tap]
 //             backward-data pack  the same order for the transposed, flipped filter W'[n = ci][k = co][8 - tap]
 //   y == L  the per-step accumulators zeroed, the stem table (embedding folded through conv1), and the step's
