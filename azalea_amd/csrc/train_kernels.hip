@@ -357,8 +357,19 @@ __device__ __forceinline__ void split_store(float *X, int pos, int c, float4 v) 
     *reinterpret_cast<uint2 *>(row + 2 * C + 2 * c) = *reinterpret_cast<const uint2 *>(lo);
 }
 
+// The layer's tensors as DIRECT kernel arguments (the host indexes the per-layer arrays): fetched out of TrnDev's arrays
+// inside the kernel they are a second scalar load that waits for the first (the layer index), ahead of every vector
+// load of the prologue -- one round trip of the scalar cache per launch, 24 launches per step.
+struct ConvPtrs {
+    const float *in0, *in1;          // FWD: raw_{l-1}, act_{l-3} (or in0 again); BWD: g_l, raw_l
+    const float *bnw, *bnb;          // the affine pair of the BatchNorm the prologue applies (FWD: l - 1; BWD: l)
+    const void *w;                   // the layer's filter fragments for this role
+    float *act_out, *out;            // FWD: act_{l-1} (written for the backward pass), raw_l; BWD: -, g_{l-1}
+    const float *e_act, *e_raw, *e_skip;   // BWD epilogue: act_{l-1}, raw_{l-1}, g_{l+1} (or e_act again)
+};
+
 template <int C, int ROLE>
-__device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, const int nt, const int b, float *lds) {
+__device__ __forceinline__ void trn_conv_body(const ConvPtrs &A, const TrnDev &P, const int l, const int nt, const int b, float *lds) {
     constexpr int NT = (C + 31) / 32, LDW = C + 4, Q = C / 8, C4 = C / 4;
     float *X = lds;                                    // [(cells + 1)][LDW]
     const int N = P.N, cells = P.cells;
@@ -384,11 +395,10 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     const size_t base0 = (size_t)b * cells * C;
     const int total = cells * C4;
     const bool has_res = FORWARD && ((l - 1) & 1) == 0 && l - 1 >= 2;
-    const float4 *src0 = reinterpret_cast<const float4 *>((FORWARD ? P.raw[l - 1] : P.g[l]) + base0);
+    const float4 *src0 = reinterpret_cast<const float4 *>(A.in0 + base0);
     // (a layer without a skip input reads its own input twice and multiplies the copy away: a null pointer would put
     // the loads behind a branch whose join the compiler waits at)
-    const float4 *src1 = FORWARD ? (has_res ? reinterpret_cast<const float4 *>(P.act[l - 3] + base0) : src0)
-                                          : reinterpret_cast<const float4 *>(P.raw[l] + base0);
+    const float4 *src1 = reinterpret_cast<const float4 *>(A.in1 + base0);
     const float res_on = has_res ? 1.f : 0.f;
     // (the per-board partial sums this kernel is the first to need go out before them: the coefficients are computed
     // while the bulk is still on its way)
@@ -396,7 +406,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     // sums of the layers this kernel is not the first to look at, the layer's scales -- requested behind the barrier
     // they would each cost a trip to L2 with nothing to hide it.
     const int cc = min(tid, C - 1);
-    const float e_w = P.bn_w[FORWARD ? l - 1 : l][cc], e_b = FORWARD ? P.bn_b[l - 1][cc] : 0.f;
+    const float e_w = A.bnw[cc], e_b = FORWARD ? A.bnb[cc] : 0.f;
     const double2 e_sl = FORWARD ? make_double2(0, 0) : *reinterpret_cast<const double2 *>(P.sums + ((size_t)l * C + cc) * 4);
     const double2 e_sp = FORWARD ? make_double2(0, 0) : *reinterpret_cast<const double2 *>(P.sums + ((size_t)(l - 1) * C + cc) * 4);
     const float4 e_fs = F16 ? P.fsc[l] : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -423,8 +433,8 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= P.L;
     const float skip_on = has_skip ? 1.f : 0.f;
     auto epi_loads = [&]() {
-        const float *pact = P.act[l - 1] + base0 + nt * 32, *praw = P.raw[l - 1] + base0 + nt * 32;
-        const float *skip = has_skip ? P.g[l + 1] + base0 + nt * 32 : pact;        // (no skip: a copy that is multiplied away)
+        const float *pact = A.e_act + base0 + nt * 32, *praw = A.e_raw + base0 + nt * 32;
+        const float *skip = A.e_skip + base0 + nt * 32;       // (no skip: act again, a copy that is multiplied away)
 #pragma unroll
         for (int k = 0; k < ITERO; ++k) {
             const int i = min(tid + 256 * k, totalo - 1), pos = i / O4, c = (i - pos * O4) * 4;
@@ -492,7 +502,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
 
     // ---- stage the input operand ---------------------------------------------------------------------------
     if (FORWARD) {
-        float4 *dst = reinterpret_cast<float4 *>(P.act[l - 1] + base0);
+        float4 *dst = reinterpret_cast<float4 *>(A.act_out + base0);
 #pragma unroll
         for (int k = 0; k < ITER; ++k) {
             const int i = tid + 256 * k;
@@ -558,7 +568,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
         // 170 B/clk of reads per CU against 128 --, same launch time, and at 116 KB of LDS the block no longer shares a
         // CU with the filter-gradient kernel beside it: 0.590 vs 0.559 ms per step).
         constexpr int Q16 = C / 16, ROWB = LDW * 4;
-        const uint4 *w16 = reinterpret_cast<const uint4 *>(FORWARD ? P.Wf16[l] : P.Wb16[l]) + (size_t)nt * 128 + lane;
+        const uint4 *w16 = reinterpret_cast<const uint4 *>(A.w) + (size_t)nt * 128 + lane;
         uint4 wc[Q16][2], wn[Q16][2];
 #pragma unroll
         for (int q = 0; q < Q16; ++q) { wc[q][0] = w16[(size_t)q * NT * 128]; wc[q][1] = w16[(size_t)q * NT * 128 + 64]; }
@@ -593,7 +603,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
             }
         }
     } else {
-    const float4 *wl = reinterpret_cast<const float4 *>(ROLE == ROLE_FWD ? P.Wf[l] : P.Wb[l]) + (size_t)nt * 64 + lane;
+    const float4 *wl = reinterpret_cast<const float4 *>(A.w) + (size_t)nt * 64 + lane;
     float4 bcur[Q], bnxt[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) bcur[q] = wl[(size_t)q * NT * 64];
@@ -633,7 +643,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
     float s1 = 0.f, s2 = 0.f;
     const size_t base = base0;
     if (FORWARD) {
-        float *out = P.raw[l] + base;
+        float *out = A.out + base;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
@@ -657,7 +667,7 @@ __device__ __forceinline__ void trn_conv_body(const TrnDev &P, const int l, cons
             if (row < cells) Y[(size_t)row * LDO + li] = F16 ? acc[i] * unscale : acc[i];
         }
         __syncthreads();
-        float *out = P.g[l - 1] + base + nt * 32;
+        float *out = A.out + base + nt * 32;
         // a thread's items all have the same four channels (256 is a multiple of O4): four pairs of running sums
         float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f}, vmax = 0.f;
         const int c0 = (tid % O4) * 4;
@@ -1044,9 +1054,9 @@ __device__ __forceinline__ void trn_wgrad16_body(const TrnDev &P, const int l, c
 }
 
 template <int C, int ROLE>
-__global__ __launch_bounds__(256) void k_trn_conv(TrnDev P, int l) {
+__global__ __launch_bounds__(256) void k_trn_conv(ConvPtrs Q, int l, TrnDev P) {
     extern __shared__ __align__(16) float lds[];
-    trn_conv_body<C, ROLE>(P, l, blockIdx.x, blockIdx.y, lds);
+    trn_conv_body<C, ROLE>(Q, P, l, blockIdx.x, blockIdx.y, lds);
 }
 
 template <int C>
@@ -2073,8 +2083,17 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
     hipLaunchKernelGGL(k_trn_stem_fwd<C>, dim3(B), dim3(SMALL), 0, st, d);
     const size_t conv_lds = ((size_t)std::max(std::max((cells + 1) * (C + 4), cells * 36), 2048) + 8 * C + 264 + 1024) * sizeof(float);
     for (int l = 1; l <= L; ++l)
-        if (t->fwd16) hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD16>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
-        else hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
+    {
+        ConvPtrs q;
+        const bool has_res = ((l - 1) & 1) == 0 && l - 1 >= 2;
+        q.in0 = t->raw[l - 1]; q.in1 = has_res ? t->act[l - 3] : t->raw[l - 1];
+        q.bnw = d.bn_w[l - 1]; q.bnb = d.bn_b[l - 1];
+        q.w = t->fwd16 ? (const void *)d.Wf16[l] : (const void *)t->Wf[l];
+        q.act_out = t->act[l - 1]; q.out = t->raw[l];
+        q.e_act = q.e_raw = q.e_skip = nullptr;
+        if (t->fwd16) hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD16>), dim3(NT, B), dim3(256), conv_lds, st, q, l, d);
+        else hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD>), dim3(NT, B), dim3(256), conv_lds, st, q, l, d);
+    }
     const size_t hc_lds = ((size_t)((cells * (C + 1) + 8 * C + 16 + 3) & ~3)) * sizeof(float) + (size_t)SMALL * 16;
     hipLaunchKernelGGL(k_trn_heads_conv<C>, dim3(B), dim3(SMALL), hc_lds, st, d);
     hipLaunchKernelGGL(k_trn_heads_fc, dim3(B), dim3(SMALL), 0, st, d);
@@ -2112,8 +2131,15 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
         // of their 205 us hide under the data chain)
         if (t->wgrad16) hipLaunchKernelGGL(k_trn_wgrad16<C>, dim3(NT * NT, G), dim3(256), wg16_lds, ws, d, l, G);
         else hipLaunchKernelGGL(k_trn_wgrad<C>, dim3(NT * NT, G), dim3(256), wg_lds, ws, d, l, G);
-        if (t->bwd16) hipLaunchKernelGGL((k_trn_conv<C, ROLE_BWD16>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
-        else hipLaunchKernelGGL((k_trn_conv<C, ROLE_BWD>), dim3(NT, B), dim3(256), conv_lds, st, d, l);
+        ConvPtrs q;
+        const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= L;
+        q.in0 = t->g[l]; q.in1 = t->raw[l];
+        q.bnw = d.bn_w[l]; q.bnb = d.bn_b[l];
+        q.w = t->bwd16 ? (const void *)d.Wb16[l] : (const void *)t->Wb[l];
+        q.act_out = nullptr; q.out = t->g[l - 1];
+        q.e_act = t->act[l - 1]; q.e_raw = t->raw[l - 1]; q.e_skip = has_skip ? t->g[l + 1] : t->act[l - 1];
+        if (t->bwd16) hipLaunchKernelGGL((k_trn_conv<C, ROLE_BWD16>), dim3(NT, B), dim3(256), conv_lds, st, q, l, d);
+        else hipLaunchKernelGGL((k_trn_conv<C, ROLE_BWD>), dim3(NT, B), dim3(256), conv_lds, st, q, l, d);
     }
     const size_t sb_lds = ((size_t)cells * C + 5 * C) * sizeof(float) + (size_t)SMALL * 16;
     hipLaunchKernelGGL(k_trn_stem_bwd<C>, dim3(B), dim3(SMALL), sb_lds, st, d);
