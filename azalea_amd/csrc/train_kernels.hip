@@ -97,6 +97,9 @@ struct TrnDev {
     unsigned short *Wf16[TRN_MAXL + 1];   // (index 1..L) forward filters as hi / lo f16 MFMA fragments (ROLE_FWD16)
     unsigned short *Wb16[TRN_MAXL + 1];   // the same for the backward-data pass (transposed, taps flipped)
     unsigned int *gmax;                   // [L + 1] bits of max |g_l| (non-negative floats order as their bits)
+    // the last tower layer's tensors once more, as plain members: P.raw[P.L] is two dependent scalar loads
+    float *rawL, *actL, *actLm2, *gL;
+    const float *bnwL, *bnbL;
     float4 *fsc;                          // [L + 1] (act scale, 1 / (act scale x filter scale), filter scale, 1 / filter scale): k_trn_stem_fwd
     float2 *pstat, *pgsum;                // [L + 1][B][C] per-board (sum, sum of squares) of raw_l / (sum g_l, sum g_l xhat_l)
     float *wpmax;                         // [L + 1][C C 9 / 256] max |filter| per k_trn_prep block
@@ -739,8 +742,10 @@ __device__ __forceinline__ void trn_conv_body(const ConvPtrs &A, const TrnDev &P
 //   staged input, the off-board taps read a zero row; its 4 waves split the positions and are summed through LDS.
 //   Partials are reduced by k_trn_update in a fixed order: the step is reproducible.
 // =================================================================================================================
+struct WgradPtrs { const float *g, *raw, *act, *bnw; };        // g_l, raw_l, act_{l-1}, BatchNorm l's gamma (see ConvPtrs)
+
 template <int C>
-__device__ __forceinline__ void trn_wgrad_body(const TrnDev &P, const int l, const int G, const int pair, const int grp, float *lds) {
+__device__ __forceinline__ void trn_wgrad_body(const WgradPtrs &W_, const TrnDev &P, const int l, const int G, const int pair, const int grp, float *lds) {
     constexpr int NT = (C + 31) / 32, CH = C < 32 ? C : 32, H4 = CH / 4, ITER = (121 * H4 + 255) / 256;
     const int N = P.N, cells = P.cells, KP = (cells + 1) & ~1, NP = N + 2;
     float *D = lds;                                     // [KP][32] draw, this block's co half (rows >= cells zero)
@@ -761,7 +766,7 @@ __device__ __forceinline__ void trn_wgrad_body(const TrnDev &P, const int l, con
     float4 vg[ITER], vr[ITER], va[ITER];
     auto request = [&](int b) {
         const size_t base = (size_t)b * cells * C;
-        const float *gs = P.g[l] + base + tm * 32, *rs = P.raw[l] + base + tm * 32, *as = P.act[l - 1] + base + tn * 32;
+        const float *gs = W_.g + base + tm * 32, *rs = W_.raw + base + tm * 32, *as = W_.act + base + tn * 32;
 #pragma unroll
         for (int k = 0; k < ITER; ++k) {       // (clamped, unconditional: the staging skips the items beyond `total`)
             const int i = min(tid + 256 * k, total - 1), pos = i / H4, c = (i - pos * H4) * 4;
@@ -779,7 +784,7 @@ __device__ __forceinline__ void trn_wgrad_body(const TrnDev &P, const int l, con
         bn_coeffs(P, l, c, mean, inv);
         cM[tid] = mean;
         cI[tid] = inv;
-        cA[tid] = P.bn_w[l][c] * inv;
+        cA[tid] = W_.bnw[c] * inv;
         cK[tid] = (float)(t0 * (double)P.invN);
         cK[32 + tid] = (float)(t1 * (double)P.invN);
     }
@@ -889,7 +894,7 @@ __device__ __forceinline__ f16x8 tr_frag(const unsigned char *p) {
 }
 
 template <int C>
-__device__ __forceinline__ void trn_wgrad16_body(const TrnDev &P, const int l, const int G, const int pair, const int grp, float *lds) {
+__device__ __forceinline__ void trn_wgrad16_body(const WgradPtrs &W_, const TrnDev &P, const int l, const int G, const int pair, const int grp, float *lds) {
     constexpr int NT = (C + 31) / 32, CH = C < 32 ? C : 32, H4 = CH / 4, ITER = (121 * H4 + 255) / 256;
     const int N = P.N, cells = P.cells, KR = N * 16, BR = (N + 3) * 16;
     unsigned char *Dh = reinterpret_cast<unsigned char *>(lds), *Dl = Dh + (size_t)KR * 64;     // [KR][32] f16 draw hi / lo
@@ -905,7 +910,7 @@ __device__ __forceinline__ void trn_wgrad16_body(const TrnDev &P, const int l, c
     float4 vg[ITER], vr[ITER], va[ITER];
     auto request = [&](int b) {
         const size_t base = (size_t)b * cells * C;
-        const float *gs = P.g[l] + base + tm * 32, *rs = P.raw[l] + base + tm * 32, *as = P.act[l - 1] + base + tn * 32;
+        const float *gs = W_.g + base + tm * 32, *rs = W_.raw + base + tm * 32, *as = W_.act + base + tn * 32;
 #pragma unroll
         for (int k = 0; k < ITER; ++k) {       // (clamped, unconditional: the staging skips the items beyond `total`)
             const int i = min(tid + 256 * k, total - 1), pos = i / H4, c = (i - pos * H4) * 4;
@@ -918,7 +923,7 @@ __device__ __forceinline__ void trn_wgrad16_body(const TrnDev &P, const int l, c
     // beside this kernel): requested first, added up while the first board's tensors travel
     // (and before those, the few words the coefficient phase needs -- see trn_conv_body)
     const int cc = tm * 32 + min(tid, CH - 1);
-    const float e_w = P.bn_w[l][cc], e_gmax = __uint_as_float(P.gmax[l]);
+    const float e_w = W_.bnw[cc], e_gmax = __uint_as_float(P.gmax[l]);
     const double2 e_sl = *reinterpret_cast<const double2 *>(P.sums + ((size_t)l * C + cc) * 4);
     float2 pv[16];
     sum_partials_request<CH, 256, 16>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.B, tid, pv);
@@ -1060,15 +1065,15 @@ __global__ __launch_bounds__(256) void k_trn_conv(ConvPtrs Q, int l, TrnDev P) {
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void k_trn_wgrad(TrnDev P, int l, int G) {
+__global__ __launch_bounds__(256) void k_trn_wgrad(WgradPtrs A, int l, int G, TrnDev P) {
     extern __shared__ __align__(16) float lds[];
-    trn_wgrad_body<C>(P, l, G, blockIdx.x, blockIdx.y, lds);
+    trn_wgrad_body<C>(A, P, l, G, blockIdx.x, blockIdx.y, lds);
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void k_trn_wgrad16(TrnDev P, int l, int G) {
+__global__ __launch_bounds__(256) void k_trn_wgrad16(WgradPtrs A, int l, int G, TrnDev P) {
     extern __shared__ __align__(16) float lds[];
-    trn_wgrad16_body<C>(P, l, G, blockIdx.x, blockIdx.y, lds);
+    trn_wgrad16_body<C>(A, P, l, G, blockIdx.x, blockIdx.y, lds);
 }
 
 // (Measured and dropped: one launch per backward layer with both consumers of g_l -- k_trn_conv<BWD>'s workgroups and
@@ -1099,17 +1104,17 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_conv(TrnDev P) 
             P.sums[((size_t)L * C + tid) * 4 + 1] = t1;
         }
         bn_from_sums(t0, t1, P.invN, mean, inv);
-        const float a = P.bn_w[L][tid] * inv;
+        const float a = P.bnwL[tid] * inv;
         cA[tid] = a;
-        cB[tid] = P.bn_b[L][tid] - mean * a;
+        cB[tid] = P.bnbL[tid] - mean * a;
     }
     for (int i = tid; i < 6 * C; i += NTH) W[i] = i < 2 * C ? P.vconv[i] : P.pconv[i - 2 * C];
     if (tid < 12) red[tid] = 0.f;
     const size_t base = (size_t)b * cells * C;
-    const float4 *src = reinterpret_cast<const float4 *>(P.raw[L] + base);
+    const float4 *src = reinterpret_cast<const float4 *>(P.rawL + base);
     const bool has_res = L >= 2;
-    const float4 *res = has_res ? reinterpret_cast<const float4 *>(P.act[L - 2] + base) : nullptr;
-    float4 *dst = reinterpret_cast<float4 *>(P.act[L] + base);
+    const float4 *res = has_res ? reinterpret_cast<const float4 *>(P.actLm2 + base) : nullptr;
+    float4 *dst = reinterpret_cast<float4 *>(P.actL + base);
     const int total = cells * C4;
     float4 va[ITER], vr[ITER];
 #pragma unroll
@@ -1412,7 +1417,7 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_bwd(TrnDev P) {
     __shared__ float pM[C], pI[C];
     const int b = blockIdx.x, tid = threadIdx.x, cells = P.cells, L = P.L;
     const size_t base = (size_t)b * cells * C;
-    const float4 *act4 = reinterpret_cast<const float4 *>(P.act[L] + base), *raw4 = reinterpret_cast<const float4 *>(P.raw[L] + base);
+    const float4 *act4 = reinterpret_cast<const float4 *>(P.actL + base), *raw4 = reinterpret_cast<const float4 *>(P.rawL + base);
     const int total = cells * C4;
     float4 va[ITER], vr[ITER];
 #pragma unroll
@@ -1439,7 +1444,7 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_bwd(TrnDev P) {
         dh[o * 128 + (i - o * cells)] = cA[o] * (g6[i] - cK1[o] - (hraw[i] - cMn[o]) * cIv[o] * cK2[o]);
     }
     __syncthreads();
-    float4 *gL = reinterpret_cast<float4 *>(P.g[L] + base);
+    float4 *gL = reinterpret_cast<float4 *>(P.gL + base);
     float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f}, vmax = 0.f;
     __shared__ float wmax[NTH / 64];
     const int c0 = (tid % C4) * 4;              // NTH is a multiple of C4: a thread's items share their four channels
@@ -1885,6 +1890,7 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     for (int l = 0; l <= L; ++l) {
         d.raw[l] = t->raw[l]; d.act[l] = t->act[l]; d.g[l] = t->g[l]; d.Wf[l] = t->Wf[l]; d.Wb[l] = t->Wb[l];
     }
+    d.rawL = t->raw[L]; d.actL = t->act[L]; d.actLm2 = L >= 2 ? t->act[L - 2] : nullptr; d.gL = t->g[L];
     for (int l = 0; l <= L; ++l) {
         char nm[32];
         snprintf(nm, sizeof nm, "raw%d", l); t->dbg[nm] = {t->raw[l], A * 4};
@@ -2015,6 +2021,8 @@ int azx_trn_bind(AzxTrain *t, int n, const char *const *names, void *const *ptrs
     d.fc3b = (const float *)fc3b->ptr; d.mfw = (const float *)mfw->ptr; d.mfb = (const float *)mfb->ptr;
     {
         for (int l = 0; l <= L; ++l) { d.bn_w[l] = (const float *)bnw[l]->ptr; d.bn_b[l] = (const float *)bnb[l]->ptr; }
+        d.bnwL = d.bn_w[L];
+        d.bnbL = d.bn_b[L];
         std::vector<size_t> gw(L + 3), gb(L + 3);
         std::vector<float *> rm(L + 3), rv(L + 3);
         std::vector<long long *> tk(L + 3);
@@ -2129,8 +2137,9 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
         // (measured with these launches removed: 0.500 ms per step with the fork events, 0.488 without them -- an event
         // costs the data chain ~1 us -- against 0.549 as shipped and 0.681 with the filter gradients in line: two thirds
         // of their 205 us hide under the data chain)
-        if (t->wgrad16) hipLaunchKernelGGL(k_trn_wgrad16<C>, dim3(NT * NT, G), dim3(256), wg16_lds, ws, d, l, G);
-        else hipLaunchKernelGGL(k_trn_wgrad<C>, dim3(NT * NT, G), dim3(256), wg_lds, ws, d, l, G);
+        const WgradPtrs wq = {t->g[l], t->raw[l], t->act[l - 1], d.bn_w[l]};
+        if (t->wgrad16) hipLaunchKernelGGL(k_trn_wgrad16<C>, dim3(NT * NT, G), dim3(256), wg16_lds, ws, wq, l, G, d);
+        else hipLaunchKernelGGL(k_trn_wgrad<C>, dim3(NT * NT, G), dim3(256), wg_lds, ws, wq, l, G, d);
         ConvPtrs q;
         const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= L;
         q.in0 = t->g[l]; q.in1 = t->raw[l];
