@@ -22,10 +22,11 @@
 //   backward : heads, L x k_trn_conv<BWD16> (prologue: BatchNorm backward of the incoming gradient; implicit GEMM with
 //              the flipped / transposed filters; epilogue: skip-connection add, ReLU mask, the next BatchNorm's two
 //              reductions, max |g|), L x k_trn_wgrad16 (split over boards and channel-tile pairs, partial copies), stem
-//   update   : k_trn_finalize (BN gradients, running statistics, small reductions), k_trn_update twice (the tower
-//              filters -- second stage of the filter-gradient reduction in a fixed order -- behind the last
-//              filter-gradient kernel on its stream; everything else at the end of the data chain): SGD IN PLACE in the
-//              trainer's torch tensors
+//   update   : k_trn_update twice (the tower filters -- second stage of the filter-gradient reduction in a fixed order --
+//              behind the last filter-gradient kernel on its stream; everything else at the end of the data chain, each
+//              element's gradient taken from where the backward pass left it -- BatchNorm sums, the stem table's and the
+//              head convolutions' accumulators -- with the running statistics and the loss on the way): SGD IN PLACE in
+//              the trainer's torch tensors
 // Layouts: activations [B][cells][C] fp32; per BatchNorm layer per-board partial pairs (x, x^2) and (g, g xhat), summed
 // in a fixed order by the kernels that consume them (sum_partials), the totals filed as four f64 per channel.
 #include "train.h"
@@ -67,6 +68,8 @@ struct TrnDev {
     const float *prob, *reward;    // [B][cells], [B]
     // parameters (torch tensors, updated in place)
     const float *emb, *w1;         // encoder.weight [3][4], conv1.weight [C][4][3][3]
+    float *embw1_old;              // [12 + C 36] their values at the start of the step (k_trn_prep): each one's gradient
+                                   // is made from the other while k_trn_update is already moving both
     const float *bn_w[TRN_MAXL + 1], *bn_b[TRN_MAXL + 1];      // [L + 1] -> [C]
     const float *vconv, *pconv;    // [2][C], [4][C]
     const float *hbn_w[2], *hbn_b[2];            // value_bn1 (2), move_bn1 (4)
@@ -86,7 +89,7 @@ struct TrnDev {
     float *loss3;
     float *wpart;                  // [L][G][C*C*9] weight-gradient partial sums (index l - 1)
     // (TRN_REP copies each, board b adds into copy b % TRN_REP: 2 K double atomics per cache line and launch cost a
-    // kernel ~4 us -- see the BatchNorm sums --, 256 do not; k_trn_finalize adds the copies up)
+    // kernel ~4 us -- see the BatchNorm sums --, 256 do not; k_trn_update adds the copies up)
     double *stem_dT;               // [TRN_REP][27][C]  dL/d(stem table), summed over the boards (f64 atomics)
     double *hconv_acc;             // [TRN_REP][6][C]   gradient of the two 1x1 head convolutions
     float *grad;                   // flat gradient buffer (offsets in the segment table)
@@ -122,7 +125,7 @@ __device__ __forceinline__ void bn_coeffs(const TrnDev &P, int l, int c, float &
 // 32 K double atomics on 16 cache lines cost a convolution launch ~4.5 us of its ~17) and summed over the boards, in
 // a fixed order, by the kernels that consume them: thread (c = tid % CW, part = tid / CW) takes the boards part,
 // part + PARTS, ...; the parts meet in LDS (`sh`: NTH double2) and threads tid < CW return the totals of channel
-// c0 + tid.  The first consumer's workgroup 0 files the totals in P.sums for everything later (k_trn_finalize, the
+// c0 + tid.  The first consumer's workgroup 0 files the totals in P.sums for everything later (k_trn_update, the
 // backward kernels' bn_coeffs).  Contains a barrier.
 // In two halves so that a kernel can request the partials before its bulk input and add them up when it needs them.
 // The loads are unconditional (a clamped board index, the surplus multiplied away): behind a branch the compiler waits
@@ -1504,7 +1507,7 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_bwd(TrnDev P) {
 }
 
 // =================================================================================================================
-// stem backward: BN_0 backward, then dL/dT[tap][cell value][cout] (this board's share); k_trn_finalize turns the
+// stem backward: BN_0 backward, then dL/dT[tap][cell value][cout] (this board's share); k_trn_update turns the
 // table's gradient into conv1.weight's and the embedding's
 // =================================================================================================================
 template <int C>
@@ -1581,106 +1584,73 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_bwd(TrnDev P) {
 }
 
 // =================================================================================================================
-// finalize: everything small between the backward pass and the update
-//   block 0      stem: dT = sum of the boards' shares -> conv1.weight / encoder.weight gradients
-//   block 1      head 1x1 convolutions: sum of the boards' shares; the loss
-//   blocks 2..   BatchNorm: dgamma / dbeta from the sums, running statistics, num_batches_tracked
-// =================================================================================================================
-struct FinalizeArgs {
-    size_t g_emb, g_w1, g_vconv, g_pconv;           // offsets into the flat gradient buffer
-    const size_t *g_bnw, *g_bnb;                    // [L + 1 + 2] (device): tower layers 0..L, then value_bn1, move_bn1
-    float *const *run_mean, *const *run_var;        // [L + 3] (device)
-    long long *const *tracked;                      // [L + 3] (device)
-};
-
-template <int C>
-__global__ __launch_bounds__(256) void k_trn_finalize(TrnDev P, FinalizeArgs F) {
-    __shared__ float dT[27 * C];
-    const int tid = threadIdx.x, B = P.B, L = P.L;
-    if (blockIdx.x == 0) {
-        for (int i = tid; i < 27 * C; i += 256) {
-            double v[TRN_REP], s = 0;
-#pragma unroll
-            for (int r = 0; r < TRN_REP; ++r) v[r] = P.stem_dT[(size_t)r * 27 * C + i];
-#pragma unroll
-            for (int r = 0; r < TRN_REP; ++r) s += v[r];
-            dT[i] = (float)s;
-        }
-        __syncthreads();
-        for (int i = tid; i < C * 36; i += 256) {       // conv1.weight [co][i4][tap]
-            const int co = i / 36, r = i - co * 36, i4 = r / 9, tap = r - i4 * 9;
-            float s = 0.f;
-            for (int v = 0; v < 3; ++v) s += P.emb[v * 4 + i4] * dT[(tap * 3 + v) * C + co];
-            P.grad[F.g_w1 + i] = s;
-        }
-        if (tid < 12 * 16) {                             // encoder.weight [v][i4]: 16 threads per entry
-            const int e = tid / 16, j = tid % 16, v = e / 4, i4 = e - v * 4;
-            float s = 0.f;
-            for (int k = j; k < 9 * C; k += 16) {
-                const int tap = k / C, co = k - tap * C;
-                s += P.w1[(co * 4 + i4) * 9 + tap] * dT[(tap * 3 + v) * C + co];
-            }
-#pragma unroll
-            for (int sft = 8; sft >= 1; sft >>= 1) s += __shfl_xor(s, sft);
-            if (j == 0) P.grad[F.g_emb + e] = s;
-        }
-    } else if (blockIdx.x == 1) {
-        for (int i = tid; i < 6 * C; i += 256) {
-            double v[TRN_REP], sd = 0;
-#pragma unroll
-            for (int r = 0; r < TRN_REP; ++r) v[r] = P.hconv_acc[(size_t)r * 6 * C + i];
-#pragma unroll
-            for (int r = 0; r < TRN_REP; ++r) sd += v[r];
-            const float s = (float)sd;
-            if (i < 2 * C) P.grad[F.g_vconv + i] = s;
-            else P.grad[F.g_pconv + i - 2 * C] = s;
-        }
-        if (tid == 0) {
-            const float lv = (float)(P.lossacc[0] / (double)B), lm = (float)(P.lossacc[1] / (double)B);
-            P.loss3[0] = lv + lm;
-            P.loss3[1] = lv;
-            P.loss3[2] = lm;
-        }
-    } else {
-        // (layer, channel) pairs: tower BN layers have C channels, the two head BNs 2 and 4
-        const int total = (L + 1) * C + 6;
-        const double Nn = 1.0 / (double)P.invN;
-        for (int e = (blockIdx.x - 2) * 256 + tid; e < total; e += (gridDim.x - 2) * 256) {
-            int lay, c;
-            const double *s;
-            if (e < (L + 1) * C) { lay = e / C; c = e - lay * C; s = P.sums + ((size_t)lay * C + c) * 4; }
-            else { const int h = e - (L + 1) * C; lay = h < 2 ? L + 1 : L + 2; c = h < 2 ? h : h - 2; s = P.hsums + (size_t)h * 4; }
-            P.grad[F.g_bnw[lay] + c] = (float)s[3];
-            P.grad[F.g_bnb[lay] + c] = (float)s[2];
-            const double mean = s[0] / Nn, var = s[1] / Nn - mean * mean;
-            float *rm = F.run_mean[lay] + c, *rv = F.run_var[lay] + c;
-            *rm = (float)(0.9 * (double)*rm + 0.1 * mean);
-            *rv = (float)(0.9 * (double)*rv + 0.1 * (var > 0 ? var : 0) * Nn / (Nn - 1.0));
-            if (c == 0) *F.tracked[lay] += 1;
-        }
-    }
-}
-
-// =================================================================================================================
 // SGD update of every tensor, in place (torch.optim.SGD: d = g + wd p; buf = mu buf + d; p -= lr buf).  A block
-// handles 256 consecutive elements of one segment.
+// handles 256 consecutive elements of one segment; the gradient of an element comes from wherever the backward pass left
+// it -- there is no kernel between the backward pass and the update:
+//   SEG_CONV    tower filter: the G partial copies of k_trn_wgrad, summed here in a fixed order
+//   SEG_PLAIN   already in the flat gradient buffer (the FC layers: k_trn_heads_wgrad)
+//   SEG_BNW / SEG_BNB  BatchNorm gamma / beta: the layer's sums {x, x^2, g, g xhat}; the gamma thread also moves the
+//               running statistics (momentum 0.1, unbiased variance) and num_batches_tracked
+//   SEG_HCONV   the heads' 1x1 convolutions: the boards' shares (TRN_REP copies of f64 atomics)
+//   SEG_W1 / SEG_EMB  conv1.weight / encoder.weight from the stem table's gradient dT and each OTHER's value at the
+//               start of the step (embw1_old: this kernel is moving both); the SEG_EMB block also writes the loss
 // =================================================================================================================
+enum { SEG_PLAIN = 0, SEG_CONV, SEG_BNW, SEG_BNB, SEG_HCONV, SEG_W1, SEG_EMB };
 struct Segment {
     float *p, *mom;
     size_t n, goff;
-    int layer;          // >= 1: tower conv filter of that layer; 0: anything else
+    int layer;          // SEG_CONV: tower conv layer 1..L; SEG_BNW / SEG_BNB: BatchNorm 0..L, L + 1 = value_bn1, L + 2 = move_bn1
+    int kind, aux;      // SEG_HCONV: offset of the tensor in the [6][C] head-conv gradient
+    float *run_mean, *run_var;
+    long long *tracked;
 };
 
 template <int C>
 __global__ __launch_bounds__(256) void k_trn_update(TrnDev P, const Segment *segs, const int2 *blocks, int G) {
+    __shared__ float dT[27 * C];
     const int2 bk = blocks[blockIdx.x];
     const Segment S = segs[bk.x];
     const float lr = P.hp[0], mu = P.hp[1], wd = P.hp[2];
-    const size_t ei = (size_t)bk.y * 256 + threadIdx.x;
+    const int tid = threadIdx.x, L = P.L;
+    if (S.kind == SEG_EMB) {
+        // (one block: 12 entries) dT = the copies' sum, then encoder.weight [v][i4] with 16 threads per entry
+        for (int i = tid; i < 27 * C; i += 256) {
+            double v[TRN_REP], sd = 0;
+#pragma unroll
+            for (int r = 0; r < TRN_REP; ++r) v[r] = P.stem_dT[(size_t)r * 27 * C + i];
+#pragma unroll
+            for (int r = 0; r < TRN_REP; ++r) sd += v[r];
+            dT[i] = (float)sd;
+        }
+        __syncthreads();
+        if (tid == 255) {
+            const float lv = (float)(P.lossacc[0] / (double)P.B), lm = (float)(P.lossacc[1] / (double)P.B);
+            P.loss3[0] = lv + lm;
+            P.loss3[1] = lv;
+            P.loss3[2] = lm;
+        }
+        if (tid >= 12 * 16) return;
+        const int e = tid / 16, j = tid % 16, v = e / 4, i4 = e - v * 4;
+        const float *w1 = P.embw1_old + 12;
+        float s = 0.f;
+        for (int k = j; k < 9 * C; k += 16) {
+            const int tap = k / C, co = k - tap * C;
+            s += w1[(co * 4 + i4) * 9 + tap] * dT[(tap * 3 + v) * C + co];
+        }
+#pragma unroll
+        for (int sft = 8; sft >= 1; sft >>= 1) s += __shfl_xor(s, sft);
+        if (j != 0) return;
+        P.grad[S.goff + e] = s;
+        const float p = S.p[e], d = s + wd * p, buf = mu * S.mom[e] + d;
+        S.mom[e] = buf;
+        S.p[e] = p - lr * buf;
+        return;
+    }
+    const size_t ei = (size_t)bk.y * 256 + tid;
     if (ei >= S.n) return;
     size_t e = ei;
     float gr;
-    if (S.layer >= 1) {
+    if (S.kind == SEG_CONV) {
         // the G partial copies of k_trn_wgrad, laid out [tap][co][ci], summed in a fixed order: threads walk THAT
         // order (coalesced reads) and touch the filter / momentum / gradient at (co C + ci) 9 + tap.  All of a
         // thread's reads are requested before the first is used (unconditional at a clamped copy index: in a counted
@@ -1695,10 +1665,45 @@ __global__ __launch_bounds__(256) void k_trn_update(TrnDev P, const Segment *seg
 #pragma unroll
         for (int g = 0; g < TRN_WG_GROUPS; ++g) s4[g & 3] += g < G ? v[g] : 0.f;
         gr = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-        P.grad[S.goff + e] = gr;
+    } else if (S.kind == SEG_BNW || S.kind == SEG_BNB) {
+        const int c = (int)ei;
+        const double *sm = S.layer <= L ? P.sums + ((size_t)S.layer * C + c) * 4 : P.hsums + (size_t)(S.layer == L + 1 ? c : 2 + c) * 4;
+        const double s0 = sm[0], s1 = sm[1], s2 = sm[2], s3 = sm[3];
+        gr = (float)(S.kind == SEG_BNW ? s3 : s2);
+        if (S.kind == SEG_BNW) {
+            const double Nn = 1.0 / (double)P.invN, mean = s0 / Nn, var = s1 / Nn - mean * mean;
+            float *rm = S.run_mean + c, *rv = S.run_var + c;
+            *rm = (float)(0.9 * (double)*rm + 0.1 * mean);
+            *rv = (float)(0.9 * (double)*rv + 0.1 * (var > 0 ? var : 0) * Nn / (Nn - 1.0));
+            if (c == 0) *S.tracked += 1;
+        }
+    } else if (S.kind == SEG_HCONV) {
+        double v[TRN_REP], sd = 0;
+#pragma unroll
+        for (int r = 0; r < TRN_REP; ++r) v[r] = P.hconv_acc[(size_t)r * 6 * C + S.aux + ei];
+#pragma unroll
+        for (int r = 0; r < TRN_REP; ++r) sd += v[r];
+        gr = (float)sd;
+    } else if (S.kind == SEG_W1) {
+        // conv1.weight [co][i4][tap] = sum over the three cell values of embedding[v][i4] dT[tap][v][co]
+        const int co = (int)ei / 36, r = (int)ei - co * 36, i4 = r / 9, tap = r - i4 * 9;
+        double v[3][TRN_REP];
+#pragma unroll
+        for (int cv = 0; cv < 3; ++cv)
+#pragma unroll
+            for (int rr = 0; rr < TRN_REP; ++rr) v[cv][rr] = P.stem_dT[(size_t)rr * 27 * C + (tap * 3 + cv) * C + co];
+        gr = 0.f;
+#pragma unroll
+        for (int cv = 0; cv < 3; ++cv) {
+            double sd = 0;
+#pragma unroll
+            for (int rr = 0; rr < TRN_REP; ++rr) sd += v[cv][rr];
+            gr += P.embw1_old[cv * 4 + i4] * (float)sd;
+        }
     } else {
         gr = P.grad[S.goff + e];
     }
+    if (S.kind != SEG_PLAIN) P.grad[S.goff + e] = gr;
     const float p = S.p[e], d = gr + wd * p, buf = mu * S.mom[e] + d, np = p - lr * buf;
     S.mom[e] = buf;
     S.p[e] = np;
@@ -1727,6 +1732,7 @@ __global__ __launch_bounds__(256) void k_trn_prep(TrnDev P) {
             P.stemT[e] = sum;
         }
         if (e <= (size_t)P.L) P.gmax[e] = 0u;
+        if (e < (size_t)12 + C * 36) P.embw1_old[e] = e < 12 ? P.emb[e] : P.w1[e - 12];
         if (e == 0) {
             const unsigned int step = *P.step_ctr;
             const float *slot = P.hp_ring + (size_t)(step % TRN_HP_SLOTS) * 4;
@@ -1778,7 +1784,6 @@ struct AzxTrain {
     Segment *segs = nullptr;
     int2 *blocks = nullptr;
     int n_blocks = 0, n_conv_blocks = 0;
-    FinalizeArgs fin;
     HeadGradOffs hoffs;
     std::vector<size_t> conv_goff;
     float *hp_dev = nullptr, *hp_ring = nullptr;       // hp_ring: pinned host memory the prep kernel reads
@@ -1882,7 +1887,8 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     }
     d.wmax = d.gmax + (TRN_MAXL + 2);
     d.fsc = talloc<float4>(t, TRN_MAXL + 2);
-    if (!d.fsc) {
+    d.embw1_old = talloc<float>(t, (size_t)12 + C * 36);
+    if (!d.fsc || !d.embw1_old) {
         azx_trn_destroy(t);
         return tfail(AZX_ENOMEM, "train: hipMalloc failed");
     }
@@ -2023,18 +2029,6 @@ int azx_trn_bind(AzxTrain *t, int n, const char *const *names, void *const *ptrs
         for (int l = 0; l <= L; ++l) { d.bn_w[l] = (const float *)bnw[l]->ptr; d.bn_b[l] = (const float *)bnb[l]->ptr; }
         d.bnwL = d.bn_w[L];
         d.bnbL = d.bn_b[L];
-        std::vector<size_t> gw(L + 3), gb(L + 3);
-        std::vector<float *> rm(L + 3), rv(L + 3);
-        std::vector<long long *> tk(L + 3);
-        for (int i = 0; i < L + 3; ++i) {
-            gw[i] = bnw[i]->goff; gb[i] = bnb[i]->goff;
-            rm[i] = (float *)rmean[i]->ptr; rv[i] = (float *)rvar[i]->ptr; tk[i] = (long long *)trk[i]->ptr;
-        }
-        t->fin.g_emb = emb->goff; t->fin.g_w1 = w1->goff; t->fin.g_vconv = vconv->goff; t->fin.g_pconv = pconv->goff;
-        t->fin.g_bnw = upload_table(t, gw); t->fin.g_bnb = upload_table(t, gb);
-        t->fin.run_mean = upload_table(t, rm); t->fin.run_var = upload_table(t, rv); t->fin.tracked = upload_table(t, tk);
-        if (!t->fin.g_bnw || !t->fin.g_bnb || !t->fin.run_mean || !t->fin.run_var || !t->fin.tracked)
-            return tfail(AZX_ENOMEM, "train: uploading the parameter tables failed");
     }
     t->hoffs = {fc2w->goff, fc2b->goff, fc3w->goff, fc3b->goff, mfw->goff, mfb->goff};
     // update segments and the block table
@@ -2045,12 +2039,24 @@ int azx_trn_bind(AzxTrain *t, int n, const char *const *names, void *const *ptrs
         std::vector<int2> blocks, rest;
         for (Bound *b : params) {
             Segment s;
-            s.p = (float *)b->ptr; s.mom = b->mom; s.n = b->n; s.goff = b->goff; s.layer = 0;
-            for (int l = 1; l <= L; ++l) if (conv[l] == b) s.layer = l;
-            if (s.layer) { t->conv_goff.resize(L + 1); t->conv_goff[s.layer] = b->goff; }
+            memset(&s, 0, sizeof s);
+            s.p = (float *)b->ptr; s.mom = b->mom; s.n = b->n; s.goff = b->goff; s.kind = SEG_PLAIN;
+            for (int l = 1; l <= L; ++l) if (conv[l] == b) { s.layer = l; s.kind = SEG_CONV; }
+            for (int i = 0; i < L + 3; ++i) {
+                if (bnw[i] == b) {
+                    s.layer = i; s.kind = SEG_BNW;
+                    s.run_mean = (float *)rmean[i]->ptr; s.run_var = (float *)rvar[i]->ptr; s.tracked = (long long *)trk[i]->ptr;
+                }
+                if (bnb[i] == b) { s.layer = i; s.kind = SEG_BNB; }
+            }
+            if (b == vconv) { s.kind = SEG_HCONV; s.aux = 0; }
+            if (b == pconv) { s.kind = SEG_HCONV; s.aux = 2 * C; }
+            if (b == w1) s.kind = SEG_W1;
+            if (b == emb) s.kind = SEG_EMB;
+            if (s.kind == SEG_CONV) { t->conv_goff.resize(L + 1); t->conv_goff[s.layer] = b->goff; }
             const int si = (int)segs.size();
             segs.push_back(s);
-            for (size_t e = 0; e < b->n; e += 256) (s.layer ? blocks : rest).push_back(make_int2(si, (int)(e / 256)));
+            for (size_t e = 0; e < b->n; e += 256) (s.kind == SEG_CONV ? blocks : rest).push_back(make_int2(si, (int)(e / 256)));
         }
         t->n_conv_blocks = (int)blocks.size();
         blocks.insert(blocks.end(), rest.begin(), rest.end());
@@ -2163,8 +2169,6 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
     if (!join_side()) return tfail(AZX_EHIP, "train: joining the weight-gradient stream failed");
     if (t->n_conv_blocks > 0)
         hipLaunchKernelGGL(k_trn_update<C>, dim3(t->n_conv_blocks), dim3(256), 0, ws, d, (const Segment *)t->segs, (const int2 *)t->blocks, G);
-    const int fin_blocks = 2 + ((L + 1) * C + 6 + 255) / 256;
-    hipLaunchKernelGGL(k_trn_finalize<C>, dim3(fin_blocks), dim3(256), 0, st, d, t->fin);
     if (t->n_blocks > t->n_conv_blocks)
         hipLaunchKernelGGL(k_trn_update<C>, dim3(t->n_blocks - t->n_conv_blocks), dim3(256), 0, st, d, (const Segment *)t->segs,
                            (const int2 *)t->blocks + t->n_conv_blocks, G);
