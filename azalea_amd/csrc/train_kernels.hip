@@ -222,8 +222,11 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_fwd(TrnDev P) {
         __shared__ float sW[TRN_MAXL + 1], sBn[TRN_MAXL + 1];
         const int lane = tid & 63, wave = tid >> 6;
         for (int l = 1 + wave; l <= P.L; l += NW) {
-            float m = 0.f;
-            for (int j = lane; j < NB; j += 64) m = fmaxf(m, P.wpmax[l * NB + j]);
+            float m = 0.f, pm[(NB + 63) / 64];
+#pragma unroll
+            for (int u = 0; u < (NB + 63) / 64; ++u) pm[u] = P.wpmax[l * NB + min(lane + 64 * u, NB - 1)];     // (unconditional: all in flight)
+#pragma unroll
+            for (int u = 0; u < (NB + 63) / 64; ++u) m = fmaxf(m, pm[u]);
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
             if (lane == 0) {
@@ -255,7 +258,8 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_fwd(TrnDev P) {
         for (unsigned idx = b * NTH + tid; idx < 2 * items; idx += gridDim.x * NTH) {
             const bool bwd = idx >= items;
             const unsigned it = bwd ? idx - items : idx;
-            const int l = (int)(it / per) + 1;
+            // (a wave's 64 items are one layer's -- `per` is a multiple of 64 --: the layer's pointers are scalar loads)
+            const int l = __builtin_amdgcn_readfirstlane((int)(it / per) + 1);
             unsigned r = it - (unsigned)(l - 1) * per;
             const int ln = (int)(r & 63u); r >>= 6;
             const int nt = (int)(r % NTl); r /= NTl;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_fwd(TrnDev P) {
             for (int t = 0; t < 8; ++t) {
                 // forward: n = co, k = ci; backward-data: n = ci, k = co
                 const int co = bwd ? k0 + t : n, ci = bwd ? n : k0 + t;
-                const float v = n < C ? w[((size_t)co * C + ci) * 9 + tap] * sc : 0.f;
+                const float v = (NTl * 32 == C || n < C) ? w[((size_t)min(co, C - 1) * C + min(ci, C - 1)) * 9 + tap] * sc : 0.f;
                 hi[t] = (_Float16)v;
                 lo[t] = (_Float16)(v - (float)hi[t]);
             }
