@@ -251,7 +251,7 @@ def train_step_flops(n, blocks, chans, batch):
     return 3.0 * batch * flop_per_position(n, blocks, chans)
 
 
-TRAIN_MODES = ("eager", "eager_nosync", "hip_graph", "native")
+TRAIN_MODES = ("eager", "eager_nosync", "hip_graph", "native_fp32", "native")
 
 
 def train_step_mode(args, local_rank, torch, mode):
@@ -276,7 +276,7 @@ def train_step_mode(args, local_rank, torch, mode):
     net = HexNetwork(board_size=args.board, num_blocks=args.blocks, base_chans=args.chans).to(dev)
     opt = optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
     gs = (GraphedTrainStep(net, opt, B, dev) if mode == "hip_graph" else
-          NativeTrainStep(net, opt, B, dev) if mode == "native" else None)
+          NativeTrainStep(net, opt, B, dev) if mode in ("native", "native_fp32") else None)
     n_steps = steps if gs is not None else 60
     for i in range(n_steps + warm):
         if i == warm:
@@ -300,7 +300,7 @@ def train_step_mode(args, local_rank, torch, mode):
     dt = time.perf_counter() - t0
     out = {"steps_per_sec": n_steps / dt, "ms_per_step": 1e3 * dt / n_steps, "positions_per_sec": n_steps * B / dt,
            "steps": n_steps, "ring_rows": len(buf)}
-    if mode == "native":
+    if mode in ("native", "native_fp32"):
         # the step alone (inputs resident, no collate): HIP events on torch's stream around `steps` launches
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -312,8 +312,9 @@ def train_step_mode(args, local_rank, torch, mode):
         fl = train_step_flops(args.board, args.blocks, args.chans, B)
         out.update({"step_only_ms": ms, "step_only_steps_per_sec": 1e3 / ms,
                     "algorithmic_tflops": fl / (ms * 1e-3) / 1e12,
-                    "arithmetic": "split f16 (hi, lo) x3 on v_mfma_f32_32x32x16_f16, fp32 accumulate, operands scaled per layer "
-                                  "by powers of two; AZX_TRAIN_FWD / _BWD / _WGRAD=fp32 select the exact-fp32 MFMA kernels",
+                    "arithmetic": ("exact fp32 on v_mfma_f32_32x32x2_f32 (AZX_TRAIN_FWD / _BWD / _WGRAD=fp32)" if mode == "native_fp32" else
+                                   "split f16 (hi, lo) x3 on v_mfma_f32_32x32x16_f16, fp32 accumulate, operands scaled per layer "
+                                   "by powers of two; AZX_TRAIN_FWD / _BWD / _WGRAD=fp32 select the exact-fp32 MFMA kernels"),
                     "frac_of_f16_mfma_peak": fl / (ms * 1e-3) / 1e12 / 2500.0,
                     "issued_frac_of_f16_mfma_peak": 3.0 * fl / (ms * 1e-3) / 1e12 / 2500.0,
                     "vs_fp32_mfma_peak": fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
@@ -328,8 +329,9 @@ def run_train_step(args, local_rank, torch):
     """SURVEY 8(f).4 beside the path: the reference's training step (policy_trainer.py:123-142) at its own batch of 128
     (config/hex11_train_config.yml), fed from the HBM replay ring, four ways: as the reference runs it (eager, a host
     sync per step for loss.item()), eager without that sync, the same stock kernels captured as a HIP graph
-    (policy_trainer.GraphedTrainStep), and the hand-written step (native_train.NativeTrainStep: fp32-MFMA kernels,
-    csrc/train_kernels.hip; no autograd, no MIOpen).  Each mode runs in a child process of its own."""
+    (policy_trainer.GraphedTrainStep), and the hand-written step (native_train.NativeTrainStep, csrc/train_kernels.hip; no
+    autograd, no MIOpen) -- with its exact-fp32 MFMA kernels (`native_fp32`: AZX_TRAIN_FWD / _BWD / _WGRAD=fp32) and as it
+    ships, on the scaled split-f16 arithmetic (`native`).  Each mode runs in a child process of its own."""
     import subprocess
     out = {"what": "policy_trainer.supervised_step(train=True): %dx%d on %dx%d, SGD(momentum 0.9, weight decay 1e-4), "
                    "batch 128 collated from a 20000-row HBM ring, fp32; every mode in a fresh process"
@@ -338,11 +340,14 @@ def run_train_step(args, local_rank, torch):
         cmd = [sys.executable, os.path.abspath(__file__), "--train-step-only", mode, "--board", str(args.board),
                "--blocks", str(args.blocks), "--chans", str(args.chans)]
         env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank)))
+        if mode == "native_fp32":
+            env.update(AZX_TRAIN_FWD="fp32", AZX_TRAIN_BWD="fp32", AZX_TRAIN_WGRAD="fp32")
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         out[mode] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": (r.stderr or r.stdout)[-400:]}
     if all("steps_per_sec" in out[m] for m in TRAIN_MODES):
         out["speedup_native_vs_hip_graph"] = out["native"]["steps_per_sec"] / out["hip_graph"]["steps_per_sec"]
+        out["speedup_split_f16_vs_fp32_kernels"] = out["native"]["steps_per_sec"] / out["native_fp32"]["steps_per_sec"]
         out["speedup_native_vs_reference_style_eager"] = out["native"]["steps_per_sec"] / out["eager"]["steps_per_sec"]
         out["speedup_native_vs_eager_nosync"] = out["native"]["steps_per_sec"] / out["eager_nosync"]["steps_per_sec"]
         out["speedup_hip_graph_vs_eager_nosync"] = out["hip_graph"]["steps_per_sec"] / out["eager_nosync"]["steps_per_sec"]
