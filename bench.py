@@ -318,7 +318,7 @@ def train_step_mode(args, local_rank, torch, mode):
                     "frac_of_f16_mfma_peak": fl / (ms * 1e-3) / 1e12 / 2500.0,
                     "issued_frac_of_f16_mfma_peak": 3.0 * fl / (ms * 1e-3) / 1e12 / 2500.0,
                     "vs_fp32_mfma_peak": fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
-                    "bound": "launch chain: ~40 dependent kernels of 13-17 us whose matrix work is ~1.5 us each (DESIGN 8.4)",
+                    "bound": "launch chain: ~31 dependent kernels of 12-16 us on the data stream whose matrix work is ~1.5 us each (DESIGN 8.4)",
                     "flop_per_step": fl})
         gs.close()
     E.close()
