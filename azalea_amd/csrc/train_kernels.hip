@@ -963,10 +963,16 @@ __device__ __forceinline__ void trn_wgrad16_body(const WgradPtrs &W_, const TrnD
         float4 *z = reinterpret_cast<float4 *>(lds);
         for (int i = tid; i < (KR + BR) * 128 / 16; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // The nine taps are shared out over the waves (wave w: taps w, w + 4 and, wave 0, tap 8), every wave walks all the
-    // board rows: a tap's tile is then complete in one wave's accumulators and leaves for HBM straight from them (C/D
-    // layout: a register's lanes 0..31 are 32 consecutive ci of one co: 128-byte rows) -- no reduction over the waves.
-    const int wv = __builtin_amdgcn_readfirstlane(wave), ntap = wv == 0 ? 3 : 2;
+    // The nine taps are shared out by COLUMN: wave w < 3 owns dx = w - 1 and its three dy, every owner walks all the
+    // board rows; the fourth wave only helps with the staging.  A tap's tile is then complete in one wave's accumulators
+    // and leaves for HBM straight from them (C/D layout: a register's lanes 0..31 are 32 consecutive ci of one co:
+    // 128-byte rows) -- no reduction over the waves -- and, the point of the column: the input fragment of (row s, dy)
+    // is the fragment of (row s + dy, 0), so a k-step needs ONE new input fragment (row s + 2, requested two rows
+    // ahead) and rotates three.  That is 8 transposed reads per k-step (4 draw + 4 input: hi, lo x two halves of k)
+    // instead of 16: a wave can have 15 LDS operations outstanding (lgkmcnt is four bits), and with 32 in a k-step the
+    // loop ran at two LDS latencies per step -- 565 cycles against 288 of MFMA.
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const bool owner = wv < 3;
     f32x16 acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -978,12 +984,8 @@ __device__ __forceinline__ void trn_wgrad16_body(const WgradPtrs &W_, const TrnD
     // this lane's corner of the transposed reads: row 8 (lane >> 5) + ((lane & 15) >> 2) of the k-step, channels
     // 16 ((lane >> 4) & 1) + 4 (lane & 3) ..
     const int frag_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-    int toff[3];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        const int t = wv + 4 * u < 9 ? wv + 4 * u : 8;
-        toff[u] = (17 + (t / 3 - 1) * 16 + (t % 3 - 1)) * 64 + frag_off;
-    }
+    // input fragment of board row r (r = -1 .. N: the zero border included) in this wave's column
+    const int col_off = (17 + (owner ? wv - 1 : 0)) * 64 + frag_off;
     for (int b = grp; b < P.B; b += G) {
 #pragma unroll
         for (int k = 0; k < ITER; ++k) {
@@ -1011,49 +1013,43 @@ __device__ __forceinline__ void trn_wgrad16_body(const WgradPtrs &W_, const TrnD
         __syncthreads();
         if (b + G < P.B) request(b + G);                 // travels under this board's k-loop
         TS_MARK(1)
-        // board row s = one k-step; the fragments of row s + 1 are requested before row s's MFMAs (every lane takes
-        // part in a transposed read: the loop bounds are uniform)
-        f16x8 dhi = tr_frag(Dh + frag_off), dlo = tr_frag(Dl + frag_off), bhi[3], blo[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            bhi[u] = tr_frag(Bh + toff[u]);
-            blo[u] = tr_frag(Bl + toff[u]);
-        }
-        for (int s = 0; s < N; ++s) {
-            const int sn = s + 1 < N ? s + 1 : s;
-            const size_t ko = (size_t)sn * 16 * 64;
-            const f16x8 ndhi = tr_frag(Dh + frag_off + ko), ndlo = tr_frag(Dl + frag_off + ko);
-            f16x8 nbhi[3], nblo[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                nbhi[u] = tr_frag(Bh + toff[u] + ko);
-                nblo[u] = tr_frag(Bl + toff[u] + ko);
+        if (owner) {
+            // board row s = one k-step (every lane takes part in a transposed read: the branch and the loop bounds are
+            // uniform).  in0 / in1 / in2 = the input fragments of rows s - 1, s, s + 1
+            f16x8 dhi = tr_frag(Dh + frag_off), dlo = tr_frag(Dl + frag_off);
+            f16x8 h0 = tr_frag(Bh + col_off - 16 * 64), l0 = tr_frag(Bl + col_off - 16 * 64);
+            f16x8 h1 = tr_frag(Bh + col_off), l1 = tr_frag(Bl + col_off);
+            f16x8 h2 = tr_frag(Bh + col_off + 16 * 64), l2 = tr_frag(Bl + col_off + 16 * 64);
+            for (int s = 0; s < N; ++s) {
+                const int sn = s + 1 < N ? s + 1 : s;
+                const f16x8 ndhi = tr_frag(Dh + frag_off + (size_t)sn * 16 * 64), ndlo = tr_frag(Dl + frag_off + (size_t)sn * 16 * 64);
+                // row s + 2 (for the last k-step a row inside the image that is never used)
+                const size_t r3 = (size_t)(s + 2 <= N ? s + 2 : N) * 16 * 64;
+                const f16x8 h3 = tr_frag(Bh + col_off + r3), l3 = tr_frag(Bl + col_off + r3);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, h0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, h1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, h2, acc[2], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, l0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, l1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, l2, acc[2], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, h0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, h1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, h2, acc[2], 0, 0, 0);
+                dhi = ndhi; dlo = ndlo;
+                h0 = h1; l0 = l1; h1 = h2; l1 = l2; h2 = h3; l2 = l3;
             }
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, bhi[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, bhi[1], acc[1], 0, 0, 0);
-            if (ntap == 3) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, bhi[2], acc[2], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, blo[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, blo[1], acc[1], 0, 0, 0);
-            if (ntap == 3) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, blo[2], acc[2], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, bhi[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, bhi[1], acc[1], 0, 0, 0);
-            if (ntap == 3) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, bhi[2], acc[2], 0, 0, 0);
-            dhi = ndhi;
-            dlo = ndlo;
-#pragma unroll
-            for (int u = 0; u < 3; ++u) { bhi[u] = nbhi[u]; blo[u] = nblo[u]; }
         }
         __syncthreads();
         TS_MARK(2)
     }
-    // the scale leaves here
+    // the scale leaves here: tap (dy = u - 1, dx = wave - 1) is tap index 3 u + wave
     const float unscale = cS[1];
     float *part = P.wpart + ((size_t)(l - 1) * G + grp) * ((size_t)C * C * 9);
     const int li = lane & 31, lh = lane >> 5, ci = tn * 32 + li;
+    if (owner) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        if (u < ntap) {
-            const int t = wv + 4 * u;
+        for (int u = 0; u < 3; ++u) {
+            const int t = 3 * u + wv;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int co = tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
