@@ -434,9 +434,10 @@ __device__ __forceinline__ void trn_conv_body(const ConvPtrs &A, const TrnDev &P
     for (int k = 0; k < ITER; ++k) v1[k] = src1[min(tid + 256 * k, total - 1)];
     // ---- BWD: what the epilogue reads per output element (the ReLU mask's activation, the BatchNorm input of layer
     // l - 1 and the skip gradient, this block's 32 channels), requested when the k-loop is done.  Requesting them earlier
-    // was measured twice and lost twice: before the fp32 k-loop (0.884 vs 0.863 ms per step: they queue ahead of the
-    // first taps' filter fragments in the in-order vmcnt) and, with the split-f16 k-loop, together with the inputs
-    // (18.3 vs 17.1 us per launch: 12 more 16-byte loads per thread ahead of the staging's).
+    // was measured three times and lost three times: before the fp32 k-loop (0.884 vs 0.863 ms per step: they queue
+    // ahead of the first taps' filter fragments in the in-order vmcnt); with the split-f16 k-loop, together with the
+    // inputs (18.3 vs 17.1 us per launch: 12 more 16-byte loads per thread ahead of the staging's); and behind the last
+    // tap's filter fragments, to travel under the last two taps' MFMAs (15.8 vs 15.6 us, 0.496 vs 0.487 ms per step).
     constexpr int LDO = 36, CHo = C < 32 ? C : 32, O4 = CHo / 4, ITERO = (121 * O4 + 255) / 256;
     const int totalo = cells * O4;
     float4 ea[ITERO], er[ITERO], es[ITERO];
