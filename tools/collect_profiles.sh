@@ -9,7 +9,7 @@ cp gpurun_out/r4/summary/kernel_durations.json profiles/r4_selfplay_kernel_durat
 tail -1 gpurun_out/bench_r4.json > profiles/r4_selfplay_bench.json
 cp gpurun_out/prof_train_r4/kernel_stats.csv profiles/r4_train_step_kernel_stats.csv
 (echo "hand-written training step (split-f16 kernels), 6x64 on 11x11, batch 128: per-kernel time with the launches in line (AZX_TRAIN_GRAPH=0 AZX_TRAIN_FORK=0), 30 steps"; cat gpurun_out/prof_train_r4.txt) > profiles/r4_train_step_kernel_summary.txt
-cp gpurun_out/prof_traintl_r4.txt profiles/r4_train_step_timeline.txt
+(echo "one step as it ships (two streams) under rocprofv3 --kernel-trace.  NOTE: traced, the HOST needs ~0.7 ms to queue a step (0.25 ms untraced,"; echo "0.49 ms of device time per step untraced): the gaps between kernels below are the host's; read the durations and the two-stream order."; cat gpurun_out/prof_traintl_r4.txt) > profiles/r4_train_step_timeline.txt
 grep -v "NCCL\|RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|amdgpu.ids" gpurun_out/stamps_r4.txt > profiles/r4_train_step_phase_stamps.txt
 tail -1 gpurun_out/train_loop_r4.json > profiles/r4_train_loop_bench.json
 cp gpurun_out/perf_floor.json profiles/r4_perf_floor.json
