@@ -584,22 +584,31 @@ __device__ __forceinline__ void trn_conv_body(const ConvPtrs &A, const TrnDev &P
 #pragma unroll
         for (int q = 0; q < Q16; ++q) { wc[q][0] = w16[(size_t)q * NT * 128]; wc[q][1] = w16[(size_t)q * NT * 128 + 64]; }
         const unsigned char *Xb = reinterpret_cast<const unsigned char *>(X);
+        // The activation fragments of tap t + 1 (8 LDS reads) are requested BEFORE tap t's MFMAs, like the filter
+        // fragments: left to itself the compiler sinks every LDS read to just ahead of the MFMA that uses it and the
+        // k-loop runs at one LDS latency per k-step (8.4 K cycles for 3.5 K of MFMA).  The scheduling barriers are what
+        // keeps the requests where they are written.
+        uint4 ah[Q16], al[Q16], nh[Q16], nl[Q16];
+        auto areq = [&](int tap, uint4 (&h)[Q16], uint4 (&lo_)[Q16]) {
+            const int yy = ry + tap / 3 - 1, xx = rx + tap % 3 - 1;
+            const bool ok = rvalid && yy >= 0 && yy < N && xx >= 0 && xx < N;
+            const unsigned char *arow = Xb + (size_t)(ok ? yy * N + xx : cells) * ROWB + 16 * lh;
+#pragma unroll
+            for (int q = 0; q < Q16; ++q) {
+                h[q] = *reinterpret_cast<const uint4 *>(arow + 32 * q);
+                lo_[q] = *reinterpret_cast<const uint4 *>(arow + 2 * C + 32 * q);
+            }
+        };
+        areq(0, ah, al);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             if (tap < 8) {
                 const uint4 *wt = w16 + (size_t)(tap + 1) * Q16 * NT * 128;
 #pragma unroll
                 for (int q = 0; q < Q16; ++q) { wn[q][0] = wt[(size_t)q * NT * 128]; wn[q][1] = wt[(size_t)q * NT * 128 + 64]; }
+                areq(tap + 1, nh, nl);
             }
-            const int yy = ry + tap / 3 - 1, xx = rx + tap % 3 - 1;
-            const bool ok = rvalid && yy >= 0 && yy < N && xx >= 0 && xx < N;
-            const unsigned char *arow = Xb + (size_t)(ok ? yy * N + xx : cells) * ROWB + 16 * lh;
-            uint4 ah[Q16], al[Q16];
-#pragma unroll
-            for (int q = 0; q < Q16; ++q) {
-                ah[q] = *reinterpret_cast<const uint4 *>(arow + 32 * q);
-                al[q] = *reinterpret_cast<const uint4 *>(arow + 2 * C + 32 * q);
-            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < Q16; ++q) {
                 const f16x8 xh = *reinterpret_cast<const f16x8 *>(&ah[q]), xl = *reinterpret_cast<const f16x8 *>(&al[q]);
@@ -608,9 +617,10 @@ __device__ __forceinline__ void trn_conv_body(const ConvPtrs &A, const TrnDev &P
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wlo, acc2, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc, 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
             if (tap < 8) {
 #pragma unroll
-                for (int q = 0; q < Q16; ++q) { wc[q][0] = wn[q][0]; wc[q][1] = wn[q][1]; }
+                for (int q = 0; q < Q16; ++q) { wc[q][0] = wn[q][0]; wc[q][1] = wn[q][1]; ah[q] = nh[q]; al[q] = nl[q]; }
             }
         }
     } else {
