@@ -571,13 +571,14 @@ __device__ __forceinline__ void trn_conv_body(const ConvPtrs &A, const TrnDev &P
         // 9 taps x C / 16 k-steps x 3 MFMAs (hi hi, hi lo, lo hi) of 32 cycles; fragments: A = the positions' 8
         // consecutive channels 16 q + 8 (lane >> 5) .. (one 16-byte LDS read per plane; 272-byte rows: conflict-free),
         // B = the filter's, packed by k_trn_stem_fwd as [tap][q][ntile][hi, lo][lane][8]; a tap's filter fragments are
-        // requested a tap ahead.  The k-loop (6.5-8.5 K cycles per wave for 3.5 K of MFMA) is bound by operand
-        // delivery, not by latency: each of the block's four waves pulls the same 72 KB of fragments through the CU's
-        // one 64 B/clk vector-memory path (4.6 K cycles).  Measured and dropped: the fragments requested three taps
-        // ahead (k-loop 8.4 -> 6.5 K cycles, the staging that now issues them 3.8 -> 5.5 K: 12.9 vs 13.0 us per launch)
-        // and the fragments staged ONCE per block through LDS (k-loop 5.8 K, now LDS-bound -- A and B fragments are
-        // 170 B/clk of reads per CU against 128 --, same launch time, and at 116 KB of LDS the block no longer shares a
-        // CU with the filter-gradient kernel beside it: 0.590 vs 0.559 ms per step).
+        // requested a tap ahead.  With the LDS reads pinned ahead of the MFMAs (below) what bounds the k-loop is
+        // operand delivery: each of the block's four waves pulls the same 72 KB of filter fragments through the CU's
+        // one 64 B/clk vector-memory path (4.6 K cycles against 3.5 K of MFMA).  Measured and dropped: the filter
+        // fragments requested two or three taps ahead (with the pinned schedule: 0.479-0.484 vs 0.480 ms per step;
+        // before it the wait only moved from the k-loop into the staging) and the fragments staged ONCE per block
+        // through LDS (k-loop 5.8 K, LDS-bound -- A and B fragments are 170 B/clk of reads per CU against 128 --, same
+        // launch time, and at 116 KB of LDS the block no longer shares a CU with the filter-gradient kernel beside it:
+        // 0.590 vs 0.559 ms per step).
         constexpr int Q16 = C / 16, ROWB = LDW * 4;
         const uint4 *w16 = reinterpret_cast<const uint4 *>(A.w) + (size_t)nt * 128 + lane;
         uint4 wc[Q16][2], wn[Q16][2];
