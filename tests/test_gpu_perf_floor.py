@@ -65,7 +65,7 @@ def test_tree_move_floor():
 
 def test_native_training_step_floor():
     """The hand-written training step at the reference's shape (6x64, 11x11, batch 128): <= 0.72 ms per step with the
-    inputs resident (measured 0.49-0.51 box to box; 0.83 before the split-f16 kernels; the stock kernels captured as a
+    inputs resident (measured 0.48-0.51 box to box; 0.83 before the split-f16 kernels; the stock kernels captured as a
     HIP graph take 2.1)."""
     import time
     from azalea_amd.native_train import NativeTrainStep
