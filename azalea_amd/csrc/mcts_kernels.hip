@@ -1774,12 +1774,13 @@ __device__ __forceinline__ void choose_body(const DevEngine &E) {
         gh->n_rows = row + 1;
         gh->move_id = chosen;
         const float logp = __logf(chosen_w / tot);
-        E.stat_sums[(size_t)g * 8 + 0] += (double)(th->search_value);
+        const float sval = th->search_value / (float)E.selects_per_search;   // mcts.py:291 (as azx_get_root reports it)
+        E.stat_sums[(size_t)g * 8 + 0] += (double)sval;
         E.stat_sums[(size_t)g * 8 + 1] += (double)width;
         E.stat_sums[(size_t)g * 8 + 2] += (double)logp;
         // search_tree.py:109-112: width, mean child visits, nodes ever allocated, children
         float4 *meta = reinterpret_cast<float4 *>(E.row_meta) + ((size_t)g * E.ncells + row) * 2;
-        meta[0] = make_float4(th->search_value, (float)width, logp, 0.0f);
+        meta[0] = make_float4(sval, (float)width, logp, 0.0f);
         meta[1] = make_float4(nv_sum / (float)mk.k, (float)(th->num_nodes + th->dropped), (float)mk.k, 0.0f);
     }
 }

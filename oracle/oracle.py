@@ -345,9 +345,12 @@ def as_distribution(counts, temperature=1.0):
 
 def play_game(n, evaluator, *, simulations, batch_size, c_puct, exploration_depth, noise_alpha,
               noise_scale, temperature, seed, move_sampling=True, move_exploration=True,
-              tree_cap=1 << 22, max_plies=300):
+              tree_cap=1 << 22, max_plies=300, noise_until=None):
     """One self-play game: play_game.py:44-67 over Policy.choose_action (policy.py:132-168),
-    with AzaleaAgent.seed's policy.seed(seed + 1) convention (azalea_agent.py:41-44)."""
+    with AzaleaAgent.seed's policy.seed(seed + 1) convention (azalea_agent.py:41-44).
+    `noise_until` (tests only): a deliberately WRONG variant that also gates the Dirichlet noise by ply
+    (the reference gates only the temperature, policy.py:142-149) -- the power check of
+    tests/test_gpu_game_distribution.py."""
     rng = np.random.RandomState(seed + 1)
     game, tree = Hex(n), Tree(tree_cap)
     rows = []
@@ -358,6 +361,8 @@ def play_game(n, evaluator, *, simulations, batch_size, c_puct, exploration_dept
         eps = noise_scale if (move_sampling and move_exploration) else 0.0
         if ply >= exploration_depth:
             T = 0.0
+        if noise_until is not None and ply >= noise_until:
+            eps = 0.0
         lm = game.legal_moves()
         noise = None
         if eps:
@@ -371,7 +376,7 @@ def play_game(n, evaluator, *, simulations, batch_size, c_puct, exploration_dept
         rows.append(dict(board=game.board, color=game.color, legal_moves=lm,
                          moves_prob=probs.astype(np.float32), move=int(lm[move_id]),
                          value=np.float32(rt) / np.float32(rv), search_value=st.search_value,
-                         num_nodes=tree.num_nodes))
+                         num_nodes=tree.num_nodes, child_visits=nv.copy(), move_id=move_id))
         tree.move(move_id)
         game.step(int(lm[move_id]))
         ply += 1

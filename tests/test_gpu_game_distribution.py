@@ -1,0 +1,156 @@
+"""Whole-game distribution parity of THROUGHPUT MODE (device RNG, k_play / k_choose / k_advance: the mode every
+reported number runs in) against the reference's algorithm under its own RNG.
+
+Parity mode replays the reference's games bit for bit because numpy's RandomState stays on the host (G5).  Throughput
+mode draws its Dirichlet rows and its moves on the device (Gamma by CDF inversion, Philox), so it cannot be compared
+game by game -- it is compared as a DISTRIBUTION: the engine plays >= 4096 games of 7x7 Hex (and 512 of 11x11) with
+the uniform-prior / board-hash evaluator, noise eps 0.25 / alpha 0.3, T = 1, exploration_depth 6, and the CPU oracle
+plays as many under numpy's `RandomState.dirichlet` + `multinomial` exactly as mcts.py:126-131 and policy.py:142-160
+do (tests/oracle_games.py; held bit for bit to the REFERENCE's own games of these configurations by G11).  Two-sample
+tests (tests/game_stats.py), each at p > 1e-3:
+
+  * game-length histogram (chi-square), first-player win rate (two-proportion z);
+  * per ply: root-child-visit entropy and mcts.py:291's search value (Kolmogorov-Smirnov), root width, total child
+    visits incl. the carried subtree (search_tree.py:109-110), support of the recorded moves_prob (chi-square);
+  * recorded moves_prob rows are visits / sum below `exploration_depth` and uniform over the visit maxima from it on
+    (search_tree.py:327-344), while the noise still acts there (policy.py:142-149: T is gated by depth, noise is not).
+
+Thresholds: the oracle against ITSELF on disjoint seeds gives min p = 0.02 over the 77 tests at 7x7 (0.024 over 67
+at 11x11), re-measured by this test on the box; the engine is compared with both oracle runs pooled (68 / 60 tests:
+measured min p 1.5e-3 / 0.056, 3 / 0 of them below 0.05); an oracle that (wrongly) gates the noise by depth as well
+fails the same tests at p < 1e-100 (power check below).  The engine's games are a deterministic function of its seed,
+so the verdict does not flicker from run to run.
+
+What this test found when it was first run (round 5): the per-ply `search_value` metric of throughput mode was the
+raw sum of the leaf values, not divided by num_batches * batch_size as mcts.py:291 does (KS p = 0 at every ply;
+everything else agreed) -- fixed in k_choose.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import game_stats as gs          # noqa: E402
+import oracle_games as og        # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = {
+    # tag: (n, sims, games, plies tested, min games still running at a tested ply)
+    "7": (7, 60, 4096, [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 28], 200),
+    "11": (11, 100, 512, [0, 1, 2, 3, 4, 5, 6, 8, 12, 20, 30, 40, 50], 150),
+}
+CFG = dict(batch=10, c=0.5, depth=6, alpha=0.3, eps=0.25, temp=1.0)
+
+
+def oracle_sample(tmp_path, n, sims, games, seed0, extra=()):
+    out = str(tmp_path / ("oracle_%d_%d_%d%s.npz" % (n, games, seed0, "_w" if extra else "")))
+    cmd = [sys.executable, os.path.join(HERE, "oracle_games.py"), "--n", str(n), "--sims", str(sims),
+           "--games", str(games), "--seed0", str(seed0), "--out", out]
+    for k, v in CFG.items():
+        cmd += ["--" + k, str(v)]
+    subprocess.check_call(cmd + list(extra))
+    return dict(np.load(out))
+
+
+def engine_sample(n, sims, games, seed):
+    """The first `games` games (uids 0..games-1: the first generation of the pool, so no length bias from taking
+    whichever games finish first) of a throughput-mode engine, summarised like tests/oracle_games.py."""
+    from azalea_amd import engine as eng
+    cells = n * n
+    E = eng.Engine(board_size=n, n_games=games, simulations=sims, search_batch_size=CFG["batch"],
+                   exploration_coef=CFG["c"], exploration_depth=CFG["depth"], noise_alpha=CFG["alpha"],
+                   noise_scale=CFG["eps"], temperature=CFG["temp"], evaluator=eng.EVAL_UNIFORM_HASH, seed=seed)
+    E.set_prior_table(og.prior_table(n))
+    out = dict(length=np.zeros(games, np.int32), first_wins=np.zeros(games, np.int8),
+               **{c: np.full((games, cells), np.nan, np.float32) for c in og.COLUMNS})
+    seen = np.zeros(games, bool)
+    onehot_rows = checked = 0
+    for _ in range(64):
+        rows, st = E.play(games * 4)
+        m = E.play_row_metrics()
+        assert len(m) == len(rows["reward"]) and st["game_errors"] == 0
+        uid = rows["game_uid"]
+        starts = np.flatnonzero(m[:, 3] > 0.5)
+        ends = np.r_[starts[1:], len(uid)]
+        for s, e in zip(starts, ends):
+            u = int(uid[s])
+            assert (uid[s:e] == u).all()
+            if u >= games:
+                continue
+            assert not seen[u]
+            seen[u] = True
+            L = e - s
+            out["length"][u] = L
+            out["first_wins"][u] = rows["reward"][s] > 0           # row 0 is the first player's: +1 = they won
+            prob = rows["moves_prob"][s:e].astype(np.float64)
+            nl = rows["nlegal"][s:e]
+            assert np.array_equal(nl, cells - np.arange(L))
+            for i in range(L):
+                p = prob[i, :nl[i]]
+                assert abs(p.sum() - 1.0) < 1e-5 and (prob[i, nl[i]:] == 0).all()
+                sup = int((p > 0).sum())
+                out["support"][u, i] = sup
+                if i < CFG["depth"]:
+                    out["entropy"][u, i] = og.entropy(p)               # T = 1: moves_prob = visits / sum
+                else:                                                   # T = 0: uniform over the maxima
+                    assert np.allclose(p[p > 0], 1.0 / sup, rtol=1e-6)
+                    onehot_rows += sup == 1
+                    checked += 1
+            out["width"][u, :L] = m[s:e, 1]
+            out["mean_visits"][u, :L] = m[s:e, 4]
+            out["search_value"][u, :L] = m[s:e, 0]
+            out["action_prob"][u, :L] = np.exp(m[s:e, 2].astype(np.float64))
+            # below the depth the visit distribution is on the row itself: the metrics must agree with it
+            d = min(L, CFG["depth"])
+            assert np.array_equal(out["support"][u, :d], out["width"][u, :d])
+        if seen.all():
+            break
+    E.close()
+    assert seen.all(), "%d first-generation games never harvested" % (~seen).sum()
+    assert checked > 0 and onehot_rows > 0.5 * checked
+    return out
+
+
+@pytest.mark.parametrize("tag", ["7", "11"])
+def test_throughput_mode_plays_the_reference_game_distribution(tag, tmp_path):
+    n, sims, games, plies, min_games = CASES[tag]
+    a = oracle_sample(tmp_path, n, sims, games, 0)
+    b = oracle_sample(tmp_path, n, sims, games, 100000)
+    same = gs.compare(a, b, CFG["depth"], plies, min_games)
+    e = engine_sample(n, sims, games, seed=20261003)
+    if os.environ.get("AZX_DIST_DUMP"):      # keep the three samples for offline analysis
+        for name, smp in (("engine", e), ("oracle_a", a), ("oracle_b", b)):
+            np.savez_compressed(os.path.join(os.environ["AZX_DIST_DUMP"], "dist_%s_%s.npz" % (tag, name)), **smp)
+    ref = {k: np.concatenate([a[k], b[k]]) for k in a}       # the reference sample: both oracle runs, 2 x the engine's
+    res = gs.compare(e, ref, CFG["depth"], plies, min_games)
+    low, low_same = sum(v < 0.05 for v in res.values()), sum(v < 0.05 for v in same.values())
+    print("oracle vs oracle: %d tests, worst %s p=%.3g, %d below 0.05" % ((len(same),) + gs.worst(same) + (low_same,)))
+    print("engine vs oracle: %d tests, worst %s p=%.3g, %d below 0.05" % ((len(res),) + gs.worst(res) + (low,)))
+    print("lengths: engine %.2f oracle %.2f / %.2f; first player wins: %.4f vs %.4f / %.4f" % (
+        e["length"].mean(), a["length"].mean(), b["length"].mean(),
+        e["first_wins"].mean(), a["first_wins"].mean(), b["first_wins"].mean()))
+    # every statistic the oracle's games have is tested on the engine's (entropy: below the depth, where the rows carry it)
+    assert len(res) >= len(same) - sum(p >= CFG["depth"] for p in plies) and len(res) >= 50
+    assert gs.worst(same)[1] > gs.P_MIN, gs.worst(same)
+    bad = {k: v for k, v in res.items() if v <= gs.P_MIN}
+    assert not bad, bad
+    # ... and no drift too small for any single test: the count of p < 0.05 stays binomial (99.9 % quantile)
+    from scipy import stats as sps
+    assert low <= sps.binom.ppf(0.999, len(res), 0.05), (low, len(res))
+
+
+def test_distribution_test_has_the_power_to_see_a_wrong_noise_gate(tmp_path):
+    """The same comparison rejects an implementation that gates the Dirichlet noise by exploration_depth as well
+    (the obvious misreading of policy.py:142-149)."""
+    n, sims, games, plies, min_games = CASES["7"]
+    games = 1024
+    a = oracle_sample(tmp_path, n, sims, games, 0)
+    w = oracle_sample(tmp_path, n, sims, games, 300000, extra=["--noise-until", str(CFG["depth"])])
+    res = gs.compare(a, w, CFG["depth"], plies, min_games)
+    assert res["width@6"] < 1e-50 and res["width@8"] < 1e-50
+    assert all(res["width@%d" % p] > gs.P_MIN for p in range(CFG["depth"]))    # and only from the depth on

@@ -278,3 +278,26 @@ def test_timed_network_path_matches_the_parity_path():
         v, lp = N.forward(boards, lm)
         vf, lpf = N.forward(boards, lm, fast=True)
         assert np.abs(v - vf).max() <= 1e-5 and np.abs(lp - lpf)[lm > 0].max() <= 1e-5, (n, blocks, chans)
+
+
+@pytest.mark.parametrize("tag", ["7", "11"])
+def test_oracle_game_sampler_replays_the_reference_games_g11(tag):
+    """tests/oracle_games.py -- the reference side of the GPU whole-game distribution test -- plays, seed for seed, the
+    games the REFERENCE played in that test's configurations (G11: tests/golden/make_game_stats.py): the same moves,
+    winner, and per-ply root width / mean visits / search value / moves_prob support / probability of the move
+    drawn, bit for bit."""
+    import oracle_games as og
+    z = np.load(os.path.join(GOLDEN, "g11_game_summaries.npz"))
+    n, sims, bs, c, depth, alpha, eps, temp, games = z["cfg_" + tag]
+    cfg = dict(n=int(n), sims=int(sims), batch=int(bs), c=float(c), depth=int(depth), alpha=float(alpha),
+               eps=float(eps), temp=float(temp))
+    got = og.sample(cfg, range(int(games)), procs=1 if tag == "7" else 4)
+    assert np.array_equal(got["length"], z["length_" + tag])
+    assert np.array_equal(got["first_wins"], z["first_wins_" + tag])
+    assert np.array_equal(got["moves"], z["moves_" + tag])
+    for g in range(int(games)):
+        L = int(got["length"][g])
+        for k in ("width", "support"):
+            assert np.array_equal(got[k][g, :L], z[k + "_" + tag][g, :L].astype(np.float32)), (k, g)
+        for k in ("mean_visits", "search_value", "action_prob"):
+            assert np.array_equal(got[k][g, :L].view(np.uint32), z[k + "_" + tag][g, :L].view(np.uint32)), (k, g)
