@@ -125,7 +125,20 @@ def cpu_baseline(args, workload, net_state=None, sims=None, max_plies=None, game
     if ref and (workload == "tree" or (args.board, args.blocks, args.chans) == (11, 6, 64)):
         base["reference_shim"] = dict(ref)
         base["port_vs_reference_per_core"] = base["per_core"] / ref["per_core"]
+        # what the reference itself would do on THIS box if it scaled linearly to these threads at its per-core rate of
+        # the survey container: an upper estimate, quoted so that no GPU/CPU ratio is read off the port alone
+        base["reference_scaled"] = {"value": ref["per_core"] * threads, "unit": "sims/s", "cores": threads,
+                                    "how": "reference_shim.per_core (survey container) x this box's threads: not measured here"}
+        if workload != "tree":
+            base["same_container"] = dict(SAME_CONTAINER)
+            base["note"] = ("per_core on this box (%d threads) is below the reference's per-core figure of the survey container, "
+                            "but on that container the port does %.0f sims/s per core against the reference's %.0f: the two "
+                            "are equal per core on equal hardware" % (threads, SAME_CONTAINER["port_per_core_8"],
+                                                                       SAME_CONTAINER["reference_per_core_8"]))
     return base
+
+
+PMC_EXTRA = {}     # file name -> further per-launch figures of the counter file last attached (k_heads bytes)
 
 
 def src_sha(kernels):
@@ -152,6 +165,7 @@ def pmc_traffic(name, key, kernels=None):
     if t.get("src_sha") != sha:
         return None, ("profiles/%s was recorded on kernel sources %s, this library is %s: not attached"
                       % (name, t.get("src_sha"), sha))
+    PMC_EXTRA[name] = {k: t[k] for k in ("heads_hbm_bytes_per_launch",) if t.get(k) is not None}
     return t.get("hbm_bytes_per_launch"), "profiles/%s (PMC, same command, kernel sources %s)" % (name, sha)
 
 
@@ -456,15 +470,17 @@ def tree_roofline(st, args, steps, warmup, kernels=None):
         "bytes_per_sim": b / max(1, st["selects"]),
         "mean_depth": st["sum_depth"] / max(1, st["selects"]),
         "note": ("algorithmic bytes follow SURVEY 8(d)'s six-array reference model; the kernel keeps the root level "
-                 "on chip, so its measured HBM traffic is below the model and it is issue-bound, not HBM-bound "
-                 "(DESIGN 3.1)"),
+                 "on chip, so its measured HBM traffic is below the model"),
+        "limiter": ("dependent-latency chain, not HBM bandwidth and not issue: 410 serial simulations per game-wave, each "
+                    "a chain of ~1.84 dependent child-block loads, 4 waves per SIMD; VALU busy 17 %, SALU+VALU issue 32 % "
+                    "(profiles/*_tree_pmc_counters.json; DESIGN 3.1)"),
     }
     key = [args.games, args.board, args.sims, args.batch, steps, warmup, args.noise_scale, args.desync, args.settle]
     roof["traffic"], src = pmc_traffic(PMC_FILES["tree"], key, kernels)
     roof["traffic_source"] = src
     if roof["traffic"]:
         # what the HBM actually delivered, beside the model fraction above (the model prices the reference's
-        # six-array layout; the kernel moves fewer bytes and is issue-bound)
+        # six-array layout; the kernel moves fewer bytes and is latency-bound)
         roof["achieved_hbm_gbs"] = roof["traffic"] / (1e-3 * roof["avg_launch_ms"]) / 1e9
         roof["achieved_hbm_frac"] = roof["achieved_hbm_gbs"] / HBM_PEAK_GBS
         roof["frac_is"] = "model bytes (SURVEY 8(d)) / time / peak; achieved_hbm_frac = counter bytes / time / peak"
@@ -506,8 +522,15 @@ def resnet_roofline(st, args, steps, warmup, kernels=None):
     roof["traffic"], src = pmc_traffic(PMC_FILES["config5" if wide else "resnet"], key, kernels)
     roof["traffic_source"] = src
     if roof["traffic"]:
-        roof["traffic_scope"] = ("HBM bytes of one leaf-batch forward: the stem + %d per-layer launches (k_heads not counted)"
-                                 % (2 * args.blocks)) if wide else "HBM bytes of one k_tower_f16x3_s16 launch (k_heads not counted)"
+        heads = PMC_EXTRA.get(PMC_FILES["config5" if wide else "resnet"], {}).get("heads_hbm_bytes_per_launch")
+        what = ("one leaf-batch forward: the stem + %d per-layer launches" % (2 * args.blocks)) if wide \
+            else "one k_tower_f16x3_s16 launch"
+        if heads is not None:     # the pair `achieved` is timed over: tower + heads
+            roof["traffic_tower"], roof["traffic_heads"] = roof["traffic"], heads
+            roof["traffic"] = roof["traffic"] + heads
+            roof["traffic_scope"] = "HBM bytes of %s + the k_heads launch behind it" % what
+        else:
+            roof["traffic_scope"] = "HBM bytes of %s (k_heads not counted)" % what
     return roof
 
 
@@ -555,6 +578,67 @@ def replay_exchange(E, dist, torch, local_rank, exchange_plies=0):
             "game_uids": uids.tolist() if len(uids) <= 256 else None,
             "pack_seconds": t_pack, "allgather_seconds": t_gather, "ring_put_seconds": t_put,
             "path": "k_rows_pack -> all_gather(counts) + all_gather(records, device tensors) -> k_records_put"}
+
+
+# the reference and the C port side by side ON ONE MACHINE (the survey / build container, 8 cores, where the reference
+# can run): BASELINE.md section 2 for the reference, `oracle.bench_selfplay(11, 400, 10, T, T, net, max_plies=4,
+# start_max=92)` for the port.  The GPU box's host has more, slower-per-thread cores; the reference cannot travel there.
+SAME_CONTAINER = {"reference_per_core_8": 376.4, "port_per_core_8": 380.8, "reference_single_thread": 437.0,
+                  "port_single_thread": 546.1, "unit": "sims/s",
+                  "what": "11x11, 400 sims, 6x64, build container (8 cores): the port is not slower than the reference "
+                          "per core on the same machine; the lower per_core on the GPU box is that host at 64 threads"}
+
+
+def pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and d.get(k) is not None}
+
+
+def fold_legs(line):
+    """The driver's record keeps `roofline`, `cpu_baseline` and `config` whole and every other nested dict by name
+    only, so the essentials of every nested leg are repeated inside those two: enough to recompute each kernel's
+    fraction (achieved = flop_or_bytes_per_launch / avg_launch_ms) from the driver-held record alone."""
+    roof, cpu = line.get("roofline"), line.get("cpu_baseline")
+    if not isinstance(roof, dict):
+        return
+    RK = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_tower", "traffic_heads",
+          "issued_frac", "avg_launch_ms", "launches", "positions_per_launch", "flop_per_launch", "bytes_per_launch",
+          "moves_per_launch", "ms_per_move", "bytes_per_sim", "mean_depth", "achieved_hbm_gbs", "achieved_hbm_frac",
+          "limiter")
+    TK = ("value", "unit", "games_per_sec", "plies_per_sec", "ms_per_step", "steps", "warmup", "elapsed_s", "evals")
+    legs = {"headline": dict(pick(line, TK), workload="configs[2]")}
+    for name, tag in (("tree", "configs[1]"), ("config5", "configs[4] shape, one GPU")):
+        leg = line.get(name)
+        if isinstance(leg, dict) and "roofline" in leg:
+            legs[name] = dict(pick(leg, TK), workload=tag, **pick(leg["roofline"], RK))
+            if isinstance(leg.get("config"), dict):
+                legs[name].update(pick(leg["config"], ("games_per_gpu", "board", "simulations")))
+        elif isinstance(leg, dict) and "error" in leg:
+            legs[name] = {"error": leg["error"]}
+    ts = line.get("train_step")
+    if isinstance(ts, dict):
+        t = {"batch": ts.get("batch")}
+        for mode in ("eager", "eager_nosync", "hip_graph", "native_fp32", "native"):
+            if isinstance(ts.get(mode), dict):
+                t[mode] = pick(ts[mode], ("steps_per_sec", "ms_per_step", "step_only_ms", "flop_per_step",
+                                          "algorithmic_tflops", "frac_of_f16_mfma_peak", "issued_frac_of_f16_mfma_peak"))
+        for k in ("scaling", "wide", "error"):
+            if ts.get(k) is not None:
+                t[k] = ts[k]
+        legs["train_step"] = t
+    api = line.get("api")
+    if isinstance(api, dict):
+        legs["api"] = pick(api, ("rows_per_sec", "plies_per_sec", "rows_over_plies", "host_overhead_frac", "error"))
+    roof["legs"] = legs
+    if isinstance(cpu, dict):
+        CK = ("value", "unit", "cores", "per_core", "kind", "sample", "seconds", "error")
+        cl = {}
+        for name in ("tree", "config5"):
+            c = (line.get(name) or {}).get("cpu_baseline") if isinstance(line.get(name), dict) else None
+            if isinstance(c, dict):
+                cl[name] = pick(c, CK)
+                if isinstance(c.get("reference_shim"), dict):
+                    cl[name]["reference_per_core"] = c["reference_shim"].get("per_core")
+        cpu["legs"] = cl
 
 
 def main():
@@ -764,6 +848,7 @@ def main():
             line["train_step"] = {"error": repr(exc)}
 
     if rank == 0:
+        fold_legs(line)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

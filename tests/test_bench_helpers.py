@@ -73,3 +73,24 @@ def test_cpu_baseline_carries_the_reference_shim_context():
     r = bench.REFERENCE_SHIM["resnet"]
     assert r["sims_per_s"] == 3011.0 and r["cores"] == 8 and abs(r["per_core"] - 3011.0 / 8) < 0.1
     assert bench.REFERENCE_SHIM["tree"]["sims_per_s"] == 870.0
+
+
+def test_every_leg_s_fraction_can_be_recomputed_from_the_dicts_the_driver_keeps():
+    """The driver's record keeps `roofline` / `cpu_baseline` / `config` whole and other nested dicts by name only
+    (VERDICT r4 weak #9): after fold_legs, `roofline` alone must carry what recomputes each leg's fraction."""
+    line = json.load(open(os.path.join(ROOT, "profiles", "r4_selfplay_bench.json")))
+    bench.fold_legs(line)
+    kept = {"roofline": line["roofline"], "cpu_baseline": line["cpu_baseline"]}      # what survives
+    legs = kept["roofline"]["legs"]
+    t = legs["tree"]
+    assert abs(t["bytes_per_launch"] / (t["avg_launch_ms"] * 1e-3) / 1e9 / t["peak"] - line["tree"]["roofline"]["frac"]) < 1e-9
+    assert t["achieved_hbm_frac"] == line["tree"]["roofline"]["achieved_hbm_frac"] and t["value"] == line["tree"]["value"]
+    c = legs["config5"]
+    assert abs(c["flop_per_launch"] / (c["avg_launch_ms"] * 1e-3) / 1e12 / c["peak"] - line["config5"]["roofline"]["frac"]) < 1e-9
+    assert c["traffic"] == line["config5"]["roofline"]["traffic"] and c["positions_per_launch"] > 0
+    tr = legs["train_step"]
+    assert tr["native"]["steps_per_sec"] == line["train_step"]["native"]["steps_per_sec"]
+    assert tr["native"]["step_only_ms"] and tr["hip_graph"]["steps_per_sec"] and tr["eager"]["steps_per_sec"]
+    assert legs["api"]["rows_over_plies"] == line["api"]["rows_over_plies"]
+    cl = kept["cpu_baseline"]["legs"]
+    assert cl["tree"]["value"] == line["tree"]["cpu_baseline"]["value"] and cl["config5"]["cores"] == 64

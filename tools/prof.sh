@@ -22,8 +22,10 @@ PASSES=${@:-stats fetch write sq1 sq2}
 # on ONE stream and 200 instead of 800 sims per move (21 instead of 81 leaf batches per move: the same kernels
 # on the same 512-game batches, so the same bytes and cycles per forward, which is what the summary reports).
 export TMPDIR=/tmp
-ARGS="--steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --api-moves 0 ${EXTRA:-}"
-C5="--workload resnet --board 13 --blocks 19 --chans 256 --sims 200 --games ${C5GAMES:-512} --steps 1 --warmup 0 --no-cpu-baseline --no-replay-exchange"
+# --no-train-step: the training-step leg runs each mode in a CHILD process, which would inherit the profiler's
+# preload and write into the same -d directory (tools/prof_train.sh profiles the training step on its own)
+ARGS="--steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --api-moves 0 --no-train-step ${EXTRA:-}"
+C5="--workload resnet --board 13 --blocks 19 --chans 256 --sims 200 --games ${C5GAMES:-512} --steps 1 --warmup 0 --no-cpu-baseline --no-replay-exchange --no-train-step"
 pmc() {   # name, counters...
   local name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py $ARGS --no-config5 > $OUT/$name.json 2> $OUT/$name.err

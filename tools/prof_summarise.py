@@ -126,10 +126,18 @@ for name in ("fetch", "write", "sq1", "sq2"):
     for cn, vals in counters(name, is_tower).items():
         timed = vals[-ntimed:]
         res[cn] = sum(timed) / len(timed)
+heads = {}
+for name in ("fetch", "write"):
+    for cn, vals in counters(name, lambda kn: "k_heads" in kn).items():
+        timed = vals[-ntimed:]
+        heads[cn] = sum(timed) / len(timed)
 if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     t = traffic(res["FETCH_SIZE"], res["WRITE_SIZE"])
     t["bench_key"] = [games, board, sims, batch, 6, 64, steps, warmup, 0.25, desync, settle]
-    t["kernel"] = "k_tower_f16x3_s16 (mean of the %d timed launches; k_heads not included)" % ntimed
+    t["kernel"] = "k_tower_f16x3_s16 (mean of the %d timed launches; the k_heads launch behind each is heads_hbm_bytes_per_launch)" % ntimed
+    if "FETCH_SIZE" in heads and "WRITE_SIZE" in heads:
+        t["heads_hbm_bytes_per_launch"] = (2.0 * heads["FETCH_SIZE"] + heads["WRITE_SIZE"]) * 1024.0
+        t["heads_FETCH_SIZE_KiB"], t["heads_WRITE_SIZE_KiB"] = heads["FETCH_SIZE"], heads["WRITE_SIZE"]
     t["algorithmic_bytes_per_launch"] = "boards in: positions x 192 B; head planes out: positions x 6 x 121 x 4 B (~119 MB at 40 960 positions)"
     json.dump(t, open(os.path.join(summ, "resnet_pmc_traffic.json"), "w"), indent=1)
 
@@ -192,6 +200,10 @@ if c5 or c5line:
             sums[cn] = sums.get(cn, 0.0) + float(r["Counter_Value"])
             n_fwd[cn] = fw
     per_fwd = {cn: v / max(1, n_fwd[cn]) for cn, v in sums.items()}
+    heads5 = {}
+    for name in ("fetch_c5", "write_c5"):
+        for cn, vals in counters(name, lambda kn: "k_heads" in kn).items():
+            heads5[cn] = sum(vals) / len(vals)
     cc = (c5 or c5line)["config"]
     key5 = [cc["games_per_gpu"], 13, cc["search_batch_size"], 19, 256, "per forward"]
     pos = (c5line.get("roofline") or (c5 or {}).get("roofline") or {}).get("positions_per_launch")
@@ -203,6 +215,8 @@ if c5 or c5line:
                         "stream: rocprofv3 --pmc falls over on the second stream and past ~10 k dispatches; same kernels, "
                         "same 512-game batches; k_heads not included)" % n_fwd["FETCH_SIZE"])
         t5["positions_per_forward"] = pos
+        if "FETCH_SIZE" in heads5 and "WRITE_SIZE" in heads5:
+            t5["heads_hbm_bytes_per_launch"] = (2.0 * heads5["FETCH_SIZE"] + heads5["WRITE_SIZE"]) * 1024.0
         t5["algorithmic_bytes_per_forward"] = ("activations [169][256 hi | 256 lo] f16 = 173 KB per position, read and written "
                                                 "by each of 38 layers + read as residual by 19: ~16.4 MB per position")
         json.dump(t5, open(os.path.join(summ, "config5_pmc_traffic.json"), "w"), indent=1)
