@@ -1800,6 +1800,7 @@ struct AzxTrain {
     std::vector<size_t> conv_goff;
     float *hp_dev = nullptr, *hp_ring = nullptr;       // hp_ring: pinned host memory the prep kernel reads
     unsigned long long host_steps = 0;
+    bool broken = false;                                 // a step failed while being queued (see azx_trn_step)
     hipEvent_t ring_ev[2] = {nullptr, nullptr};         // marks of steps TRN_HP_SLOTS / 2 apart: the host never laps the device
     int32_t *in_board = nullptr, *in_legal = nullptr;
     float *in_prob = nullptr, *in_reward = nullptr;
@@ -2227,6 +2228,9 @@ static int step_done(AzxTrain *t, hipStream_t st) {
 
 int azx_trn_step(AzxTrain *t, float lr, float momentum, float weight_decay, hipStream_t st) {
     if (!t->is_bound) return tfail(AZX_ESTATE, "train: azx_train_bind has not been called");
+    // a step that failed half-way may have run its first kernel, which advances the device's step count, without the
+    // host's having moved: every later step would read another step's hyper-parameter slot.  Refuse instead.
+    if (t->broken) return tfail(AZX_ESTATE, "train: an earlier step failed while it was being queued; create a new trainer");
     if (!t->cap) {
         if (int rc = raise_limits(t->d.C)) return rc;
         if (hipStreamCreateWithFlags(&t->cap, hipStreamNonBlocking) != hipSuccess ||
@@ -2239,15 +2243,17 @@ int azx_trn_step(AzxTrain *t, float lr, float momentum, float weight_decay, hipS
     // ring ago.
     {
         const unsigned long long sidx = t->host_steps % TRN_HP_SLOTS;
+        // about to re-use the half ring starting at sidx: its previous occupants are the steps that ended with the mark
+        // recorded half a ring BEFORE the latest one, i.e. the other event (the latest mark is the step just queued)
         if (t->host_steps >= TRN_HP_SLOTS && sidx % (TRN_HP_SLOTS / 2) == 0)
-            if (hipEventSynchronize(t->ring_ev[(sidx / (TRN_HP_SLOTS / 2)) & 1]) != hipSuccess)
+            if (hipEventSynchronize(t->ring_ev[((sidx / (TRN_HP_SLOTS / 2)) & 1) ^ 1]) != hipSuccess)
                 return tfail(AZX_EHIP, "train: waiting for the hyper-parameter ring failed");
         float *slot = t->hp_ring + sidx * 4;
         slot[0] = lr; slot[1] = momentum; slot[2] = weight_decay; slot[3] = 0.f;
     }
     if (!t->use_graph) {
         // plain launches: the weight-gradient passes fork onto the side stream after an event on `st`
-        if (int rc = enqueue_any(t, st, t->side, t->fork)) return rc;
+        if (int rc = enqueue_any(t, st, t->side, t->fork)) { t->broken = true; return rc; }
         return step_done(t, st);
     }
     if (!t->exec) {
@@ -2256,13 +2262,13 @@ int azx_trn_step(AzxTrain *t, float lr, float momentum, float weight_decay, hipS
         int rc = enqueue_any(t, t->cap, t->side, t->fork);
         hipGraph_t graph = nullptr;
         const hipError_t ce = hipStreamEndCapture(t->cap, &graph);
-        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); t->broken = true; return rc; }
         if (ce != hipSuccess || !graph) return tfail(AZX_EHIP, std::string("train: hipStreamEndCapture failed: ") + hipGetErrorString(ce));
         t->graph = graph;
         if (hipGraphInstantiate(&t->exec, graph, nullptr, nullptr, 0) != hipSuccess)
             return tfail(AZX_EHIP, "train: hipGraphInstantiate failed");
     }
-    if (hipGraphLaunch(t->exec, st) != hipSuccess) return tfail(AZX_EHIP, "train: hipGraphLaunch failed");
+    if (hipGraphLaunch(t->exec, st) != hipSuccess) { t->broken = true; return tfail(AZX_EHIP, "train: hipGraphLaunch failed"); }
     return step_done(t, st);
 }
 

@@ -30,6 +30,7 @@ class DeviceReplayBuffer:
         engine.replay_create(self.capacity)
         self.fresh_counter = 0
         self.shared = shared
+        self.learner = None             # actor_learner.Learner: refills are PULLED from the actors' backlogs (rank 0 only)
         self.last_exchange = None       # timing of the last shared refill (bench / diagnostics)
         self.device = getattr(engine, "torch_device", None) or torch.device("cuda", engine.cfg.device)
         if contents is not None and len(contents):
@@ -68,7 +69,9 @@ class DeviceReplayBuffer:
         if getattr(self, "_async_reads", False):       # collate_async reads queued on torch's stream come first
             torch.cuda.synchronize(self.device)
             self._async_reads = False
-        if self.shared and azdist.is_distributed():
+        if self.learner is not None:
+            rows, st = self._pull(int(np.ceil(refill)))
+        elif self.shared and azdist.is_distributed():
             rows, st = self.refill_shared(int(np.ceil(refill)), player)
         else:
             if player is not None and hasattr(player, "prepare_device_engine"):
@@ -76,9 +79,9 @@ class DeviceReplayBuffer:
             rows, st = self.engine.replay_fill(int(np.ceil(refill)))
             st = dict(st, **self._game_sums(rows))
         self.fresh_counter += rows
-        out = {"games": float(st["games"]), "reward": st["sum_reward_last"],
-               "moves_per_game": float(rows), "seconds_per_game": st["seconds"],
-               "game_error": float(st["game_errors"])}
+        out = {"games": float(st.get("games", 0.0)), "reward": st.get("sum_reward_last", 0.0),
+               "moves_per_game": float(rows), "seconds_per_game": st.get("seconds", 0.0),
+               "game_error": float(st.get("game_errors", 0.0))}
         out.update({k: float(st.get("game_" + k, 0.0)) for k in self._SEARCH_KEYS})
         return out
 
@@ -102,6 +105,19 @@ class DeviceReplayBuffer:
         if player is not None and hasattr(player, "prepare_device_engine"):
             player.prepare_device_engine(self.engine)
         return self._fill_shared(refill)
+
+    def _pull(self, refill: int):
+        """Actor / learner mode (azalea_amd/actor_learner.py): this rank trains and does not play; the rows come out
+        of the other ranks' backlogs -- one announcement, the same two record collectives as a shared refill, and
+        every rank's records appended to the ring in rank order."""
+        parts, counts, st = self.learner.pull(refill, self.device, self.engine.record_bytes)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)         # the gathered records were written on torch's / RCCL's streams
+        for part, count in zip(parts, counts):
+            if count:
+                self.engine.replay_put_records(count, part.data_ptr())
+        self.last_exchange = dict(self.learner.last_pull)
+        return int(sum(counts)), st
 
     def _fill_shared(self, refill: int):
         """One refill played by all ranks: each rank plays its share of whole games into its harvest

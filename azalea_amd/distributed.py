@@ -18,6 +18,24 @@ import torch.distributed as dist
 from . import _lib
 
 
+_in_data_collective = 0
+
+
+def _data_collective(fn):
+    """Marks the record / metric / weight collectives: a failure raised INSIDE one cannot be followed by an
+    announcement (the other ranks are in that collective, not listening) -- see abort()."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        global _in_data_collective
+        _in_data_collective += 1
+        out = fn(*a, **k)
+        _in_data_collective -= 1          # deliberately not in a finally: an exception leaves the mark set
+        return out
+    return wrapped
+
+
 def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
@@ -70,6 +88,7 @@ def empty_rows(board_size: int) -> Dict[str, np.ndarray]:
     return unpack_rows(np.zeros((0, record_bytes(board_size * board_size)), np.uint8), board_size)
 
 
+@_data_collective
 def all_gather_records(rec: torch.Tensor) -> Tuple[List[torch.Tensor], List[int]]:
     """rec: uint8 [P, record_bytes] on the communication device (HBM under RCCL).  Two collectives:
     the per-rank counts, then the records padded to the largest count -- a direct all-gather over
@@ -110,6 +129,7 @@ def all_gather_rows(rows: Dict[str, np.ndarray], board_size: int) -> Dict[str, n
     return unpack_rows(rec, board_size)
 
 
+@_data_collective
 def all_reduce_metrics(metrics: Dict[str, float]) -> Dict[str, float]:
     """Sum the per-rank self-play metrics (parallel_player.py:50-51 sums over games).  Ranks may hold
     different key sets (one that played nothing holds none), so the dicts themselves are gathered."""
@@ -141,28 +161,97 @@ def broadcast_int(value: int, src: int = 0) -> int:
 # policy_trainer.serve_selfplay, doing what rank 0 announces (`follow`): their control flow never depends on
 # their own arithmetic, so replicas cannot drift apart and nobody waits in a collective the others skip.
 OP_STOP, OP_READ, OP_REFILL = 0, 1, 2
+# actor / learner mode (azalea_amd/actor_learner.py): the followers play continuously, rank 0 only trains
+OP_PULL, OP_WEIGHTS, OP_ABORT = 3, 4, 5
+
+
+class LeaderLost(RuntimeError):
+    """A follower waited longer than its timeout for rank 0's next announcement, or rank 0 said it is aborting."""
+
+
+_control = None
+
+
+def control_group():
+    """The group announcements travel on: gloo (host side), so that a follower can POLL for the next one while its
+    GPU keeps playing, and so that waiting has a timeout of ours instead of the RCCL watchdog's.  Records and weights
+    stay on the default group (RCCL).  Created collectively: every rank must make its first lead() / follow() /
+    control_group() call at the same point (train() does, right after the ranks split)."""
+    global _control
+    if _control is None:
+        _control = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    return _control
+
+
+def reset_control_group() -> None:
+    """Forget the control group (after destroy_process_group; tests that re-initialise torch.distributed)."""
+    global _control
+    _control = None
 
 
 def rank() -> int:
     return dist.get_rank() if is_distributed() else 0
 
 
+def follow_timeout() -> float:
+    """Seconds a follower waits for an announcement before it gives up (AZX_FOLLOW_TIMEOUT, default 30 min)."""
+    import os
+    return float(os.environ.get("AZX_FOLLOW_TIMEOUT", "1800"))
+
+
 def lead(op: int, arg: int = 0) -> None:
     """Rank 0: announce the next collective production (OP_READ: Player.read(arg); OP_REFILL: a shared
-    DeviceReplayBuffer refill of arg rows; OP_STOP: training is over)."""
+    DeviceReplayBuffer refill of arg rows; OP_PULL: hand over arg rows played ahead; OP_WEIGHTS: a weight broadcast
+    follows; OP_STOP: training is over; OP_ABORT: rank 0 failed, leave without another collective)."""
     if is_distributed():
-        t = torch.tensor([int(op), int(arg)], dtype=torch.int64, device=_comm_device())
-        dist.broadcast(t, src=0)
+        t = torch.tensor([int(op), int(arg)], dtype=torch.int64)
+        dist.broadcast(t, src=0, group=control_group())
 
 
-def follow() -> Tuple[int, int]:
-    """Ranks != 0: wait for rank 0's announcement."""
-    t = torch.zeros(2, dtype=torch.int64, device=_comm_device())
-    dist.broadcast(t, src=0)
-    op, arg = (int(x) for x in t.tolist())
-    return op, arg
+def abort() -> bool:
+    """Rank 0 failed: tell the other ranks to leave (their follow() raises LeaderLost) -- unless the failure came out
+    of a data collective, in which case they are not listening and their own timeouts end them.  True if announced."""
+    if not is_distributed() or _in_data_collective:
+        return False
+    lead(OP_ABORT)
+    return True
 
 
+class Pending:
+    """A follower's posted receive of rank 0's next announcement: `ready()` polls, `result()` waits (with a
+    timeout) and returns (op, arg)."""
+
+    def __init__(self):
+        self.t = torch.zeros(2, dtype=torch.int64)
+        self.work = dist.broadcast(self.t, src=0, group=control_group(), async_op=True)
+
+    def ready(self) -> bool:
+        return self.work.is_completed()
+
+    def result(self, timeout: Optional[float] = None) -> Tuple[int, int]:
+        import time
+        limit = follow_timeout() if timeout is None else timeout
+        deadline = time.monotonic() + limit
+        pause = 1e-4
+        while not self.work.is_completed():
+            if time.monotonic() > deadline:
+                raise LeaderLost("no announcement from rank 0 within %.0f s" % limit)
+            time.sleep(pause)
+            pause = min(0.01, pause * 2)
+        self.work.wait()
+        op, arg = (int(x) for x in self.t.tolist())
+        if op == OP_ABORT:
+            raise LeaderLost("rank 0 aborted the run")
+        return op, arg
+
+
+def follow(timeout: Optional[float] = None) -> Tuple[int, int]:
+    """Ranks != 0: wait for rank 0's announcement (LeaderLost after `timeout` / AZX_FOLLOW_TIMEOUT seconds, or when
+    rank 0 announces that it is aborting)."""
+    return Pending().result(timeout)
+
+
+@_data_collective
 def broadcast_weights(net: torch.nn.Module, src: int = 0) -> None:
     """One flat broadcast of parameters + buffers (2.1 MB for the 6x64 net): conv / linear weights and the
     BatchNorm affine terms AND running statistics -- self-play folds the statistics into the convolutions, so a

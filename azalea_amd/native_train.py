@@ -29,6 +29,40 @@ class _DeviceArray:
                                          "version": 2, "strides": None}
 
 
+def unsupported_reason(model, optimizer, device):
+    """None when NativeTrainStep covers this (module, optimizer, device); otherwise why not -- policy_trainer.train
+    picks the hand-written step by default where this returns None and the stock step elsewhere."""
+    from .network import HexNetwork
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return "NativeTrainStep needs a CUDA (ROCm) device"
+    if not isinstance(model, HexNetwork):
+        return "NativeTrainStep trains azalea_amd.network.HexNetwork"
+    if not isinstance(optimizer, optim.SGD) or len(optimizer.param_groups) != 1:
+        return "NativeTrainStep implements torch.optim.SGD with one parameter group"
+    g = optimizer.param_groups[0]
+    if g.get("dampening", 0) or g.get("nesterov", False) or g.get("maximize", False):
+        return "NativeTrainStep: dampening / nesterov / maximize are not implemented"
+    if {id(p) for p in g["params"]} != {id(p) for p in model.parameters()}:
+        return "NativeTrainStep: the optimizer must hold exactly the module's parameters"
+    chans = model.conv1.weight.shape[0]
+    if (model.board_size, chans) not in SUPPORTED_SHAPES:
+        return ("NativeTrainStep covers boards up to 11x11 with 16 / 32 / 64 channels; got %dx%d, %d channels"
+                % (model.board_size, model.board_size, chans))
+    return None
+
+
+class _Shapes:
+    """`(board_size, channels) in SUPPORTED_SHAPES`: what azx_train_create accepts (csrc/train_kernels.hip)."""
+
+    def __contains__(self, key):
+        n, c = key
+        return 2 <= n <= 11 and c in (16, 32, 64)
+
+
+SUPPORTED_SHAPES = _Shapes()
+
+
 class NativeTrainStep:
     """Same surface as policy_trainer.GraphedTrainStep: `step(batch)`, `step_from_ring(replaybuf, indices)`,
     `outputs(k)`, `.loss` (three device floats: total, value, moves).
@@ -39,17 +73,9 @@ class NativeTrainStep:
     def __init__(self, model, optimizer, batch_size: int, device):
         from .network import HexNetwork
         dev = torch.device(device)
-        if dev.type != "cuda":
-            raise ValueError("NativeTrainStep needs a CUDA (ROCm) device")
-        if not isinstance(model, HexNetwork):
-            raise ValueError("NativeTrainStep trains azalea_amd.network.HexNetwork")
-        if not isinstance(optimizer, optim.SGD) or len(optimizer.param_groups) != 1:
-            raise ValueError("NativeTrainStep implements torch.optim.SGD with one parameter group")
-        g = optimizer.param_groups[0]
-        if g.get("dampening", 0) or g.get("nesterov", False) or g.get("maximize", False):
-            raise ValueError("NativeTrainStep: dampening / nesterov / maximize are not implemented")
-        if {id(p) for p in g["params"]} != {id(p) for p in model.parameters()}:
-            raise ValueError("NativeTrainStep: the optimizer must hold exactly the module's parameters")
+        why = unsupported_reason(model, optimizer, dev)
+        if why:
+            raise ValueError(why)
         if dev.index is None:                      # "cuda" -> the current device, as torch resolves it
             dev = torch.device("cuda", torch.cuda.current_device())
         self.model, self.optimizer, self.B, self.device = model, optimizer, int(batch_size), dev

@@ -75,6 +75,7 @@ class Player:
         self.running = True
         self.gather = gather
         self.role = role if (gather and azdist.is_distributed()) else None
+        self.learner = None            # actor_learner.Learner: read() pulls the actors' backlogs instead of playing
         self.weight_syncs = 0          # broadcasts of the trainer's weights this player took part in
         self.n_games = n_games or int(os.environ.get("AZX_GAMES", "4096"))
         self._games = deque()          # finished games waiting to be read: (rows dict, metrics)
@@ -88,6 +89,8 @@ class Player:
         """Whole games until at least `size` positions (parallel_player.py:41-52).  A game that
         overflowed its tree (SearchTreeFull) is skipped like the reference's worker does
         (parallel_player.py:73-76) and counted in metrics['game_error']."""
+        if self.learner is not None:
+            return self._read_pulled(size)
         shared = self.gather and azdist.is_distributed()
         self.announce(azdist.OP_READ, int(np.ceil(size)))
         self._agree_seed_base()       # a collective when shared: every rank passes here, whatever its quota
@@ -119,6 +122,20 @@ class Player:
             rows = azdist.all_gather_rows(rows, n)
             metrics = azdist.all_reduce_metrics(dict(metrics))
         return rows_to_frame(rows), dict(metrics)
+
+    def _read_pulled(self, size) -> Tuple[ReplayDataFrame, Metrics]:
+        """read() of the learner in actor / learner mode (azalea_amd/actor_learner.py): whole games out of the other
+        ranks' backlogs, as a host frame; metrics in play_game's keys, summed over the games returned."""
+        n = self.agents[0].game.board_size
+        dev = azdist._comm_device()
+        parts, counts, st = self.learner.pull(size, dev, azdist.record_bytes(n * n))
+        rec = torch.cat(parts).cpu().numpy() if sum(counts) else np.zeros((0, azdist.record_bytes(n * n)), np.uint8)
+        rows = azdist.unpack_rows(rec, n)
+        metrics = {"games": st.get("games", 0.0), "reward": st.get("sum_reward_last", 0.0),
+                   "moves_per_game": float(len(rows["reward"])), "seconds_per_game": st.get("seconds", 0.0),
+                   "game_error": st.get("game_errors", 0.0)}
+        metrics.update({k[5:]: v for k, v in st.items() if k.startswith("game_") and k != "game_errors"})
+        return rows_to_frame(rows), metrics
 
     def announce(self, op: int, arg: int) -> None:
         """Leader / follower topology only: rank 0 says what all ranks produce next, then its network --

@@ -187,14 +187,14 @@ def initialize_replay_buffer(pool, game_factory, size: int) -> ReplayBuffer:
     return buf
 
 
-def serve_selfplay(player, replaybuf=None) -> int:
-    """Ranks != 0 of a training job: play what rank 0 announces, with the weights rank 0 broadcasts, until it
-    says stop (azalea_amd/distributed.py).  The counterpart of the reference's worker loop
-    (parallel_player.py:55-76) -- with the trainer's live network arriving over RCCL instead of CUDA IPC.
-    Returns the number of productions served."""
+def serve_selfplay(player, replaybuf=None, timeout=None) -> int:
+    """Ranks != 0 of a LOCK-STEP training job: play what rank 0 announces, with the weights rank 0 broadcasts, until
+    it says stop (azalea_amd/distributed.py).  The deterministic mode; azalea_amd/actor_learner.py is the one in which
+    self-play runs beside training.  Raises distributed.LeaderLost when rank 0 goes silent for `timeout` seconds
+    (AZX_FOLLOW_TIMEOUT) or announces that it is aborting.  Returns the number of productions served."""
     served = 0
     while True:
-        op, arg = azdist.follow()
+        op, arg = azdist.follow(timeout)
         if op == azdist.OP_STOP:
             break
         if op == azdist.OP_READ:
@@ -209,6 +209,26 @@ def serve_selfplay(player, replaybuf=None) -> int:
     if pol is not None:
         azdist.broadcast_weights(pol.net, src=0)   # everyone leaves with the trained network
     return served
+
+
+def make_train_step(net, optimizer, batch_size, device, config):
+    """The step train() runs full batches through, and its name.  By default the hand-written step
+    (native_train.NativeTrainStep) wherever it applies -- HexNetwork, SGD, a board and width its kernels cover -- and
+    the stock PyTorch step elsewhere: captured as a HIP graph when config["train_step_graph"], eager otherwise.
+    config["train_step_native"]: False = never the hand-written step; True = it or a ValueError naming what is outside
+    its envelope (raised here, before any rank has been told to wait for this one)."""
+    want = config.get("train_step_native")
+    if torch.device(device).type == "cuda" and want is not False:
+        from .native_train import NativeTrainStep, unsupported_reason
+        why = unsupported_reason(net, optimizer, device)
+        if why is None:
+            return NativeTrainStep(net, optimizer, batch_size, device), "native"
+        if want:
+            raise ValueError("train_step_native was asked for, but: " + why)
+        logging.info("stock training step (%s)", why)
+    if config.get("train_step_graph") and torch.device(device).type == "cuda":
+        return GraphedTrainStep(net, optimizer, batch_size, device), "hip_graph"
+    return None, "eager"
 
 
 def save_checkpoint(policy, name, *, optimizer=None, replaybuf=None) -> str:
@@ -228,12 +248,18 @@ def save_checkpoint(policy, name, *, optimizer=None, replaybuf=None) -> str:
 
 def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False, history=None) -> str:
     """The reference training loop (policy_trainer.py:23-119) over this package's Player.
-    `history`: optional dict; receives the learning rate each epoch trained with under "lr".
+    `history`: optional dict; receives the learning rate each epoch trained with under "lr", the name of the training
+    step under "train_step" and, under torch.distributed, the self-play mode and the learner's / actor's counters.
 
     Under torch.distributed (one process per GPU) rank 0 is the trainer: it alone runs the optimizer and writes
-    checkpoints.  Every shared production -- a Player.read or a device-ring refill -- is announced by rank 0, which
-    broadcasts its network first; the other ranks serve self-play (`serve_selfplay`) and return when rank 0 stops,
-    holding the trained weights.  All ranks pass the same config and must call train() together."""
+    checkpoints; all ranks pass the same config and must call train() together.  config["selfplay_mode"]:
+    * "actor_learner" (default): the other ranks play continuously into bounded backlogs with the last network rank 0
+      broadcast (every config["weight_sync_steps"] steps, default 50); rank 0 does not play and pulls rows when its
+      buffer asks for them (azalea_amd/actor_learner.py) -- the reference's in-flight self-play;
+    * "lockstep": every shared production -- a Player.read or a device-ring refill -- is announced by rank 0, which
+      broadcasts its network first, and played by all ranks; the others serve it (`serve_selfplay`).  Deterministic.
+    Either way the other ranks return when rank 0 stops, holding the trained weights; if rank 0 fails they are told
+    (distributed.LeaderLost) instead of being left in a collective."""
     os.makedirs("%s/checkpoints" % rundir, exist_ok=True)
     np.random.seed(config["seed"])
     torch.manual_seed(config["seed"])
@@ -249,6 +275,12 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
     game_factory = partial(game_class, board_size=config["board_size"])
     shared = azdist.is_distributed()
     leader = azdist.rank() == 0
+    mode = None
+    if shared:
+        mode = config.get("selfplay_mode", "actor_learner")
+        if mode not in ("actor_learner", "lockstep"):
+            raise ValueError("selfplay_mode must be 'actor_learner' or 'lockstep'")
+        azdist.control_group()             # collective: created where every rank is
     if replaybuf is None:
         # symmetric under torch.distributed: every rank plays its share of the random-mover games, all get all rows
         replaybuf = initialize_replay_buffer(None, game_factory, config["replaybuf_size"])
@@ -260,79 +292,112 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
     policy.settings["move_exploration"] = True
     policy.settings["move_sampling"] = True
     agent = AzaleaAgent(game_factory, policy=policy, device=config["device"])
-    player = Player(None, [agent], n_games=config.get("selfplay_games"),
-                    role=("leader" if leader else "follower") if shared else None)
+    lockstep_role = ("leader" if leader else "follower") if mode == "lockstep" else None
+    player = Player(None, [agent], n_games=config.get("selfplay_games"), role=lockstep_role)
+    if mode == "actor_learner" and player._device_policy() is None:
+        raise ValueError("selfplay_mode 'actor_learner' needs a Policy that holds a HexNetwork; use 'lockstep'")
     from_ring = False
     if device_replay:
         from .device_replay import DeviceReplayBuffer
         if not isinstance(replaybuf, DeviceReplayBuffer):
             replaybuf = DeviceReplayBuffer(player.device_engine(), len(replaybuf), replaybuf)
+    elif mode == "actor_learner":
+        player._agree_seed_base()          # a collective the actors make in device_engine(): rank 0 joins it here
+    if history is not None and mode:
+        history["selfplay_mode"] = mode
     if shared and not leader:
-        serve_selfplay(player, replaybuf)
+        if mode == "actor_learner":
+            from .actor_learner import serve_selfplay_ahead
+            stats = serve_selfplay_ahead(player, ahead_rows=config.get("selfplay_ahead_rows"),
+                                         poll_plies=config.get("selfplay_poll_plies", 1))
+            if history is not None:
+                history["actor"] = stats
+        else:
+            serve_selfplay(player, replaybuf)
         player.stop()
         return "%s/checkpoints/final.policy.pth" % rundir      # written by rank 0
-    if device_replay:
-        batches = lambda: replaybuf.loader(batch_size)
-        if (config.get("train_step_graph") or config.get("train_step_native")) and device.type == "cuda":
-            # the captured step reads its rows straight from the ring: iterate the epoch's index chunks, the same
-            # order loader() visits (random_reflect is the identity for Hex, hex.py:124-134)
-            def index_chunks():
-                order = replaybuf.epoch_indices()
-                for s in range(0, len(order), batch_size):
-                    yield order[s:s + batch_size]
-            batches, from_ring = index_chunks, True
-    else:
-        loader = DataLoader(replaybuf, batch_size=batch_size, shuffle=True, pin_memory=(device.type == "cuda"),
-                            num_workers=config.get("num_dataloader_workers", 0), collate_fn=torch_batch_replays)
-        batches = lambda: iter(loader)
-    # config["train_step_graph"]: full batches go through the captured step (GraphedTrainStep); their losses stay on
-    # the device until the next log line.  The epoch's ragged last batch takes the eager step.
-    # config["train_step_native"]: the hand-written step (native_train.NativeTrainStep: no autograd, no MIOpen).
-    gstep = None
-    if config.get("train_step_native") and device.type == "cuda":
-        from .native_train import NativeTrainStep
-        gstep = NativeTrainStep(policy.net, optimizer, batch_size, device)
-    elif config.get("train_step_graph") and device.type == "cuda":
-        gstep = GraphedTrainStep(policy.net, optimizer, batch_size, device)
-    loss_dev = None
-    loss, step, start_time = 0.0, 0, time.time()
-    for epoch in range(1, config["total_epochs"] + 1):
-        # The reference calls scheduler.step() at the top of every epoch (policy_trainer.py:81) under the torch
-        # it pins (0.4.1 / 1.0.1), where StepLR starts at last_epoch = -1: epoch e trains with
-        # lr_initial * lr_decay ** ((e - 1) // lr_decay_epochs).  Modern torch counts the constructor as step 0,
-        # so the same schedule is "no step before epoch 1, one step before every later epoch".
-        if epoch > 1:
-            scheduler.step()
+
+    # ---- rank 0 (or the only rank) from here on.  Under torch.distributed everything up to the final announcement
+    # runs inside try: a failure -- a train step outside its envelope, AZX_ERANGE from a refill, SearchTreeFull, an
+    # out-of-memory -- is announced (OP_ABORT) so that the other ranks leave instead of waiting in a broadcast
+    learner = None
+    try:
+        if mode == "actor_learner":
+            from .actor_learner import Learner
+            learner = Learner(policy.net, config.get("weight_sync_steps", 50))
+            replaybuf.learner = player.learner = learner
+        gstep, step_name = make_train_step(policy.net, optimizer, batch_size, device, config)
+        logging.info("training step: %s", step_name)
         if history is not None:
-            history.setdefault("lr", []).append(optimizer.param_groups[0]["lr"])
-        for item in batches():
-            batch = item
-            if from_ring:                                        # item: a chunk of ring row indices
-                if len(item) == batch_size:
-                    l3, _ = gstep.step_from_ring(replaybuf, item)
-                    loss_dev = l3[0].clone() if loss_dev is None else loss_dev + l3[0]
-                    batch = None
-                else:
-                    batch = replaybuf.sample(item)              # the epoch's ragged last chunk: eager step below
-            if batch is not None:
-                batch = game_class.random_reflect(batch)
-                if gstep is not None and len(batch["reward"]) == batch_size:
-                    l3 = gstep.step({k: v.to(device) for k, v in batch.items()})
-                    loss_dev = l3[0].clone() if loss_dev is None else loss_dev + l3[0]
-                else:
-                    output, loss_ = supervised_step(policy.net, batch, train=True, optimizer=optimizer, device=device)
-                    loss += loss_
-            replaybuf.consume(batch_size / oversampling, player)
-            if config.get("log_interval") and step % config["log_interval"] == 0:
-                if loss_dev is not None:
-                    loss, loss_dev = loss + float(loss_dev.item()), None
-                sps = config["log_interval"] / max(1e-9, time.time() - start_time)
-                logging.info("step %d loss %.4f steps/sec %.2f", step, loss / config["log_interval"], sps)
-                loss, start_time = 0.0, time.time()
-            if config.get("model_checkpoint_interval") and step % config["model_checkpoint_interval"] == 0:
-                save_checkpoint(policy, "%s/checkpoints/checkpoint.%d" % (rundir, step), optimizer=optimizer)
-            step += 1
-    if shared:
+            history["train_step"] = step_name
+        if device_replay:
+            batches = lambda: replaybuf.loader(batch_size)
+            if gstep is not None:
+                # the captured / hand-written step reads its rows straight from the ring: iterate the epoch's index
+                # chunks, the same order loader() visits (random_reflect is the identity for Hex, hex.py:124-134)
+                def index_chunks():
+                    order = replaybuf.epoch_indices()
+                    for s in range(0, len(order), batch_size):
+                        yield order[s:s + batch_size]
+                batches, from_ring = index_chunks, True
+        else:
+            loader = DataLoader(replaybuf, batch_size=batch_size, shuffle=True, pin_memory=(device.type == "cuda"),
+                                num_workers=config.get("num_dataloader_workers", 0), collate_fn=torch_batch_replays)
+            batches = lambda: iter(loader)
+        if learner is not None:
+            learner.sync_weights()         # the actors start playing with rank 0's network, whatever they were built with
+        loss_dev = None
+        loss, step, start_time = 0.0, 0, time.time()
+        for epoch in range(1, config["total_epochs"] + 1):
+            # The reference calls scheduler.step() at the top of every epoch (policy_trainer.py:81) under the torch
+            # it pins (0.4.1 / 1.0.1), where StepLR starts at last_epoch = -1: epoch e trains with
+            # lr_initial * lr_decay ** ((e - 1) // lr_decay_epochs).  Modern torch counts the constructor as step 0,
+            # so the same schedule is "no step before epoch 1, one step before every later epoch".
+            if epoch > 1:
+                scheduler.step()
+            if history is not None:
+                history.setdefault("lr", []).append(optimizer.param_groups[0]["lr"])
+            for item in batches():
+                batch = item
+                if from_ring:                                        # item: a chunk of ring row indices
+                    if len(item) == batch_size:
+                        l3, _ = gstep.step_from_ring(replaybuf, item)
+                        loss_dev = l3[0].clone() if loss_dev is None else loss_dev + l3[0]
+                        batch = None
+                    else:
+                        batch = replaybuf.sample(item)              # the epoch's ragged last chunk: eager step below
+                if batch is not None:
+                    batch = game_class.random_reflect(batch)
+                    if gstep is not None and len(batch["reward"]) == batch_size:
+                        l3 = gstep.step({k: v.to(device) for k, v in batch.items()})
+                        loss_dev = l3[0].clone() if loss_dev is None else loss_dev + l3[0]
+                    else:
+                        output, loss_ = supervised_step(policy.net, batch, train=True, optimizer=optimizer, device=device)
+                        loss += loss_
+                if learner is not None:
+                    learner.after_step()
+                replaybuf.consume(batch_size / oversampling, player)
+                if config.get("log_interval") and step % config["log_interval"] == 0:
+                    if loss_dev is not None:
+                        loss, loss_dev = loss + float(loss_dev.item()), None
+                    sps = config["log_interval"] / max(1e-9, time.time() - start_time)
+                    logging.info("step %d loss %.4f steps/sec %.2f", step, loss / config["log_interval"], sps)
+                    loss, start_time = 0.0, time.time()
+                if config.get("model_checkpoint_interval") and step % config["model_checkpoint_interval"] == 0:
+                    save_checkpoint(policy, "%s/checkpoints/checkpoint.%d" % (rundir, step), optimizer=optimizer)
+                step += 1
+    except BaseException:
+        if shared:
+            try:
+                azdist.abort()
+            except Exception:               # the control group itself is gone: the followers' timeout ends them
+                logging.exception("could not announce the abort")
+        raise
+    if history is not None and learner is not None:
+        history["learner"] = dict(steps=learner.steps, pulls=learner.pulls, weight_syncs=learner.weight_syncs)
+    if learner is not None:
+        learner.stop()
+    elif shared:
         azdist.lead(azdist.OP_STOP)
         azdist.broadcast_weights(policy.net, src=0)
     player.stop()

@@ -276,7 +276,7 @@ def _train_config(rundir_seed=0):
     return dict(seed=7, device="cpu", replaybuf_oversampling=4, batch_size=8, game="azalea_amd.game.hex.HexGame",
                 board_size=4, replaybuf_size=64, lr_initial=0.05, momentum=0.9, l2_regularization=1e-4,
                 lr_decay_epochs=100, lr_decay=0.1, total_epochs=3, selfplay_games=8, log_interval=0,
-                model_checkpoint_interval=10)
+                model_checkpoint_interval=10, selfplay_mode="lockstep")
 
 
 def _train_worker(rank, world, port, rundir, out):
@@ -335,7 +335,13 @@ def _train_worker(rank, world, port, rundir, out):
     finally:
         pp._eng.Engine, pp.Player.announce = real, real_announce
     out[rank] = fails
+    azd_reset()
     dist.destroy_process_group()
+
+
+def azd_reset():
+    from azalea_amd import distributed as azd
+    azd.reset_control_group()
 
 
 def _spawn(fn, world, *args):
@@ -403,3 +409,279 @@ def _world8_worker(rank, world, port, out):
 def test_world8_gloo_quota_zero_ranks_join_the_collectives():
     out = _spawn(_world8_worker, 8)
     assert out == {r: [] for r in range(8)}
+
+
+# ---- actor / learner: the other ranks play AHEAD while rank 0 trains ---------------------------------------------
+
+class ActorEngine(DigestEngine):
+    """DigestEngine with the device-side production surface the actors use (play_device -> rows_pack), on host
+    memory: every call plays a couple of whole random games, slowly enough that training steps run beside it."""
+
+    def __init__(self, board_size, n_games, seed, game_index_stride, game_index_offset, **kw):
+        super().__init__(board_size, n_games, seed, game_index_stride, game_index_offset, **kw)
+        from azalea_amd import _lib
+        self.cells = board_size * board_size
+        self.record_bytes = _lib.record_bytes(self.cells)
+        self.torch_device = torch.device("cpu")
+        self.queue = np.zeros((0, self.record_bytes), np.uint8)
+        self.produced_with = []          # (digest of the weights in force, rows) per production
+
+    def play_device(self, min_positions, max_plies=0):
+        import time
+        from azalea_amd import distributed as azd
+        time.sleep(0.002)
+        rows, _ = self.play(6)
+        self.queue = azd.pack_rows(rows, self.cells)
+        self.produced_with.append((self.digests[-1] if self.digests else None, len(self.queue)))
+        games = len(np.unique(rows["game_uid"]))
+        return len(self.queue), dict(games=games, plies=len(self.queue), game_errors=0, seconds=0.002,
+                                     sum_reward_last=float(games))
+
+    def rows_pack(self, first, n, ptr):
+        StubEngine._host(ptr, n * self.record_bytes)[:] = self.queue[first:first + n].reshape(-1)
+
+
+def _net_digest(net):
+    e = DigestEngine.__new__(DigestEngine)
+    e.digests = []
+    e.set_weights({k: v.detach().cpu().numpy() for k, v in net.state_dict().items() if v.dtype == torch.float32})
+    return e.digests[0]
+
+
+def _policy(seed):
+    from azalea_amd import Policy
+    cfg = dict(device="cpu", network="HexNetwork", board_size=4, num_blocks=1, base_chans=8, simulations=20,
+               search_batch_size=10, exploration_coef=0.5, exploration_depth=3, exploration_noise_alpha=0.3,
+               exploration_noise_scale=0.25, exploration_temperature=1.0, seed=5)
+    torch.manual_seed(seed)
+    pol = Policy()
+    pol.initialize(cfg)
+    return pol
+
+
+def _actor_learner_worker(rank, world, port, rundir, fail_at, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["AZX_FOLLOW_TIMEOUT"] = "60"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import glob
+    from azalea_amd import actor_learner as al
+    from azalea_amd import distributed as azd
+    from azalea_amd import parallel_player as pp
+    from azalea_amd import policy_trainer as pt
+    real, real_sync = pp._eng.Engine, al.Learner.sync_weights
+    pp._eng.Engine = ActorEngine
+    sent = []
+
+    def sync(self):
+        if fail_at is not None and self.weight_syncs == fail_at:
+            raise RuntimeError("injected trainer failure")
+        real_sync(self)
+        sent.append(_net_digest(self.net))
+    al.Learner.sync_weights = sync
+    fails = []
+    try:
+        pol = _policy(100 + rank)                      # the ranks START with different networks
+        StubPlayEngine.created.clear()
+        cfg = dict(_train_config(), total_epochs=4, weight_sync_steps=3, selfplay_ahead_rows=40)
+        del cfg["selfplay_mode"]                       # the default under torch.distributed is actor_learner
+        hist = {}
+        raised = None
+        try:
+            path = pt.train(pol, cfg, rundir, history=hist)
+        except Exception as exc:                       # noqa: BLE001
+            raised = exc
+        if fail_at is not None:
+            # rank 0 failed between two announcements: it re-raises its error, every actor is told and leaves
+            want = RuntimeError if rank == 0 else azd.LeaderLost
+            fails += [] if isinstance(raised, want) else [520]
+            out[rank] = fails
+            return
+        fails += [] if raised is None else [500]
+        if os.environ.get("AZX_TEST_VERBOSE"):
+            print(rank, hist, flush=True)
+        engines = [e for e in StubPlayEngine.created if isinstance(e, ActorEngine)]
+        if rank == 0:
+            L = hist["learner"]
+            # rank 0 never played; it pulled rows and sent its network every 3 steps (+ once before the first step)
+            fails += [] if (hist["selfplay_mode"] == "actor_learner" and not any(e.produced_with for e in engines)) else [501]
+            fails += [] if (L["pulls"] >= 2 and L["weight_syncs"] == 1 + L["steps"] // 3 and L["steps"] >= 24) else [502]
+            mine = sent
+        else:
+            A = hist["actor"]
+            eng = engines[0]
+            mine = eng.digests
+            # the actor produced BETWEEN announcements (self-play ran beside training), never before the first
+            # broadcast, never more than its bound ahead, and answered every pull
+            fails += [] if (A["max_productions_between_announcements"] >= 1 and A["pulls"] >= 2) else [503]
+            fails += [] if all(d is not None for d, _ in eng.produced_with) else [504]
+            fails += [] if A["weight_syncs"] == len(eng.digests) >= 2 else [505]
+        alld = [None] * world
+        dist.all_gather_object(alld, mine)
+        # every broadcast left every rank with the same network; it changed from broadcast to broadcast
+        fails += [] if (all(d == alld[0] for d in alld) and len(set(alld[0])) >= 3) else [506]
+        sd = torch.cat([t.detach().reshape(-1).double() for t in pol.net.state_dict().values() if t.is_floating_point()])
+        sums = [None] * world
+        dist.all_gather_object(sums, float(sd.sum()))
+        fails += [] if all(x == sums[0] for x in sums) else [507]          # everyone leaves with the trained network
+        dist.barrier()
+        files = sorted(glob.glob(os.path.join(rundir, "checkpoints", "*.policy.pth")))
+        fails += [] if (os.path.exists(path) and any("checkpoint.0." in f for f in files)) else [508]
+        if rank == 0:
+            state = torch.load(path, weights_only=False)["policy"]["net"]
+            fails += [] if all(torch.equal(state[k], v) for k, v in pol.net.state_dict().items()) else [509]
+    finally:
+        pp._eng.Engine, al.Learner.sync_weights = real, real_sync
+        out[rank] = fails
+        azd_reset()
+        dist.destroy_process_group()
+
+
+def test_actor_learner_followers_play_ahead_while_rank0_trains(tmp_path):
+    """policy_trainer.train's default topology under torch.distributed (world 2 and 3): rank 0 trains and never plays;
+    the other ranks produce between its announcements into bounded backlogs, hand rows over when it pulls, and pack
+    the network it broadcasts every `weight_sync_steps` steps -- identical digests on every rank at every broadcast,
+    one set of checkpoint files, everyone returns with the trained network."""
+    for world in (2, 3):
+        out = _spawn(_actor_learner_worker, world, str(tmp_path / ("al%d" % world)), None)
+        assert out == {r: [] for r in range(world)}
+
+
+def test_actor_learner_trainer_failure_releases_the_actors(tmp_path):
+    """a rank 0 that raises (here: at its third weight broadcast) must not leave the others waiting in a
+    broadcast -- it announces OP_ABORT, the actors raise LeaderLost and exit, rank 0 re-raises its own error."""
+    out = _spawn(_actor_learner_worker, 2, str(tmp_path / "abort"), 2)
+    assert out == {0: [], 1: []}
+
+
+def _lockstep_abort_worker(rank, world, port, rundir, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["AZX_FOLLOW_TIMEOUT"] = "60"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from azalea_amd import distributed as azd
+    from azalea_amd import parallel_player as pp
+    from azalea_amd import policy_trainer as pt
+    real, real_make = pp._eng.Engine, pt.make_train_step
+    pp._eng.Engine = DigestEngine
+
+    def make(*a, **k):
+        raise ValueError("train_step_native was asked for, but: 13x13 is outside the envelope")
+    pt.make_train_step = make
+    raised = None
+    try:
+        pt.train(_policy(100 + rank), _train_config(), rundir)
+    except Exception as exc:                           # noqa: BLE001
+        raised = exc
+    finally:
+        pp._eng.Engine, pt.make_train_step = real, real_make
+    out[rank] = [] if isinstance(raised, ValueError if rank == 0 else azd.LeaderLost) else [600 + rank]
+    azd_reset()
+    dist.destroy_process_group()
+
+
+def test_lockstep_trainer_failure_before_the_first_step_releases_the_followers(tmp_path):
+    """The case ADVICE r4 names: the training step cannot be built for this network (a ValueError on rank 0 before
+    its loop starts); the followers, already waiting for an announcement, are told and leave."""
+    out = _spawn(_lockstep_abort_worker, 2, str(tmp_path / "ls_abort"))
+    assert out == {0: [], 1: []}
+
+
+def _timeout_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+    from azalea_amd import distributed as azd
+    azd.control_group()
+    fails = []
+    if rank == 0:
+        time.sleep(1.5)                                # silent for longer than the follower's patience
+        azd.lead(azd.OP_STOP)                          # (matches the follower's still-posted receive)
+    else:
+        t0 = time.monotonic()
+        try:
+            azd.follow(timeout=0.5)
+            fails.append(700)
+        except azd.LeaderLost:
+            fails += [] if 0.4 < time.monotonic() - t0 < 1.4 else [701]
+    out[rank] = fails
+    dist.barrier()
+    azd_reset()
+    dist.destroy_process_group()
+
+
+def test_follow_times_out_when_rank0_goes_silent():
+    out = _spawn(_timeout_worker, 2)
+    assert out == {0: [], 1: []}
+
+
+def test_learner_pull_fills_the_device_ring_from_the_actors_backlogs():
+    out = _spawn(_pull_ring_worker, 3)
+    assert out == {r: [] for r in range(3)}
+
+
+def _pull_ring_worker(rank, world, port, out):
+    """DeviceReplayBuffer.consume in actor / learner mode, without train(): rank 0's ring receives exactly the rows
+    the two actors hand over, in rank order, whole chunks only; a pull larger than a backlog makes the actor play."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from azalea_amd import actor_learner as al
+    from azalea_amd import distributed as azd
+    from azalea_amd.device_replay import DeviceReplayBuffer
+    from azalea_amd.network import HexNetwork
+    azd.control_group()
+    fails = []
+    torch.manual_seed(rank)
+    net = HexNetwork(board_size=4, num_blocks=1, base_chans=8)
+    per_pull = []                                      # this rank's handed-over records, one array per pull
+    if rank == 0:
+        E = StubEngine(4, seed=50)
+        buf = DeviceReplayBuffer(E, capacity=400)
+        buf.learner = L = al.Learner(net, weight_sync_steps=1000)
+        L.sync_weights()
+        m = buf.consume(15)                            # refill 30 -> 15 rows per actor
+        c = L.last_pull["rows_per_rank"]
+        fails += [] if (c[0] == 0 and min(c[1:]) >= 15 and len(buf) == sum(c) and buf.fresh_counter == sum(c) - 15) else [801]
+        fails += [] if (m["games"] >= 2 and m["moves_per_game"] == sum(c)) else [802]
+        buf.fresh_counter = 0
+        buf.consume(100)                               # refill 200: more than the backlogs hold -> the actors play on
+        c2 = L.last_pull["rows_per_rank"]
+        fails += [] if (c2[0] == 0 and min(c2[1:]) >= 100) else [803]
+        L.stop()
+    else:
+        class P:                                       # the slice of Player the actor loop uses
+            n_games, weight_syncs = 8, 0
+            eng = ActorEngine(4, 8, 1234, world, rank)
+            pol = type("Pol", (), {"net": net})()
+
+            def _device_policy(self):
+                return self.pol
+
+            def device_engine(self):
+                return self.eng
+
+            def prepare_device_engine(self, eng):
+                eng.set_weights({k: v.detach().numpy() for k, v in net.state_dict().items() if v.dtype == torch.float32})
+        real_take = al.RecordBacklog.take
+
+        def take(self, quota):
+            recs, tot = real_take(self, quota)
+            per_pull.append(np.concatenate([r.numpy() for r in recs]))
+            return recs, tot
+        al.RecordBacklog.take = take
+        try:
+            stats = al.serve_selfplay_ahead(P(), ahead_rows=40)
+        finally:
+            al.RecordBacklog.take = real_take
+        fails += [] if (stats["pulls"] == 2 and stats["weight_syncs"] == 1 and stats["rows"] >= 115) else [810]
+        fails += [] if stats["max_productions_between_announcements"] >= 1 else [811]
+    got = [None] * world
+    dist.all_gather_object(got, per_pull)
+    if rank == 0:                                      # ring order: pull 1 (actor 1, actor 2), pull 2 (actor 1, actor 2)
+        want = np.concatenate([got[r][p] for p in range(2) for r in range(1, world)])
+        fails += [] if np.array_equal(E.ring[:E.size], want) else [804]
+    out[rank] = fails
+    azd_reset()
+    dist.destroy_process_group()

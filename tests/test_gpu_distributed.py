@@ -150,13 +150,27 @@ def test_bench_eight_ranks_dry_run():
     assert one["plies"] == eight["plies"] == 64 * 3 and one["games_finished"] == eight["games_finished"]
 
 
-def _train_worker(rank, world, port, rundir, native, out):
+def _module_digest(net):
+    import hashlib
+    h = hashlib.sha256()
+    for k, v in sorted(net.state_dict().items()):
+        if v.dtype == torch.float32:
+            h.update(k.encode())
+            h.update(v.detach().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def _train_worker(rank, world, port, rundir, native, mode, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["AZX_FOLLOW_TIMEOUT"] = "300"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import glob
     from azalea_amd import Policy
+    from azalea_amd import actor_learner as al
     from azalea_amd import device_replay as dr
+    from azalea_amd import distributed as azd
+    from azalea_amd import parallel_player as pp
     from azalea_amd.policy_trainer import train
     fails = []
     n = 5
@@ -166,26 +180,51 @@ def _train_worker(rank, world, port, rundir, native, out):
     torch.manual_seed(100 + rank)                       # the ranks START from different networks
     policy = Policy()
     policy.initialize(cfg)
-    digests = []
-    real_fill = dr.DeviceReplayBuffer._fill_shared
+    digests, packed = [], []
+    real_fill, real_sync, real_prep = dr.DeviceReplayBuffer._fill_shared, al.Learner.sync_weights, pp.Player.prepare_device_engine
 
-    def fill(self, refill):                             # the engine's packed weights at every shared refill
+    def fill(self, refill):                             # lock-step: the engine's packed weights at every shared refill
         digests.append(self.engine.weights_digest())
         return real_fill(self, refill)
-    dr.DeviceReplayBuffer._fill_shared = fill
+
+    def sync(self):                                     # actor / learner, rank 0: the module it has just broadcast
+        real_sync(self)
+        digests.append(_module_digest(self.net))
+
+    def prep(self, engine):                             # actor / learner, rank 1: the module it packs after a broadcast
+        real_prep(self, engine)
+        if mode == "actor_learner" and rank != 0:
+            digests.append(_module_digest(self._device_policy().net))
+            packed.append(engine.weights_digest())
+    dr.DeviceReplayBuffer._fill_shared, al.Learner.sync_weights, pp.Player.prepare_device_engine = fill, sync, prep
     tcfg = dict(seed=11, device="cuda:0", replaybuf_oversampling=2, batch_size=16, game="azalea_amd.game.hex.HexGame",
                 board_size=n, replaybuf_size=320, lr_initial=0.05, momentum=0.9, l2_regularization=1e-4,
                 lr_decay_epochs=100, lr_decay=0.1, total_epochs=1, selfplay_games=16, log_interval=0,
-                model_checkpoint_interval=8, train_step_native=native)
+                model_checkpoint_interval=8, selfplay_mode=mode, weight_sync_steps=4, selfplay_ahead_rows=64)
+    if not native:
+        tcfg["train_step_native"] = False              # native=True: the DEFAULT picks the hand-written step (1x64 on 5x5)
+    hist = {}
     try:
-        path = train(policy, tcfg, rundir, device_replay=True)
+        path = train(policy, tcfg, rundir, device_replay=True, history=hist)
     finally:
-        dr.DeviceReplayBuffer._fill_shared = real_fill
+        dr.DeviceReplayBuffer._fill_shared, al.Learner.sync_weights, pp.Player.prepare_device_engine = real_fill, real_sync, real_prep
     alld = [None] * world
     dist.all_gather_object(alld, digests)
-    # 20 steps x 8 rows consumed: several shared refills, each searched with rank 0's weights of that moment on BOTH
-    # ranks (the digests are of the engines' packed operands), and those weights moved as rank 0 trained
-    fails += [] if (len(digests) >= 3 and alld[0] == alld[1]) else [1]
+    if mode == "lockstep":
+        # 20 steps x 8 rows consumed: several shared refills, each searched with rank 0's weights of that moment on BOTH
+        # ranks (the digests are of the engines' packed operands), and those weights moved as rank 0 trained
+        fails += [] if (len(digests) >= 3 and alld[0] == alld[1]) else [1]
+    else:
+        # 20 steps, a broadcast before the first and after every 4th: the module rank 1 packed after each broadcast is
+        # the one rank 0 had just sent; rank 1 played between announcements and handed its rows over when asked
+        fails += [] if (len(alld[0]) == 1 + 20 // 4 and alld[0] == alld[1]) else [1]
+        if rank == 0:
+            L = hist["learner"]
+            fails += [] if (hist["train_step"] == ("native" if native else "eager") and L["pulls"] >= 2 and L["steps"] == 20) else [6]
+        else:
+            A = hist["actor"]
+            fails += [] if (A["pulls"] >= 2 and A["rows"] >= 100 and A["max_productions_between_announcements"] >= 1) else [7]
+            fails += [] if len(set(packed)) == len(packed) >= 3 else [8]     # the packed operands moved with every broadcast
     fails += [] if len(set(alld[0])) >= 3 else [2]
     sd = torch.cat([t.detach().reshape(-1).double().cpu() for t in policy.net.state_dict().values() if t.is_floating_point()])
     sums = [None] * world
@@ -199,19 +238,23 @@ def _train_worker(rank, world, port, rundir, native, out):
         state = torch.load(path, weights_only=False)["policy"]["net"]
         fails += [] if all(torch.equal(state[k].cpu(), v.cpu()) for k, v in policy.net.state_dict().items()) else [5]
     out[rank] = fails
+    azd.reset_control_group()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["lockstep", "actor_learner"])
 @pytest.mark.parametrize("native", [False, True])
-def test_train_two_ranks_rank0_trains_both_play_with_its_weights(tmp_path, native):
-    """VERDICT r3 #1(b, c): policy_trainer.train with world 2 (gloo, both ranks on this GPU, real engines, the HBM
-    replay ring): rank 0 runs the optimizer -- the eager step, or the hand-written one with its rows collated
-    asynchronously on the trainer's stream -- and broadcasts its network before every shared refill, rank 1 serves
-    self-play; identical engine weight digests at every refill, one set of checkpoint files."""
+def test_train_two_ranks_rank0_trains_both_play_with_its_weights(tmp_path, native, mode):
+    """policy_trainer.train with world 2 (gloo, both ranks on this GPU, real engines, the HBM replay ring).
+    lockstep: rank 0 runs the optimizer -- the eager step, or the hand-written one, which is the default where it
+    applies -- and broadcasts its network before every shared refill, rank 1 serves self-play; identical engine weight
+    digests at every refill.  actor_learner (the default mode): rank 1 plays ahead into its backlog between rank 0's
+    announcements, rank 0 never plays, pulls rows and broadcasts every 4 steps.  Either way one set of checkpoint
+    files and both ranks leave with the trained network."""
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path / "run"), native, out), nprocs=world, join=True)
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path / "run"), native, mode, out), nprocs=world, join=True)
     assert dict(out) == {0: [], 1: []}
 
 
@@ -235,6 +278,14 @@ def test_rccl_single_rank_carries_the_records_and_the_weights():
         t = torch.tensor([azd.OP_REFILL, 77], dtype=torch.int64, device="cuda:0")
         dist.broadcast(t, src=0)
         assert t.tolist() == [azd.OP_REFILL, 77]
+        # announcements travel on a gloo group created beside the RCCL one (pollable, with our own timeout)
+        g = azd.control_group()
+        assert dist.get_backend(g) == "gloo"
+        c = torch.tensor([azd.OP_PULL, 5], dtype=torch.int64)
+        w = dist.broadcast(c, src=0, group=g, async_op=True)
+        w.wait()
+        assert w.is_completed() and c.tolist() == [azd.OP_PULL, 5]
+        azd.reset_control_group()
         net = HexNetwork(board_size=5, num_blocks=1, base_chans=64).to("cuda:0")
         before = [v.clone() for v in net.state_dict().values()]
         flat = torch.cat([v.detach().reshape(-1).float() for v in net.state_dict().values() if v.is_floating_point()])

@@ -13,7 +13,11 @@ import torch
 from azalea_amd import engine as eng
 from azalea_amd.network import HexNetwork
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("AZX_PERF_FLOOR") == "0",
+                                 reason="AZX_PERF_FLOOR=0: wall-clock floors switched off (a shared or throttled box)")]
+# Every floor is DEVICE time (HIP events on the stream the kernels run on), best of three measurements: host jitter
+# and a neighbour's burst do not reach it, which is what lets the bounds sit 7-15 % above the measured values.
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -40,10 +44,13 @@ def test_tower_and_heads_floor():
     E.set_weights({k: (v.data_ptr(), v.numel()) for k, v in net.state_dict().items() if v.dtype == torch.float32},
                   on_device=True)
     E.play_steps(1)
-    st = E.play_steps(3)
-    per_launch_ms = 1e3 * st["net_seconds"] / st["net_launches"]
-    positions = st["evals"] / st["net_launches"]
-    ms_40960 = per_launch_ms * 40960.0 / positions
+    ms_40960 = 1e9
+    for _ in range(3):
+        st = E.play_steps(2)
+        ms = 1e3 * st["net_seconds"] / st["net_launches"]
+        pos = st["evals"] / st["net_launches"]
+        if ms * 40960.0 / pos < ms_40960:
+            per_launch_ms, positions, ms_40960 = ms, pos, ms * 40960.0 / pos
     _record("tower_heads", {"ms_per_launch_pair": per_launch_ms, "positions_per_launch": positions,
                             "ms_per_40960_positions": ms_40960, "kernels": E.kernel_info()})
     E.close()
@@ -54,8 +61,10 @@ def test_tower_and_heads_floor():
 def test_tree_move_floor():
     E = _pool(eng.EVAL_UNIFORM)
     E.play_steps(120)                                                   # settle: the pool spreads over all plies
-    st = E.play_steps(100)
-    ms_per_move = 1e3 * st["mcts_seconds"] / st["mcts_launches"]
+    ms_per_move = 1e9
+    for _ in range(3):
+        st = E.play_steps(60)
+        ms_per_move = min(ms_per_move, 1e3 * st["mcts_seconds"] / st["mcts_launches"])
     _record("tree", {"ms_per_move": ms_per_move, "moves": st["mcts_launches"], "kernel_launches": st["mcts_kernel_launches"],
                      "kernels": E.kernel_info()})
     E.close()
@@ -64,7 +73,7 @@ def test_tree_move_floor():
 
 
 def test_native_training_step_floor():
-    """The hand-written training step at the reference's shape (6x64, 11x11, batch 128): <= 0.65 ms per step with the
+    """The hand-written training step at the reference's shape (6x64, 11x11, batch 128): <= 0.55 ms per step with the
     inputs resident (measured 0.48-0.51 box to box; 0.83 before the split-f16 kernels; the stock kernels captured as a
     HIP graph take 2.1)."""
     import time
@@ -89,11 +98,17 @@ def test_native_training_step_floor():
     for _ in range(20):
         step._run()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(200):
-        step._run()
-    torch.cuda.synchronize()
-    ms = 1e3 * (time.perf_counter() - t0) / 200
-    _record("train_step", {"ms_per_step": ms, "steps_per_sec": 1e3 / ms})
+    ms, host_ms = 1e9, 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()                       # the step's data chain runs on torch's current stream; its side stream joins it
+        for _ in range(200):
+            step._run()
+        e1.record()
+        torch.cuda.synchronize()
+        host_ms = min(host_ms, 1e3 * (time.perf_counter() - t0) / 200)
+        ms = min(ms, e0.elapsed_time(e1) / 200)
+    _record("train_step", {"ms_per_step": ms, "steps_per_sec": 1e3 / ms, "host_clock_ms_per_step": host_ms})
     step.close()
-    assert ms <= 0.65, ms
+    assert ms <= 0.55, (ms, host_ms)
