@@ -217,10 +217,13 @@ def _train_worker(rank, world, port, rundir, native, mode, out):
     else:
         # 20 steps, a broadcast before the first and after every 4th: the module rank 1 packed after each broadcast is
         # the one rank 0 had just sent; rank 1 played between announcements and handed its rows over when asked
-        fails += [] if (len(alld[0]) == 1 + 20 // 4 and alld[0] == alld[1]) else [1]
+        fails += [] if (len(alld[0]) >= 1 + 20 // 4 and alld[0] == alld[1]) else [1]
         if rank == 0:
-            L = hist["learner"]
-            fails += [] if (hist["train_step"] == ("native" if native else "eager") and L["pulls"] >= 2 and L["steps"] == 20) else [6]
+            L = hist["learner"]      # >= 20 steps: the initial buffer holds whole games, so a few rows more than 320
+            fails += [] if (hist["train_step"] == ("native" if native else "eager") and L["pulls"] >= 2
+                            and 20 <= L["steps"] <= 24 and len(digests) == L["weight_syncs"] == 1 + L["steps"] // 4) else [6]
+            if fails:
+                print("learner", hist, len(digests), flush=True)
         else:
             A = hist["actor"]
             fails += [] if (A["pulls"] >= 2 and A["rows"] >= 100 and A["max_productions_between_announcements"] >= 1) else [7]

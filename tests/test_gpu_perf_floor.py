@@ -69,7 +69,7 @@ def test_tree_move_floor():
                      "kernels": E.kernel_info()})
     E.close()
     assert st["mcts_kernel_launches"] < st["mcts_launches"]            # the persistent k_play path was taken
-    assert ms_per_move <= 1.35, ms_per_move
+    assert ms_per_move <= 1.45, ms_per_move
 
 
 def test_native_training_step_floor():
