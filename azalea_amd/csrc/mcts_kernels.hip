@@ -1125,6 +1125,11 @@ __device__ __forceinline__ void mcts_body(const DevEngine &E, int mode_arg, int 
             if (go_deeper) deeper_issue();
             __builtin_amdgcn_sched_barrier(0);                 // the requests leave before the next root level
             if (i + 1 < bs) root_pick_any(select_count + 1);   // in the shadow of that load
+            // (Round 5: the NEXT descent's first child block is known here, a whole descent before its load -- touching
+            // one dword per 128-byte line of it now, so that the load finds the lines in L2, was built and measured:
+            // 1.327 vs 1.217 ms per move, three alternating runs on one box, profiles/r5_tree_touch_ab.txt.  The stamps
+            // say why: waiting for and scoring child blocks is 17.6 % of a wave's cycles, and the touch's own address
+            // arithmetic + one more vector-memory instruction per descent cost more than the latency they hide.)
             if (go_deeper) {
                 if (!pshort) {
                     // the child block is first touched HERE (the compiler otherwise copies parts of it
