@@ -23,3 +23,11 @@ void azx_net_eval(AzxNet *net, const DevEngine &d, hipStream_t st);
 // Network.run on host arrays (network.py:87-105): value[B], moves_logprob[B][K]
 int azx_net_forward_host(AzxNet *net, int B, int K, const int32_t *boards,
                          const int32_t *legal_moves, float *value, float *logprob, hipStream_t st);
+
+// One 3x3 convolution of a wide tower (C a multiple of 128, boards up to 13x13) for the TRAINING step (train_wide.hip):
+// k_conv_wide_f16x3_s16's staging and k-loop on a split-f16 image `in` [boards][cells][C hi | C lo] and one layer's
+// fragments `w16` in the wide pack; writes the raw fp32 product times `*unscale` (a device word: the scales are made on
+// the device) to out32 [boards][cells][C] and, when `stat` is given, per-board per-channel (sum, sum of squares) pairs
+// [boards][C].
+int azx_net_wide_train_conv(int N, int C, const unsigned short *w16, const unsigned short *in, float *out32, int n_boards,
+                            const float *unscale, float2 *stat, hipStream_t st);

@@ -1121,11 +1121,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3(NetDev P, int layer,
 #endif
 #define WIDE16_MT 6
 #define WIDE16_NT 4
-__global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int layer, const unsigned short *__restrict__ in,
-                                                                unsigned short *out, const unsigned short *resid,
-                                                                float *__restrict__ out32,
-                                                                const int32_t *__restrict__ n_eval_ptr, int n_eval_host,
-                                                                int e_base, int e_end) {
+// TRAIN = 1 (csrc/train_wide.hip, the training step's forward and backward-data convolutions of a wide tower): the same
+// product on the same staging and k-loop, but the accumulators start from zero (no bias, no residual), and the epilogue
+// writes the RAW fp32 output times `unscale` (the operands' power-of-two scales taken out) -- no ReLU, no f16 image --
+// plus, when `stat` is given, this board's per-channel (sum, sum of squares) of what it wrote: train-mode BatchNorm's
+// batch statistics as per-board partial pairs (summed over the boards in a fixed order by their consumers).
+template <int TRAIN>
+__device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, const unsigned short *__restrict__ in,
+                                                   unsigned short *out, const unsigned short *resid,
+                                                   float *__restrict__ out32,
+                                                   const int32_t *__restrict__ n_eval_ptr, int n_eval_host,
+                                                   int e_base, int e_end, float unscale, float2 *__restrict__ stat) {
     constexpr int MT = WIDE16_MT, NT = WIDE16_NT, ROWB = WIDE_ROWB;
     float satmax = 0.f;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1195,7 +1201,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     // memory round trip, nothing else to do yet) instead of in the epilogue, where every wave of the block
     // waited for it with the matrix pipe idle.
     f32x4 acc[MT][NT];
-    {
+    if (TRAIN) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
         const unsigned char *gres0 = resid ? reinterpret_cast<const unsigned char *>(resid) + (size_t)e * ncells * rowg : nullptr;
 #if AZX_WIDE_ABLATE & 16
         gres0 = nullptr;
@@ -1347,6 +1358,62 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     if (wm == 0) main_loop(std::integral_constant<int, 0>{});
     else main_loop(std::integral_constant<int, 1>{});
 
+    if (TRAIN) {
+        // ---- training epilogue: raw fp32 out, per-board channel sums ---------------------------------------------
+        float s1[2][8], s2[2][8];
+#pragma unroll
+        for (int np = 0; np < 2; ++np)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[np][j] = 0.f; s2[np][j] = 0.f; }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r = row0 + 16 * m + lrow;
+#pragma unroll
+            for (int np = 0; np < 2; ++np) {
+                const bool mine = !(wm == 0 ? (m == MT - 1 && np == 1) : (m == 0 && np == 0));   // else the other wave's
+                if (r < ncells && mine) {
+                    float vv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        vv[j] = acc[m][2 * np + (j >> 2)][j & 3] * unscale;
+                        s1[np][j] += vv[j];
+                        s2[np][j] += vv[j] * vv[j];
+                    }
+                    float *o32 = out32 + ((size_t)e * ncells + r) * C + chan0(np);
+                    *reinterpret_cast<float4 *>(o32) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    *reinterpret_cast<float4 *>(o32 + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+                }
+            }
+        }
+        if (stat) {
+            // a channel's rows sit in the 16 lanes li of one lane group lh and in both position waves: lanes first
+            // (xor 1, 2, 4, 8 stay inside the group), then the two waves through LDS (the chunk image is done with)
+#pragma unroll
+            for (int np = 0; np < 2; ++np)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        s1[np][j] += __shfl_xor(s1[np][j], o);
+                        s2[np][j] += __shfl_xor(s2[np][j], o);
+                    }
+            __syncthreads();                            // every wave has left the k-loop: the image can be overwritten
+            float2 *sst = reinterpret_cast<float2 *>(smem);     // [wm][128 channels of the block]
+            if (li == 0) {
+#pragma unroll
+                for (int np = 0; np < 2; ++np)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        sst[wm * 128 + 64 * wn + 32 * np + 8 * lh + j] = make_float2(s1[np][j], s2[np][j]);
+            }
+            __syncthreads();
+            if (tid < 128) {
+                const float2 a = sst[tid], b = sst[128 + tid];
+                stat[(size_t)e * C + co_base + tid] = make_float2(a.x + b.x, a.y + b.y);
+            }
+        }
+        return;
+    }
     // ---- epilogue: ReLU -> split -> HBM, one 16-byte piece per lane and plane -----------------------
     NT_MARK(2)
     unsigned char *gout = reinterpret_cast<unsigned char *>(out) + (size_t)e * ncells * rowg;
@@ -1386,6 +1453,38 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
     if (satmax > 65504.0f) atomicOr(P.sat_flag, 1u);     // an activation left the f16 range: its hi half is +inf (NetDev::sat_flag)
     NT_MARK(3)
     WT_FLUSH
+}
+
+__global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int layer, const unsigned short *__restrict__ in,
+                                                                unsigned short *out, const unsigned short *resid,
+                                                                float *__restrict__ out32,
+                                                                const int32_t *__restrict__ n_eval_ptr, int n_eval_host,
+                                                                int e_base, int e_end) {
+    conv_wide_s16_body<0>(P, layer, in, out, resid, out32, n_eval_ptr, n_eval_host, e_base, e_end, 1.f, nullptr);
+}
+
+// the training step's convolutions (TRAIN = 1 above): `w16` = one layer's fragments in the wide pack
+// ([tap][chunk][half][ntile][hi, lo][lane][8]: k_tw_pack), boards [0, n_boards)
+__global__ __launch_bounds__(256, 2) void k_conv_wide_train(int N, int C, const unsigned short *__restrict__ w16,
+                                                            const unsigned short *__restrict__ in, float *__restrict__ out32,
+                                                            int n_boards, const float *__restrict__ unscale, float2 *__restrict__ stat) {
+    NetDev P;
+    P.N = N; P.ncells = N * N; P.C = C; P.Wh16 = w16; P.bias = nullptr; P.sat_flag = nullptr;
+    conv_wide_s16_body<1>(P, 0, in, nullptr, nullptr, out32, nullptr, n_boards, 0, n_boards, *unscale, stat);
+}
+
+int azx_net_wide_train_conv(int N, int C, const unsigned short *w16, const unsigned short *in, float *out32, int n_boards,
+                            const float *unscale, float2 *stat, hipStream_t st) {
+    static bool raised = false;
+    const size_t lds = (size_t)(N * N + 2) * WIDE_ROWB;
+    if (!raised) {
+        if (hipFuncSetAttribute((const void *)k_conv_wide_train, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+            return AZX_EHIP;
+        raised = true;
+    }
+    const dim3 g(8 * (C / 128), (n_boards + 7) / 8);
+    hipLaunchKernelGGL(k_conv_wide_train, g, dim3(256), lds, st, N, C, w16, in, out32, n_boards, unscale, stat);
+    return AZX_OK;
 }
 
 // stem of the wide tower: the one-hot K = 27 product of k_tower_f16x3's stem, one board x 128

@@ -109,6 +109,8 @@ struct TrnDev {
     unsigned int *wmax;                   // [L + 1] bits of max |filter of layer l| (k_trn_stem_fwd, from wpmax)
     double *zero_base;             // the per-step accumulators (sums | hsums | lossacc | stem_dT | hconv_acc), zero_count doubles
     int zero_count;
+    // wide towers (C = 128 / 256: the "wide tower" section below)
+    float2 *bsc;                   // [L + 1] (scale of layer l's BatchNorm-backward image, 1 / (that x the filter scale))
 };
 
 __device__ __forceinline__ double dsum(const double *s, int l, int C, int c, int k) { return s[((size_t)l * C + c) * 4 + k]; }
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_fwd(TrnDev P) {
     __shared__ unsigned char cellv[128];
     __shared__ float red[2][NTH];
     const int b = blockIdx.x, tid = threadIdx.x, N = P.N, cells = P.cells;
-    if (P.Wf16[1] != nullptr || P.Wb16[1] != nullptr) {
+    if (C <= 64 && (P.Wf16[1] != nullptr || P.Wb16[1] != nullptr)) {
         // The tower filters as hi / lo f16 fragments of v_mfma_f32_32x32x16_f16, scaled by the layer's power of two.
         // Every block first reduces k_trn_prep's per-block maxima (and the BatchNorm bounds) -- block 0 publishes them
         // for the convolution kernels --, then the grid shares the fragments: an item is one lane's 8 halves of one
@@ -1420,9 +1422,10 @@ __global__ __launch_bounds__(256) void k_trn_heads_wgrad(TrnDev P, HeadGradOffs 
 // heads, backward: BatchNorm backward of the two 1x1 convolutions, their weight gradients (per-board partials), the
 // gradient into the tower's output with its ReLU mask and BN_L's two reductions
 // =================================================================================================================
-template <int C>
-__global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_bwd(TrnDev P) {
-    constexpr int C4 = C / 4, LDX = C + 1, NTH = TRN_SMALL_THREADS, ITER = (121 * C4 + NTH - 1) / NTH;
+// (NTH: 1024 threads; 512 at C = 256, where the board image and 1024 threads' running sums do not fit the LDS together)
+template <int C, int NTH = (C > 128 ? 512 : TRN_SMALL_THREADS)>
+__global__ __launch_bounds__(NTH) void k_trn_heads_bwd(TrnDev P) {
+    constexpr int C4 = C / 4, LDX = C + 1, ITER = (121 * C4 + NTH - 1) / NTH;
     extern __shared__ __align__(16) float lds[];
     float *X = lds;                          // [cells][LDX] the tower's output (for the ReLU mask and the conv gradients)
     float *rs = X + (size_t)P.cells * LDX;   // [NTH][8] per-thread channel sums
@@ -1770,8 +1773,279 @@ __global__ __launch_bounds__(256) void k_trn_prep(TrnDev P) {
     if (!on) return;
     const int tap = (int)(e % 9), ci = (int)(e / 9 % C), co = (int)(e / 9 / C);
     float *wf = P.Wf[l], *wb = P.Wb[l];
+    if (wf == nullptr) return;            // wide towers: no exact-fp32 roles, no fp32 packs
     wf[((((size_t)tap * Q + (ci >> 3)) * NT + (co >> 5)) * 64 + (co & 31) + 32 * ((ci >> 2) & 1)) * 4 + (ci & 3)] = v;
     wb[((((size_t)(8 - tap) * Q + (co >> 3)) * NT + (ci >> 5)) * 64 + (ci & 31) + 32 * ((co >> 2) & 1)) * 4 + (co & 3)] = v;
+}
+
+// =================================================================================================================
+// wide towers: C = 128 / 256 (BASELINE configs[4]'s width), boards up to 11x11
+//
+// A 6x64 step is a chain of launches whose matrix work is ~1.5 us each: everything above is built around latency.  At
+// 256 channels a layer pass is 18 GFLOP: throughput-bound, and a (board, 32 channels) workgroup that stages the whole
+// input would re-read and re-normalise it eight times.  So the wide step is built the other way round:
+//   * the three 3x3 convolutions per layer -- forward, backward-data, filter gradient -- run on the split-f16 MFMA
+//     kernels that exist for this shape: the self-play tower's k_conv_wide_f16x3_s16 (net_kernels.hip) in its TRAIN mode
+//     (raw fp32 output, per-board channel sums in the epilogue, no bias / residual / ReLU) for the first two, on
+//     split-f16 IMAGES [B][cells][C hi | C lo] of their operand, and k_trn_wgrad16<C> as it is for the third;
+//   * everything between two convolutions is one elementwise pass that writes the next convolution's image:
+//       k_tw_bnact   act_l = relu(BN_l(raw_l) [+ act_{l-2}]) on batch statistics -> act_l (fp32, for the backward
+//                    pass and the filter gradient) and its image, scaled by the layer's power of two
+//       k_tw_bnbwd   draw_l = BatchNorm backward of g_l -> its image, scaled from max |g_l| like ROLE_BWD16
+//       k_tw_relubwd g_{l-1} = (conv^T output [+ g_{l+1}]) * (act_{l-1} > 0), per-board (sum g, sum g xhat), max |g|
+//     with the batch sums of a block's 64 channels taken from the per-board partial pairs in the block (fixed order);
+//   * the stem, the heads and the update are the kernels above, instantiated at this width.
+// =================================================================================================================
+int azx_net_wide_train_conv(int N, int C, const unsigned short *w16, const unsigned short *in, float *out32, int n_boards,
+                            const float *unscale, float2 *stat, hipStream_t st);      // net_kernels.hip
+
+// per-layer scales (the narrow path makes them in k_trn_stem_fwd): filter scale from k_trn_prep's per-block maxima,
+// activation scale from the BatchNorm bounds (all C channels), fsc[l] = (sa, 1 / (sa sw), sw, 1 / sw).  One block.
+// (grid L + 1: block l reduces layer l's two maxima into bsc[l] -- free until the backward pass --, then a one-block
+// launch with `finish` set turns them into fsc)
+template <int C>
+__global__ __launch_bounds__(256) void k_tw_scales(TrnDev P, int finish) {
+    constexpr int NB = (C * C * 9 + 255) / 256;
+    __shared__ float sW[TRN_MAXL + 1], sBn[TRN_MAXL + 1], red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cells = P.cells;
+    if (!finish) {
+        const int l = blockIdx.x;
+        float mw = 0.f, mb = 0.f;
+        if (l >= 1)
+            for (int i = tid; i < NB; i += 256) mw = fmaxf(mw, P.wpmax[(size_t)l * NB + i]);
+        const float sq = sqrtf((float)P.B * cells);
+        for (int c = tid; c < C; c += 256) mb = fmaxf(mb, fabsf(P.bn_w[l][c]) * sq + fabsf(P.bn_b[l][c]));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { mw = fmaxf(mw, __shfl_xor(mw, o)); mb = fmaxf(mb, __shfl_xor(mb, o)); }
+        if (lane == 0) { red[0][wave] = mw; red[1][wave] = mb; }
+        __syncthreads();
+        if (tid == 0) {
+            const float m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+            P.bsc[l] = make_float2(pow2_scale(m), fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])));
+            if (l >= 1) P.wmax[l] = __float_as_uint(m);
+        }
+        return;
+    }
+    if (tid <= P.L) { const float2 x = P.bsc[tid]; sW[tid] = x.x; sBn[tid] = x.y; }
+    __syncthreads();
+    if (tid >= 1 && tid <= P.L) {
+        const int l = tid;                  // layer l convolves act_{l-1}: bounded by its BatchNorm's bound + its skip chain's
+        float bd = sBn[l - 1];
+        if (((l - 1) & 1) == 0 && l - 1 >= 2)
+            for (int j = l - 3; j >= 0; j -= 2) bd += sBn[j];
+        const float sa = pow2_scale(bd), sw = sW[l];
+        P.fsc[l] = make_float4(sa, 1.f / (sa * sw), sw, 1.f / sw);
+    }
+}
+
+// The tower filters of layers l0 .. as hi / lo f16 fragments in the wide pack of k_conv_wide_f16x3_s16
+// ([tap][chunk of 64 k][half][ntile of 16][hi, lo][lane = j + 16 h][8 consecutive k], tile row j <-> channel by the wide
+// permutation, see net_pack.hip), scaled by the layer's power of two.  A thread owns (n, 8 consecutive k) and all nine
+// taps: forward (n = co, k = ci) it reads 72 contiguous floats; backward-data (n = ci, k = co, taps flipped) eight runs
+// of nine, consecutive lanes consecutive runs.  grid (C C / 8 / 256, L, 2).
+template <int C>
+__global__ __launch_bounds__(256) void k_tw_pack(TrnDev P, unsigned short *const *wf, unsigned short *const *wb) {
+    constexpr int NCH = C / 64, NT16 = C / 16, KB = C / 8;
+    const int l = blockIdx.y + 1, bwd = blockIdx.z;
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= C * KB) return;
+    // forward: kb fastest (a row of w is contiguous in ci); backward: n fastest
+    const int n = bwd ? it % C : it / KB, kb = bwd ? it / C : it % KB;
+    const float sc = P.fsc[l].z;
+    const float *w = P.convw[l];
+    float v[8][9];
+    if (!bwd) {
+        const float *src = w + ((size_t)n * C + 8 * kb) * 9;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) v[t][tap] = src[t * 9 + tap] * sc;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float *src = w + ((size_t)(8 * kb + t) * C + n) * 9;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) v[t][8 - tap] = src[tap] * sc;
+        }
+    }
+    // n -> (ntile, row j) by the inverse of: n = 64 (nt / 4) + 32 ((nt % 4) >> 1) + 8 (j >> 2) + 4 (nt & 1) + (j & 3)
+    const int g4 = n >> 6, a = (n >> 5) & 1, jq = (n >> 3) & 3, bq = (n >> 2) & 1, r = n & 3;
+    const int nt = 4 * g4 + 2 * a + bq, j = 4 * jq + r;
+    const int k0 = 8 * kb, ch = k0 >> 6, half = (k0 >> 5) & 1, h = (k0 >> 3) & 3, lane = j + 16 * h;
+    uint4 *dst = reinterpret_cast<uint4 *>(bwd ? wb[l] : wf[l]);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        _Float16 hi[8], lo[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { hi[t] = (_Float16)v[t][tap]; lo[t] = (_Float16)(v[t][tap] - (float)hi[t]); }
+        uint4 *o = dst + ((((size_t)(tap * NCH + ch) * 2 + half) * NT16 + nt) * 2) * 64 + lane;
+        o[0] = *reinterpret_cast<const uint4 *>(hi);
+        o[64] = *reinterpret_cast<const uint4 *>(lo);
+    }
+}
+
+// eight consecutive channels of one position as hi / lo halves into an image row [C hi | C lo]
+__device__ __forceinline__ void image_store(unsigned short *img, size_t row, int C, int c, const float (&v)[8]) {
+    _Float16 hi[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)v[j]; lo[j] = (_Float16)(v[j] - (float)hi[j]); }
+    unsigned short *r = img + row * (size_t)(2 * C);
+    *reinterpret_cast<uint4 *>(r + c) = *reinterpret_cast<const uint4 *>(hi);
+    *reinterpret_cast<uint4 *>(r + C + c) = *reinterpret_cast<const uint4 *>(lo);
+}
+
+// elementwise passes: grid (C / 64, B), 256 threads; thread = (8 channels c8, positions p0, p0 + 32, ...)
+// this block's 64 channels of a layer's per-board partial pairs [B][C], summed over the boards in a fixed order (thread
+// = channel x one of four board phases; all of a thread's loads in flight together); threads < 64 return the totals
+__device__ __forceinline__ void tw_slice_totals(const float2 *part, int B, int C, int c0, double2 *sh, int tid, double &a, double &q) {
+    const int c = c0 + (tid & 63), ph = tid >> 6;
+    double sa = 0, sq = 0;
+    for (int b0 = ph; b0 < B; b0 += 64) {
+        float2 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int b = b0 + 4 * u;
+            const float2 x = part[(size_t)min(b, B - 1) * C + c];
+            const float on = b < B ? 1.f : 0.f;
+            v[u] = make_float2(x.x * on, x.y * on);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { sa += (double)v[u].x; sq += (double)v[u].y; }
+    }
+    sh[tid] = make_double2(sa, sq);
+    __syncthreads();
+    a = 0;
+    q = 0;
+    if (tid < 64) {
+        const double2 x0 = sh[tid], x1 = sh[64 + tid], x2 = sh[128 + tid], x3 = sh[192 + tid];
+        a = (x0.x + x1.x) + (x2.x + x3.x);
+        q = (x0.y + x1.y) + (x2.y + x3.y);
+    }
+}
+
+struct TwAct { const float *raw, *skip, *bnw, *bnb; const float2 *pstat; double *sums; float *act; unsigned short *img; const float4 *fsc; };
+__global__ __launch_bounds__(256) void k_tw_bnact(TwAct A, int cells, int C, int B, float invN) {
+    __shared__ float cA[64], cB[64];
+    __shared__ double2 sh[256];
+    const int tid = threadIdx.x, c0 = blockIdx.x * 64, b = blockIdx.y;
+    double t0, t1;
+    tw_slice_totals(A.pstat, B, C, c0, sh, tid, t0, t1);
+    if (tid < 64) {
+        const int c = c0 + tid;
+        if (b == 0) { A.sums[(size_t)c * 4] = t0; A.sums[(size_t)c * 4 + 1] = t1; }      // for the backward pass and the update
+        float mean, inv;
+        bn_from_sums(t0, t1, invN, mean, inv);
+        const float a = A.bnw[c] * inv;
+        cA[tid] = a;
+        cB[tid] = A.bnb[c] - mean * a;
+    }
+    const float sa = A.img ? A.fsc->x : 1.f;
+    __syncthreads();
+    const int cl = (tid & 7) * 8, c = c0 + cl;
+    for (int pos = tid >> 3; pos < cells; pos += 32) {
+        const size_t o = ((size_t)b * cells + pos) * C + c;
+        const float4 r0 = *reinterpret_cast<const float4 *>(A.raw + o), r1 = *reinterpret_cast<const float4 *>(A.raw + o + 4);
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+        if (A.skip) { s0 = *reinterpret_cast<const float4 *>(A.skip + o); s1 = *reinterpret_cast<const float4 *>(A.skip + o + 4); }
+        const float x[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w}, k[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        float v[8], vs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = fmaxf(x[j] * cA[cl + j] + cB[cl + j] + k[j], 0.f); vs[j] = v[j] * sa; }
+        *reinterpret_cast<float4 *>(A.act + o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4 *>(A.act + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        if (A.img) image_store(A.img, (size_t)b * cells + pos, C, c, vs);
+    }
+}
+
+struct TwBnBwd { const float *g, *raw, *bnw; const float2 *pgsum; double *sums; const unsigned int *gmax; const float4 *fsc; unsigned short *img; float2 *bsc; };
+__global__ __launch_bounds__(256) void k_tw_bnbwd(TwBnBwd A, int cells, int C, int B, float invN) {
+    __shared__ float cA[64], cM[64], cI[64], cK0[64], cK1[64], red[4];
+    __shared__ double2 sh[256];
+    const int tid = threadIdx.x, c0 = blockIdx.x * 64, b = blockIdx.y;
+    const float gmax = __uint_as_float(*A.gmax), sqn = sqrtf((float)B * cells);
+    // The image has ONE scale, so every block needs a bound over all channels.  With the channels' own (mean g, mean g
+    // xhat) that would be every channel's partial sums in every block; |mean g| <= max |g| and |mean g xhat| <= max |g|
+    // (mean |xhat| <= 1) give |draw| <= |gamma inv| max |g| (2 + sqrt n) from what the forward pass filed -- a bound up
+    // to ~sqrt(n) looser, i.e. the pair resolves 2^-31 of the largest entry instead of 2^-38: far below fp32's rounding.
+    float bd = 0.f;
+    for (int c = tid; c < C; c += 256) {
+        float mean, inv;
+        bn_from_sums(A.sums[(size_t)c * 4], A.sums[(size_t)c * 4 + 1], invN, mean, inv);
+        const float a = A.bnw[c] * inv;
+        bd = fmaxf(bd, fabsf(a) * gmax * (2.f + sqn));
+        if (c >= c0 && c < c0 + 64) { cA[c - c0] = a; cM[c - c0] = mean; cI[c - c0] = inv; }
+    }
+    double t0, t1;
+    tw_slice_totals(A.pgsum, B, C, c0, sh, tid, t0, t1);     // (sum g_l, sum g_l xhat_l) of this block's channels
+    if (tid < 64) {
+        if (b == 0) { A.sums[(size_t)(c0 + tid) * 4 + 2] = t0; A.sums[(size_t)(c0 + tid) * 4 + 3] = t1; }   // k_trn_update's BatchNorm gradients
+        cK0[tid] = (float)(t0 * (double)invN);
+        cK1[tid] = (float)(t1 * (double)invN);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bd = fmaxf(bd, __shfl_xor(bd, o));
+    if ((tid & 63) == 0) red[tid >> 6] = bd;
+    __syncthreads();
+    const float sc = pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (blockIdx.x == 0 && b == 0 && tid == 0) *A.bsc = make_float2(sc, A.fsc->w / sc);
+    const int cl = (tid & 7) * 8, c = c0 + cl;
+    for (int pos = tid >> 3; pos < cells; pos += 32) {
+        const size_t o = ((size_t)b * cells + pos) * C + c;
+        const float4 g0 = *reinterpret_cast<const float4 *>(A.g + o), g1 = *reinterpret_cast<const float4 *>(A.g + o + 4);
+        const float4 r0 = *reinterpret_cast<const float4 *>(A.raw + o), r1 = *reinterpret_cast<const float4 *>(A.raw + o + 4);
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = sc * (cA[cl + j] * (gv[j] - cK0[cl + j] - (rv[j] - cM[cl + j]) * cI[cl + j] * cK1[cl + j]));
+        image_store(A.img, (size_t)b * cells + pos, C, c, v);
+    }
+}
+
+struct TwRelu { const float *dact, *act, *skip, *raw; const double *sums; float *g; float2 *pgsum; unsigned int *gmax; };
+__global__ __launch_bounds__(256) void k_tw_relubwd(TwRelu A, int cells, int C, float invN) {
+    __shared__ float pM[64], pI[64], rs[256][17], wm[4];
+    const int tid = threadIdx.x, c0 = blockIdx.x * 64, b = blockIdx.y;
+    if (tid < 64) bn_from_sums(A.sums[(size_t)(c0 + tid) * 4], A.sums[(size_t)(c0 + tid) * 4 + 1], invN, pM[tid], pI[tid]);
+    __syncthreads();
+    const int cl = (tid & 7) * 8, c = c0 + cl;
+    float a8[8], q8[8], vmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a8[j] = 0.f; q8[j] = 0.f; }
+    for (int pos = tid >> 3; pos < cells; pos += 32) {
+        const size_t o = ((size_t)b * cells + pos) * C + c;
+        const float4 d0 = *reinterpret_cast<const float4 *>(A.dact + o), d1 = *reinterpret_cast<const float4 *>(A.dact + o + 4);
+        const float4 m0 = *reinterpret_cast<const float4 *>(A.act + o), m1 = *reinterpret_cast<const float4 *>(A.act + o + 4);
+        const float4 r0 = *reinterpret_cast<const float4 *>(A.raw + o), r1 = *reinterpret_cast<const float4 *>(A.raw + o + 4);
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+        if (A.skip) { s0 = *reinterpret_cast<const float4 *>(A.skip + o); s1 = *reinterpret_cast<const float4 *>(A.skip + o + 4); }
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w}, mv[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        const float rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = mv[j] > 0.f ? dv[j] + sv[j] : 0.f;
+            vmax = fmaxf(vmax, fabsf(v[j]));
+            a8[j] += v[j];
+            q8[j] += v[j] * (rv[j] - pM[cl + j]) * pI[cl + j];
+        }
+        *reinterpret_cast<float4 *>(A.g + o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4 *>(A.g + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { rs[tid][j] = a8[j]; rs[tid][8 + j] = q8[j]; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if ((tid & 63) == 0) wm[tid >> 6] = vmax;
+    __syncthreads();
+    if (tid == 64) atomicMax(A.gmax, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+    if (tid < 64) {
+        // channel c0 + tid: threads with (t & 7) == tid / 8, element tid % 8 -- the 32 of them in a fixed order
+        const int grp = tid >> 3, j = tid & 7;
+        double a = 0, q = 0;
+        for (int p = 0; p < 32; ++p) { a += rs[p * 8 + grp][j]; q += rs[p * 8 + grp][8 + j]; }
+        A.pgsum[(size_t)b * C + c0 + tid] = make_float2((float)a, (float)q);
+    }
 }
 
 // =================================================================================================================
@@ -1816,6 +2090,12 @@ struct AzxTrain {
     bool bwd16 = true;           // AZX_TRAIN_BWD=fp32: the backward-data convolutions ...
     bool wgrad16 = true;         // AZX_TRAIN_WGRAD=fp32: ... and the filter gradients
     bool fork = true;            // AZX_TRAIN_FORK=0: the weight-gradient passes in line with the data chain (profiling)
+    // wide towers (C = 128 / 256)
+    bool wide = false;
+    std::vector<unsigned short *> Ww16f, Ww16b, A16;       // per layer: the wide filter packs, the activations' images
+    unsigned short **Ww16f_dev = nullptr, **Ww16b_dev = nullptr;
+    unsigned short *D16 = nullptr;                          // the BatchNorm-backward image of the layer in flight
+    float *dact = nullptr;                                  // conv^T output of the layer in flight
 };
 
 template <typename T>
@@ -1837,7 +2117,10 @@ static T *upload_table(AzxTrain *t, const std::vector<T> &v) {
 
 int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int device) {
     if (N < 2 || N > 11) return tfail(AZX_EINVAL, "train: the native step covers boards up to 11x11 (121 cells = four 32-row MFMA tiles)");
-    if (chans != 16 && chans != 32 && chans != 64) return tfail(AZX_EINVAL, "train: base_chans must be 16, 32 or 64");
+    if (chans != 16 && chans != 32 && chans != 64 && chans != 128 && chans != 256)
+        return tfail(AZX_EINVAL, "train: base_chans must be 16, 32, 64, 128 or 256");
+    const bool wide = chans >= 128;
+    if (wide && N < 3) return tfail(AZX_EINVAL, "train: the wide towers (128 / 256 channels) need a board of 3x3 or more");
     if (blocks < 1 || batch < 1 || 2 * blocks > TRN_MAXL) return tfail(AZX_EINVAL, "train: num_blocks must be 1..19 and the batch positive");
     AzxTrain *t = new AzxTrain();
     memset(&t->d, 0, sizeof t->d);
@@ -1849,6 +2132,9 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     d.N = N; d.cells = N * N; d.C = chans; d.L = 2 * blocks; d.B = batch;
     d.invN = (float)(1.0 / ((double)batch * d.cells));
     t->G = std::min(batch, TRN_WG_GROUPS);
+    t->wide = wide;
+    // wide: (C / 32)^2 tile pairs already fill the chip with few board groups, and a group costs a partial copy of C C 9
+    if (wide) t->G = std::min(batch, chans == 256 ? 16 : 32);
     if (getenv("AZX_TRAIN_WG_GROUPS")) t->G = std::max(1, std::min(t->G, atoi(getenv("AZX_TRAIN_WG_GROUPS"))));
     const int L = d.L, C = chans, cells = d.cells, B = batch;
     const size_t A = (size_t)B * cells * C;
@@ -1856,12 +2142,23 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     bool ok = true;
     for (int l = 0; l <= L; ++l) {
         ok = ok && (t->raw[l] = talloc<float>(t, A)) && (t->act[l] = talloc<float>(t, A)) && (t->g[l] = talloc<float>(t, A));
-        if (l >= 1) {
+        if (l >= 1 && !wide) {
             const size_t wn = (size_t)9 * (C / 8) * ((C + 31) / 32) * 64 * 4;
             ok = ok && (t->Wf[l] = talloc<float>(t, wn)) && (t->Wb[l] = talloc<float>(t, wn));
             if (t->fwd16) ok = ok && (d.Wf16[l] = talloc<unsigned short>(t, (size_t)9 * (C / 16) * ((C + 31) / 32) * 2 * 64 * 8));
             if (t->bwd16) ok = ok && (d.Wb16[l] = talloc<unsigned short>(t, (size_t)9 * (C / 16) * ((C + 31) / 32) * 2 * 64 * 8));
         }
+    }
+    if (wide) {
+        // the wide packs ([tap][chunk][half][ntile][hi, lo][lane][8]: 2 x 9 C C halves per layer and direction), the
+        // activations' images (as many bytes as the fp32 tensors) and the two per-layer scratch tensors
+        t->Ww16f.assign(L + 1, nullptr); t->Ww16b.assign(L + 1, nullptr); t->A16.assign(L + 1, nullptr);
+        for (int l = 1; l <= L && ok; ++l)
+            ok = (t->Ww16f[l] = talloc<unsigned short>(t, (size_t)2 * 9 * C * C)) && (t->Ww16b[l] = talloc<unsigned short>(t, (size_t)2 * 9 * C * C));
+        for (int l = 0; l < L && ok; ++l) ok = (t->A16[l] = talloc<unsigned short>(t, 2 * A)) != nullptr;
+        ok = ok && (t->D16 = talloc<unsigned short>(t, 2 * A)) && (t->dact = talloc<float>(t, A)) &&
+             (t->Ww16f_dev = upload_table(t, t->Ww16f)) && (t->Ww16b_dev = upload_table(t, t->Ww16b)) &&
+             (d.bsc = talloc<float2>(t, TRN_MAXL + 2));
     }
     // sums | hsums | lossacc contiguous: one memset per step
     const size_t nsum = (size_t)(L + 1) * C * 4 + 6 * 4 + 2 + (size_t)TRN_REP * (27 * C + 6 * C);
@@ -2190,7 +2487,106 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
     return AZX_OK;
 }
 
-static int raise_limits(int C) {
+// the wide step (C = 128 / 256): see "wide towers" above
+template <int C>
+static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork) {
+    const TrnDev &d = t->d;
+    const int L = d.L, B = d.B, cells = d.cells, G = t->G, N = d.N;
+    constexpr int NT = C / 32, SMALL = TRN_SMALL_THREADS;
+    const dim3 eg(C / 64, B), eb(256);
+    hipLaunchKernelGGL(k_trn_prep<C>, dim3((C * C * 9 + 255) / 256, L + 1), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_tw_scales<C>, dim3(L + 1), dim3(256), 0, st, d, 0);
+    hipLaunchKernelGGL(k_tw_scales<C>, dim3(1), dim3(256), 0, st, d, 1);
+    hipLaunchKernelGGL(k_tw_pack<C>, dim3((C * (C / 8) + 255) / 256, L, 2), dim3(256), 0, st, d, t->Ww16f_dev, t->Ww16b_dev);
+    hipLaunchKernelGGL(k_trn_stem_fwd<C>, dim3(B), dim3(SMALL), 0, st, d);
+    for (int l = 0; l < L; ++l) {
+        // act_l from raw_l (batch statistics from the per-board partials), then raw_{l+1} = conv(act_l)
+        const bool has_res = (l & 1) == 0 && l >= 2;
+        const TwAct a = {t->raw[l], has_res ? t->act[l - 2] : nullptr, d.bn_w[l], d.bn_b[l], d.pstat + (size_t)l * B * C,
+                         d.sums + (size_t)l * C * 4, t->act[l], t->A16[l], d.fsc + (l + 1)};
+        hipLaunchKernelGGL(k_tw_bnact, eg, eb, 0, st, a, cells, C, B, d.invN);
+        if (int rc = azx_net_wide_train_conv(N, C, t->Ww16f[l + 1], t->A16[l], t->raw[l + 1], B, &d.fsc[l + 1].y,
+                                             d.pstat + (size_t)(l + 1) * B * C, st))
+            return tfail(rc, "train: launching a wide forward convolution failed");
+    }
+    const size_t hc_lds = ((size_t)((cells * (C + 1) + 8 * C + 16 + 3) & ~3)) * sizeof(float) + (size_t)SMALL * 16;
+    hipLaunchKernelGGL(k_trn_heads_conv<C>, dim3(B), dim3(SMALL), hc_lds, st, d);
+    hipLaunchKernelGGL(k_trn_heads_fc, dim3(B), dim3(SMALL), 0, st, d);
+    size_t ev = 0;
+    auto next_event = [&]() -> hipEvent_t {
+        if (ev == t->events.size()) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return nullptr;
+            t->events.push_back(e);
+        }
+        return t->events[ev++];
+    };
+    hipStream_t ws = fork ? side : st;
+    auto fork_side = [&]() -> bool {
+        if (!fork) return true;
+        hipEvent_t e = next_event();
+        return e && hipEventRecord(e, st) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess;
+    };
+    auto join_side = [&]() -> bool {
+        if (!fork) return true;
+        hipEvent_t e = next_event();
+        return e && hipEventRecord(e, side) == hipSuccess && hipStreamWaitEvent(st, e, 0) == hipSuccess;
+    };
+    if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
+    const int hw_blocks = ((4 * cells + 255) / 256) * ((cells + 3) / 4) + 16 + (cells + 129 + 3) / 4;
+    hipLaunchKernelGGL(k_trn_heads_wgrad, dim3(hw_blocks), dim3(256), 0, ws, d, t->hoffs);
+    constexpr int HB = C > 128 ? 512 : SMALL;
+    const size_t hb_lds = ((size_t)cells * (C + 1) + (size_t)HB * 8) * sizeof(float);
+    hipLaunchKernelGGL((k_trn_heads_bwd<C, HB>), dim3(B), dim3(HB), hb_lds, st, d);
+    const size_t wg16_lds = (size_t)(N * 16 + (N + 3) * 16) * 128 + (1024 + 5 * 32 + 2) * sizeof(float);
+    for (int l = L; l >= 1; --l) {
+        if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
+        const WgradPtrs wq = {t->g[l], t->raw[l], t->act[l - 1], d.bn_w[l]};
+        hipLaunchKernelGGL(k_trn_wgrad16<C>, dim3(NT * NT, G), dim3(256), wg16_lds, ws, wq, l, G, d);
+        // (sum g_l, sum g_l xhat_l) come from the partials of k_trn_heads_bwd (l = L) / k_tw_relubwd
+        const TwBnBwd bb = {t->g[l], t->raw[l], d.bn_w[l], d.pgsum + (size_t)l * B * C, d.sums + (size_t)l * C * 4, d.gmax + l,
+                            d.fsc + l, t->D16, d.bsc + l};
+        hipLaunchKernelGGL(k_tw_bnbwd, eg, eb, 0, st, bb, cells, C, B, d.invN);
+        if (int rc = azx_net_wide_train_conv(N, C, t->Ww16b[l], t->D16, t->dact, B, &d.bsc[l].y, nullptr, st))
+            return tfail(rc, "train: launching a wide backward convolution failed");
+        const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= L;
+        const TwRelu rr = {t->dact, t->act[l - 1], has_skip ? t->g[l + 1] : nullptr, t->raw[l - 1], d.sums + (size_t)(l - 1) * C * 4,
+                           t->g[l - 1], d.pgsum + (size_t)(l - 1) * B * C, d.gmax + (l - 1)};
+        hipLaunchKernelGGL(k_tw_relubwd, eg, eb, 0, st, rr, cells, C, d.invN);
+    }
+    const size_t sb_lds = ((size_t)cells * C + 5 * C) * sizeof(float) + (size_t)SMALL * 16;
+    hipLaunchKernelGGL(k_trn_stem_bwd<C>, dim3(B), dim3(SMALL), sb_lds, st, d);
+    if (!join_side()) return tfail(AZX_EHIP, "train: joining the weight-gradient stream failed");
+    if (t->n_conv_blocks > 0)
+        hipLaunchKernelGGL(k_trn_update<C>, dim3(t->n_conv_blocks), dim3(256), 0, ws, d, (const Segment *)t->segs, (const int2 *)t->blocks, G);
+    if (t->n_blocks > t->n_conv_blocks)
+        hipLaunchKernelGGL(k_trn_update<C>, dim3(t->n_blocks - t->n_conv_blocks), dim3(256), 0, st, d, (const Segment *)t->segs,
+                           (const int2 *)t->blocks + t->n_conv_blocks, G);
+    if (!join_side()) return tfail(AZX_EHIP, "train: joining the weight-gradient stream failed");
+    if (hipGetLastError() != hipSuccess) return tfail(AZX_EHIP, "train: a kernel of the step failed to launch");
+    return AZX_OK;
+}
+
+// (what each kernel asks for, not a blanket cap: static + dynamic LDS together must stay within the CU's 160 KB)
+template <int C>
+static int raise_limits_wide(int cells, int N) {
+    constexpr int HB = C > 128 ? 512 : TRN_SMALL_THREADS, SMALL = TRN_SMALL_THREADS;
+    const size_t need[4] = {(size_t)(N * 16 + (N + 3) * 16) * 128 + (1024 + 5 * 32 + 2) * sizeof(float),
+                            ((size_t)((cells * (C + 1) + 8 * C + 16 + 3) & ~3)) * sizeof(float) + (size_t)SMALL * 16,
+                            ((size_t)cells * C + 5 * C) * sizeof(float) + (size_t)SMALL * 16,
+                            ((size_t)cells * (C + 1) + (size_t)HB * 8) * sizeof(float)};
+    const void *f[4] = {(const void *)k_trn_wgrad16<C>, (const void *)k_trn_heads_conv<C>, (const void *)k_trn_stem_bwd<C>,
+                        (const void *)k_trn_heads_bwd<C, HB>};
+    for (int i = 0; i < 4; ++i)
+        if (need[i] > 48 * 1024 && hipFuncSetAttribute(f[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)need[i]) != hipSuccess)
+            return tfail(AZX_EHIP, "train: raising a kernel's dynamic LDS limit failed (kernel " + std::to_string(i) + ", " +
+                                   std::to_string(need[i]) + " bytes)");
+    return AZX_OK;
+}
+
+static int raise_limits(int C, int cells = 0, int N = 0) {
+    if (C == 128) return raise_limits_wide<128>(cells, N);
+    if (C == 256) return raise_limits_wide<256>(cells, N);
     const int cap = 128 * 1024;     // the largest user (k_trn_wgrad<64>) takes 94 KB; some kernels add static LDS on top
     const void *f64[] = {(const void *)k_trn_conv<64, ROLE_FWD>, (const void *)k_trn_conv<64, ROLE_FWD16>, (const void *)k_trn_conv<64, ROLE_BWD>, (const void *)k_trn_conv<64, ROLE_BWD16>, (const void *)k_trn_wgrad<64>, (const void *)k_trn_wgrad16<64>,
                          (const void *)k_trn_heads_conv<64>, (const void *)k_trn_stem_bwd<64>, (const void *)k_trn_heads_bwd<64>};
@@ -2207,6 +2603,8 @@ static int raise_limits(int C) {
 
 static int enqueue_any(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork) {
     switch (t->d.C) {
+        case 256: return enqueue_step_wide<256>(t, st, side, fork);
+        case 128: return enqueue_step_wide<128>(t, st, side, fork);
         case 64: return enqueue_step<64>(t, st, side, fork);
         case 32: return enqueue_step<32>(t, st, side, fork);
         default: return enqueue_step<16>(t, st, side, fork);
@@ -2232,7 +2630,7 @@ int azx_trn_step(AzxTrain *t, float lr, float momentum, float weight_decay, hipS
     // host's having moved: every later step would read another step's hyper-parameter slot.  Refuse instead.
     if (t->broken) return tfail(AZX_ESTATE, "train: an earlier step failed while it was being queued; create a new trainer");
     if (!t->cap) {
-        if (int rc = raise_limits(t->d.C)) return rc;
+        if (int rc = raise_limits(t->d.C, t->d.cells, t->d.N)) return rc;
         if (hipStreamCreateWithFlags(&t->cap, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) != hipSuccess)
             return tfail(AZX_EHIP, "train: creating the capture streams failed");

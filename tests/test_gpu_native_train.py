@@ -49,7 +49,8 @@ def _net(n, blocks, chans, seed=0):
     return net.to(DEV)
 
 
-@pytest.mark.parametrize("n,blocks,chans,B", [(11, 2, 64, 8), (11, 1, 16, 5), (9, 2, 32, 7), (11, 6, 64, 128)])
+@pytest.mark.parametrize("n,blocks,chans,B", [(11, 2, 64, 8), (11, 1, 16, 5), (9, 2, 32, 7), (11, 6, 64, 128),
+                                              (5, 1, 128, 4), (7, 2, 256, 6), (11, 2, 128, 9), (11, 3, 256, 16)])
 def test_every_intermediate_matches_autograd(n, blocks, chans, B):
     from azalea_amd.native_train import NativeTrainStep
     net, ref = _net(n, blocks, chans), _net(n, blocks, chans)
@@ -149,7 +150,8 @@ def test_exact_fp32_kernels_stay_green(monkeypatch, passes):
     test_every_intermediate_matches_autograd(9, 2, 32, 7)
 
 
-@pytest.mark.parametrize("n,blocks,chans,B", [(11, 1, 64, 200), (7, 2, 32, 300), (3, 1, 16, 1), (11, 2, 16, 131), (2, 1, 64, 3)])
+@pytest.mark.parametrize("n,blocks,chans,B", [(11, 1, 64, 200), (7, 2, 32, 300), (3, 1, 16, 1), (11, 2, 16, 131), (2, 1, 64, 3),
+                                              (11, 1, 128, 131), (3, 1, 256, 1), (9, 2, 256, 70)])
 def test_odd_batches_and_boards(n, blocks, chans, B):
     """Batches that are not a multiple of anything the kernels tile by -- more boards than one round of partial-sum
     loads covers (> 128), filter-gradient groups of unequal size (B not a multiple of 64), a single board -- and the
@@ -280,16 +282,17 @@ def test_native_step_matches_the_reference_recorded_steps():
     step.close()
 
 
-def test_native_step_tracks_the_eager_step_over_twelve_steps():
-    """6x64 on 11x11, batch 128 (config/hex11_train_config.yml), SGD 0.1 -> 0.03 after eight steps, against
+@pytest.mark.parametrize("blocks,chans,B", [(6, 64, 128), (3, 256, 32)])
+def test_native_step_tracks_the_eager_step_over_twelve_steps(blocks, chans, B):
+    """6x64 on 11x11, batch 128 (config/hex11_train_config.yml) -- and a wide tower, 3x256 --, SGD 0.1 -> 0.03 after eight steps, against
     policy_trainer.supervised_step: twelve steps of the eager trajectory, the native step taken from the SAME state
     each time (weights, BatchNorm buffers, momentum copied over before the step -- two fp32 trajectories at lr 0.1
     drift apart by themselves, which would measure the optimisation's sensitivity, not the step): losses, outputs,
     then every tensor and every momentum buffer after the step."""
     from azalea_amd.native_train import NativeTrainStep
     from azalea_amd.policy_trainer import supervised_step
-    B, n = 128, 11
-    nets = [_net(n, 6, 64, seed=2), _net(n, 6, 64, seed=2)]
+    n = 11
+    nets = [_net(n, blocks, chans, seed=2), _net(n, blocks, chans, seed=2)]
     opts = [torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4) for m in nets]
     step = NativeTrainStep(nets[1], opts[1], B, DEV)
     worst = {"loss": 0.0, "out": 0.0, "tensor": 0.0, "momentum": 0.0}
