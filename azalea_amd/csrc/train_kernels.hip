@@ -111,6 +111,7 @@ struct TrnDev {
     int zero_count;
     // wide towers (C = 128 / 256: the "wide tower" section below)
     float2 *bsc;                   // [L + 1] (scale of layer l's BatchNorm-backward image, 1 / (that x the filter scale))
+    int dl_stride;                 // row stride of dlogit: 128 (boards up to 11x11), 192 beyond
 };
 
 __device__ __forceinline__ double dsum(const double *s, int l, int C, int c, int k) { return s[((size_t)l * C + c) * 4 + k]; }
@@ -210,7 +211,7 @@ template <int C>
 __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_fwd(TrnDev P) {
     constexpr int NTH = TRN_SMALL_THREADS;
     __shared__ float T[27 * C];
-    __shared__ unsigned char cellv[128];
+    __shared__ unsigned char cellv[176];
     __shared__ float red[2][NTH];
     const int b = blockIdx.x, tid = threadIdx.x, N = P.N, cells = P.cells;
     if (C <= 64 && (P.Wf16[1] != nullptr || P.Wb16[1] != nullptr)) {
@@ -914,9 +915,9 @@ __device__ __forceinline__ f16x8 tr_frag(const unsigned char *p) {
     return *reinterpret_cast<const f16x8 *>(&r);
 }
 
-template <int C>
+template <int C, int MAXCELLS>
 __device__ __forceinline__ void trn_wgrad16_body(const WgradPtrs &W_, const TrnDev &P, const int l, const int G, const int pair, const int grp, float *lds) {
-    constexpr int NT = (C + 31) / 32, CH = C < 32 ? C : 32, H4 = CH / 4, ITER = (121 * H4 + 255) / 256;
+    constexpr int NT = (C + 31) / 32, CH = C < 32 ? C : 32, H4 = CH / 4, ITER = (MAXCELLS * H4 + 255) / 256;
     const int N = P.N, cells = P.cells, KR = N * 16, BR = (N + 3) * 16;
     unsigned char *Dh = reinterpret_cast<unsigned char *>(lds), *Dl = Dh + (size_t)KR * 64;     // [KR][32] f16 draw hi / lo
     unsigned char *Bh = Dl + (size_t)KR * 64, *Bl = Bh + (size_t)BR * 64;                       // [BR][32] f16 input hi / lo
@@ -1087,10 +1088,11 @@ __global__ __launch_bounds__(256) void k_trn_wgrad(WgradPtrs A, int l, int G, Tr
     trn_wgrad_body<C>(A, P, l, G, blockIdx.x, blockIdx.y, lds);
 }
 
-template <int C>
+// (MAXCELLS: the largest board a thread's staging registers are sized for -- 121 cells, 169 for the wide towers)
+template <int C, int MAXCELLS = (C > 64 ? 169 : 121)>
 __global__ __launch_bounds__(256) void k_trn_wgrad16(WgradPtrs A, int l, int G, TrnDev P) {
     extern __shared__ __align__(16) float lds[];
-    trn_wgrad16_body<C>(A, P, l, G, blockIdx.x, blockIdx.y, lds);
+    trn_wgrad16_body<C, MAXCELLS>(A, P, l, G, blockIdx.x, blockIdx.y, lds);
 }
 
 // (Measured and dropped: one launch per backward layer with both consumers of g_l -- k_trn_conv<BWD>'s workgroups and
@@ -1357,21 +1359,22 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_fc(TrnDev P) {
 
 // gradients of the FC layers: the batch is the reduction (fixed order).  Block roles by index:
 //   [0, nM)        move_fc.weight  [cells][4 cells]: 4 rows x 256 columns per block
-//   [nM, nM + 16)  value_fc2.weight [64][2 cells]:   4 rows x all columns per block
+//   [nM, nM + nV)  value_fc2.weight [64][2 cells]:   4 rows x 256 columns per block
 //   the rest       the biases and value_fc3, four outputs per block
 struct HeadGradOffs { size_t fc2w, fc2b, fc3w, fc3b, mfw, mfb; };
 __global__ __launch_bounds__(256) void k_trn_heads_wgrad(TrnDev P, HeadGradOffs O) {
     __shared__ float dl[4][256];             // the block's four gradient rows over the batch (B <= 256 per pass)
     const int cells = P.cells, B = P.B, KV = 2 * cells, KPp = 4 * cells, tid = threadIdx.x;
     const int ichunks = (KPp + 255) / 256, tgroups = (cells + 3) / 4, nM = ichunks * tgroups;
+    const int vchunks = (KV + 255) / 256, nV = 16 * vchunks;      // (one chunk up to 11x11; two at 13x13: 338 columns)
     const int blk = blockIdx.x;
-    if (blk < nM + 16) {
+    if (blk < nM + nV) {
         const bool mf = blk < nM;
-        const int r0 = mf ? (blk / ichunks) * 4 : (blk - nM) * 4;
-        const int i = mf ? (blk % ichunks) * 256 + tid : tid;
+        const int r0 = mf ? (blk / ichunks) * 4 : ((blk - nM) / vchunks) * 4;
+        const int i = mf ? (blk % ichunks) * 256 + tid : ((blk - nM) % vchunks) * 256 + tid;
         const int rows = mf ? cells : 64, cols = mf ? KPp : KV;
         const float *src = mf ? P.dlogit : P.dh2;
-        const int sstride = mf ? 128 : 64;
+        const int sstride = mf ? P.dl_stride : 64;
         const float *x = P.hact + (mf ? 2 * cells : 0);
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         for (int b0 = 0; b0 < B; b0 += 256) {
@@ -1398,11 +1401,11 @@ __global__ __launch_bounds__(256) void k_trn_heads_wgrad(TrnDev P, HeadGradOffs 
         }
     } else {
         // biases and value_fc3: a wave per output, its lanes along the batch (blocks nM + 16 ..: four outputs each)
-        const int e = (blk - nM - 16) * 4 + (tid >> 6), lane = tid & 63;
+        const int e = (blk - nM - nV) * 4 + (tid >> 6), lane = tid & 63;
         if (e < cells + 64 + 64 + 1) {
             float s = 0.f;
             for (int b = lane; b < B; b += 64) {
-                if (e < cells) s += P.dlogit[(size_t)b * 128 + e];
+                if (e < cells) s += P.dlogit[(size_t)b * P.dl_stride + e];
                 else if (e < cells + 64) s += P.dh2[(size_t)b * 64 + e - cells];
                 else if (e < cells + 128) s += P.dv3[b] * P.h2[(size_t)b * 64 + e - cells - 64];
                 else s += P.dv3[b];
@@ -2048,6 +2051,308 @@ __global__ __launch_bounds__(256) void k_tw_relubwd(TwRelu A, int cells, int C, 
     }
 }
 
+// ---- the heads and the stem's backward for the wide towers: boards up to 13x13 (the kernels above keep a whole board
+// x all channels in LDS and lay the head planes out 128 wide) ---------------------------------------------------------
+#define TW_CP 192                  // head-plane / logit arrays: cells padded
+
+// the two 1x1 head convolutions on act_L (k_tw_bnact made it) and their batch sums: a wave per position
+__global__ __launch_bounds__(TRN_SMALL_THREADS) void k_tw_hconv(TrnDev P) {
+    __shared__ float W[6 * 256], red[12];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cells = P.cells, C = P.C;
+    for (int i = tid; i < 6 * C; i += TRN_SMALL_THREADS) W[i] = i < 2 * C ? P.vconv[i] : P.pconv[i - 2 * C];
+    if (tid < 12) red[tid] = 0.f;
+    __syncthreads();
+    float a1[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, a2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float *hraw = P.hraw + (size_t)b * 6 * cells;
+    for (int pos = wave; pos < cells; pos += TRN_SMALL_THREADS / 64) {
+        const float *x = P.actL + ((size_t)b * cells + pos) * C;
+        float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c = lane * 4; c < C; c += 256) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + c);
+#pragma unroll
+            for (int o = 0; o < 6; ++o) s[o] += v.x * W[o * C + c] + v.y * W[o * C + c + 1] + v.z * W[o * C + c + 2] + v.w * W[o * C + c + 3];
+        }
+#pragma unroll
+        for (int o = 0; o < 6; ++o) {
+            const float r = wave_sum(s[o]);
+            if (lane == 0) { hraw[o * cells + pos] = r; a1[o] += r; a2[o] += r * r; }
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int o = 0; o < 6; ++o) { atomicAdd(&red[o * 2], a1[o]); atomicAdd(&red[o * 2 + 1], a2[o]); }
+    }
+    __syncthreads();
+    if (tid < 12) atomicAdd(&P.hsums[(tid >> 1) * 4 + (tid & 1)], (double)red[tid]);
+}
+
+// k_trn_heads_fc for any board up to TW_CP cells: BN + ReLU of the head planes, the FC layers, masked log-softmax, the
+// loss and the gradient back to the head planes (network.py:77-102, :146-152); plain loops, one block per board
+__global__ __launch_bounds__(TRN_SMALL_THREADS) void k_tw_heads_fc(TrnDev P) {
+    constexpr int NTH = TRN_SMALL_THREADS, NW = NTH / 64, CP = TW_CP;
+    __shared__ float ha[6 * CP], xh[6 * CP], h2[64], dh2s[64], logit[CP], dlog[CP], gflat[6 * CP];
+    __shared__ float cS[6], cT[6], cMn[6], cIv[6];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cells = P.cells, B = P.B;
+    if (tid < 6) {
+        const double m = P.hsums[tid * 4] * (double)P.invN, v = P.hsums[tid * 4 + 1] * (double)P.invN - m * m;
+        const float inv = (float)(1.0 / sqrt((v > 0 ? v : 0) + TRN_EPS));
+        const float gmm = tid < 2 ? P.hbn_w[0][tid] : P.hbn_w[1][tid - 2], bt = tid < 2 ? P.hbn_b[0][tid] : P.hbn_b[1][tid - 2];
+        cMn[tid] = (float)m;
+        cIv[tid] = inv;
+        cS[tid] = gmm * inv;
+        cT[tid] = bt - (float)m * gmm * inv;
+    }
+    __syncthreads();
+    const float *hraw = P.hraw + (size_t)b * 6 * cells;
+    float *hact = P.hact + (size_t)b * 6 * cells;
+    for (int i = tid; i < 6 * cells; i += NTH) {
+        const int o = i / cells;
+        const float r = hraw[i], v = fmaxf(r * cS[o] + cT[o], 0.f);
+        ha[i] = v;
+        xh[i] = (r - cMn[o]) * cIv[o];
+        hact[i] = v;
+    }
+    __syncthreads();
+    const int KV = 2 * cells, KPp = 4 * cells;
+    // value_fc2 (2 cells -> 64) + ReLU and move_fc (4 cells -> cells): a wave per output, lanes along the input
+    for (int o = wave; o < 64 + cells; o += NW) {
+        const bool v = o < 64;
+        const int oo = v ? o : o - 64, K = v ? KV : KPp;
+        const float *w = (v ? P.fc2w : P.mfw) + (size_t)oo * K, *x = v ? ha : ha + 2 * cells;
+        float s = 0.f;
+        for (int i = lane; i < K; i += 64) s += w[i] * x[i];
+        s = wave_sum(s);
+        if (lane == 0) {
+            if (v) h2[oo] = fmaxf(s + P.fc2b[oo], 0.f);
+            else logit[oo] = s + P.mfb[oo];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float s = wave_sum(P.fc3w[lane] * h2[lane]);
+        const float value = tanhf(s + P.fc3b[0]), rew = P.reward[b];
+        const float dv = 2.f * (value - rew) / (float)B, d3 = dv * (1.f - value * value);
+        dh2s[lane] = h2[lane] > 0.f ? P.fc3w[lane] * d3 : 0.f;
+        P.h2[(size_t)b * 64 + lane] = h2[lane];
+        P.dh2[(size_t)b * 64 + lane] = dh2s[lane];
+        if (lane == 0) {
+            P.value[b] = value;
+            P.dv3[b] = d3;
+            atomicAdd(&P.lossacc[0], (double)((value - rew) * (value - rew)));
+        }
+    } else if (wave == 1) {
+        // gather the legal moves' logits, log-softmax over them (padding entries: -99 in the reference, exp(-99 - max)
+        // of the sum: below fp32's resolution), policy loss and dL/dlogit by tile
+        const int32_t *lm = P.legal + (size_t)b * cells;
+        const float *mp = P.prob + (size_t)b * cells;
+        float *lp = P.logprob + (size_t)b * cells;
+        constexpr int R = CP / 64;
+        int m[R];
+        float x[R], pr[R];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = lane + 64 * r;
+            m[r] = j < cells ? lm[j] : 0;
+            pr[r] = j < cells ? mp[j] : 0.f;
+            x[r] = m[r] > 0 ? logit[m[r] - 1] : -INFINITY;
+            mx = fmaxf(mx, x[r]);
+        }
+        mx = wave_max(mx);
+        float es = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) es += m[r] > 0 ? expf(x[r] - mx) : 0.f;
+        const float lse = mx + logf(wave_sum(es));
+        float S = 0.f, nll = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            S += m[r] > 0 ? pr[r] : 0.f;
+            nll += m[r] > 0 ? -pr[r] * (x[r] - lse) : 0.f;
+        }
+        S = wave_sum(S);
+        nll = wave_sum(nll);
+        for (int t = lane; t < CP; t += 64) dlog[t] = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = lane + 64 * r;
+            if (j < cells) lp[j] = m[r] > 0 ? x[r] - lse : -99.f - lse;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (m[r] > 0) dlog[m[r] - 1] = (expf(x[r] - lse) * S - pr[r]) / (float)B;
+        if (lane == 0) atomicAdd(&P.lossacc[1], (double)nll);
+    }
+    __syncthreads();
+    for (int t = tid; t < P.dl_stride; t += NTH) P.dlogit[(size_t)b * P.dl_stride + t] = t < cells ? dlog[t] : 0.f;
+    // back through the FC layers to the head planes: a thread per input
+    for (int i = tid; i < KV + KPp; i += NTH) {
+        float sg = 0.f;
+        if (i < KV) {
+            for (int o = 0; o < 64; ++o) sg += P.fc2w[(size_t)o * KV + i] * dh2s[o];
+        } else {
+            const int ip = i - KV;
+            for (int t = 0; t < cells; ++t) sg += P.mfw[(size_t)t * KPp + ip] * dlog[t];
+        }
+        gflat[i] = ha[i] > 0.f ? sg : 0.f;
+    }
+    __syncthreads();
+    float *g6 = P.g6 + (size_t)b * 6 * cells;
+    for (int i = tid; i < 6 * cells; i += NTH) g6[i] = gflat[i];
+    if (tid < 6 * 32) {        // the two reductions the head BatchNorms' backward needs
+        const int o = tid >> 5, j = tid & 31;
+        float a = 0.f, q = 0.f;
+        for (int pos = j; pos < cells; pos += 32) { const float gv = gflat[o * cells + pos]; a += gv; q += gv * xh[o * cells + pos]; }
+#pragma unroll
+        for (int sft = 16; sft >= 1; sft >>= 1) { a += __shfl_xor(a, sft); q += __shfl_xor(q, sft); }
+        if (j == 0) {
+            atomicAdd(&P.hsums[o * 4 + 2], (double)a);
+            atomicAdd(&P.hsums[o * 4 + 3], (double)q);
+        }
+    }
+}
+
+// k_trn_heads_bwd by (64 channels, board): BatchNorm backward of the head planes, the gradient into the tower's output
+// with its ReLU mask, BN_L's two reductions as this board's partial pair, max |g_L|, and the 1x1 filters' gradients
+__global__ __launch_bounds__(256) void k_tw_heads_bwd(TrnDev P) {
+    __shared__ float dh[6][TW_CP], W6[6][64], pM[64], pI[64], rs[256][17], wm[4];
+    __shared__ float cA[6], cMn[6], cIv[6], cK1[6], cK2[6];
+    const int tid = threadIdx.x, c0 = blockIdx.x * 64, b = blockIdx.y, cells = P.cells, C = P.C, L = P.L;
+    if (tid < 6) {
+        const double m = P.hsums[tid * 4] * (double)P.invN, v = P.hsums[tid * 4 + 1] * (double)P.invN - m * m;
+        const float inv = (float)(1.0 / sqrt((v > 0 ? v : 0) + TRN_EPS));
+        cMn[tid] = (float)m;
+        cIv[tid] = inv;
+        cA[tid] = (tid < 2 ? P.hbn_w[0][tid] : P.hbn_w[1][tid - 2]) * inv;
+        cK1[tid] = (float)(P.hsums[tid * 4 + 2] * (double)P.invN);
+        cK2[tid] = (float)(P.hsums[tid * 4 + 3] * (double)P.invN);
+    }
+    if (tid >= 64 && tid < 128) bn_coeffs(P, L, c0 + tid - 64, pM[tid - 64], pI[tid - 64]);
+    for (int i = tid; i < 6 * 64; i += 256) {
+        const int o = i >> 6, cc = c0 + (i & 63);
+        W6[o][i & 63] = o < 2 ? P.vconv[(size_t)o * C + cc] : P.pconv[(size_t)(o - 2) * C + cc];
+    }
+    __syncthreads();
+    const float *g6 = P.g6 + (size_t)b * 6 * cells, *hraw = P.hraw + (size_t)b * 6 * cells;
+    for (int i = tid; i < 6 * cells; i += 256) {
+        const int o = i / cells;
+        dh[o][i - o * cells] = cA[o] * (g6[i] - cK1[o] - (hraw[i] - cMn[o]) * cIv[o] * cK2[o]);
+    }
+    __syncthreads();
+    const int cl = (tid & 7) * 8, c = c0 + cl;
+    float a8[8], q8[8], wacc[6][8], vmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a8[j] = 0.f; q8[j] = 0.f; }
+#pragma unroll
+    for (int o = 0; o < 6; ++o)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wacc[o][j] = 0.f;
+    for (int pos = tid >> 3; pos < cells; pos += 32) {
+        const size_t off = ((size_t)b * cells + pos) * C + c;
+        const float4 m0 = *reinterpret_cast<const float4 *>(P.actL + off), m1 = *reinterpret_cast<const float4 *>(P.actL + off + 4);
+        const float4 r0 = *reinterpret_cast<const float4 *>(P.rawL + off), r1 = *reinterpret_cast<const float4 *>(P.rawL + off + 4);
+        const float mv[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v[8];
+#pragma unroll
+        for (int o = 0; o < 6; ++o) {
+            const float h = dh[o][pos];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { d[j] += h * W6[o][cl + j]; wacc[o][j] += h * mv[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = mv[j] > 0.f ? d[j] : 0.f;
+            vmax = fmaxf(vmax, fabsf(v[j]));
+            a8[j] += v[j];
+            q8[j] += v[j] * (rv[j] - pM[cl + j]) * pI[cl + j];
+        }
+        *reinterpret_cast<float4 *>(P.gL + off) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4 *>(P.gL + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { rs[tid][j] = a8[j]; rs[tid][8 + j] = q8[j]; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if ((tid & 63) == 0) wm[tid >> 6] = vmax;
+    __syncthreads();
+    if (tid == 64) atomicMax(&P.gmax[L], __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+    const int grp = (tid & 63) >> 3, jj = tid & 7;
+    if (tid < 64) {
+        double a = 0, q = 0;
+        for (int p = 0; p < 32; ++p) { a += rs[p * 8 + grp][jj]; q += rs[p * 8 + grp][8 + jj]; }
+        P.pgsum[((size_t)L * P.B + b) * C + c0 + tid] = make_float2((float)a, (float)q);
+    }
+    // the 1x1 filters' gradients: this board's share of [6][C], two planes per round through rs
+#pragma unroll
+    for (int o0 = 0; o0 < 6; o0 += 2) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { rs[tid][j] = wacc[o0][j]; rs[tid][8 + j] = wacc[o0 + 1][j]; }
+        __syncthreads();
+        if (tid < 128) {
+            const int u = tid >> 6;
+            float sacc = 0.f;
+            for (int p = 0; p < 32; ++p) sacc += rs[p * 8 + grp][8 * u + jj];
+            atomicAdd(&P.hconv_acc[(size_t)(b % TRN_REP) * 6 * C + (size_t)(o0 + u) * C + c0 + (tid & 63)], (double)sacc);
+        }
+    }
+}
+
+// k_trn_stem_bwd by (64 channels, board): BN_0 backward, then this board's share of dL/dT[tap][cell value][cout]
+__global__ __launch_bounds__(256) void k_tw_stem_bwd(TrnDev P) {
+    __shared__ float Dr[176][65];
+    __shared__ float cA[64], cM[64], cI[64], cK0[64], cK1[64];
+    __shared__ double2 sh[256];
+    __shared__ unsigned char cellv[176], nbv[9][176];
+    const int tid = threadIdx.x, c0 = blockIdx.x * 64, b = blockIdx.y, cells = P.cells, C = P.C, N = P.N;
+    double t0, t1;
+    tw_slice_totals(P.pgsum, P.B, C, c0, sh, tid, t0, t1);
+    if (tid < 64) {
+        const int c = c0 + tid;
+        if (b == 0) { P.sums[(size_t)c * 4 + 2] = t0; P.sums[(size_t)c * 4 + 3] = t1; }
+        float mean, inv;
+        bn_coeffs(P, 0, c, mean, inv);
+        cM[tid] = mean;
+        cI[tid] = inv;
+        cA[tid] = P.bn_w[0][c] * inv;
+        cK0[tid] = (float)(t0 * (double)P.invN);
+        cK1[tid] = (float)(t1 * (double)P.invN);
+    }
+    for (int i = tid; i < cells; i += 256) cellv[i] = (unsigned char)P.board[(size_t)b * cells + i];
+    __syncthreads();
+    const int cl = (tid & 7) * 8;
+    for (int pos = tid >> 3; pos < cells; pos += 32) {
+        const size_t off = ((size_t)b * cells + pos) * C + c0 + cl;
+        const float4 g0 = *reinterpret_cast<const float4 *>(P.g[0] + off), g1 = *reinterpret_cast<const float4 *>(P.g[0] + off + 4);
+        const float4 r0 = *reinterpret_cast<const float4 *>(P.raw[0] + off), r1 = *reinterpret_cast<const float4 *>(P.raw[0] + off + 4);
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            Dr[pos][cl + j] = cA[cl + j] * (gv[j] - cK0[cl + j] - (rv[j] - cM[cl + j]) * cI[cl + j] * cK1[cl + j]);
+    }
+    for (int i = tid; i < 9 * cells; i += 256) {
+        const int tap = i / cells, pos = i - tap * cells;
+        const int y = pos / N, x = pos - y * N, yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        nbv[tap][pos] = (yy >= 0 && yy < N && xx >= 0 && xx < N) ? cellv[yy * N + xx] : (unsigned char)3;
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * 64; i += 256) {
+        const int tap = i >> 6, co = i & 63;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int pos = 0; pos < cells; ++pos) {
+            const float v = Dr[pos][co];
+            const int cv = nbv[tap][pos];
+            a0 += cv == 0 ? v : 0.f;
+            a1 += cv == 1 ? v : 0.f;
+            a2 += cv == 2 ? v : 0.f;
+        }
+        double *dT = P.stem_dT + (size_t)(b % TRN_REP) * 27 * C;
+        atomicAdd(&dT[(tap * 3 + 0) * C + c0 + co], (double)a0);
+        atomicAdd(&dT[(tap * 3 + 1) * C + c0 + co], (double)a1);
+        atomicAdd(&dT[(tap * 3 + 2) * C + c0 + co], (double)a2);
+    }
+}
+
 // =================================================================================================================
 // host side
 // =================================================================================================================
@@ -2116,10 +2421,12 @@ static T *upload_table(AzxTrain *t, const std::vector<T> &v) {
 }
 
 int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int device) {
-    if (N < 2 || N > 11) return tfail(AZX_EINVAL, "train: the native step covers boards up to 11x11 (121 cells = four 32-row MFMA tiles)");
     if (chans != 16 && chans != 32 && chans != 64 && chans != 128 && chans != 256)
         return tfail(AZX_EINVAL, "train: base_chans must be 16, 32, 64, 128 or 256");
     const bool wide = chans >= 128;
+    if (N < 2 || N > (wide ? 13 : 11))
+        return tfail(AZX_EINVAL, "train: the native step covers boards up to 11x11 with 16 / 32 / 64 channels (121 cells = four 32-row "
+                                 "MFMA tiles) and up to 13x13 with 128 / 256");
     if (wide && N < 3) return tfail(AZX_EINVAL, "train: the wide towers (128 / 256 channels) need a board of 3x3 or more");
     if (blocks < 1 || batch < 1 || 2 * blocks > TRN_MAXL) return tfail(AZX_EINVAL, "train: num_blocks must be 1..19 and the batch positive");
     AzxTrain *t = new AzxTrain();
@@ -2131,6 +2438,7 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     TrnDev &d = t->d;
     d.N = N; d.cells = N * N; d.C = chans; d.L = 2 * blocks; d.B = batch;
     d.invN = (float)(1.0 / ((double)batch * d.cells));
+    d.dl_stride = d.cells > 128 ? 192 : 128;
     t->G = std::min(batch, TRN_WG_GROUPS);
     t->wide = wide;
     // wide: (C / 32)^2 tile pairs already fill the chip with few board groups, and a group costs a partial copy of C C 9
@@ -2174,7 +2482,7 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     ok = ok && (d.hraw = talloc<float>(t, (size_t)B * 6 * cells)) && (d.hact = talloc<float>(t, (size_t)B * 6 * cells)) &&
          (d.g6 = talloc<float>(t, (size_t)B * 6 * cells)) && (d.h2 = talloc<float>(t, (size_t)B * 64)) &&
          (d.dh2 = talloc<float>(t, (size_t)B * 64)) && (d.dv3 = talloc<float>(t, B)) &&
-         (d.dlogit = talloc<float>(t, (size_t)B * 128)) && (d.value = talloc<float>(t, B)) &&
+         (d.dlogit = talloc<float>(t, (size_t)B * (d.cells > 128 ? 192 : 128))) && (d.value = talloc<float>(t, B)) &&
          (d.logprob = talloc<float>(t, (size_t)B * cells)) && (d.loss3 = talloc<float>(t, 4)) &&
          (d.wpart = talloc<float>(t, (size_t)L * t->G * C * C * 9)) &&
          (t->in_board = talloc<int32_t>(t, (size_t)B * cells)) && (t->in_legal = talloc<int32_t>(t, (size_t)B * cells)) &&
@@ -2218,7 +2526,7 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     t->dbg["hraw"] = {d.hraw, (size_t)B * 6 * cells * 4};
     t->dbg["hact"] = {d.hact, (size_t)B * 6 * cells * 4};
     t->dbg["hg"] = {d.g6, (size_t)B * 6 * cells * 4};
-    t->dbg["dlogit"] = {d.dlogit, (size_t)B * 128 * 4};
+    t->dbg["dlogit"] = {d.dlogit, (size_t)B * d.dl_stride * 4};
     // AZX_TRAIN_GRAPH=1: the step as one captured HIP graph.  Off by default: with the weight-gradient passes on their
     // own stream, plain launches run the step in 0.92 ms where the graph executor's placement of the two branches
     // takes 1.01 ms (the host needs ~0.3 ms to queue a step: it stays ahead either way).
@@ -2439,7 +2747,7 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
         return e && hipEventRecord(e, st) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess;
     };
     if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
-    const int hw_blocks = ((4 * cells + 255) / 256) * ((cells + 3) / 4) + 16 + (cells + 129 + 3) / 4;
+    const int hw_blocks = ((4 * cells + 255) / 256) * ((cells + 3) / 4) + 16 * ((2 * cells + 255) / 256) + (cells + 129 + 3) / 4;
     hipLaunchKernelGGL(k_trn_heads_wgrad, dim3(hw_blocks), dim3(256), 0, ws, d, t->hoffs);
     const size_t hb_lds = ((size_t)cells * (C + 1) + (size_t)SMALL * 8) * sizeof(float);
     hipLaunchKernelGGL(k_trn_heads_bwd<C>, dim3(B), dim3(SMALL), hb_lds, st, d);
@@ -2509,9 +2817,13 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
                                              d.pstat + (size_t)(l + 1) * B * C, st))
             return tfail(rc, "train: launching a wide forward convolution failed");
     }
-    const size_t hc_lds = ((size_t)((cells * (C + 1) + 8 * C + 16 + 3) & ~3)) * sizeof(float) + (size_t)SMALL * 16;
-    hipLaunchKernelGGL(k_trn_heads_conv<C>, dim3(B), dim3(SMALL), hc_lds, st, d);
-    hipLaunchKernelGGL(k_trn_heads_fc, dim3(B), dim3(SMALL), 0, st, d);
+    {   // act_L (and BN_L's totals), the head convolutions, the FC layers and the loss
+        const TwAct a = {t->raw[L], L >= 2 ? t->act[L - 2] : nullptr, d.bn_w[L], d.bn_b[L], d.pstat + (size_t)L * B * C,
+                         d.sums + (size_t)L * C * 4, t->act[L], nullptr, d.fsc};
+        hipLaunchKernelGGL(k_tw_bnact, eg, eb, 0, st, a, cells, C, B, d.invN);
+    }
+    hipLaunchKernelGGL(k_tw_hconv, dim3(B), dim3(SMALL), 0, st, d);
+    hipLaunchKernelGGL(k_tw_heads_fc, dim3(B), dim3(SMALL), 0, st, d);
     size_t ev = 0;
     auto next_event = [&]() -> hipEvent_t {
         if (ev == t->events.size()) {
@@ -2533,11 +2845,9 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
         return e && hipEventRecord(e, side) == hipSuccess && hipStreamWaitEvent(st, e, 0) == hipSuccess;
     };
     if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
-    const int hw_blocks = ((4 * cells + 255) / 256) * ((cells + 3) / 4) + 16 + (cells + 129 + 3) / 4;
+    const int hw_blocks = ((4 * cells + 255) / 256) * ((cells + 3) / 4) + 16 * ((2 * cells + 255) / 256) + (cells + 129 + 3) / 4;
     hipLaunchKernelGGL(k_trn_heads_wgrad, dim3(hw_blocks), dim3(256), 0, ws, d, t->hoffs);
-    constexpr int HB = C > 128 ? 512 : SMALL;
-    const size_t hb_lds = ((size_t)cells * (C + 1) + (size_t)HB * 8) * sizeof(float);
-    hipLaunchKernelGGL((k_trn_heads_bwd<C, HB>), dim3(B), dim3(HB), hb_lds, st, d);
+    hipLaunchKernelGGL(k_tw_heads_bwd, eg, eb, 0, st, d);
     const size_t wg16_lds = (size_t)(N * 16 + (N + 3) * 16) * 128 + (1024 + 5 * 32 + 2) * sizeof(float);
     for (int l = L; l >= 1; --l) {
         if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
@@ -2554,8 +2864,7 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
                            t->g[l - 1], d.pgsum + (size_t)(l - 1) * B * C, d.gmax + (l - 1)};
         hipLaunchKernelGGL(k_tw_relubwd, eg, eb, 0, st, rr, cells, C, d.invN);
     }
-    const size_t sb_lds = ((size_t)cells * C + 5 * C) * sizeof(float) + (size_t)SMALL * 16;
-    hipLaunchKernelGGL(k_trn_stem_bwd<C>, dim3(B), dim3(SMALL), sb_lds, st, d);
+    hipLaunchKernelGGL(k_tw_stem_bwd, eg, eb, 0, st, d);
     if (!join_side()) return tfail(AZX_EHIP, "train: joining the weight-gradient stream failed");
     if (t->n_conv_blocks > 0)
         hipLaunchKernelGGL(k_trn_update<C>, dim3(t->n_conv_blocks), dim3(256), 0, ws, d, (const Segment *)t->segs, (const int2 *)t->blocks, G);
@@ -2570,14 +2879,10 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
 // (what each kernel asks for, not a blanket cap: static + dynamic LDS together must stay within the CU's 160 KB)
 template <int C>
 static int raise_limits_wide(int cells, int N) {
-    constexpr int HB = C > 128 ? 512 : TRN_SMALL_THREADS, SMALL = TRN_SMALL_THREADS;
-    const size_t need[4] = {(size_t)(N * 16 + (N + 3) * 16) * 128 + (1024 + 5 * 32 + 2) * sizeof(float),
-                            ((size_t)((cells * (C + 1) + 8 * C + 16 + 3) & ~3)) * sizeof(float) + (size_t)SMALL * 16,
-                            ((size_t)cells * C + 5 * C) * sizeof(float) + (size_t)SMALL * 16,
-                            ((size_t)cells * (C + 1) + (size_t)HB * 8) * sizeof(float)};
-    const void *f[4] = {(const void *)k_trn_wgrad16<C>, (const void *)k_trn_heads_conv<C>, (const void *)k_trn_stem_bwd<C>,
-                        (const void *)k_trn_heads_bwd<C, HB>};
-    for (int i = 0; i < 4; ++i)
+    (void)cells;
+    const size_t need[1] = {(size_t)(N * 16 + (N + 3) * 16) * 128 + (1024 + 5 * 32 + 2) * sizeof(float)};
+    const void *f[1] = {(const void *)k_trn_wgrad16<C>};
+    for (int i = 0; i < 1; ++i)
         if (need[i] > 48 * 1024 && hipFuncSetAttribute(f[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)need[i]) != hipSuccess)
             return tfail(AZX_EHIP, "train: raising a kernel's dynamic LDS limit failed (kernel " + std::to_string(i) + ", " +
                                    std::to_string(need[i]) + " bytes)");

@@ -280,7 +280,9 @@ def train_step_mode(args, local_rank, torch, mode):
     from azalea_amd.network import HexNetwork
     from azalea_amd.policy_trainer import GraphedTrainStep, supervised_step
     dev = torch.device("cuda", local_rank)
-    B, steps, warm = 128, 200, 20
+    B, steps = 128, args.train_steps
+    warm = max(3, steps // 10)
+    wide = args.chans >= 128
     E = eng.Engine(board_size=args.board, n_games=1024, simulations=50, search_batch_size=10,
                    evaluator=eng.EVAL_UNIFORM, noise_scale=0.25, device=local_rank)
     buf = DeviceReplayBuffer(E, 20000, shared=False)
@@ -291,7 +293,7 @@ def train_step_mode(args, local_rank, torch, mode):
     opt = optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
     gs = (GraphedTrainStep(net, opt, B, dev) if mode == "hip_graph" else
           NativeTrainStep(net, opt, B, dev) if mode in ("native", "native_fp32") else None)
-    n_steps = steps if gs is not None else 60
+    n_steps = steps if gs is not None else min(steps, 60)
     for i in range(n_steps + warm):
         if i == warm:
             torch.cuda.synchronize(dev)
@@ -332,7 +334,9 @@ def train_step_mode(args, local_rank, torch, mode):
                     "frac_of_f16_mfma_peak": fl / (ms * 1e-3) / 1e12 / 2500.0,
                     "issued_frac_of_f16_mfma_peak": 3.0 * fl / (ms * 1e-3) / 1e12 / 2500.0,
                     "vs_fp32_mfma_peak": fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
-                    "bound": "launch chain: ~31 dependent kernels of 12-16 us on the data stream whose matrix work is ~1.5 us each (DESIGN 8.4)",
+                    "bound": ("throughput: per layer three split-f16 MFMA convolutions (k_conv_wide_train forward and backward-data, "
+                              "k_trn_wgrad16 filter gradient) and three elementwise passes (DESIGN 8.5)") if wide else
+                             "launch chain: ~31 dependent kernels of 12-16 us on the data stream whose matrix work is ~1.5 us each (DESIGN 8.4)",
                     "flop_per_step": fl})
         gs.close()
     E.close()
@@ -359,6 +363,20 @@ def run_train_step(args, local_rank, torch):
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         out[mode] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": (r.stderr or r.stdout)[-400:]}
+    # the same step at BASELINE configs[4]'s network (19x256 on 13x13), where it is throughput-bound: stock kernels
+    # captured as a HIP graph against the hand-written wide step
+    wide = {"what": "19x256 on 13x13 (BASELINE configs[4]'s network), batch 128, SGD(momentum 0.9, weight decay 1e-4), rows "
+                    "collated from the HBM ring; each mode in a fresh process", "batch": 128}
+    for mode in ("hip_graph", "native"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--train-step-only", mode, "--board", "13", "--blocks", "19",
+               "--chans", "256", "--train-steps", "20"]
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank)))
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        wide[mode] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": (r.stderr or r.stdout)[-400:]}
+    if all("steps_per_sec" in wide[m] for m in ("hip_graph", "native")):
+        wide["speedup_native_vs_hip_graph"] = wide["native"]["steps_per_sec"] / wide["hip_graph"]["steps_per_sec"]
+    out["wide"] = wide
     if all("steps_per_sec" in out[m] for m in TRAIN_MODES):
         out["speedup_native_vs_hip_graph"] = out["native"]["steps_per_sec"] / out["hip_graph"]["steps_per_sec"]
         out["speedup_split_f16_vs_fp32_kernels"] = out["native"]["steps_per_sec"] / out["native_fp32"]["steps_per_sec"]
@@ -621,9 +639,12 @@ def fold_legs(line):
             if isinstance(ts.get(mode), dict):
                 t[mode] = pick(ts[mode], ("steps_per_sec", "ms_per_step", "step_only_ms", "flop_per_step",
                                           "algorithmic_tflops", "frac_of_f16_mfma_peak", "issued_frac_of_f16_mfma_peak"))
-        for k in ("scaling", "wide", "error"):
-            if ts.get(k) is not None:
-                t[k] = ts[k]
+        if isinstance(ts.get("wide"), dict):
+            t["wide"] = {m: (pick(v, ("steps_per_sec", "ms_per_step", "step_only_ms", "flop_per_step", "algorithmic_tflops",
+                                      "frac_of_f16_mfma_peak", "issued_frac_of_f16_mfma_peak", "error")) if isinstance(v, dict) else v)
+                         for m, v in ts["wide"].items() if m != "what"}
+        if ts.get("error") is not None:
+            t["error"] = ts["error"]
         legs["train_step"] = t
     api = line.get("api")
     if isinstance(api, dict):
@@ -671,6 +692,7 @@ def main():
     ap.add_argument("--api-moves", type=int, default=190,
                     help="engine moves the nested product-surface leg (Player.read) is driven for; 0 = skip")
     ap.add_argument("--no-train-step", action="store_true", help="skip the nested training-step leg (SURVEY 8(f).4)")
+    ap.add_argument("--train-steps", type=int, default=200, help="internal: timed steps of a --train-step-only run")
     ap.add_argument("--train-step-only", choices=list(TRAIN_MODES), default=None,
                     help="internal: run ONE mode of the training-step leg in this process and print its JSON")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -50,7 +50,8 @@ def _net(n, blocks, chans, seed=0):
 
 
 @pytest.mark.parametrize("n,blocks,chans,B", [(11, 2, 64, 8), (11, 1, 16, 5), (9, 2, 32, 7), (11, 6, 64, 128),
-                                              (5, 1, 128, 4), (7, 2, 256, 6), (11, 2, 128, 9), (11, 3, 256, 16)])
+                                              (5, 1, 128, 4), (7, 2, 256, 6), (11, 2, 128, 9), (11, 3, 256, 16),
+                                              (13, 1, 128, 5), (13, 2, 256, 7), (12, 1, 256, 3)])
 def test_every_intermediate_matches_autograd(n, blocks, chans, B):
     from azalea_amd.native_train import NativeTrainStep
     net, ref = _net(n, blocks, chans), _net(n, blocks, chans)
@@ -151,7 +152,7 @@ def test_exact_fp32_kernels_stay_green(monkeypatch, passes):
 
 
 @pytest.mark.parametrize("n,blocks,chans,B", [(11, 1, 64, 200), (7, 2, 32, 300), (3, 1, 16, 1), (11, 2, 16, 131), (2, 1, 64, 3),
-                                              (11, 1, 128, 131), (3, 1, 256, 1), (9, 2, 256, 70)])
+                                              (11, 1, 128, 131), (3, 1, 256, 1), (9, 2, 256, 70), (13, 1, 128, 67)])
 def test_odd_batches_and_boards(n, blocks, chans, B):
     """Batches that are not a multiple of anything the kernels tile by -- more boards than one round of partial-sum
     loads covers (> 128), filter-gradient groups of unequal size (B not a multiple of 64), a single board -- and the
