@@ -2399,7 +2399,7 @@ struct AzxTrain {
     bool wide = false;
     std::vector<unsigned short *> Ww16f, Ww16b, A16;       // per layer: the wide filter packs, the activations' images
     unsigned short **Ww16f_dev = nullptr, **Ww16b_dev = nullptr;
-    unsigned short *D16 = nullptr;                          // the BatchNorm-backward image of the layer in flight
+    std::vector<unsigned short *> D16;                      // per layer: the BatchNorm-backward images (k_tw_wgrad reads them later)
     float *dact = nullptr;                                  // conv^T output of the layer in flight
 };
 
@@ -2464,7 +2464,9 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
         for (int l = 1; l <= L && ok; ++l)
             ok = (t->Ww16f[l] = talloc<unsigned short>(t, (size_t)2 * 9 * C * C)) && (t->Ww16b[l] = talloc<unsigned short>(t, (size_t)2 * 9 * C * C));
         for (int l = 0; l < L && ok; ++l) ok = (t->A16[l] = talloc<unsigned short>(t, 2 * A)) != nullptr;
-        ok = ok && (t->D16 = talloc<unsigned short>(t, 2 * A)) && (t->dact = talloc<float>(t, A)) &&
+        t->D16.assign(L + 1, nullptr);
+        for (int l = 1; l <= L && ok; ++l) ok = (t->D16[l] = talloc<unsigned short>(t, 2 * A)) != nullptr;
+        ok = ok && (t->dact = talloc<float>(t, A)) &&
              (t->Ww16f_dev = upload_table(t, t->Ww16f)) && (t->Ww16b_dev = upload_table(t, t->Ww16b)) &&
              (d.bsc = talloc<float2>(t, TRN_MAXL + 2));
     }
@@ -2795,6 +2797,111 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
     return AZX_OK;
 }
 
+// The filter gradient of a wide layer from the two IMAGES that exist anyway -- draw_l's (k_tw_bnbwd, kept per layer) and
+// act_{l-1}'s (k_tw_bnact): trn_wgrad16_body's tiling, operand layout and k-loop (a (32 co, 32 ci) tile pair x a group
+// of boards per block, K = positions through ds_read_b64_tr_b16, the nine taps owned by column), with the staging
+// reduced to 16-byte copies -- no BatchNorm arithmetic, no per-board sums, two tensors instead of three.
+struct TwWgrad { const unsigned short *dimg, *aimg; const float2 *bsc; const float4 *fsc; float *part; };
+template <int C>
+__global__ __launch_bounds__(256) void k_tw_wgrad(TwWgrad A, int N, int B, int G) {
+    constexpr int NT = C / 32, ITER = (169 * 16 + 255) / 256;
+    extern __shared__ __align__(16) float lds[];
+    const int cells = N * N, KR = N * 16, BR = (N + 3) * 16;
+    unsigned char *Dh = reinterpret_cast<unsigned char *>(lds), *Dl = Dh + (size_t)KR * 64;     // [KR][32] f16 draw hi / lo
+    unsigned char *Bh = Dl + (size_t)KR * 64, *Bl = Bh + (size_t)BR * 64;                       // [BR][32] f16 input hi / lo
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware block order: consecutive workgroups go to the eight XCDs round-robin, each with its own 4 MB L2.  All
+    // (C / 32)^2 tile pairs of a board group read the same boards' two images (344 KB a board at 256 channels), so a
+    // group is given to ONE XCD (workgroup id mod 8 = group mod 8) and its pairs to consecutive slots there: the XCD's 64
+    // resident blocks walk one group's boards together and an image comes from HBM once, not once per tile column.
+    int pair = blockIdx.x, grp = blockIdx.y;
+    if ((G & 7) == 0) {
+        const int id = blockIdx.y * gridDim.x + blockIdx.x, xcd = id & 7, slot = id >> 3, np = gridDim.x;
+        grp = 8 * (slot / np) + xcd;
+        pair = slot % np;
+    }
+    const int tm = pair / NT, tn = pair % NT;
+    const int total = cells * 16;
+    // (the native vector type: an array of HIP's uint4 STRUCT stays in scratch memory, see DESIGN 8.4's compiler traps)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v[ITER];
+    auto request = [&](int b) {
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) {       // (clamped, unconditional: the staging skips the items beyond `total`)
+            const int i = min(tid + 256 * k, total - 1), pos = i >> 4, q = i & 15;
+            const unsigned short *src = ((q >> 3) ? A.aimg : A.dimg) + ((size_t)b * cells + pos) * (2 * C) + ((q >> 2) & 1) * C +
+                                        ((q >> 3) ? tn : tm) * 32 + (q & 3) * 8;
+            v[k] = *reinterpret_cast<const u32x4 *>(src);
+        }
+    };
+    request(grp);
+    const float unscale = 1.f / (A.bsc->x * A.fsc->x);
+    {   // the operand images start zero: the rows x >= N of draw and the border of the input stay that way
+        float4 *z = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < (KR + BR) * 128 / 16; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const bool owner = wv < 3;
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    __syncthreads();
+    const int frag_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const int col_off = (17 + (owner ? wv - 1 : 0)) * 64 + frag_off;
+    for (int b = grp; b < B; b += G) {
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) {
+            const int i = tid + 256 * k;
+            if (i >= total) break;
+            const int pos = i >> 4, q = i & 15, y = pos / N, krow = y * 16 + (pos - y * N);
+            unsigned char *dst = (q >> 3) ? (((q >> 2) & 1) ? Bl : Bh) + (size_t)(krow + 17) * 64
+                                          : (((q >> 2) & 1) ? Dl : Dh) + (size_t)krow * 64;
+            *reinterpret_cast<u32x4 *>(dst + (q & 3) * 16) = v[k];
+        }
+        __syncthreads();
+        if (b + G < B) request(b + G);                 // travels under this board's k-loop
+        if (owner) {
+            f16x8 dhi = tr_frag(Dh + frag_off), dlo = tr_frag(Dl + frag_off);
+            f16x8 h0 = tr_frag(Bh + col_off - 16 * 64), l0 = tr_frag(Bl + col_off - 16 * 64);
+            f16x8 h1 = tr_frag(Bh + col_off), l1 = tr_frag(Bl + col_off);
+            f16x8 h2 = tr_frag(Bh + col_off + 16 * 64), l2 = tr_frag(Bl + col_off + 16 * 64);
+            for (int s = 0; s < N; ++s) {
+                const int sn = s + 1 < N ? s + 1 : s;
+                const f16x8 ndhi = tr_frag(Dh + frag_off + (size_t)sn * 16 * 64), ndlo = tr_frag(Dl + frag_off + (size_t)sn * 16 * 64);
+                const size_t r3 = (size_t)(s + 2 <= N ? s + 2 : N) * 16 * 64;
+                const f16x8 h3 = tr_frag(Bh + col_off + r3), l3 = tr_frag(Bl + col_off + r3);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, h0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, h1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, h2, acc[2], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, l0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, l1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, l2, acc[2], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, h0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, h1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, h2, acc[2], 0, 0, 0);
+                dhi = ndhi; dlo = ndlo;
+                h0 = h1; l0 = l1; h1 = h2; l1 = l2; h2 = h3; l2 = l3;
+            }
+        }
+        __syncthreads();
+    }
+    float *part = A.part + (size_t)grp * ((size_t)C * C * 9);
+    const int li = lane & 31, lh = lane >> 5, ci = tn * 32 + li;
+    if (owner) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int t = 3 * u + wv;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                part[((size_t)t * C + co) * C + ci] = acc[u][i] * unscale;
+            }
+        }
+    }
+}
+
 // the wide step (C = 128 / 256): see "wide towers" above
 template <int C>
 static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork) {
@@ -2848,16 +2955,23 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
     const int hw_blocks = ((4 * cells + 255) / 256) * ((cells + 3) / 4) + 16 * ((2 * cells + 255) / 256) + (cells + 129 + 3) / 4;
     hipLaunchKernelGGL(k_trn_heads_wgrad, dim3(hw_blocks), dim3(256), 0, ws, d, t->hoffs);
     hipLaunchKernelGGL(k_tw_heads_bwd, eg, eb, 0, st, d);
+    const size_t wgi_lds = (size_t)(N * 16 + (N + 3) * 16) * 128;
     const size_t wg16_lds = (size_t)(N * 16 + (N + 3) * 16) * 128 + (1024 + 5 * 32 + 2) * sizeof(float);
     for (int l = L; l >= 1; --l) {
-        if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
-        const WgradPtrs wq = {t->g[l], t->raw[l], t->act[l - 1], d.bn_w[l]};
-        hipLaunchKernelGGL(k_trn_wgrad16<C>, dim3(NT * NT, G), dim3(256), wg16_lds, ws, wq, l, G, d);
         // (sum g_l, sum g_l xhat_l) come from the partials of k_trn_heads_bwd (l = L) / k_tw_relubwd
         const TwBnBwd bb = {t->g[l], t->raw[l], d.bn_w[l], d.pgsum + (size_t)l * B * C, d.sums + (size_t)l * C * 4, d.gmax + l,
-                            d.fsc + l, t->D16, d.bsc + l};
+                            d.fsc + l, t->D16[l], d.bsc + l};
         hipLaunchKernelGGL(k_tw_bnbwd, eg, eb, 0, st, bb, cells, C, B, d.invN);
-        if (int rc = azx_net_wide_train_conv(N, C, t->Ww16b[l], t->D16, t->dact, B, &d.bsc[l].y, nullptr, st))
+        // draw_l's image is complete: the filter gradient of layer l runs beside the rest of the data chain
+        if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
+        if (t->wgrad16) {
+            const TwWgrad wq = {t->D16[l], t->A16[l - 1], d.bsc + l, d.fsc + l, d.wpart + (size_t)(l - 1) * G * ((size_t)C * C * 9)};
+            hipLaunchKernelGGL(k_tw_wgrad<C>, dim3(NT * NT, G), dim3(256), wgi_lds, ws, wq, N, B, G);
+        } else {      // AZX_TRAIN_WGRAD=fp32 here: the filter gradient from the fp32 tensors (k_trn_wgrad16, BatchNorm backward on the way in)
+            const WgradPtrs wq = {t->g[l], t->raw[l], t->act[l - 1], d.bn_w[l]};
+            hipLaunchKernelGGL(k_trn_wgrad16<C>, dim3(NT * NT, G), dim3(256), wg16_lds, ws, wq, l, G, d);
+        }
+        if (int rc = azx_net_wide_train_conv(N, C, t->Ww16b[l], t->D16[l], t->dact, B, &d.bsc[l].y, nullptr, st))
             return tfail(rc, "train: launching a wide backward convolution failed");
         const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= L;
         const TwRelu rr = {t->dact, t->act[l - 1], has_skip ? t->g[l + 1] : nullptr, t->raw[l - 1], d.sums + (size_t)(l - 1) * C * 4,
@@ -2880,9 +2994,10 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
 template <int C>
 static int raise_limits_wide(int cells, int N) {
     (void)cells;
-    const size_t need[1] = {(size_t)(N * 16 + (N + 3) * 16) * 128 + (1024 + 5 * 32 + 2) * sizeof(float)};
-    const void *f[1] = {(const void *)k_trn_wgrad16<C>};
-    for (int i = 0; i < 1; ++i)
+    const size_t need[2] = {(size_t)(N * 16 + (N + 3) * 16) * 128 + (1024 + 5 * 32 + 2) * sizeof(float),
+                            (size_t)(N * 16 + (N + 3) * 16) * 128};
+    const void *f[2] = {(const void *)k_trn_wgrad16<C>, (const void *)k_tw_wgrad<C>};
+    for (int i = 0; i < 2; ++i)
         if (need[i] > 48 * 1024 && hipFuncSetAttribute(f[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)need[i]) != hipSuccess)
             return tfail(AZX_EHIP, "train: raising a kernel's dynamic LDS limit failed (kernel " + std::to_string(i) + ", " +
                                    std::to_string(need[i]) + " bytes)");
