@@ -237,7 +237,7 @@ __device__ __forceinline__ void split2_f16(float a, float b, uint32_t &hpk, uint
 #endif
 }
 
-// Diagnostic build only (-DAZX_NET_STAMP): per-region s_memtime sums of k_tower_f16x3 (wave 0 of
+// Diagnostic build only (-DAZX_NET_STAMP): per-region s_memtime sums of k_tower_f16x3_s16 (wave 0 of
 // every block), printed by azx_net_destroy.  The shipped kernel executes no stamp.
 #ifdef AZX_NET_STAMP
 __device__ unsigned long long g_tower_stamp[10];   // 7 regions, block count, s_memrealtime ticks (100 MHz)
@@ -262,339 +262,11 @@ __device__ unsigned long long g_wide_stamp[10];
 #ifndef F16X3_BPB
 #define F16X3_BPB 2   // boards per block: 2 -> 70 KB LDS, two blocks per CU overlap each other's prologue/epilogue
 #endif
-// SPLIT_M: how the two waves of a board divide its 4 x 2 output tiles (32 positions x 32 channels):
-//   false: each wave takes all 4 position tiles of one channel tile  (8 LDS + 2 L2 fragment loads / k-step)
-//   true : each wave takes 2 position tiles of both channel tiles    (4 LDS + 4 L2 fragment loads / k-step)
-template <bool SPLIT_M>
-__global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3(NetDev P, const uint8_t *__restrict__ ev_board,
-                                                         const int32_t *__restrict__ n_eval_ptr,
-                                                         int n_eval_host, float *__restrict__ act_out,
-                                                         float *__restrict__ hfeat) {
-    constexpr int C = 64, ROWB = 272;
-    constexpr int MW = SPLIT_M ? 2 : 4, NW = SPLIT_M ? 2 : 1;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
-    const int e0 = blockIdx.x * F16X3_BPB;
-    if (e0 >= n_eval) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wb = wave >> 1, wh = wave & 1;             // board within the block, which half of its tiles
-    const int mbase = SPLIT_M ? 2 * wh : 0, nbase = SPLIT_M ? 0 : wh;
-    const int N = P.N, ncells = P.ncells;
-    const int e = e0 + wb;
-    const bool live = e < n_eval;
-    const int board_b = 128 * ROWB;                      // 128 rows: the tile tail is scratch, never read
-    const int x_off = wb * board_b;
-    unsigned char *X = smem + x_off;                     // this wave pair's board
-    const int zero_off = F16X3_BPB * board_b;            // shared all-zero row
-
-    NT_DECL
-    // lane (i = lane&31, h = lane>>5).  The product is computed transposed (weights as the MFMA A
-    // operand, activations as B), so in a 32x32 result tile a LANE is a board position (row
-    // (mbase+m)*32 + li) and the 16 registers are output channels cb + (r&3) + 8*(r>>2): four
-    // consecutive channels per register quad -> 8-byte packed f16 epilogue writes.
-    const int li = lane & 31, lh = lane >> 5;
-    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
-    // A-fragment byte offsets of one tap: row offset + the tap's (wave-uniform) displacement when
-    // the neighbour is on the board, else the shared zero row; validity is one precomputed bit
-    unsigned long long tapok = 0ull;                     // bit tap*4 + m
-    int rbase[MW], ry_[MW], rx_[MW];
-#pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        const int r = (mbase + m) * 32 + li;
-        const int ry = r / N, rx = r - ry * N;
-        ry_[m] = ry;
-        rx_[m] = rx;
-        rbase[m] = x_off + r * ROWB + 16 * lh;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = ry + tap / 3 - 1, xx = rx + tap % 3 - 1;
-            if (r < ncells && yy >= 0 && yy < N && xx >= 0 && xx < N) tapok |= 1ull << (tap * 4 + m);
-        }
-    }
-    const int zbase = zero_off + 16 * lh;
-    auto tap_offsets = [&](int tap, int *aoff) {
-        const int delta = ((tap / 3 - 1) * N + (tap % 3 - 1)) * ROWB;
-#pragma unroll
-        for (int m = 0; m < MW; ++m)
-            aoff[m] = ((tapok >> (tap * 4 + m)) & 1ull) ? rbase[m] + delta : zbase;
-    };
-
-    // ---- epilogue of a layer: + bias (+ residual) -> ReLU -> split f16 rows of the board in LDS.
-    // kind 0: conv1 of a Resblock; 1: conv2, y += x (network.py:37), the sum is the next block's
-    // input; 2: stem, its output is the first block's input.  The block input stays in registers.
-    f32x16 res[MW][NW];
-    float satmax = 0.f;                              // largest activation this lane has split into hi + lo halves
-    auto epilogue = [&](f32x16 (&acc)[MW][NW], const float *bias, auto kind_tag) {
-        constexpr int kind = decltype(kind_tag)::value;
-#pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            const int cb = (nbase + n) * 32 + 4 * lh;    // channel of register 0
-            float bv[16];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const float4 b4 = *reinterpret_cast<const float4 *>(bias + cb + 8 * g4);
-                bv[4 * g4] = b4.x; bv[4 * g4 + 1] = b4.y; bv[4 * g4 + 2] = b4.z; bv[4 * g4 + 3] = b4.w;
-            }
-#pragma unroll
-            for (int m = 0; m < MW; ++m) {
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    f16x4 h4, l4;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r = 4 * g4 + j;
-                        float v = acc[m][n][r] + bv[r];
-                        if (kind == 1) v += res[m][n][r];
-                        v = fmaxf(v, 0.0f);
-                        if (kind != 0) res[m][n][r] = v;
-                        if (AZX_SAT_TRACK) satmax = fmaxf(satmax, v);
-                        _Float16 hi, lo;
-                        split_f16(v, hi, lo);
-                        h4[j] = hi;
-                        l4[j] = lo;
-                    }
-                    unsigned char *pw = X + ((mbase + m) * 32 + li) * ROWB + (cb + 8 * g4) * 2;
-                    *reinterpret_cast<f16x4 *>(pw) = h4;
-                    *reinterpret_cast<f16x4 *>(pw + 128) = l4;
-                }
-            }
-        }
-    };
-
-    // ---- stem on the matrix cores: embedding -> conv1 -> bn1 (network.py:125,:141-142,:47-48,:73)
-    // folded to a 27-row table (tap x colour) is a K=27 product with ONE-HOT activations:
-    // out[co][pos] = sum_k Ws[co][k] * (cell(pos + tap(k)) == colour(k)).  One-hot is exact in f16,
-    // so only the weights are split (hi, lo): 2 MFMAs per tile and 16-wide k-step, two k-steps.
-    {
-        // the board with a one-cell "off board" (3) border, in the not yet used tail rows 121..127
-        const int NH = N + 2;
-        unsigned char *cells = X + 121 * ROWB;           // 7 * 272 B = 1904 B >= 15 * 15
-        const uint8_t *bd = ev_board + (size_t)(live ? e : n_eval - 1) * AZX_CELL_STRIDE;
-        if (wh == 0) {
-            for (int i = lane; i < NH * NH; i += 64) {
-                const int y = i / NH - 1, x = i - (y + 1) * NH - 1;
-                cells[i] = (y >= 0 && y < N && x >= 0 && x < N) ? bd[y * N + x] : (uint8_t)3;
-            }
-        }
-        if (tid < ROWB / 4) reinterpret_cast<uint32_t *>(smem + zero_off)[tid] = 0u;
-        __syncthreads();
-        uint32_t onehot[MW];                             // bit k = 3*tap + colour of that neighbour
-#pragma unroll
-        for (int m = 0; m < MW; ++m) {
-            onehot[m] = 0u;
-            const unsigned char *c0 = cells + ry_[m] * NH + rx_[m];   // halo coordinates of tap (0, 0)
-            if ((mbase + m) * 32 + li < ncells) {
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const uint32_t v = c0[(tap / 3) * NH + tap % 3];
-                    onehot[m] |= (v < 3u ? 1u : 0u) << (3 * tap + v);
-                }
-            }
-        }
-        f32x16 acc[MW][NW];
-#pragma unroll
-        for (int m = 0; m < MW; ++m)
-#pragma unroll
-            for (int n = 0; n < NW; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-        const uint4 *ws = reinterpret_cast<const uint4 *>(P.Ws);   // [kk][ntile][hi,lo][lane]
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            f16x8 bfr[MW];
-#pragma unroll
-            for (int m = 0; m < MW; ++m) {
-                const uint32_t byte = (onehot[m] >> (16 * kk + 8 * lh)) & 0xffu;
-                uint4 q;                                 // f16 1.0 = 0x3C00 per set bit
-                q.x = ((byte >> 0) & 1u) * 0x3C00u | ((byte >> 1) & 1u) * 0x3C000000u;
-                q.y = ((byte >> 2) & 1u) * 0x3C00u | ((byte >> 3) & 1u) * 0x3C000000u;
-                q.z = ((byte >> 4) & 1u) * 0x3C00u | ((byte >> 5) & 1u) * 0x3C000000u;
-                q.w = ((byte >> 6) & 1u) * 0x3C00u | ((byte >> 7) & 1u) * 0x3C000000u;
-                bfr[m] = *reinterpret_cast<const f16x8 *>(&q);
-            }
-#pragma unroll
-            for (int n = 0; n < NW; ++n) {
-                const uint4 *pa = ws + ((kk * 2 + nbase + n) * 2) * 64 + lane;
-                const uint4 qh = pa[0], ql = pa[64];
-                const f16x8 wh8 = *reinterpret_cast<const f16x8 *>(&qh);
-                const f16x8 wl8 = *reinterpret_cast<const f16x8 *>(&ql);
-#pragma unroll
-                for (int m = 0; m < MW; ++m) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh8, bfr[m], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl8, bfr[m], acc[m][n], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();   // every wave has read the staged cells: the tail rows are free again
-        epilogue(acc, P.stem_b, std::integral_constant<int, 2>{});
-    }
-    __syncthreads();
-    NT_MARK(0)
-
-    // fragments of one k-step (16 input channels of one tap): activations (hi, lo) for this wave's
-    // row tiles from LDS, weights (hi, lo) for its channel tiles straight from L2 (packed in
-    // fragment order).  LDS answers in ~100 cycles, L2 in several hundred: activations are
-    // fetched one k-step ahead, weights two (three rotating register sets).
-    struct FragA { f16x8 ah[MW], al[MW]; };
-    struct FragB { f16x8 bh[NW], bl[NW]; };
-    const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.Wh);     // 512 uint4 per stage
-    auto load_b = [&](FragB &f, int kk, int stage) {
-#pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            // weights: [stage][kk][ntile][part][lane][8 f16]
-            const uint4 *pb = wsrc + (size_t)stage * 512 + ((kk * 2 + nbase + n) * 2) * 64 + lane;
-#if AZX_NET_ABLATE & 4
-            const uint4 qh = make_uint4(stage, kk, 1, 2), ql = qh; (void)pb;
-#else
-            const uint4 qh = pb[0], ql = pb[64];
-#endif
-            f.bh[n] = *reinterpret_cast<const f16x8 *>(&qh);
-            f.bl[n] = *reinterpret_cast<const f16x8 *>(&ql);
-        }
-    };
-    auto load_a = [&](FragA &f, const int *aoff, int half, int kk) {
-#pragma unroll
-        for (int m = 0; m < MW; ++m) {
-            const unsigned char *pa = smem + aoff[m] + (half * 32 + kk * 16) * 2;
-            f.ah[m] = *reinterpret_cast<const f16x8 *>(pa);
-            f.al[m] = *reinterpret_cast<const f16x8 *>(pa + 128);
-        }
-    };
-
-    NT_MARK(1)
-    int stage = 0;                                       // weight stage = (layer, tap, half of the input channels)
-    auto conv_layer = [&](int layer, auto residual_tag) {
-        constexpr bool residual = decltype(residual_tag)::value;   // conv2 of a Resblock: y += x (network.py:37)
-        f32x16 acc[MW][NW];
-#pragma unroll
-        for (int m = 0; m < MW; ++m)
-#pragma unroll
-            for (int n = 0; n < NW; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-        // k-step t = 0..35: stage t/2 (tap t/4, channel half (t/2)%2), 16-channel slice t%2.
-        // The prefetch loads are issued ONE PER MFMA, each in the shadow of the MFMA before it (an
-        // MFMA occupies the issue port for 8 of its 32 cycles): a block of loads ahead of the
-        // MFMAs would let the matrix pipe drain for ~70 cycles every k-step.
-        int aoff[MW];
-        tap_offsets(0, aoff);
-        FragA fa[2];
-        FragB fb[3];
-        load_b(fb[0], 0, stage);
-        load_b(fb[1], 1, stage);
-        load_a(fa[0], aoff, 0, 0);
-        constexpr int NMF = 3 * MW * NW, NLB = 2 * NW, NLA = 2 * MW;
-#pragma unroll
-        for (int t = 0; t < 36; ++t) {
-            const FragA &ca = fa[t & 1];
-            const FragB &cb = fb[t % 3];
-            FragA &na = fa[(t + 1) & 1];
-            FragB &nb = fb[(t + 2) % 3];
-#pragma unroll
-            for (int i = 0; i < NMF; ++i) {
-                // ---- one prefetch load -------------------------------------------------------
-                if (i < NLA) {                            // activations first: they are due next k-step
-                    if (t + 1 < 36) {
-                        const int m = i >> 1, part = i & 1;
-                        if (i == 0 && ((t + 1) & 3) == 0) tap_offsets((t + 1) / 4, aoff);
-                        const unsigned char *pa = smem + aoff[m] + ((((t + 1) >> 1) & 1) * 32 + ((t + 1) & 1) * 16) * 2 + part * 128;
-                        if (part) na.al[m] = *reinterpret_cast<const f16x8 *>(pa);
-                        else na.ah[m] = *reinterpret_cast<const f16x8 *>(pa);
-                    }
-                } else if (i < NLA + NLB) {
-                    if (t + 2 < 36) {
-                        const int j = i - NLA, n = j >> 1, part = j & 1, kk2 = (t + 2) & 1, st2 = stage + (t + 2) / 2;
-                        const uint4 q = wsrc[(size_t)st2 * 512 + ((kk2 * 2 + nbase + n) * 2 + part) * 64 + lane];
-                        if (part) nb.bl[n] = *reinterpret_cast<const f16x8 *>(&q);
-                        else nb.bh[n] = *reinterpret_cast<const f16x8 *>(&q);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- one MFMA: the three split products of a tile are MW*NW instructions apart ----
-                {
-                    const int part = i / (MW * NW), mn = i % (MW * NW), m = mn / NW, n = mn % NW;
-                    const f16x8 wv = part == 1 ? cb.bl[n] : cb.bh[n];
-                    const f16x8 xv = part == 2 ? ca.al[m] : ca.ah[m];
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, xv, acc[m][n], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        stage += 18;
-        NT_MARK(2)
-        __syncthreads();   // both waves of the board finished reading it
-        NT_MARK(3)
-        epilogue(acc, P.bias + layer * C, std::integral_constant<int, residual ? 1 : 0>{});
-        NT_MARK(4)
-        __syncthreads();   // the partner wave wrote the other tiles of this board
-        NT_MARK(5)
-    };
-    for (int blk = 0; blk < P.blocks; ++blk) {
-        conv_layer(2 * blk, std::false_type{});
-        conv_layer(2 * blk + 1, std::true_type{});
-    }
-
-    // ---- heads' 1x1 convs + folded BN + ReLU (network.py:77, :83) straight from the registers:
-    // hfeat[e][o][cell], o = 0,1 value planes, 2..5 policy planes -- 6 floats per cell leave the
-    // kernel instead of 64.  A cell's 64 channels sit in the lanes li and li + 32.
-    if (SPLIT_M && hfeat != nullptr) {
-        float part[MW][6];
-#pragma unroll
-        for (int o = 0; o < 6; ++o) {
-            const float *w = o < 2 ? P.wv + o * C : P.wp + (o - 2) * C;
-#pragma unroll
-            for (int m = 0; m < MW; ++m) part[m][o] = 0.0f;
-#pragma unroll
-            for (int n = 0; n < NW; ++n)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const float4 w4 = *reinterpret_cast<const float4 *>(w + (nbase + n) * 32 + 4 * lh + 8 * g4);
-#pragma unroll
-                    for (int m = 0; m < MW; ++m)
-                        part[m][o] += res[m][n][4 * g4] * w4.x + res[m][n][4 * g4 + 1] * w4.y +
-                                      res[m][n][4 * g4 + 2] * w4.z + res[m][n][4 * g4 + 3] * w4.w;
-                }
-        }
-#pragma unroll
-        for (int m = 0; m < MW; ++m) {
-            const int row = (mbase + m) * 32 + li;
-#pragma unroll
-            for (int o = 0; o < 6; ++o) {
-                const float tot = part[m][o] + __shfl_xor(part[m][o], 32);
-                const float b = o < 2 ? P.bv[o] : P.bp[o - 2];
-                if (live && row < ncells && lh == (o & 1))
-                    hfeat[((size_t)e * 6 + o) * ncells + row] = fmaxf(tot + b, 0.0f);
-            }
-        }
-    }
-    // ---- tower output (fp32, from registers) -> HBM [e][ncells][C] -----------------------------
-    if (live && act_out != nullptr) {
-        float *out = act_out + (size_t)e * ncells * C;
-#pragma unroll
-        for (int m = 0; m < MW; ++m) {
-            const int row = (mbase + m) * 32 + li;
-            if (row < ncells) {
-#pragma unroll
-                for (int n = 0; n < NW; ++n)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4)
-                        *reinterpret_cast<float4 *>(out + row * C + (nbase + n) * 32 + 4 * lh + 8 * g4) =
-                            make_float4(res[m][n][4 * g4], res[m][n][4 * g4 + 1], res[m][n][4 * g4 + 2],
-                                        res[m][n][4 * g4 + 3]);
-            }
-        }
-    }
-    if (satmax > 65504.0f) atomicOr(P.sat_flag, 1u);     // an activation left the f16 range: its hi half is +inf (NetDev::sat_flag)
-    NT_MARK(6)
-    NT_FLUSH
-}
-
 // ============================================================================================
 // k_tower_f16x3_s16: the fused split-f16 tower on v_mfma_f32_16x16x32_f16.  Dense f16 MFMA on this
 // chip is power-limited: a saturated 32x32x16 stream holds ~1.5-1.6 GHz (~1.4-1.5 PFLOP/s on random
 // data), the 16x16x32 shape ~1.8 GHz (~1.75 PFLOP/s) -- tools/microbench/mfma_shapes.hip -- so the
-// same products are issued as 16x16 tiles.  Same block layout as k_tower_f16x3<true> (2 boards per
+// same products are issued as 16x16 tiles.  Block layout: 2 boards per
 // 256-thread block, a wave owns 64 positions x 64 channels = 4 x 4 tiles of 16 x 16); the LDS image has
 // the same 272-byte rows, with the chunks of a row and the rows of a tile ordered for the lane groups of
 // ds_read_b128 (see lrow / lchunk below).  A k-step is one tap x 32 input channels (18 per layer): 8 weight fragments (4 channel
@@ -712,7 +384,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
         }
     };
 
-    // ---- stem: one 32-wide k-step with one-hot activations (see k_tower_f16x3) ------------------
+    // ---- stem: one 32-wide k-step with one-hot activations (see k_tower_f16x3_s16) ------------------
     {
         const int NH = N + 2;
         unsigned char *cells = X + 121 * ROWB;
@@ -912,7 +584,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
 // ============================================================================================
 // wide residual tower (C a multiple of 128, N <= 13: BASELINE configs[4], 13x13 / 19x256): one
 // launch per conv layer, activations in HBM.  A board's activations (169 x 256 x (hi,lo) f16 =
-// 173 KB) do not fit the 160 KB LDS, so the in-LDS fusion of k_tower_f16x3 is not available; at
+// 173 KB) do not fit the 160 KB LDS, so the in-LDS fusion of k_tower_f16x3_s16 is not available; at
 // 7.6 GFLOP per position the 13 MB of activation traffic per position is < 15 % of the MFMA time.
 //   * HBM layout per board: [cell][C hi f16 | C lo f16] (the same hi/lo split as above);
 //   * a 256-thread block computes ONE board x 128 output channels: wave (wm, wn) owns position
@@ -921,7 +593,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
 //   * the input is staged through LDS in 64-channel chunks with the row format of k_tower_f16x3
 //     (128 B hi | 128 B lo | 16 B pad, conflict-free ds_read_b128 fragments, one zero row for the
 //     padding taps); weights stream from L2 in fragment order; the k-loop is the one of
-//     k_tower_f16x3 (one prefetch load in each MFMA's shadow);
+//     k_tower_f16x3_s16 (one prefetch load in each MFMA's shadow);
 //   * epilogue: + folded-BN bias (+ residual, read from the block input's buffer) -> ReLU -> split
 //     -> HBM; conv2 of a Resblock writes over the block input in place (a block reads exactly the
 //     residual elements it overwrites); the last layer also writes the fp32 copy k_heads reads.
@@ -929,181 +601,6 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
 #define WIDE_ROWB 272
 #define WIDE_MW 3
 #define WIDE_NW 2
-
-__global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3(NetDev P, int layer, const unsigned short *__restrict__ in,
-                                                            unsigned short *out, const unsigned short *resid,
-                                                            float *__restrict__ out32,
-                                                            const int32_t *__restrict__ n_eval_ptr, int n_eval_host) {
-    constexpr int MW = WIDE_MW, NW = WIDE_NW, ROWB = WIDE_ROWB;
-    float satmax = 0.f;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
-    const int e = blockIdx.x;
-    if (e >= n_eval) return;
-    const int C = P.C, N = P.N, ncells = P.ncells;
-    const int NCH = C / 64, NT = C / 32;
-    const int co_base = blockIdx.y * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
-    const int li = lane & 31, lh = lane >> 5;
-    const size_t rowg = (size_t)C * 4;                   // bytes of one cell's activations in HBM
-    const unsigned char *gin = reinterpret_cast<const unsigned char *>(in) + (size_t)e * ncells * rowg;
-    const int zero_off = ncells * ROWB;
-    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
-    unsigned long long tapok = 0ull;                     // bit tap*4 + m
-    int rbase[MW];
-#pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        const int r = (MW * wm + m) * 32 + li;
-        const int ry = r / N, rx = r - ry * N;
-        rbase[m] = r * ROWB + 16 * lh;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = ry + tap / 3 - 1, xx = rx + tap % 3 - 1;
-            if (r < ncells && yy >= 0 && yy < N && xx >= 0 && xx < N) tapok |= 1ull << (tap * 4 + m);
-        }
-    }
-    const int zbase = zero_off + 16 * lh;
-    auto tap_offsets = [&](int tap, int *aoff) {
-        const int delta = ((tap / 3 - 1) * N + (tap % 3 - 1)) * ROWB;
-#pragma unroll
-        for (int m = 0; m < MW; ++m)
-            aoff[m] = ((tapok >> (tap * 4 + m)) & 1ull) ? rbase[m] + delta : zbase;
-    };
-    if (tid < ROWB / 4) reinterpret_cast<uint32_t *>(smem + zero_off)[tid] = 0u;
-
-    f32x16 acc[MW][NW];
-#pragma unroll
-    for (int m = 0; m < MW; ++m)
-#pragma unroll
-        for (int n = 0; n < NW; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-
-    struct FragA { f16x8 ah[MW], al[MW]; };
-    struct FragB { f16x8 bh[NW], bl[NW]; };
-    const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.Wh);
-    const int nt0 = co_base / 32 + 2 * wn;               // this wave's first channel tile
-    // weights of k-step q (global index over layer, tap, chunk, half, kk): [q][ntile][part][lane]
-    auto wptr = [&](int q, int n, int part) -> const uint4 * {
-        return wsrc + ((size_t)q * (NT * 2) + (size_t)((nt0 + n) * 2 + part)) * 64 + lane;
-    };
-
-    for (int chunk = 0; chunk < NCH; ++chunk) {
-        __syncthreads();                                 // the previous chunk has been consumed
-        for (int idx = tid; idx < ncells * 16; idx += 256) {
-            const int row = idx >> 4, piece = idx & 15;
-            const size_t src = (size_t)row * rowg + (piece < 8 ? (size_t)chunk * 128 + piece * 16
-                                                               : (size_t)C * 2 + (size_t)chunk * 128 + (piece - 8) * 16);
-            const int dst = row * ROWB + (piece < 8 ? piece * 16 : 128 + (piece - 8) * 16);
-            *reinterpret_cast<uint4 *>(smem + dst) = *reinterpret_cast<const uint4 *>(gin + src);
-        }
-        __syncthreads();
-        // k-step t = 0..35 of this chunk: tap t/4, channel half (t/2)%2, 16-channel slice t%2
-        auto qof = [&](int t) { return ((((layer * 9 + t / 4) * NCH + chunk) * 2 + ((t >> 1) & 1)) * 2 + (t & 1)); };
-        int aoff[MW];
-        tap_offsets(0, aoff);
-        FragA fa[2];
-        FragB fb[3];
-#pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            const uint4 q0h = *wptr(qof(0), n, 0), q0l = *wptr(qof(0), n, 1);
-            const uint4 q1h = *wptr(qof(1), n, 0), q1l = *wptr(qof(1), n, 1);
-            fb[0].bh[n] = *reinterpret_cast<const f16x8 *>(&q0h);
-            fb[0].bl[n] = *reinterpret_cast<const f16x8 *>(&q0l);
-            fb[1].bh[n] = *reinterpret_cast<const f16x8 *>(&q1h);
-            fb[1].bl[n] = *reinterpret_cast<const f16x8 *>(&q1l);
-        }
-#pragma unroll
-        for (int m = 0; m < MW; ++m) {
-            fa[0].ah[m] = *reinterpret_cast<const f16x8 *>(smem + aoff[m]);
-            fa[0].al[m] = *reinterpret_cast<const f16x8 *>(smem + aoff[m] + 128);
-        }
-        constexpr int NMF = 3 * MW * NW, NLB = 2 * NW, NLA = 2 * MW;
-#pragma unroll
-        for (int t = 0; t < 36; ++t) {
-            const FragA &ca = fa[t & 1];
-            const FragB &cb = fb[t % 3];
-            FragA &na = fa[(t + 1) & 1];
-            FragB &nb = fb[(t + 2) % 3];
-#pragma unroll
-            for (int i = 0; i < NMF; ++i) {
-                if (i < NLA) {                            // activations first: they are due next k-step
-                    if (t + 1 < 36) {
-                        const int m = i >> 1, part = i & 1;
-                        if (i == 0 && ((t + 1) & 3) == 0) tap_offsets((t + 1) / 4, aoff);
-                        const unsigned char *pa = smem + aoff[m] + ((((t + 1) >> 1) & 1) * 32 + ((t + 1) & 1) * 16) * 2 + part * 128;
-                        if (part) na.al[m] = *reinterpret_cast<const f16x8 *>(pa);
-                        else na.ah[m] = *reinterpret_cast<const f16x8 *>(pa);
-                    }
-                } else if (i < NLA + NLB) {
-                    if (t + 2 < 36) {
-                        const int j = i - NLA, n = j >> 1, part = j & 1;
-                        const uint4 q = *wptr(qof(t + 2), n, part);
-                        if (part) nb.bl[n] = *reinterpret_cast<const f16x8 *>(&q);
-                        else nb.bh[n] = *reinterpret_cast<const f16x8 *>(&q);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                {
-                    const int part = i / (MW * NW), mn = i % (MW * NW), m = mn / NW, n = mn % NW;
-                    const f16x8 wv = part == 1 ? cb.bl[n] : cb.bh[n];
-                    const f16x8 xv = part == 2 ? ca.al[m] : ca.ah[m];
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, xv, acc[m][n], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-
-    // ---- epilogue -------------------------------------------------------------------------------
-    unsigned char *gout = reinterpret_cast<unsigned char *>(out) + (size_t)e * ncells * rowg;
-    const unsigned char *gres = resid ? reinterpret_cast<const unsigned char *>(resid) + (size_t)e * ncells * rowg : nullptr;
-#pragma unroll
-    for (int n = 0; n < NW; ++n) {
-        const int cb0 = co_base + 64 * wn + 32 * n + 4 * lh;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int cb = cb0 + 8 * g4;
-            const float4 b4 = *reinterpret_cast<const float4 *>(P.bias + (size_t)layer * C + cb);
-            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-            for (int m = 0; m < MW; ++m) {
-                const int r = (MW * wm + m) * 32 + li;
-                if (r < ncells) {
-                    float rv[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (gres) {
-                        const f16x4 rh = *reinterpret_cast<const f16x4 *>(gres + (size_t)r * rowg + cb * 2);
-                        const f16x4 rl = *reinterpret_cast<const f16x4 *>(gres + (size_t)r * rowg + (size_t)C * 2 + cb * 2);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) rv[j] = (float)rh[j] + (float)rl[j];
-                    }
-                    f16x4 h4, l4;
-                    float vv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = acc[m][n][4 * g4 + j] + bv[j];
-                        v += rv[j];
-                        v = fmaxf(v, 0.0f);
-                        vv[j] = v;
-                        if (AZX_SAT_TRACK) satmax = fmaxf(satmax, v);
-                        _Float16 hi, lo;
-                        split_f16(v, hi, lo);
-                        h4[j] = hi;
-                        l4[j] = lo;
-                    }
-                    *reinterpret_cast<f16x4 *>(gout + (size_t)r * rowg + cb * 2) = h4;
-                    *reinterpret_cast<f16x4 *>(gout + (size_t)r * rowg + (size_t)C * 2 + cb * 2) = l4;
-                    if (out32)
-                        *reinterpret_cast<float4 *>(out32 + ((size_t)e * ncells + r) * C + cb) =
-                            make_float4(vv[0], vv[1], vv[2], vv[3]);
-                }
-            }
-        }
-    }
-    if (satmax > 65504.0f) atomicOr(P.sat_flag, 1u);     // an activation left the f16 range: its hi half is +inf (NetDev::sat_flag)
-}
 
 // ---- the wide tower on v_mfma_f32_16x16x32_f16 (see k_tower_f16x3_s16 for why) ----------------
 // Same block decomposition as k_conv_wide_f16x3 (one board x 128 output channels per 256-thread
@@ -1126,12 +623,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3(NetDev P, int layer,
 // writes the RAW fp32 output times `unscale` (the operands' power-of-two scales taken out) -- no ReLU, no f16 image --
 // plus, when `stat` is given, this board's per-channel (sum, sum of squares) of what it wrote: train-mode BatchNorm's
 // batch statistics as per-board partial pairs (summed over the boards in a fixed order by their consumers).
+// TRAIN = 2: the backward-data convolution with the step's next elementwise pass in its epilogue (WideBwdFuse): the product
+// is dL/dact_{l-1}; what is written is g_{l-1} = (product [+ skip]) where act_{l-1} > 0, else 0; `stat` receives this
+// board's (sum g, sum g xhat_{l-1}) per channel (xhat from raw_{l-1} and BN_{l-1}'s batch sums) and *gmax max |g|.
+struct WideBwdFuse { const float *act, *raw, *skip; const double *sums; float invN; unsigned int *gmax; };
 template <int TRAIN>
 __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, const unsigned short *__restrict__ in,
                                                    unsigned short *out, const unsigned short *resid,
                                                    float *__restrict__ out32,
                                                    const int32_t *__restrict__ n_eval_ptr, int n_eval_host,
-                                                   int e_base, int e_end, float unscale, float2 *__restrict__ stat) {
+                                                   int e_base, int e_end, float unscale, float2 *__restrict__ stat,
+                                                   const WideBwdFuse &F = WideBwdFuse{}) {
     constexpr int MT = WIDE16_MT, NT = WIDE16_NT, ROWB = WIDE_ROWB;
     float satmax = 0.f;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1365,6 +867,19 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
         for (int np = 0; np < 2; ++np)
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s1[np][j] = 0.f; s2[np][j] = 0.f; }
+        float pM[2][8], pI[2][8], vmax = 0.f;
+        if (TRAIN == 2) {
+            // mean / 1/std of BN_{l-1} for this lane's 16 channels, from the batch sums the forward pass filed
+#pragma unroll
+            for (int np = 0; np < 2; ++np)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double *sm = F.sums + (size_t)(chan0(np) + j) * 4;
+                    const double mn = sm[0] * (double)F.invN, vr = sm[1] * (double)F.invN - mn * mn;
+                    pM[np][j] = (float)mn;
+                    pI[np][j] = (float)(1.0 / sqrt((vr > 0 ? vr : 0) + 1e-5));
+                }
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int r = row0 + 16 * m + lrow;
@@ -1372,18 +887,40 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
             for (int np = 0; np < 2; ++np) {
                 const bool mine = !(wm == 0 ? (m == MT - 1 && np == 1) : (m == 0 && np == 0));   // else the other wave's
                 if (r < ncells && mine) {
+                    const size_t o = ((size_t)e * ncells + r) * C + chan0(np);
                     float vv[8];
+                    if (TRAIN == 2) {
+                        const float4 a0 = *reinterpret_cast<const float4 *>(F.act + o), a1 = *reinterpret_cast<const float4 *>(F.act + o + 4);
+                        const float4 r0 = *reinterpret_cast<const float4 *>(F.raw + o), r1 = *reinterpret_cast<const float4 *>(F.raw + o + 4);
+                        float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0;
+                        if (F.skip) { k0 = *reinterpret_cast<const float4 *>(F.skip + o); k1 = *reinterpret_cast<const float4 *>(F.skip + o + 4); }
+                        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+                        const float kv[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        vv[j] = acc[m][2 * np + (j >> 2)][j & 3] * unscale;
-                        s1[np][j] += vv[j];
-                        s2[np][j] += vv[j] * vv[j];
+                        for (int j = 0; j < 8; ++j) {
+                            vv[j] = av[j] > 0.f ? acc[m][2 * np + (j >> 2)][j & 3] * unscale + kv[j] : 0.f;
+                            vmax = fmaxf(vmax, fabsf(vv[j]));
+                            s1[np][j] += vv[j];
+                            s2[np][j] += vv[j] * (rv[j] - pM[np][j]) * pI[np][j];
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            vv[j] = acc[m][2 * np + (j >> 2)][j & 3] * unscale;
+                            s1[np][j] += vv[j];
+                            s2[np][j] += vv[j] * vv[j];
+                        }
                     }
-                    float *o32 = out32 + ((size_t)e * ncells + r) * C + chan0(np);
+                    float *o32 = out32 + o;
                     *reinterpret_cast<float4 *>(o32) = make_float4(vv[0], vv[1], vv[2], vv[3]);
                     *reinterpret_cast<float4 *>(o32 + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
                 }
             }
+        }
+        if (TRAIN == 2) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+            if (lane == 0) atomicMax(F.gmax, __float_as_uint(vmax));
         }
         if (stat) {
             // a channel's rows sit in the 16 lanes li of one lane group lh and in both position waves: lanes first
@@ -1473,6 +1010,31 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_train(int N, int C, const 
     conv_wide_s16_body<1>(P, 0, in, nullptr, nullptr, out32, nullptr, n_boards, 0, n_boards, *unscale, stat);
 }
 
+__global__ __launch_bounds__(256, 2) void k_conv_wide_train_bwd(int N, int C, const unsigned short *__restrict__ w16,
+                                                                const unsigned short *__restrict__ in, float *__restrict__ out32,
+                                                                int n_boards, const float *__restrict__ unscale, float2 *__restrict__ stat,
+                                                                WideBwdFuse F) {
+    NetDev P;
+    P.N = N; P.ncells = N * N; P.C = C; P.Wh16 = w16; P.bias = nullptr; P.sat_flag = nullptr;
+    conv_wide_s16_body<2>(P, 0, in, nullptr, nullptr, out32, nullptr, n_boards, 0, n_boards, *unscale, stat, F);
+}
+
+int azx_net_wide_train_conv_bwd(int N, int C, const unsigned short *w16, const unsigned short *in, float *g_out, int n_boards,
+                                const float *unscale, float2 *pgsum, const float *act, const float *raw, const float *skip,
+                                const double *sums, float invN, unsigned int *gmax, hipStream_t st) {
+    static bool raised = false;
+    const size_t lds = (size_t)(N * N + 2) * WIDE_ROWB;
+    if (!raised) {
+        if (hipFuncSetAttribute((const void *)k_conv_wide_train_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+            return AZX_EHIP;
+        raised = true;
+    }
+    const WideBwdFuse F = {act, raw, skip, sums, invN, gmax};
+    const dim3 g(8 * (C / 128), (n_boards + 7) / 8);
+    hipLaunchKernelGGL(k_conv_wide_train_bwd, g, dim3(256), lds, st, N, C, w16, in, g_out, n_boards, unscale, pgsum, F);
+    return AZX_OK;
+}
+
 int azx_net_wide_train_conv(int N, int C, const unsigned short *w16, const unsigned short *in, float *out32, int n_boards,
                             const float *unscale, float2 *stat, hipStream_t st) {
     static bool raised = false;
@@ -1487,7 +1049,7 @@ int azx_net_wide_train_conv(int N, int C, const unsigned short *w16, const unsig
     return AZX_OK;
 }
 
-// stem of the wide tower: the one-hot K = 27 product of k_tower_f16x3's stem, one board x 128
+// stem of the wide tower: the one-hot K = 27 product of k_tower_f16x3_s16's stem, one board x 128
 // output channels per block, straight to the HBM activation layout
 __global__ __launch_bounds__(256, 2) void k_stem_wide_f16x3(NetDev P, const uint8_t *__restrict__ ev_board,
                                                             unsigned short *out, float *__restrict__ out32,
@@ -2063,8 +1625,7 @@ __global__ __launch_bounds__(192 * HEADS_KSPLIT) void k_heads(NetDev P, const fl
 // ROCm 7.2 happens not to enforce, but the contract is the opt-in).
 static int raise_lds_limits() {
     const int cap = 160 * 1024;
-    const void *fns[] = {(const void *)k_tower_f16x3<false>, (const void *)k_tower_f16x3<true>, (const void *)k_tower_f16x3_s16,
-                         (const void *)k_conv_wide_f16x3, (const void *)k_conv_wide_f16x3_s16,
+    const void *fns[] = {(const void *)k_tower_f16x3_s16, (const void *)k_conv_wide_f16x3_s16,
                          (const void *)k_tower_mfma<64, 4, 2, 1, 2>, (const void *)k_tower_mfma<64, 6, 1, 2, 2>,
                          (const void *)k_tower_mfma<32, 6, 2, 2, 1>, (const void *)k_heads_mfma, (const void *)k_heads};
     for (const void *f : fns)
@@ -2096,24 +1657,21 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     else if (chans == 32 && ncells <= 192) net->tower_variant = 3;   // <32,6,2,2,1>
     else if (chans % 128 == 0 && ncells <= 192 && !want_fp32) net->tower_variant = 5;   // k_conv_wide_f16x3 per layer
     net->use_mfma = net->tower_variant != 0;
-    { const char *v = getenv("AZX_TOWER_SPLIT"); net->opt_split_m = v ? atoi(v) != 0 : true; }
-    { const char *v = getenv("AZX_TOWER_SHAPE"); net->opt_shape = v ? atoi(v) : 16; }
     { const char *v = getenv("AZX_WIDE_STREAMS"); net->opt_wsplit = std::min(4, std::max(1, v ? atoi(v) : 2)); }
     { const char *v = getenv("AZX_HEADS"); net->opt_heads_mfma = !(v && !strcmp(v, "valu")); }
     { const char *v = getenv("AZX_PACK"); net->pack_on_host = v && !strcmp(v, "host"); }
     {
         char b[260];
         const char *tower = "k_stem_generic + k_conv_generic (VALU)";
-        if (net->tower_variant == 4)
-            tower = net->opt_shape == 16 && net->opt_split_m ? "k_tower_f16x3_s16" : net->opt_split_m ? "k_tower_f16x3<true>" : "k_tower_f16x3<false>";
-        else if (net->tower_variant == 5) tower = net->opt_shape == 16 ? "k_stem_wide_f16x3 + k_conv_wide_f16x3_s16 per layer" : "k_stem_wide_f16x3 + k_conv_wide_f16x3 per layer";
+        if (net->tower_variant == 4) tower = "k_tower_f16x3_s16";
+        else if (net->tower_variant == 5) tower = "k_stem_wide_f16x3 + k_conv_wide_f16x3_s16 per layer";
         else if (net->tower_variant == 1) tower = "k_tower_mfma<64,4,2,1,2> (fp32 MFMA)";
         else if (net->tower_variant == 2) tower = "k_tower_mfma<64,6,1,2,2> (fp32 MFMA)";
         else if (net->tower_variant == 3) tower = "k_tower_mfma<32,6,2,2,1> (fp32 MFMA)";
-        const bool hm = net->tower_variant == 4 && net->opt_split_m && net->opt_heads_mfma && ncells <= 128;
-        snprintf(b, sizeof b, "%s + %s (%dx%d on %dx%d; AZX_TOWER=%s AZX_TOWER_SHAPE=%d AZX_TOWER_SPLIT=%d AZX_WIDE_STREAMS=%d AZX_HEADS=%s AZX_PACK=%s)",
-                 tower, hm ? "k_heads_mfma" : "k_heads", blocks, chans, N, N, want_fp32 ? "fp32" : "default", net->opt_shape,
-                 (int)net->opt_split_m, net->opt_wsplit, net->opt_heads_mfma ? "mfma" : "valu", net->pack_on_host ? "host" : "device");
+        const bool hm = net->tower_variant == 4 && net->opt_heads_mfma && ncells <= 128;
+        snprintf(b, sizeof b, "%s + %s (%dx%d on %dx%d; AZX_TOWER=%s AZX_WIDE_STREAMS=%d AZX_HEADS=%s AZX_PACK=%s)",
+                 tower, hm ? "k_heads_mfma" : "k_heads", blocks, chans, N, N, want_fp32 ? "fp32" : "default",
+                 net->opt_wsplit, net->opt_heads_mfma ? "mfma" : "valu", net->pack_on_host ? "host" : "device");
         net->info = b;
     }
     const size_t E = max_evals;
@@ -2183,7 +1741,7 @@ void azx_net_destroy(AzxNet *net) {
                                         "epilogue", "barrier after epilogue", "output store"};
             unsigned long long tot = 0;
             for (int r = 0; r < 7; ++r) tot += h[r];
-            fprintf(stderr, "k_tower_f16x3 stamps over %llu blocks: %.0f cycles/block, shader clock %.0f MHz during the kernel\n",
+            fprintf(stderr, "k_tower_f16x3_s16 stamps over %llu blocks: %.0f cycles/block, shader clock %.0f MHz during the kernel\n",
                     h[7], (double)tot / h[7], h[8] ? 100.0 * (double)tot / (double)h[8] : 0.0);
             for (int r = 0; r < 7; ++r)
                 fprintf(stderr, "  %-24s %6.1f%%  %9.0f cycles/block\n", nm[r], 100.0 * h[r] / tot, (double)h[r] / h[7]);
@@ -2214,10 +1772,10 @@ void azx_net_destroy(AzxNet *net) {
                         busy / ((double)(t1 - t0) * cu.size()), mn / 100.0, mx / 100.0, lastend_min / 100.0, lastend_max / 100.0);
             }
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_tower_f16x3<true>, F16X3_BPB * 128, net->lds_bytes);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_tower_f16x3_s16, F16X3_BPB * 128, net->lds_bytes);
             hipFuncAttributes fa;
             memset(&fa, 0, sizeof fa);
-            (void)hipFuncGetAttributes(&fa, (const void *)k_tower_f16x3<true>);
+            (void)hipFuncGetAttributes(&fa, (const void *)k_tower_f16x3_s16);
             fprintf(stderr, "  runtime occupancy: %d blocks/CU (dynamic LDS %zu B, static %zu B, %d VGPRs, max threads %d)\n", nb,
                     net->lds_bytes, (size_t)fa.sharedSizeBytes, fa.numRegs, fa.maxThreadsPerBlock);
         }
@@ -2242,20 +1800,10 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
     if (net->use_mfma) {
         const size_t lds = net->lds_bytes;
         if (net->tower_variant == 4) {
-            const bool split_m = net->opt_split_m;
-            const int shape = net->opt_shape;
             const dim3 grid((max_n + F16X3_BPB - 1) / F16X3_BPB), block(F16X3_BPB * 128);
-            if (shape == 16 && split_m) {
-                hipLaunchKernelGGL(k_tower_f16x3_s16, grid, block, lds, st, d, boards, n_eval_ptr, n_host,
-                                   (float *)nullptr, net->hfeat);
-                hfeat = net->hfeat;
-            } else if (split_m) {
-                hipLaunchKernelGGL(k_tower_f16x3<true>, grid, block, lds, st, d, boards, n_eval_ptr, n_host,
-                                   (float *)nullptr, net->hfeat);
-                hfeat = net->hfeat;
-            } else hipLaunchKernelGGL(k_tower_f16x3<false>, grid, block, lds, st, d, boards, n_eval_ptr, n_host, net->act, (float *)nullptr);
+            hipLaunchKernelGGL(k_tower_f16x3_s16, grid, block, lds, st, d, boards, n_eval_ptr, n_host, (float *)nullptr, net->hfeat);
+            hfeat = net->hfeat;
         } else if (net->tower_variant == 5) {
-            const int wshape = net->opt_shape;
             const dim3 grid(max_n, d.C / 128), block(256);
             hipLaunchKernelGGL(k_stem_wide_f16x3, grid, block, 0, st, d, boards, net->wideX,
                                d.blocks == 0 ? net->act : (float *)nullptr, n_eval_ptr, n_host);
@@ -2265,7 +1813,7 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
             // on separate streams: one part's tail round fills up with the others' blocks, whichever layer
             // those are in.
             const int wsplit = net->opt_wsplit;
-            if (wshape == 16) {
+            {
                 int parts = wsplit;
                 if (parts > 1 && !net->ev_fork) {
                     bool ok = hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -2300,12 +1848,6 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
                             (void)hipStreamSynchronize(s);
                     }
                 }
-            }
-            for (int b = 0; b < d.blocks && wshape != 16; ++b) {
-                hipLaunchKernelGGL(k_conv_wide_f16x3, grid, block, lds, st, d, 2 * b, (const unsigned short *)net->wideX, net->wideY,
-                                   (const unsigned short *)nullptr, (float *)nullptr, n_eval_ptr, n_host);
-                hipLaunchKernelGGL(k_conv_wide_f16x3, grid, block, lds, st, d, 2 * b + 1, (const unsigned short *)net->wideY, net->wideX,
-                                   (const unsigned short *)net->wideX, b == d.blocks - 1 ? net->act : (float *)nullptr, n_eval_ptr, n_host);
             }
         } else if (net->tower_variant == 1) {
             hipLaunchKernelGGL((k_tower_mfma<64, 4, 2, 1, 2>), dim3((max_n + 1) / 2), dim3(256), lds, st, d, boards, n_eval_ptr, n_host, net->act);

@@ -71,7 +71,7 @@ static std::vector<RawSlot> raw_slots(int C, int n2, int L) {
 struct Plan {
     int C, N, n2, L, NT, NT16, NCH, KVp, KPp, NTP;
     bool wg, wp, s32, s16, hd16;          // which tower operands this network's kernels read
-    size_t n_stemT, n_Wg, n_Wp, n_Ws, n_Wh, n_Ws16, n_Wh16, n_Whd16, n_hmP, n_hmV, n_fc2T, n_mfcT;
+    size_t n_stemT, n_Wg, n_Wp, n_Ws, n_Ws16, n_Wh16, n_Whd16, n_hmP, n_hmV, n_fc2T, n_mfcT;
 };
 
 static Plan make_plan(const AzxNet *net) {
@@ -83,16 +83,13 @@ static Plan make_plan(const AzxNet *net) {
     const bool f16 = v == 4 || v == 5;
     p.wg = v == 0;                                     // k_conv_generic
     p.wp = v >= 1 && v <= 3;                           // k_tower_mfma (fp32)
-    // 32x32x16 fragment order: the 32-shape kernels, the wide stem (k_stem_wide_f16x3 reads Ws whatever the shape), and
-    // the unsplit 6x64 tower (AZX_TOWER_SPLIT=0 runs k_tower_f16x3<false>, a 32-shape kernel, whatever the shape)
-    p.s32 = f16 && (net->opt_shape != 16 || v == 5 || (v == 4 && !net->opt_split_m));
-    p.s16 = f16 && net->opt_shape == 16;               // 16x16x32 fragment order
+    p.s32 = v == 5;                                    // the wide stem (k_stem_wide_f16x3) reads its table in 32x32x16 fragment order
+    p.s16 = f16;                                       // 16x16x32 fragment order: both split-f16 towers
     p.hd16 = v == 4 && p.C == 64;
     p.n_stemT = (size_t)28 * p.C;
     p.n_Wg = (size_t)p.L * 9 * p.C * p.C;
     p.n_Wp = p.n_Wg;
     p.n_Ws = (size_t)2 * p.NT * 2 * 64 * 8;
-    p.n_Wh = (size_t)p.L * 9 * p.NCH * 2 * 2 * p.NT * 2 * 64 * 8;
     p.n_Ws16 = (size_t)p.NT16 * 2 * 64 * 8;
     p.n_Wh16 = (size_t)p.L * 9 * p.NCH * 2 * p.NT16 * 2 * 64 * 8;
     p.n_Whd16 = (size_t)2 * 2 * 64 * 8;
@@ -125,7 +122,7 @@ static int ensure_buffers(AzxNet *net, const Plan &p) {
               pbuf(net, "hmP", d.hmP, p.n_hmP) && pbuf(net, "hmV", d.hmV, p.n_hmV);
     if (ok && p.wg) ok = pbuf(net, "Wg", d.Wg, p.n_Wg);
     if (ok && p.wp) ok = pbuf(net, "Wp", d.Wp, p.n_Wp);
-    if (ok && p.s32) ok = pbuf(net, "Ws", d.Ws, p.n_Ws) && pbuf(net, "Wh", d.Wh, p.n_Wh);
+    if (ok && p.s32) ok = pbuf(net, "Ws", d.Ws, p.n_Ws);
     if (ok && p.s16) ok = pbuf(net, "Ws16", d.Ws16, p.n_Ws16) && pbuf(net, "Wh16", d.Wh16, p.n_Wh16);
     if (ok && p.hd16) ok = pbuf(net, "Whd16", d.Whd16, p.n_Whd16) && pbuf(net, "hbias16", d.hbias16, 16);
     if (!ok) return azx_net_fail(AZX_ENOMEM, "net: hipMalloc of the packed weight buffers failed");
@@ -235,9 +232,9 @@ static int pack_host(AzxNet *net, const Plan &plan, const std::map<std::string, 
                                     Wg[(((size_t)l * 9 + tap) * C + ci) * C + co];
                             }
     }
-    std::vector<unsigned short> Wh, Ws;
-    if (net->tower_variant == 4 || net->tower_variant == 5) {
-        const int NT = C / 32, NCH = C / 64;
+    std::vector<unsigned short> Ws;
+    if (net->tower_variant == 5) {
+        const int NT = C / 32;
         auto f16bits = [](float w, int part) -> unsigned short {
             const _Float16 hi = (_Float16)w;
             const _Float16 lo = (_Float16)(w - (float)hi);
@@ -259,24 +256,6 @@ static int pack_host(AzxNet *net, const Plan &plan, const std::map<std::string, 
                             const int k = 16 * kk + 8 * h + t, co = 32 * nt + j;
                             Ws[os++] = f16bits(k < 27 ? stemT[(size_t)k * C + co] : 0.0f, part);
                         }
-        // conv weights, one 16-channel k-step after the other in the order the kernels walk them:
-        // [layer][tap][64-channel chunk][half][kk][ntile][part hi/lo][lane j + 32 h][t]
-        //   = split(W[tap][cin 64 chunk + 32 half + 16 kk + 8 h + t][cout 32 ntile + j])
-        Wh.resize((size_t)L * 9 * NCH * 2 * 2 * NT * 2 * 64 * 8);
-        size_t o = 0;
-        for (int l = 0; l < L; ++l)
-            for (int tap = 0; tap < 9; ++tap)
-                for (int ch = 0; ch < NCH; ++ch)
-                    for (int half = 0; half < 2; ++half)
-                        for (int kk = 0; kk < 2; ++kk)
-                            for (int nt = 0; nt < NT; ++nt)
-                                for (int part = 0; part < 2; ++part)
-                                    for (int ln = 0; ln < 64; ++ln)
-                                        for (int t = 0; t < 8; ++t) {
-                                            const int j = ln & 31, h = ln >> 5;
-                                            const int ci = 64 * ch + 32 * half + 16 * kk + 8 * h + t, co = 32 * nt + j;
-                                            Wh[o++] = f16bits(Wg[(((size_t)l * 9 + tap) * C + ci) * C + co], part);
-                                        }
     }
     std::vector<unsigned short> Wh16, Ws16;
     if (net->tower_variant == 4 || net->tower_variant == 5) {
@@ -405,7 +384,7 @@ static int pack_host(AzxNet *net, const Plan &plan, const std::map<std::string, 
     };
 #define PUTV(name, vec) put(name, (vec).data(), (vec).size() * sizeof((vec)[0]))
     PUTV("stemT", stemT); PUTV("stem_b", stem_b); PUTV("bias", bias);
-    PUTV("Wg", Wg); PUTV("Wp", Wp); PUTV("Ws", Ws); PUTV("Wh", Wh); PUTV("Ws16", Ws16); PUTV("Wh16", Wh16);
+    PUTV("Wg", Wg); PUTV("Wp", Wp); PUTV("Ws", Ws); PUTV("Ws16", Ws16); PUTV("Wh16", Wh16);
     PUTV("Whd16", Whd16); PUTV("hbias16", hbias16);
     PUTV("wv", wv); PUTV("bv", bv); PUTV("wp", wp); PUTV("bp", bp);
     PUTV("fc2T", fc2T); PUTV("fc2b", *fc2b); PUTV("fc3w", *fc3w); PUTV("fc3b", *fc3b);
@@ -573,35 +552,6 @@ static int pack_device(AzxNet *net, const Plan &p) {
                     m = fmax_abs(m, po[t]);
                 }
                 reinterpret_cast<float4 *>(Wp)[i] = o;
-            }
-            wave_atomic_max(wmax + 1 + __shfl(l, 0), m);
-        });
-    }
-    if (p.s32 && L > 0) {
-        unsigned short *Wh = const_cast<unsigned short *>(d.Wh);
-        const int NT = p.NT, NCH = p.NCH;
-        // [layer][tap][chunk][half][kk][ntile][hi,lo][lane][t]: one thread per (.., ntile, lane)
-        each(st, (size_t)L * 9 * NCH * 2 * 2 * NT * 64, [=] __device__(size_t i, bool on) {
-            float m = 0.f;
-            int l = 0;
-            if (on) {
-                size_t r = i;
-                const int ln = (int)(r % 64); r /= 64;
-                const int nt = (int)(r % NT); r /= NT;
-                const int kk = (int)(r % 2); r /= 2;
-                const int half = (int)(r % 2); r /= 2;
-                const int ch = (int)(r % NCH); r /= NCH;
-                const int tap = (int)(r % 9);
-                l = (int)(r / 9);
-                const int j = ln & 31, h = ln >> 5, co = 32 * nt + j;
-                Frag8 f;
-                for (int t = 0; t < 8; ++t) {
-                    const float v = folded(tab[RT_LAYER0 + 5 * l], sc + C * (l + 1), C, co, 64 * ch + 32 * half + 16 * kk + 8 * h + t, tap);
-                    m = fmax_abs(m, v);
-                    split_bits(v, f.h[t], f.l[t]);
-                }
-                unsigned short *base = Wh + (i / 64) * 2 * 64 * 8;
-                store_frag(base + (size_t)ln * 8, base + (size_t)(64 + ln) * 8, f);
             }
             wave_atomic_max(wmax + 1 + __shfl(l, 0), m);
         });

@@ -16,13 +16,12 @@ struct NetDev {
     // stem: embedding folded through conv1+bn1 (network.py:125,:141-142,:47-48,:73)
     const float *stemT;    // [9][3][C]   table[tap][cell value][cout], then one all-zero row
     const float *stem_b;   // [C]
-    const unsigned short *Ws;  // f16x3 pack of stemT as an MFMA A operand: [2 kk][2 ntile][hi,lo][64 lanes][8] f16 bits
+    const unsigned short *Ws;  // wide stem: f16x3 pack of stemT as a 32x32x16 MFMA A operand: [2 kk][ntile][hi,lo][64 lanes][8] f16 bits
     const unsigned short *Ws16, *Wh16;   // the same weights in 16x16x32 fragment order (k_tower_f16x3_s16)
     const unsigned short *Whd16;         // the heads' six 1x1 conv filters as one 16-row A tile: [kstep 2][hi,lo][lane][8]
     const float *hbias16;                // their folded-BN biases, padded to 16
     // tower (network.py:17-39, :50-52): BN folded into the conv weights
     const float *Wp;       // MFMA pack [layers][9][C/8][C/32][64][4]
-    const unsigned short *Wh;  // f16x3 pack [layers*18 stages][2 kk][2 ntile][hi,lo][64 lanes][8] f16 bits
     const float *Wg;       // generic   [layers][9][C][C]  (tap, cin, cout)
     const float *bias;     // [layers][C]
     // heads (network.py:54-60, :77-84, :127-128, :146)
@@ -73,8 +72,6 @@ struct AzxNet {
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     bool streams_ok = false;
     // diagnostic switches, read once per engine by azx_net_create (azx_net_kernel_info reports the outcome)
-    bool opt_split_m = true;    // AZX_TOWER_SPLIT=0: the 6x64 tower without the fused head convs / position split
-    int opt_shape = 16;         // AZX_TOWER_SHAPE=32: the 32x32x16 MFMA kernels
     int opt_wsplit = 2;         // AZX_WIDE_STREAMS: streams the wide tower's layer launches are spread over
     bool opt_heads_mfma = true; // AZX_HEADS=valu: the scalar-FMA k_heads behind the fused tower too
     std::string info;

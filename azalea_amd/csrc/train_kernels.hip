@@ -1795,12 +1795,16 @@ __global__ __launch_bounds__(256) void k_trn_prep(TrnDev P) {
 //       k_tw_bnact   act_l = relu(BN_l(raw_l) [+ act_{l-2}]) on batch statistics -> act_l (fp32, for the backward
 //                    pass and the filter gradient) and its image, scaled by the layer's power of two
 //       k_tw_bnbwd   draw_l = BatchNorm backward of g_l -> its image, scaled from max |g_l| like ROLE_BWD16
-//       k_tw_relubwd g_{l-1} = (conv^T output [+ g_{l+1}]) * (act_{l-1} > 0), per-board (sum g, sum g xhat), max |g|
+//     and the ReLU backward -- g_{l-1} = (conv^T output [+ g_{l+1}]) * (act_{l-1} > 0), its per-board (sum g, sum g xhat),
+//     max |g| -- is the backward-data convolution's epilogue (TRAIN = 2 in net_kernels.hip)
 //     with the batch sums of a block's 64 channels taken from the per-board partial pairs in the block (fixed order);
 //   * the stem, the heads and the update are the kernels above, instantiated at this width.
 // =================================================================================================================
 int azx_net_wide_train_conv(int N, int C, const unsigned short *w16, const unsigned short *in, float *out32, int n_boards,
                             const float *unscale, float2 *stat, hipStream_t st);      // net_kernels.hip
+int azx_net_wide_train_conv_bwd(int N, int C, const unsigned short *w16, const unsigned short *in, float *g_out, int n_boards,
+                                const float *unscale, float2 *pgsum, const float *act, const float *raw, const float *skip,
+                                const double *sums, float invN, unsigned int *gmax, hipStream_t st);
 
 // per-layer scales (the narrow path makes them in k_trn_stem_fwd): filter scale from k_trn_prep's per-block maxima,
 // activation scale from the BatchNorm bounds (all C channels), fsc[l] = (sa, 1 / (sa sw), sw, 1 / sw).  One block.
@@ -2002,52 +2006,6 @@ __global__ __launch_bounds__(256) void k_tw_bnbwd(TwBnBwd A, int cells, int C, i
         for (int j = 0; j < 8; ++j)
             v[j] = sc * (cA[cl + j] * (gv[j] - cK0[cl + j] - (rv[j] - cM[cl + j]) * cI[cl + j] * cK1[cl + j]));
         image_store(A.img, (size_t)b * cells + pos, C, c, v);
-    }
-}
-
-struct TwRelu { const float *dact, *act, *skip, *raw; const double *sums; float *g; float2 *pgsum; unsigned int *gmax; };
-__global__ __launch_bounds__(256) void k_tw_relubwd(TwRelu A, int cells, int C, float invN) {
-    __shared__ float pM[64], pI[64], rs[256][17], wm[4];
-    const int tid = threadIdx.x, c0 = blockIdx.x * 64, b = blockIdx.y;
-    if (tid < 64) bn_from_sums(A.sums[(size_t)(c0 + tid) * 4], A.sums[(size_t)(c0 + tid) * 4 + 1], invN, pM[tid], pI[tid]);
-    __syncthreads();
-    const int cl = (tid & 7) * 8, c = c0 + cl;
-    float a8[8], q8[8], vmax = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { a8[j] = 0.f; q8[j] = 0.f; }
-    for (int pos = tid >> 3; pos < cells; pos += 32) {
-        const size_t o = ((size_t)b * cells + pos) * C + c;
-        const float4 d0 = *reinterpret_cast<const float4 *>(A.dact + o), d1 = *reinterpret_cast<const float4 *>(A.dact + o + 4);
-        const float4 m0 = *reinterpret_cast<const float4 *>(A.act + o), m1 = *reinterpret_cast<const float4 *>(A.act + o + 4);
-        const float4 r0 = *reinterpret_cast<const float4 *>(A.raw + o), r1 = *reinterpret_cast<const float4 *>(A.raw + o + 4);
-        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-        if (A.skip) { s0 = *reinterpret_cast<const float4 *>(A.skip + o); s1 = *reinterpret_cast<const float4 *>(A.skip + o + 4); }
-        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w}, mv[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-        const float rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            v[j] = mv[j] > 0.f ? dv[j] + sv[j] : 0.f;
-            vmax = fmaxf(vmax, fabsf(v[j]));
-            a8[j] += v[j];
-            q8[j] += v[j] * (rv[j] - pM[cl + j]) * pI[cl + j];
-        }
-        *reinterpret_cast<float4 *>(A.g + o) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4 *>(A.g + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { rs[tid][j] = a8[j]; rs[tid][8 + j] = q8[j]; }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if ((tid & 63) == 0) wm[tid >> 6] = vmax;
-    __syncthreads();
-    if (tid == 64) atomicMax(A.gmax, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
-    if (tid < 64) {
-        // channel c0 + tid: threads with (t & 7) == tid / 8, element tid % 8 -- the 32 of them in a fixed order
-        const int grp = tid >> 3, j = tid & 7;
-        double a = 0, q = 0;
-        for (int p = 0; p < 32; ++p) { a += rs[p * 8 + grp][j]; q += rs[p * 8 + grp][8 + j]; }
-        A.pgsum[(size_t)b * C + c0 + tid] = make_float2((float)a, (float)q);
     }
 }
 
@@ -2400,7 +2358,6 @@ struct AzxTrain {
     std::vector<unsigned short *> Ww16f, Ww16b, A16;       // per layer: the wide filter packs, the activations' images
     unsigned short **Ww16f_dev = nullptr, **Ww16b_dev = nullptr;
     std::vector<unsigned short *> D16;                      // per layer: the BatchNorm-backward images (k_tw_wgrad reads them later)
-    float *dact = nullptr;                                  // conv^T output of the layer in flight
 };
 
 template <typename T>
@@ -2442,7 +2399,7 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     t->G = std::min(batch, TRN_WG_GROUPS);
     t->wide = wide;
     // wide: (C / 32)^2 tile pairs already fill the chip with few board groups, and a group costs a partial copy of C C 9
-    if (wide) t->G = std::min(batch, chans == 256 ? 16 : 32);
+    if (wide) t->G = std::min(batch, chans == 256 ? 8 : 32);      // (C = 256: 8 groups measured 10.7 ms per step against 11.1 with 16)
     if (getenv("AZX_TRAIN_WG_GROUPS")) t->G = std::max(1, std::min(t->G, atoi(getenv("AZX_TRAIN_WG_GROUPS"))));
     const int L = d.L, C = chans, cells = d.cells, B = batch;
     const size_t A = (size_t)B * cells * C;
@@ -2466,7 +2423,7 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
         for (int l = 0; l < L && ok; ++l) ok = (t->A16[l] = talloc<unsigned short>(t, 2 * A)) != nullptr;
         t->D16.assign(L + 1, nullptr);
         for (int l = 1; l <= L && ok; ++l) ok = (t->D16[l] = talloc<unsigned short>(t, 2 * A)) != nullptr;
-        ok = ok && (t->dact = talloc<float>(t, A)) &&
+        ok = ok &&
              (t->Ww16f_dev = upload_table(t, t->Ww16f)) && (t->Ww16b_dev = upload_table(t, t->Ww16b)) &&
              (d.bsc = talloc<float2>(t, TRN_MAXL + 2));
     }
@@ -2958,7 +2915,7 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
     const size_t wgi_lds = (size_t)(N * 16 + (N + 3) * 16) * 128;
     const size_t wg16_lds = (size_t)(N * 16 + (N + 3) * 16) * 128 + (1024 + 5 * 32 + 2) * sizeof(float);
     for (int l = L; l >= 1; --l) {
-        // (sum g_l, sum g_l xhat_l) come from the partials of k_trn_heads_bwd (l = L) / k_tw_relubwd
+        // (sum g_l, sum g_l xhat_l) come from the partials of k_tw_heads_bwd (l = L) / the backward convolution's epilogue
         const TwBnBwd bb = {t->g[l], t->raw[l], d.bn_w[l], d.pgsum + (size_t)l * B * C, d.sums + (size_t)l * C * 4, d.gmax + l,
                             d.fsc + l, t->D16[l], d.bsc + l};
         hipLaunchKernelGGL(k_tw_bnbwd, eg, eb, 0, st, bb, cells, C, B, d.invN);
@@ -2971,12 +2928,15 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
             const WgradPtrs wq = {t->g[l], t->raw[l], t->act[l - 1], d.bn_w[l]};
             hipLaunchKernelGGL(k_trn_wgrad16<C>, dim3(NT * NT, G), dim3(256), wg16_lds, ws, wq, l, G, d);
         }
-        if (int rc = azx_net_wide_train_conv(N, C, t->Ww16b[l], t->D16[l], t->dact, B, &d.bsc[l].y, nullptr, st))
-            return tfail(rc, "train: launching a wide backward convolution failed");
         const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= L;
-        const TwRelu rr = {t->dact, t->act[l - 1], has_skip ? t->g[l + 1] : nullptr, t->raw[l - 1], d.sums + (size_t)(l - 1) * C * 4,
-                           t->g[l - 1], d.pgsum + (size_t)(l - 1) * B * C, d.gmax + (l - 1)};
-        hipLaunchKernelGGL(k_tw_relubwd, eg, eb, 0, st, rr, cells, C, d.invN);
+        // conv^T with the ReLU mask, the skip gradient, g_{l-1}'s per-board (sum g, sum g xhat) and max |g| in its epilogue
+        // (as a separate elementwise launch behind a plain conv^T: 72 + 23 us per layer against 92 fused, 10.74 vs 10.68 ms
+        // per step -- the fused form saves a tensor's round trip, not time)
+        if (int rc = azx_net_wide_train_conv_bwd(N, C, t->Ww16b[l], t->D16[l], t->g[l - 1], B, &d.bsc[l].y,
+                                                 d.pgsum + (size_t)(l - 1) * B * C, t->act[l - 1], t->raw[l - 1],
+                                                 has_skip ? t->g[l + 1] : nullptr, d.sums + (size_t)(l - 1) * C * 4, d.invN,
+                                                 d.gmax + (l - 1), st))
+            return tfail(rc, "train: launching a wide backward convolution failed");
     }
     hipLaunchKernelGGL(k_tw_stem_bwd, eg, eb, 0, st, d);
     if (!join_side()) return tfail(AZX_EHIP, "train: joining the weight-gradient stream failed");

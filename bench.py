@@ -513,11 +513,10 @@ def resnet_roofline(st, args, steps, warmup, kernels=None):
     flops = st["evals"] * flop_per_position(args.board, args.blocks, args.chans)
     net_s = st["net_seconds"] if st["net_seconds"] > 0 else st["seconds"]
     achieved = flops / net_s / 1e12
-    shape32 = os.environ.get("AZX_TOWER_SHAPE") == "32"
     if args.chans == 64 and args.board <= 11:
-        kern = "k_tower_f16x3 + k_heads" if shape32 else "k_tower_f16x3_s16 + k_heads"
+        kern = "k_tower_f16x3_s16 + k_heads"
     elif args.chans % 128 == 0:
-        kern = ("k_conv_wide_f16x3" if shape32 else "k_conv_wide_f16x3_s16") + " x %d + k_heads" % (2 * args.blocks)
+        kern = "k_conv_wide_f16x3_s16 x %d + k_heads" % (2 * args.blocks)
     else:
         kern = "tower + k_heads"
     roof = {

@@ -327,7 +327,7 @@ int azx_debug_counters(azx_engine *e, uint64_t *out16);
 int azx_debug_counters_raw(azx_engine *e, uint64_t *out, int64_t n_games);
 
 /* Which kernels this engine launches, as one line of text ("tree=... play=... tower=... heads=..."): the
- * diagnostic switches AZX_MCTS_GENERIC / AZX_NO_PERSISTENT / AZX_TOWER / AZX_TOWER_SHAPE / AZX_TOWER_SPLIT /
+ * diagnostic switches AZX_MCTS_GENERIC / AZX_NO_PERSISTENT / AZX_TOWER /
  * AZX_WIDE_STREAMS are read ONCE, by azx_create, into the engine; this reports what they selected so a run
  * can prove which kernels it used.  Returns the length of the full text (it is truncated to cap - 1 bytes). */
 int azx_kernel_info(azx_engine *e, char *buf, int cap);

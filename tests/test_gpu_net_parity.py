@@ -327,12 +327,12 @@ def test_full_size_leaf_batch_sampled_against_the_oracle(eng, orc):
 
 
 def test_tower_variants_selected_by_environment():
-    """The alternative tower kernels (32x32x16 MFMA shape, unsplit wave tiling, exact-fp32 MFMA) and the scalar-FMA
-    heads kernel are chosen by environment variables read once per engine: run the golden forward tests under each."""
+    """The alternative tower kernel (exact-fp32 MFMA) and the scalar-FMA heads kernel are chosen by environment
+    variables read once per engine: run the golden forward tests under each."""
     import subprocess
     import sys
     here = os.path.abspath(__file__)
-    for env in ({"AZX_TOWER_SHAPE": "32"}, {"AZX_TOWER_SPLIT": "0"}, {"AZX_TOWER": "fp32"}, {"AZX_HEADS": "valu"}):
+    for env in ({"AZX_TOWER": "fp32"}, {"AZX_HEADS": "valu"}):
         r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-k", "g3_forward or shipped_checkpoint"],
                            env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (env, r.stdout[-2000:], r.stderr[-2000:])

@@ -72,10 +72,8 @@ def _positions(n, count, seed=3):
 
 @pytest.mark.parametrize("n,blocks,chans,env", [
     (11, 6, 64, {}),                              # k_tower_f16x3_s16: Ws16 / Wh16 / Whd16
-    (11, 2, 64, {"AZX_TOWER_SHAPE": "32"}),       # k_tower_f16x3: Ws / Wh
-    (11, 2, 64, {"AZX_TOWER_SPLIT": "0"}),        # k_tower_f16x3<false> (a 32-shape kernel whatever the shape) + k_heads
-    (13, 2, 256, {}),                             # wide tower, 16x16x32 order with the channel permutation
-    (13, 1, 128, {"AZX_TOWER_SHAPE": "32"}),      # wide tower, 32x32x16 order
+    (13, 2, 256, {}),                             # wide tower, 16x16x32 order with the channel permutation; Ws: its stem
+    (13, 1, 128, {}),
     (11, 2, 64, {"AZX_TOWER": "fp32"}),           # k_tower_mfma: Wp
     (9, 2, 32, {}),                               # k_tower_mfma<32,...>
     (7, 1, 48, {}),                               # generic VALU kernels: Wg
