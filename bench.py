@@ -335,7 +335,7 @@ def train_step_mode(args, local_rank, torch, mode):
                     "issued_frac_of_f16_mfma_peak": 3.0 * fl / (ms * 1e-3) / 1e12 / 2500.0,
                     "vs_fp32_mfma_peak": fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
                     "bound": ("throughput: per layer three split-f16 MFMA convolutions (k_conv_wide_train forward and backward-data, "
-                              "k_trn_wgrad16 filter gradient) and three elementwise passes (DESIGN 8.5)") if wide else
+                              "k_tw_wgrad filter gradient) and two elementwise passes (DESIGN 8.5)") if wide else
                              "launch chain: ~31 dependent kernels of 12-16 us on the data stream whose matrix work is ~1.5 us each (DESIGN 8.4)",
                     "flop_per_step": fl})
         gs.close()
