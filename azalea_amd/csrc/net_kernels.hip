@@ -627,14 +627,19 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
 // is dL/dact_{l-1}; what is written is g_{l-1} = (product [+ skip]) where act_{l-1} > 0, else 0; `stat` receives this
 // board's (sum g, sum g xhat_{l-1}) per channel (xhat from raw_{l-1} and BN_{l-1}'s batch sums) and *gmax max |g|.
 struct WideBwdFuse { const float *act, *raw, *skip; const double *sums; float invN; unsigned int *gmax; };
-template <int TRAIN>
+// NTW = 16-channel tiles per wave: 4 (a block = board x 128 channels: the inference decomposition) or, TRAIN only, 2 (a
+// block = board x 64 channels).  A training batch of 128 boards is 256 of the former -- one workgroup per CU, one wave per
+// SIMD, nobody to run while a block stages its next chunk -- and 512 of the latter: two independent workgroups per CU, the
+// regime the kernel was tuned in, at the price of twice the activation-fragment reads per MFMA (well inside the LDS rate).
+template <int TRAIN, int NTW = WIDE16_NT>
 __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, const unsigned short *__restrict__ in,
                                                    unsigned short *out, const unsigned short *resid,
                                                    float *__restrict__ out32,
                                                    const int32_t *__restrict__ n_eval_ptr, int n_eval_host,
                                                    int e_base, int e_end, float unscale, float2 *__restrict__ stat,
                                                    const WideBwdFuse &F = WideBwdFuse{}) {
-    constexpr int MT = WIDE16_MT, NT = WIDE16_NT, ROWB = WIDE_ROWB;
+    constexpr int MT = WIDE16_MT, NT = NTW, ROWB = WIDE_ROWB;
+    static_assert(NT == 4 || (NT == 2 && TRAIN != 0), "two tiles per wave: training instantiations only");
     float satmax = 0.f;
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_eval = n_eval_ptr ? *n_eval_ptr : n_eval_host;
@@ -649,7 +654,7 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
     // [e_base, e_end): the boards of this launch (the host splits a layer's boards over two streams)
     const int e = e_base + blockIdx.y * 8 + (blockIdx.x & 7);
     if (e >= n_eval || e >= e_end) return;
-    const int co_base = (blockIdx.x >> 3) * 128;
+    const int co_base = (blockIdx.x >> 3) * (32 * NT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Position tiles: a board of up to 176 cells is eleven 16-row tiles, not twelve.  Wave wm = 0 holds
     // tiles 0..5 and wm = 1 tiles 5..10 (rows 80..175); the shared tile 5 is computed by wm = 0 for the
@@ -698,12 +703,12 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
     // those (see azx_net_set_weights): a lane holds 8 consecutive channels per tile pair, i.e. one 16-byte
     // piece of the hi plane and one of the lo plane per row, and the four lane groups of a row together one
     // full 64-byte line -- residual loads and output stores are whole lines, half as many instructions.
-    auto chan0 = [&](int np) -> int { return co_base + 64 * wn + 32 * np + 8 * lh; };
+    auto chan0 = [&](int np) -> int { return co_base + 16 * NT * wn + 32 * np + 8 * lh; };
     // The accumulators start from bias (+ residual), fetched here together with the first input chunk (one
     // memory round trip, nothing else to do yet) instead of in the epilogue, where every wave of the block
     // waited for it with the matrix pipe idle.
     f32x4 acc[MT][NT];
-    if (TRAIN) {
+    if constexpr (TRAIN != 0) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -752,7 +757,7 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
     const uint4 *wsrc = reinterpret_cast<const uint4 *>(P.Wh16);
     // this wave's first 16-channel tile: uniform over the wave, so as a scalar the 64-bit part of the weight-fragment
     // addresses is formed on the scalar unit (per lane it was a v_mad_i64_i32 + two 64-bit shifts/adds per load)
-    const int nt0 = __builtin_amdgcn_readfirstlane(co_base / 16 + 4 * wn);
+    const int nt0 = __builtin_amdgcn_readfirstlane(co_base / 16 + NT * wn);
     // weights of k-step q (global index over layer, tap, chunk, half): [q][ntile][part][lane]
     auto wptr = [&](int q, int n, int part) -> const uint4 * {
         return wsrc + ((size_t)q * (NT16 * 2) + (size_t)((nt0 + n) * 2 + part)) * 64 + lane;
@@ -826,6 +831,41 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
             if (part) xl[mm] = *reinterpret_cast<const f16x8 *>(pa);
             else xh[mm] = *reinterpret_cast<const f16x8 *>(pa);
         };
+        if constexpr (NT == 2) {
+            // two tiles per wave: a k-step is ONE pass of 36 MFMAs (6 position tiles x 2 channel tiles x 3); the weights
+            // of k-step t + 1 go into the other of two register sets in the first MFMAs' shadows, a position tile's
+            // activation fragments are reloaded for t + 1 one tile after its MFMAs have issued, the last tile lags
+            f16x8 w2h[2][2], w2l[2][2];
+            auto load_w2 = [&](int t, int nn, int part) {
+                const uint4 qq = *wptr(qof(t), nn, part);
+                if (part) w2l[t & 1][nn] = *reinterpret_cast<const f16x8 *>(&qq);
+                else w2h[t & 1][nn] = *reinterpret_cast<const f16x8 *>(&qq);
+            };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) load_w2(0, i >> 1, i & 1);
+#pragma unroll
+            for (int m = 0; m < MT - 1; ++m) { load_x(0, m, 0); load_x(0, m, 1); }
+#pragma unroll
+            for (int t = 0; t < 18; ++t) {
+#pragma unroll
+                for (int q = 0; q < 6 * MT; ++q) {
+                    const int m = q / 6, n = (q % 6) / 3, p = q % 3;
+                    if (q == 1 || q == 4 || q == 7 || q == 10) {
+                        const int idx = (q - 1) / 3;
+                        if (t + 1 < 18) load_w2(t + 1, idx >> 1, idx & 1);
+                    } else if (q == 13 || q == 16) {
+                        load_x(t, MT - 1, q == 16);       // the lagging last tile
+                    } else if (q >= 8 && (q % 6 == 2 || q % 6 == 5)) {
+                        if (t + 1 < 18) load_x(t + 1, q / 6 - 1, q % 6 == 5);
+                    }
+                    const f16x8 wv = p == 1 ? w2l[t & 1][n] : w2h[t & 1][n];
+                    const f16x8 xv = p == 2 ? xl[m] : xh[m];
+                    if (!(WM == 0 ? (m == MT - 1 && n >= 1) : (m == 0 && n < 1)))
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, acc[m][n], 0, 0, 0);
+                    if (q % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) load_w(0, i >> 1, i & 1);
 #pragma unroll
@@ -854,24 +894,28 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
                 }
             }
         }
+        }
     }
 
     };
     if (wm == 0) main_loop(std::integral_constant<int, 0>{});
     else main_loop(std::integral_constant<int, 1>{});
 
-    if (TRAIN) {
+    if constexpr (TRAIN != 0) {
         // ---- training epilogue: raw fp32 out, per-board channel sums ---------------------------------------------
-        float s1[2][8], s2[2][8];
+        constexpr int NP = NT / 2;                         // tile pairs: a lane's 8 consecutive channels each
+        // tile n of position tile m is this wave's unless it is the shared tile's other half (see the k-loop)
+        auto tile_ok = [&](int m, int n) -> bool { return !(wm == 0 ? (m == MT - 1 && n >= NT / 2) : (m == 0 && n < NT / 2)); };
+        float s1[NP][8], s2[NP][8];
 #pragma unroll
-        for (int np = 0; np < 2; ++np)
+        for (int np = 0; np < NP; ++np)
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s1[np][j] = 0.f; s2[np][j] = 0.f; }
-        float pM[2][8], pI[2][8], vmax = 0.f;
+        float pM[NP][8], pI[NP][8], vmax = 0.f;
         if (TRAIN == 2) {
-            // mean / 1/std of BN_{l-1} for this lane's 16 channels, from the batch sums the forward pass filed
+            // mean / 1/std of BN_{l-1} for this lane's channels, from the batch sums the forward pass filed
 #pragma unroll
-            for (int np = 0; np < 2; ++np)
+            for (int np = 0; np < NP; ++np)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const double *sm = F.sums + (size_t)(chan0(np) + j) * 4;
@@ -884,9 +928,9 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
         for (int m = 0; m < MT; ++m) {
             const int r = row0 + 16 * m + lrow;
 #pragma unroll
-            for (int np = 0; np < 2; ++np) {
-                const bool mine = !(wm == 0 ? (m == MT - 1 && np == 1) : (m == 0 && np == 0));   // else the other wave's
-                if (r < ncells && mine) {
+            for (int np = 0; np < NP; ++np) {
+                const bool ok0 = tile_ok(m, 2 * np), ok1 = tile_ok(m, 2 * np + 1);
+                if (r < ncells && (ok0 || ok1)) {
                     const size_t o = ((size_t)e * ncells + r) * C + chan0(np);
                     float vv[8];
                     if (TRAIN == 2) {
@@ -898,22 +942,28 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
                         const float kv[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
+                            const bool ok = (j >> 2) ? ok1 : ok0;
                             vv[j] = av[j] > 0.f ? acc[m][2 * np + (j >> 2)][j & 3] * unscale + kv[j] : 0.f;
-                            vmax = fmaxf(vmax, fabsf(vv[j]));
-                            s1[np][j] += vv[j];
-                            s2[np][j] += vv[j] * (rv[j] - pM[np][j]) * pI[np][j];
+                            if (ok) {
+                                vmax = fmaxf(vmax, fabsf(vv[j]));
+                                s1[np][j] += vv[j];
+                                s2[np][j] += vv[j] * (rv[j] - pM[np][j]) * pI[np][j];
+                            }
                         }
                     } else {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
+                            const bool ok = (j >> 2) ? ok1 : ok0;
                             vv[j] = acc[m][2 * np + (j >> 2)][j & 3] * unscale;
-                            s1[np][j] += vv[j];
-                            s2[np][j] += vv[j] * vv[j];
+                            if (ok) {
+                                s1[np][j] += vv[j];
+                                s2[np][j] += vv[j] * vv[j];
+                            }
                         }
                     }
                     float *o32 = out32 + o;
-                    *reinterpret_cast<float4 *>(o32) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-                    *reinterpret_cast<float4 *>(o32 + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+                    if (ok0) *reinterpret_cast<float4 *>(o32) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    if (ok1) *reinterpret_cast<float4 *>(o32 + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
                 }
             }
         }
@@ -926,7 +976,7 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
             // a channel's rows sit in the 16 lanes li of one lane group lh and in both position waves: lanes first
             // (xor 1, 2, 4, 8 stay inside the group), then the two waves through LDS (the chunk image is done with)
 #pragma unroll
-            for (int np = 0; np < 2; ++np)
+            for (int np = 0; np < NP; ++np)
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -935,22 +985,23 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
                         s2[np][j] += __shfl_xor(s2[np][j], o);
                     }
             __syncthreads();                            // every wave has left the k-loop: the image can be overwritten
-            float2 *sst = reinterpret_cast<float2 *>(smem);     // [wm][128 channels of the block]
+            constexpr int BC = 32 * NT;                 // channels of the block
+            float2 *sst = reinterpret_cast<float2 *>(smem);     // [wm][BC]
             if (li == 0) {
 #pragma unroll
-                for (int np = 0; np < 2; ++np)
+                for (int np = 0; np < NP; ++np)
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        sst[wm * 128 + 64 * wn + 32 * np + 8 * lh + j] = make_float2(s1[np][j], s2[np][j]);
+                        sst[wm * BC + 16 * NT * wn + 32 * np + 8 * lh + j] = make_float2(s1[np][j], s2[np][j]);
             }
             __syncthreads();
-            if (tid < 128) {
-                const float2 a = sst[tid], b = sst[128 + tid];
+            if (tid < BC) {
+                const float2 a = sst[tid], b = sst[BC + tid];
                 stat[(size_t)e * C + co_base + tid] = make_float2(a.x + b.x, a.y + b.y);
             }
         }
         return;
-    }
+    } else {
     // ---- epilogue: ReLU -> split -> HBM, one 16-byte piece per lane and plane -----------------------
     NT_MARK(2)
     unsigned char *gout = reinterpret_cast<unsigned char *>(out) + (size_t)e * ncells * rowg;
@@ -990,6 +1041,7 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
     if (satmax > 65504.0f) atomicOr(P.sat_flag, 1u);     // an activation left the f16 range: its hi half is +inf (NetDev::sat_flag)
     NT_MARK(3)
     WT_FLUSH
+    }
 }
 
 __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int layer, const unsigned short *__restrict__ in,
@@ -1002,21 +1054,30 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_f16x3_s16(NetDev P, int la
 
 // the training step's convolutions (TRAIN = 1 above): `w16` = one layer's fragments in the wide pack
 // ([tap][chunk][half][ntile][hi, lo][lane][8]: k_tw_pack), boards [0, n_boards)
+template <int NTW>
 __global__ __launch_bounds__(256, 2) void k_conv_wide_train(int N, int C, const unsigned short *__restrict__ w16,
                                                             const unsigned short *__restrict__ in, float *__restrict__ out32,
                                                             int n_boards, const float *__restrict__ unscale, float2 *__restrict__ stat) {
     NetDev P;
     P.N = N; P.ncells = N * N; P.C = C; P.Wh16 = w16; P.bias = nullptr; P.sat_flag = nullptr;
-    conv_wide_s16_body<1>(P, 0, in, nullptr, nullptr, out32, nullptr, n_boards, 0, n_boards, *unscale, stat);
+    conv_wide_s16_body<1, NTW>(P, 0, in, nullptr, nullptr, out32, nullptr, n_boards, 0, n_boards, *unscale, stat);
 }
 
+template <int NTW>
 __global__ __launch_bounds__(256, 2) void k_conv_wide_train_bwd(int N, int C, const unsigned short *__restrict__ w16,
                                                                 const unsigned short *__restrict__ in, float *__restrict__ out32,
                                                                 int n_boards, const float *__restrict__ unscale, float2 *__restrict__ stat,
                                                                 WideBwdFuse F) {
     NetDev P;
     P.N = N; P.ncells = N * N; P.C = C; P.Wh16 = w16; P.bias = nullptr; P.sat_flag = nullptr;
-    conv_wide_s16_body<2>(P, 0, in, nullptr, nullptr, out32, nullptr, n_boards, 0, n_boards, *unscale, stat, F);
+    conv_wide_s16_body<2, NTW>(P, 0, in, nullptr, nullptr, out32, nullptr, n_boards, 0, n_boards, *unscale, stat, F);
+}
+
+// tiles per wave of the training convolutions: 2 (board x 64 channels per block) unless AZX_TRAIN_CONV_NT=4
+static int train_conv_nt() {
+    static int nt = 0;
+    if (!nt) { const char *v = getenv("AZX_TRAIN_CONV_NT"); nt = (v && atoi(v) == 4) ? 4 : 2; }
+    return nt;
 }
 
 int azx_net_wide_train_conv_bwd(int N, int C, const unsigned short *w16, const unsigned short *in, float *g_out, int n_boards,
@@ -1025,13 +1086,16 @@ int azx_net_wide_train_conv_bwd(int N, int C, const unsigned short *w16, const u
     static bool raised = false;
     const size_t lds = (size_t)(N * N + 2) * WIDE_ROWB;
     if (!raised) {
-        if (hipFuncSetAttribute((const void *)k_conv_wide_train_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_conv_wide_train_bwd<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)k_conv_wide_train_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
             return AZX_EHIP;
         raised = true;
     }
     const WideBwdFuse F = {act, raw, skip, sums, invN, gmax};
-    const dim3 g(8 * (C / 128), (n_boards + 7) / 8);
-    hipLaunchKernelGGL(k_conv_wide_train_bwd, g, dim3(256), lds, st, N, C, w16, in, g_out, n_boards, unscale, pgsum, F);
+    if (train_conv_nt() == 4)
+        hipLaunchKernelGGL(k_conv_wide_train_bwd<4>, dim3(8 * (C / 128), (n_boards + 7) / 8), dim3(256), lds, st, N, C, w16, in, g_out, n_boards, unscale, pgsum, F);
+    else
+        hipLaunchKernelGGL(k_conv_wide_train_bwd<2>, dim3(8 * (C / 64), (n_boards + 7) / 8), dim3(256), lds, st, N, C, w16, in, g_out, n_boards, unscale, pgsum, F);
     return AZX_OK;
 }
 
@@ -1040,12 +1104,15 @@ int azx_net_wide_train_conv(int N, int C, const unsigned short *w16, const unsig
     static bool raised = false;
     const size_t lds = (size_t)(N * N + 2) * WIDE_ROWB;
     if (!raised) {
-        if (hipFuncSetAttribute((const void *)k_conv_wide_train, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_conv_wide_train<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)k_conv_wide_train<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
             return AZX_EHIP;
         raised = true;
     }
-    const dim3 g(8 * (C / 128), (n_boards + 7) / 8);
-    hipLaunchKernelGGL(k_conv_wide_train, g, dim3(256), lds, st, N, C, w16, in, out32, n_boards, unscale, stat);
+    if (train_conv_nt() == 4)
+        hipLaunchKernelGGL(k_conv_wide_train<4>, dim3(8 * (C / 128), (n_boards + 7) / 8), dim3(256), lds, st, N, C, w16, in, out32, n_boards, unscale, stat);
+    else
+        hipLaunchKernelGGL(k_conv_wide_train<2>, dim3(8 * (C / 64), (n_boards + 7) / 8), dim3(256), lds, st, N, C, w16, in, out32, n_boards, unscale, stat);
     return AZX_OK;
 }
 
