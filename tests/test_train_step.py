@@ -281,3 +281,20 @@ def test_native_train_step_refuses_what_it_does_not_cover():
         NativeTrainStep(torch.nn.Linear(3, 3), sgd, 8, "cuda:0")
     with pytest.raises(ValueError):
         NativeTrainStep(net, torch.optim.SGD(list(net.parameters())[:3], lr=0.1), 8, "cuda:0")
+
+
+def test_native_step_envelope_is_what_train_picks_by():
+    """native_train.unsupported_reason (no GPU needed for the shape logic): 16 / 32 / 64 channels up to 11x11, 128 / 256
+    from 3x3 to 13x13; anything else names the reason -- train() then takes the stock step (make_train_step)."""
+    from azalea_amd.native_train import SUPPORTED_SHAPES
+    ok = [(11, 64), (2, 16), (9, 32), (13, 256), (13, 128), (3, 128), (11, 256)]
+    bad = [(13, 64), (12, 32), (2, 128), (14, 256), (11, 48), (11, 512)]
+    assert all(k in SUPPORTED_SHAPES for k in ok) and not any(k in SUPPORTED_SHAPES for k in bad)
+    import torch
+    from azalea_amd.network import HexNetwork
+    from azalea_amd.native_train import unsupported_reason
+    net = HexNetwork(board_size=5, num_blocks=1, base_chans=16)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    assert "CUDA" in unsupported_reason(net, opt, "cpu")
+    from azalea_amd.policy_trainer import make_train_step
+    assert make_train_step(net, opt, 4, "cpu", {}) == (None, "eager")
