@@ -63,7 +63,9 @@ def compare(a, b, depth, plies, min_games=200):
             continue
         xa, xb = column(a, "entropy", ply), column(b, "entropy", ply)
         if min(len(xa), len(xb)) >= min_games:     # the engine's rows carry the visit distribution below the depth only
-            out["entropy@%d" % ply] = float(stats.ks_2samp(xa, xb).pvalue)
+            # (on a 1e-4 grid, like action_prob below: the entropy of a visit distribution takes discrete values, the
+            # engine's comes from float32 probabilities and the oracle's from the counts -- the same atom a few ulp apart)
+            out["entropy@%d" % ply] = float(stats.ks_2samp(np.round(xa, 4), np.round(xb, 4)).pvalue)
         out["search_value@%d" % ply] = float(stats.ks_2samp(column(a, "search_value", ply),
                                                             column(b, "search_value", ply)).pvalue)
         out["width@%d" % ply] = chi2_two_sample(column(a, "width", ply), column(b, "width", ply))

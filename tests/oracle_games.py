@@ -55,11 +55,31 @@ def summarise_oracle_game(n, result, rows):
     return dict(length=len(rows), first_wins=int(result == 3), moves=moves, **out)
 
 
+_NETS = {}
+
+
+def _evaluator(cfg):
+    """The stub network of the reference's golden games (uniform priors, board-hash value) or, with cfg["weights"], the
+    oracle's fp32 HexNetwork on a saved state_dict (blocked AVX-512 convolutions: held to the parity forward at 1e-5)."""
+    import ctypes as C
+    from oracle import oracle as orc
+    n = cfg["n"]
+    if not cfg.get("weights"):
+        return orc.UniformEval(hash_value=True, prior_by_k=prior_table(n))
+    key = cfg["weights"]
+    if key not in _NETS:                      # one per worker process
+        z = np.load(key)
+        net = orc.Net(n, int(cfg["blocks"]), int(cfg["chans"]), {k: z[k] for k in z.files})
+        net.fn = C.cast(orc.lib().oeval_net_fast, C.c_void_p)
+        _NETS[key] = net
+    return _NETS[key]
+
+
 def _one(args):
     cfg, seed = args
     from oracle import oracle as orc
     n = cfg["n"]
-    ev = orc.UniformEval(hash_value=True, prior_by_k=prior_table(n))
+    ev = _evaluator(cfg)
     result, rows, _ = orc.play_game(
         n, ev, simulations=cfg["sims"], batch_size=cfg["batch"], c_puct=cfg["c"],
         exploration_depth=cfg["depth"], noise_alpha=cfg["alpha"], noise_scale=cfg["eps"],
@@ -100,9 +120,12 @@ def main():
     ap.add_argument("--seed0", type=int, default=0)
     ap.add_argument("--procs", type=int, default=0)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--weights", default=None, help="npz of a HexNetwork state_dict: play with the oracle's network")
+    ap.add_argument("--blocks", type=int, default=0)
+    ap.add_argument("--chans", type=int, default=0)
     a = ap.parse_args()
     cfg = dict(n=a.n, sims=a.sims, batch=a.batch, c=a.c, depth=a.depth, alpha=a.alpha, eps=a.eps, temp=a.temp,
-               noise_until=a.noise_until)
+               noise_until=a.noise_until, weights=a.weights, blocks=a.blocks, chans=a.chans)
     res = sample(cfg, range(a.seed0, a.seed0 + a.games), a.procs or None)
     np.savez_compressed(a.out, **res)
 
