@@ -344,7 +344,10 @@ int azx_debug_set_queue_cap(azx_engine *e, int64_t rows);
  * split-f16 arithmetic of the self-play tower, fp32 accumulate, operands scaled per layer by powers of two: results
  * at fp32 accuracy whatever the magnitudes; environment AZX_TRAIN_FWD / _BWD / _WGRAD=fp32 selects exact-fp32 MFMA
  * kernels per pass).  The trainer keeps owning its tensors (PyTorch holds them); this handle owns the activations
- * and scratch.  11x11 boards and below, 16 / 32 / 64 channels, any batch. */
+ * and scratch.  16 / 32 / 64 channels on boards up to 11x11, and 128 / 256 channels on boards from 3x3 to 13x13 (the
+ * wide step: the self-play wide convolution kernel in its TRAIN modes for forward and backward-data, elementwise
+ * BatchNorm / ReLU passes on split-f16 images); any batch (built for the reference's 128); other shapes are
+ * AZX_EINVAL. */
 typedef struct {
     int32_t board_size, num_blocks, base_chans;   /* policy.py:51-53 */
     int32_t batch_size;                           /* config batch_size (hex11_train_config.yml: 128) */
