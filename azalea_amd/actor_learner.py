@@ -8,7 +8,8 @@ with the trainer's live network (its CUDA-IPC tensors).  One process per GPU giv
   fresh-example counter asks for rows (replay_buffer.py:121-132) it PULLS them: one announcement on the control group
   (gloo, host side), then the two record collectives of the lock-step path (counts, records: RCCL over xGMI), to which
   it contributes nothing.  Every `weight_sync_steps` optimizer steps it broadcasts its network (parameters and
-  BatchNorm statistics, one flat tensor).
+  BatchNorm statistics, one flat tensor) -- asynchronously, from a snapshot: the training stream does not wait for the
+  actors to join.
 * ranks != 0 are ACTORS: they play whole games continuously into a BACKLOG of packed record chunks in HBM
   (`azx_play_device` one pool move at a time, `azx_rows_pack`), polling the control group between moves, and stop
   producing when the backlog holds `ahead_rows` rows (about one pool move's harvest by default) -- the bound on how far
@@ -80,10 +81,16 @@ class Learner:
         self.weight_syncs = 0
         self.pulls = 0
         self.last_pull = None
+        self._sending = None           # (work, snapshot) of the weight broadcast in flight
 
     def sync_weights(self) -> None:
+        """Announce and send the network.  The send is asynchronous on this rank: a snapshot taken on the training
+        stream goes out on the collective's own stream, so training does not wait for the actors to reach their next
+        poll; the previous send is waited for first (it has long completed: one is in flight at most)."""
+        if self._sending is not None:
+            self._sending[0].wait()
         azdist.lead(azdist.OP_WEIGHTS, self.steps)
-        azdist.broadcast_weights(self.net, src=0)
+        self._sending = azdist.send_weights_async(self.net)
         self.weight_syncs += 1
 
     def after_step(self) -> None:
@@ -94,7 +101,9 @@ class Learner:
 
     def pull(self, size: int, device: torch.device, record_bytes: int):
         """Announce a pull of `size` rows and take part in its collectives with nothing to give.  Returns the
-        per-rank record tensors, their row counts and the actors' summed production metrics."""
+        per-rank record tensors, their row counts and the actors' summed production metrics.  Blocks until every actor
+        has reached its next poll (at most one pool move of the slowest one) and has its share -- `Player.read`'s
+        contract in the reference, whose trainer waits the same way when the generator is behind."""
         t0 = time.perf_counter()
         azdist.lead(azdist.OP_PULL, int(np.ceil(size)))
         parts, counts = azdist.all_gather_records(torch.empty((0, record_bytes), dtype=torch.uint8, device=device))
@@ -109,6 +118,9 @@ class Learner:
 
     def stop(self) -> None:
         """Training is over: everyone leaves with the trained network."""
+        if self._sending is not None:
+            self._sending[0].wait()
+            self._sending = None
         azdist.lead(azdist.OP_STOP)
         azdist.broadcast_weights(self.net, src=0)
 

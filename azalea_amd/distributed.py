@@ -251,6 +251,17 @@ def follow(timeout: Optional[float] = None) -> Tuple[int, int]:
     return Pending().result(timeout)
 
 
+def send_weights_async(net: torch.nn.Module):
+    """Rank 0 of an actor / learner run: the same flat broadcast as `broadcast_weights`, from a SNAPSHOT of the network
+    taken on the current stream, as an asynchronous collective -- the training stream does not wait for the actors to
+    join (they notice the announcement between two pool moves, up to a few hundred ms later).  Returns (work, snapshot):
+    keep both until the next call."""
+    tensors = [t for t in net.state_dict().values() if t.is_floating_point()]
+    dev = _comm_device()
+    flat = torch.cat([t.detach().reshape(-1).to(dev, torch.float32) for t in tensors])
+    return dist.broadcast(flat, src=rank(), async_op=True), flat
+
+
 @_data_collective
 def broadcast_weights(net: torch.nn.Module, src: int = 0) -> None:
     """One flat broadcast of parameters + buffers (2.1 MB for the 6x64 net): conv / linear weights and the
