@@ -338,17 +338,18 @@ def test_native_step_tracks_the_eager_step_over_twelve_steps(blocks, chans, B):
     step.close()
 
 
-def test_native_and_eager_training_learn_the_same_thing():
-    """A sanity check no parity bound can give: 150 steps on a fixed set of 64 rows (5x5, 2x16) -- the hand-written step
-    and the eager one both drive the loss down, to the same level (their fp32 trajectories are not bitwise twins, the
-    optimisation is the same)."""
+@pytest.mark.parametrize("chans", [16, 128])
+def test_native_and_eager_training_learn_the_same_thing(chans):
+    """A sanity check no parity bound can give: 150 steps on a fixed set of 64 rows (5x5, 2x16 -- and 2x128, the wide
+    step) -- the hand-written step and the eager one both drive the loss down, to the same level (their fp32
+    trajectories are not bitwise twins, the optimisation is the same)."""
     from azalea_amd.native_train import NativeTrainStep
     from azalea_amd.policy_trainer import supervised_step
     n, B = 5, 32
     data = [_random_batch(n, B, 300 + i) for i in range(2)]
     finals, firsts = [], []
     for kind in ("eager", "native"):
-        net = _net(n, 2, 16, seed=4)
+        net = _net(n, 2, chans, seed=4)
         opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
         step = NativeTrainStep(net, opt, B, DEV) if kind == "native" else None
         losses = []
