@@ -2859,6 +2859,12 @@ __global__ __launch_bounds__(256) void k_tw_wgrad(TwWgrad A, int N, int B, int G
     }
 }
 
+// (Measured and dropped, round 5: a 64 x 64 tile per block -- four waves = (co half, ci half), each with all nine taps in
+// 144 accumulator registers, every SIMD with matrix work, the two 64-channel image slices staged once for four tile
+// pairs, one block per CU: 80 vs 92 us per launch, but the blocks that fill the chip once need 16 board groups instead
+// of 8 -- twice the partial copies for the update to reduce: 10.60 vs 10.45 ms per step at 19x256, 4.93 vs 4.25 at
+// 19x128.  With one block per CU the LDS store phase and its barriers are exposed.)
+
 // the wide step (C = 128 / 256): see "wide towers" above
 template <int C>
 static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork) {
