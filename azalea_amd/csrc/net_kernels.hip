@@ -924,46 +924,72 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
                     pI[np][j] = (float)(1.0 / sqrt((vr > 0 ? vr : 0) + 1e-5));
                 }
         }
+        // Three position tiles at a time, and (TRAIN = 2) all of their mask / xhat / skip pieces requested before the first
+        // is used, unconditionally at a clamped row: behind `if (row is mine)` the compiler waits for each tile's loads at
+        // the join -- six memory round trips at the end of a kernel that has nothing left to hide them under.
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int r = row0 + 16 * m + lrow;
+        for (int m0 = 0; m0 < MT; m0 += 3) {
+            float4 ea[3][NP][2], er[3][NP][2], ek[3][NP][2];
+            if (TRAIN == 2) {
 #pragma unroll
-            for (int np = 0; np < NP; ++np) {
-                const bool ok0 = tile_ok(m, 2 * np), ok1 = tile_ok(m, 2 * np + 1);
-                if (r < ncells && (ok0 || ok1)) {
-                    const size_t o = ((size_t)e * ncells + r) * C + chan0(np);
-                    float vv[8];
-                    if (TRAIN == 2) {
-                        const float4 a0 = *reinterpret_cast<const float4 *>(F.act + o), a1 = *reinterpret_cast<const float4 *>(F.act + o + 4);
-                        const float4 r0 = *reinterpret_cast<const float4 *>(F.raw + o), r1 = *reinterpret_cast<const float4 *>(F.raw + o + 4);
-                        float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0;
-                        if (F.skip) { k0 = *reinterpret_cast<const float4 *>(F.skip + o); k1 = *reinterpret_cast<const float4 *>(F.skip + o + 4); }
-                        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-                        const float kv[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+                for (int mm = 0; mm < 3; ++mm)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const bool ok = (j >> 2) ? ok1 : ok0;
-                            vv[j] = av[j] > 0.f ? acc[m][2 * np + (j >> 2)][j & 3] * unscale + kv[j] : 0.f;
-                            if (ok) {
-                                vmax = fmaxf(vmax, fabsf(vv[j]));
-                                s1[np][j] += vv[j];
-                                s2[np][j] += vv[j] * (rv[j] - pM[np][j]) * pI[np][j];
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const bool ok = (j >> 2) ? ok1 : ok0;
-                            vv[j] = acc[m][2 * np + (j >> 2)][j & 3] * unscale;
-                            if (ok) {
-                                s1[np][j] += vv[j];
-                                s2[np][j] += vv[j] * vv[j];
-                            }
+                    for (int np = 0; np < NP; ++np) {
+                        const int rc = min(row0 + 16 * (m0 + mm) + lrow, ncells - 1);
+                        const size_t o = ((size_t)e * ncells + rc) * C + chan0(np);
+                        ea[mm][np][0] = *reinterpret_cast<const float4 *>(F.act + o);
+                        ea[mm][np][1] = *reinterpret_cast<const float4 *>(F.act + o + 4);
+                        er[mm][np][0] = *reinterpret_cast<const float4 *>(F.raw + o);
+                        er[mm][np][1] = *reinterpret_cast<const float4 *>(F.raw + o + 4);
+                        if (F.skip) {        // (wave-uniform: a kernel argument)
+                            ek[mm][np][0] = *reinterpret_cast<const float4 *>(F.skip + o);
+                            ek[mm][np][1] = *reinterpret_cast<const float4 *>(F.skip + o + 4);
+                        } else {
+                            ek[mm][np][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            ek[mm][np][1] = ek[mm][np][0];
                         }
                     }
-                    float *o32 = out32 + o;
-                    if (ok0) *reinterpret_cast<float4 *>(o32) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-                    if (ok1) *reinterpret_cast<float4 *>(o32 + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+            }
+#pragma unroll
+            for (int mm = 0; mm < 3; ++mm) {
+                const int m = m0 + mm;
+                const int r = row0 + 16 * m + lrow;
+#pragma unroll
+                for (int np = 0; np < NP; ++np) {
+                    const bool ok0 = tile_ok(m, 2 * np), ok1 = tile_ok(m, 2 * np + 1);
+                    if (r < ncells && (ok0 || ok1)) {
+                        const size_t o = ((size_t)e * ncells + r) * C + chan0(np);
+                        float vv[8];
+                        if (TRAIN == 2) {
+                            const float4 a0 = ea[mm][np][0], a1 = ea[mm][np][1], r0 = er[mm][np][0], r1 = er[mm][np][1];
+                            const float4 k0 = ek[mm][np][0], k1 = ek[mm][np][1];
+                            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+                            const float kv[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const bool ok = (j >> 2) ? ok1 : ok0;
+                                vv[j] = av[j] > 0.f ? acc[m][2 * np + (j >> 2)][j & 3] * unscale + kv[j] : 0.f;
+                                if (ok) {
+                                    vmax = fmaxf(vmax, fabsf(vv[j]));
+                                    s1[np][j] += vv[j];
+                                    s2[np][j] += vv[j] * (rv[j] - pM[np][j]) * pI[np][j];
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const bool ok = (j >> 2) ? ok1 : ok0;
+                                vv[j] = acc[m][2 * np + (j >> 2)][j & 3] * unscale;
+                                if (ok) {
+                                    s1[np][j] += vv[j];
+                                    s2[np][j] += vv[j] * vv[j];
+                                }
+                            }
+                        }
+                        float *o32 = out32 + o;
+                        if (ok0) *reinterpret_cast<float4 *>(o32) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                        if (ok1) *reinterpret_cast<float4 *>(o32 + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+                    }
                 }
             }
         }
@@ -1073,12 +1099,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_train_bwd(int N, int C, co
     conv_wide_s16_body<2, NTW>(P, 0, in, nullptr, nullptr, out32, nullptr, n_boards, 0, n_boards, *unscale, stat, F);
 }
 
-// tiles per wave of the training convolutions: 2 (board x 64 channels per block) unless AZX_TRAIN_CONV_NT=4
-static int train_conv_nt() {
-    static int nt = 0;
-    if (!nt) { const char *v = getenv("AZX_TRAIN_CONV_NT"); nt = (v && atoi(v) == 4) ? 4 : 2; }
-    return nt;
-}
+// (the training convolutions run with two tiles per wave, board x 64 channels per block: the four-tile form measured
+// 73 vs 61-64 us forward, 10.8-11.0 vs 10.4-10.6 ms per step, and was removed)
 
 int azx_net_wide_train_conv_bwd(int N, int C, const unsigned short *w16, const unsigned short *in, float *g_out, int n_boards,
                                 const float *unscale, float2 *pgsum, const float *act, const float *raw, const float *skip,
@@ -1086,16 +1108,12 @@ int azx_net_wide_train_conv_bwd(int N, int C, const unsigned short *w16, const u
     static bool raised = false;
     const size_t lds = (size_t)(N * N + 2) * WIDE_ROWB;
     if (!raised) {
-        if (hipFuncSetAttribute((const void *)k_conv_wide_train_bwd<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void *)k_conv_wide_train_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_conv_wide_train_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
             return AZX_EHIP;
         raised = true;
     }
     const WideBwdFuse F = {act, raw, skip, sums, invN, gmax};
-    if (train_conv_nt() == 4)
-        hipLaunchKernelGGL(k_conv_wide_train_bwd<4>, dim3(8 * (C / 128), (n_boards + 7) / 8), dim3(256), lds, st, N, C, w16, in, g_out, n_boards, unscale, pgsum, F);
-    else
-        hipLaunchKernelGGL(k_conv_wide_train_bwd<2>, dim3(8 * (C / 64), (n_boards + 7) / 8), dim3(256), lds, st, N, C, w16, in, g_out, n_boards, unscale, pgsum, F);
+    hipLaunchKernelGGL(k_conv_wide_train_bwd<2>, dim3(8 * (C / 64), (n_boards + 7) / 8), dim3(256), lds, st, N, C, w16, in, g_out, n_boards, unscale, pgsum, F);
     return AZX_OK;
 }
 
@@ -1104,15 +1122,11 @@ int azx_net_wide_train_conv(int N, int C, const unsigned short *w16, const unsig
     static bool raised = false;
     const size_t lds = (size_t)(N * N + 2) * WIDE_ROWB;
     if (!raised) {
-        if (hipFuncSetAttribute((const void *)k_conv_wide_train<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void *)k_conv_wide_train<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_conv_wide_train<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
             return AZX_EHIP;
         raised = true;
     }
-    if (train_conv_nt() == 4)
-        hipLaunchKernelGGL(k_conv_wide_train<4>, dim3(8 * (C / 128), (n_boards + 7) / 8), dim3(256), lds, st, N, C, w16, in, out32, n_boards, unscale, stat);
-    else
-        hipLaunchKernelGGL(k_conv_wide_train<2>, dim3(8 * (C / 64), (n_boards + 7) / 8), dim3(256), lds, st, N, C, w16, in, out32, n_boards, unscale, stat);
+    hipLaunchKernelGGL(k_conv_wide_train<2>, dim3(8 * (C / 64), (n_boards + 7) / 8), dim3(256), lds, st, N, C, w16, in, out32, n_boards, unscale, stat);
     return AZX_OK;
 }
 
