@@ -51,6 +51,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TRN_SMALL_THREADS 1024    // the elementwise kernels around the tower: 16 waves per CU hide their loads' latency
 #define TRN_REP 8                  // copies of the small f64-atomic accumulators
 #define TRN_WG_GROUPS 64          // k_trn_wgrad: board groups (x 4 channel-tile pairs at C = 64: 256 workgroups)
+#define TRN_PRESUM_BATCH 256      // above this batch a totals kernel sums a layer's per-board partial pairs once (see k_trn_totals)
 
 static thread_local std::string g_trn_err;
 const char *azx_trn_error() { return g_trn_err.c_str(); }
@@ -112,6 +113,7 @@ struct TrnDev {
     // wide towers (C = 128 / 256: the "wide tower" section below)
     float2 *bsc;                   // [L + 1] (scale of layer l's BatchNorm-backward image, 1 / (that x the filter scale))
     int dl_stride;                 // row stride of dlogit: 128 (boards up to 11x11), 192 beyond
+    int presum;                    // batches beyond TRN_PRESUM_BATCH: the batch sums come from k_trn_totals, not from every consumer
 };
 
 __device__ __forceinline__ double dsum(const double *s, int l, int C, int c, int k) { return s[((size_t)l * C + c) * 4 + k]; }
@@ -141,7 +143,7 @@ __device__ __forceinline__ void sum_partials_request(const float2 *ps, int Cs, i
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int b = part + u * PARTS;
-        const float2 x = ps[(size_t)min(b, B - 1) * Cs + c0 + c];
+        const float2 x = ps[(size_t)min(b, max(B - 1, 0)) * Cs + c0 + c];      // (B = 0: presummed, nothing is taken)
         const float on = b < B ? 1.f : 0.f;           // (a multiplication, not a select: the compiler turns the select
         v[u] = make_float2(x.x * on, x.y * on);       // back into a branch around the load)
     }
@@ -185,6 +187,37 @@ __device__ __forceinline__ void sum_partials(const float2 *ps, int Cs, int c0, i
     sum_partials_request<CW, NTH, 16>(ps, Cs, c0, B, tid, v);
     sum_partials_finish<CW, NTH, 16>(ps, Cs, c0, B, sh, tid, v, a, q);
 }
+// Every consumer block summing every board's partial pair is what keeps a kernel boundary out of the 6x64 step at the
+// reference's batch (64 KB of L2 reads per block at 128 boards) -- and grows with the SQUARE of the batch over a launch
+// (2 MB per block at 4 096).  Beyond TRN_PRESUM_BATCH boards a launch of this kernel behind each producer sums a layer's
+// pairs once, in a fixed order, into P.sums, and the consumers take the totals from there (P.presum; they pass B = 0
+// to their own summation).  grid C / 16, 256 threads = 16 channels x 16 board phases.
+__global__ __launch_bounds__(256) void k_trn_totals(const float2 *part, int B, int C, double *dst) {
+    __shared__ double2 sh[256];
+    const int tid = threadIdx.x, c = blockIdx.x * 16 + (tid & 15), ph = tid >> 4;
+    double a = 0, q = 0;
+    if (c < C)
+        for (int b = ph; b < B; b += 16) {
+            const float2 x = part[(size_t)b * C + c];
+            a += (double)x.x;
+            q += (double)x.y;
+        }
+    sh[tid] = make_double2(a, q);
+    __syncthreads();
+    if (tid < 16 && c < C) {
+        double sa = 0, sq = 0;
+        for (int p = 0; p < 16; ++p) { sa += sh[p * 16 + tid].x; sq += sh[p * 16 + tid].y; }
+        dst[(size_t)c * 4] = sa;
+        dst[(size_t)c * 4 + 1] = sq;
+    }
+}
+// the presummed totals of channel c (k = 0: raw's sum / sum of squares; 2: the gradient's two sums)
+__device__ __forceinline__ void presummed(const double *sums, int l, int C, int c, int k, double &t0, double &t1) {
+    const double *sm = sums + ((size_t)l * C + c) * 4 + k;
+    t0 = sm[0];
+    t1 = sm[1];
+}
+
 __device__ __forceinline__ void bn_from_sums(double s0, double s1, float invN, float &mean, float &inv) {
     const double m = s0 * (double)invN, v = s1 * (double)invN - m * m;
     mean = (float)m;
@@ -427,7 +460,8 @@ __device__ __forceinline__ void trn_conv_body(const ConvPtrs &A, const TrnDev &P
     const float2 *psrc = FORWARD ? P.pstat + (size_t)(l - 1) * P.B * C : P.pgsum + (size_t)l * P.B * C;
     constexpr int PSU = C >= 64 ? 32 : 16;
     float2 pv[PSU];
-    sum_partials_request<C, 256, PSU>(psrc, C, 0, P.B, tid, pv);
+    const int Bsum = P.presum ? 0 : P.B;
+    sum_partials_request<C, 256, PSU>(psrc, C, 0, Bsum, tid, pv);
     // (unconditional loads at a clamped index -- the items beyond `total` are never looked at: a load behind a per-lane
     // branch makes the compiler wait at the join)
     float4 v0[ITER], v1[ITER];
@@ -468,11 +502,12 @@ __device__ __forceinline__ void trn_conv_body(const ConvPtrs &A, const TrnDev &P
     // -- are taken from the per-board partials
     double t0, t1;
     TS_MARK(5)
-    sum_partials_finish<C, 256, PSU>(psrc, C, 0, P.B, sh, tid, pv, t0, t1);
+    sum_partials_finish<C, 256, PSU>(psrc, C, 0, Bsum, sh, tid, pv, t0, t1);
     TS_MARK(4)
     if (tid < C) {
         const int c = tid;
-        if (nt == 0 && b == 0) {
+        if (P.presum) presummed(P.sums, FORWARD ? l - 1 : l, C, c, FORWARD ? 0 : 2, t0, t1);
+        if (nt == 0 && b == 0 && !P.presum) {
             double *dst = P.sums + ((size_t)(FORWARD ? l - 1 : l) * C + c) * 4 + (FORWARD ? 0 : 2);
             dst[0] = t0;
             dst[1] = t1;
@@ -799,9 +834,10 @@ __device__ __forceinline__ void trn_wgrad_body(const WgradPtrs &W_, const TrnDev
     };
     if (grp < P.B) request(grp);
     double t0, t1;       // (sum g_l, sum g_l xhat_l) of this block's channels (k_trn_conv<BWD> of layer l runs beside this kernel)
-    sum_partials<CH, 256>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.B, reinterpret_cast<double2 *>(red), tid, t0, t1);
+    sum_partials<CH, 256>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.presum ? 0 : P.B, reinterpret_cast<double2 *>(red), tid, t0, t1);
     if (tid < CH) {
         const int c = tm * 32 + tid;
+        if (P.presum) presummed(P.sums, l, C, c, 2, t0, t1);
         float mean, inv;
         bn_coeffs(P, l, c, mean, inv);
         cM[tid] = mean;
@@ -948,13 +984,14 @@ __device__ __forceinline__ void trn_wgrad16_body(const WgradPtrs &W_, const TrnD
     const float e_w = W_.bnw[cc], e_gmax = __uint_as_float(P.gmax[l]);
     const double2 e_sl = *reinterpret_cast<const double2 *>(P.sums + ((size_t)l * C + cc) * 4);
     float2 pv[16];
-    sum_partials_request<CH, 256, 16>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.B, tid, pv);
+    sum_partials_request<CH, 256, 16>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.presum ? 0 : P.B, tid, pv);
     request(grp);
     double t0, t1;
-    sum_partials_finish<CH, 256, 16>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.B, reinterpret_cast<double2 *>(red), tid, pv, t0, t1);
+    sum_partials_finish<CH, 256, 16>(P.pgsum + (size_t)l * P.B * C, C, tm * 32, P.presum ? 0 : P.B, reinterpret_cast<double2 *>(red), tid, pv, t0, t1);
     if (wave == 0) {
         float bd = 0.f;
         if (tid < CH) {
+            if (P.presum) presummed(P.sums, l, C, tm * 32 + tid, 2, t0, t1);
             float mean, inv;
             bn_from_sums(e_sl.x, e_sl.y, P.invN, mean, inv);
             cM[tid] = mean;
@@ -1114,11 +1151,12 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_conv(TrnDev P) 
     float *red = W + 6 * C;                 // [6][2]
     const int b = blockIdx.x, tid = threadIdx.x, cells = P.cells, L = P.L;
     double t0, t1;
-    sum_partials<C, NTH>(P.pstat + (size_t)L * P.B * C, C, 0, P.B,
+    sum_partials<C, NTH>(P.pstat + (size_t)L * P.B * C, C, 0, P.presum ? 0 : P.B,
                          reinterpret_cast<double2 *>(lds + ((P.cells * LDX + 8 * C + 16 + 3) & ~3)), tid, t0, t1);
     if (tid < C) {
         float mean, inv;
-        if (b == 0) {
+        if (P.presum) presummed(P.sums, L, C, tid, 0, t0, t1);
+        if (b == 0 && !P.presum) {
             P.sums[((size_t)L * C + tid) * 4] = t0;
             P.sums[((size_t)L * C + tid) * 4 + 1] = t1;
         }
@@ -1548,10 +1586,11 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_bwd(TrnDev P) {
         vr[k] = i < total ? r4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     double t0, t1;
-    sum_partials<C, NTH>(P.pgsum, C, 0, P.B, reinterpret_cast<double2 *>(cK + 2 * C), tid, t0, t1);
+    sum_partials<C, NTH>(P.pgsum, C, 0, P.presum ? 0 : P.B, reinterpret_cast<double2 *>(cK + 2 * C), tid, t0, t1);
     if (tid < C) {
         float mean, inv;
-        if (b == 0) {
+        if (P.presum) presummed(P.sums, 0, C, tid, 2, t0, t1);
+        if (b == 0 && !P.presum) {
             P.sums[(size_t)tid * 4 + 2] = t0;
             P.sums[(size_t)tid * 4 + 3] = t1;
         }
@@ -1912,7 +1951,7 @@ __device__ __forceinline__ void tw_slice_totals(const float2 *part, int B, int C
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int b = b0 + 4 * u;
-            const float2 x = part[(size_t)min(b, B - 1) * C + c];
+            const float2 x = part[(size_t)min(b, max(B - 1, 0)) * C + c];
             const float on = b < B ? 1.f : 0.f;
             v[u] = make_float2(x.x * on, x.y * on);
         }
@@ -1930,16 +1969,17 @@ __device__ __forceinline__ void tw_slice_totals(const float2 *part, int B, int C
     }
 }
 
-struct TwAct { const float *raw, *skip, *bnw, *bnb; const float2 *pstat; double *sums; float *act; unsigned short *img; const float4 *fsc; };
+struct TwAct { const float *raw, *skip, *bnw, *bnb; const float2 *pstat; double *sums; float *act; unsigned short *img; const float4 *fsc; int presum; };
 __global__ __launch_bounds__(256) void k_tw_bnact(TwAct A, int cells, int C, int B, float invN) {
     __shared__ float cA[64], cB[64];
     __shared__ double2 sh[256];
     const int tid = threadIdx.x, c0 = blockIdx.x * 64, b = blockIdx.y;
     double t0, t1;
-    tw_slice_totals(A.pstat, B, C, c0, sh, tid, t0, t1);
+    tw_slice_totals(A.pstat, A.presum ? 0 : B, C, c0, sh, tid, t0, t1);
     if (tid < 64) {
         const int c = c0 + tid;
-        if (b == 0) { A.sums[(size_t)c * 4] = t0; A.sums[(size_t)c * 4 + 1] = t1; }      // for the backward pass and the update
+        if (A.presum) { t0 = A.sums[(size_t)c * 4]; t1 = A.sums[(size_t)c * 4 + 1]; }      // k_trn_totals made them
+        else if (b == 0) { A.sums[(size_t)c * 4] = t0; A.sums[(size_t)c * 4 + 1] = t1; }      // for the backward pass and the update
         float mean, inv;
         bn_from_sums(t0, t1, invN, mean, inv);
         const float a = A.bnw[c] * inv;
@@ -1964,7 +2004,7 @@ __global__ __launch_bounds__(256) void k_tw_bnact(TwAct A, int cells, int C, int
     }
 }
 
-struct TwBnBwd { const float *g, *raw, *bnw; const float2 *pgsum; double *sums; const unsigned int *gmax; const float4 *fsc; unsigned short *img; float2 *bsc; };
+struct TwBnBwd { const float *g, *raw, *bnw; const float2 *pgsum; double *sums; const unsigned int *gmax; const float4 *fsc; unsigned short *img; float2 *bsc; int presum; };
 __global__ __launch_bounds__(256) void k_tw_bnbwd(TwBnBwd A, int cells, int C, int B, float invN) {
     __shared__ float cA[64], cM[64], cI[64], cK0[64], cK1[64], red[4];
     __shared__ double2 sh[256];
@@ -1983,9 +2023,10 @@ __global__ __launch_bounds__(256) void k_tw_bnbwd(TwBnBwd A, int cells, int C, i
         if (c >= c0 && c < c0 + 64) { cA[c - c0] = a; cM[c - c0] = mean; cI[c - c0] = inv; }
     }
     double t0, t1;
-    tw_slice_totals(A.pgsum, B, C, c0, sh, tid, t0, t1);     // (sum g_l, sum g_l xhat_l) of this block's channels
+    tw_slice_totals(A.pgsum, A.presum ? 0 : B, C, c0, sh, tid, t0, t1);     // (sum g_l, sum g_l xhat_l) of this block's channels
     if (tid < 64) {
-        if (b == 0) { A.sums[(size_t)(c0 + tid) * 4 + 2] = t0; A.sums[(size_t)(c0 + tid) * 4 + 3] = t1; }   // k_trn_update's BatchNorm gradients
+        if (A.presum) { t0 = A.sums[(size_t)(c0 + tid) * 4 + 2]; t1 = A.sums[(size_t)(c0 + tid) * 4 + 3]; }
+        else if (b == 0) { A.sums[(size_t)(c0 + tid) * 4 + 2] = t0; A.sums[(size_t)(c0 + tid) * 4 + 3] = t1; }   // k_trn_update's BatchNorm gradients
         cK0[tid] = (float)(t0 * (double)invN);
         cK1[tid] = (float)(t1 * (double)invN);
     }
@@ -2264,10 +2305,11 @@ __global__ __launch_bounds__(256) void k_tw_stem_bwd(TrnDev P) {
     __shared__ unsigned char cellv[176], nbv[9][176];
     const int tid = threadIdx.x, c0 = blockIdx.x * 64, b = blockIdx.y, cells = P.cells, C = P.C, N = P.N;
     double t0, t1;
-    tw_slice_totals(P.pgsum, P.B, C, c0, sh, tid, t0, t1);
+    tw_slice_totals(P.pgsum, P.presum ? 0 : P.B, C, c0, sh, tid, t0, t1);
     if (tid < 64) {
         const int c = c0 + tid;
-        if (b == 0) { P.sums[(size_t)c * 4 + 2] = t0; P.sums[(size_t)c * 4 + 3] = t1; }
+        if (P.presum) presummed(P.sums, 0, C, c, 2, t0, t1);
+        else if (b == 0) { P.sums[(size_t)c * 4 + 2] = t0; P.sums[(size_t)c * 4 + 3] = t1; }
         float mean, inv;
         bn_coeffs(P, 0, c, mean, inv);
         cM[tid] = mean;
@@ -2396,6 +2438,7 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     d.N = N; d.cells = N * N; d.C = chans; d.L = 2 * blocks; d.B = batch;
     d.invN = (float)(1.0 / ((double)batch * d.cells));
     d.dl_stride = d.cells > 128 ? 192 : 128;
+    d.presum = d.B > TRN_PRESUM_BATCH;
     t->G = std::min(batch, TRN_WG_GROUPS);
     t->wide = wide;
     // wide: (C / 32)^2 tile pairs already fill the chip with few board groups, and a group costs a partial copy of C C 9
@@ -2672,6 +2715,11 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
     constexpr int SMALL = TRN_SMALL_THREADS;
     hipLaunchKernelGGL(k_trn_prep<C>, dim3((C * C * 9 + 255) / 256, L + 1), dim3(256), 0, st, d);
     hipLaunchKernelGGL(k_trn_stem_fwd<C>, dim3(B), dim3(SMALL), 0, st, d);
+    // (large batches: a layer's per-board pairs are summed once behind their producer, see k_trn_totals)
+    auto totals = [&](const float2 *part, int l, int k) {
+        if (d.presum) hipLaunchKernelGGL(k_trn_totals, dim3((C + 15) / 16), dim3(256), 0, st, part + (size_t)l * B * C, B, C, d.sums + (size_t)l * C * 4 + k);
+    };
+    totals(d.pstat, 0, 0);
     const size_t conv_lds = ((size_t)std::max(std::max((cells + 1) * (C + 4), cells * 36), 2048) + 8 * C + 264 + 1024) * sizeof(float);
     for (int l = 1; l <= L; ++l)
     {
@@ -2684,6 +2732,7 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
         q.e_act = q.e_raw = q.e_skip = nullptr;
         if (t->fwd16) hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD16>), dim3(NT, B), dim3(256), conv_lds, st, q, l, d);
         else hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD>), dim3(NT, B), dim3(256), conv_lds, st, q, l, d);
+        totals(d.pstat, l, 0);
     }
     const size_t hc_lds = ((size_t)((cells * (C + 1) + 8 * C + 16 + 3) & ~3)) * sizeof(float) + (size_t)SMALL * 16;
     hipLaunchKernelGGL(k_trn_heads_conv<C>, dim3(B), dim3(SMALL), hc_lds, st, d);
@@ -2715,6 +2764,7 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
 
     const size_t wg16_lds = (size_t)(d.N * 16 + (d.N + 3) * 16) * 128 + (1024 + 5 * 32 + 2) * sizeof(float);
     for (int l = L; l >= 1; --l) {
+        totals(d.pgsum, l, 2);
         // g_l and BN_l's sums are complete here: the weight gradient of layer l runs beside the data chain
         if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
         // (measured with these launches removed: 0.500 ms per step with the fork events, 0.488 without them -- an event
@@ -2734,6 +2784,7 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
         else hipLaunchKernelGGL((k_trn_conv<C, ROLE_BWD>), dim3(NT, B), dim3(256), conv_lds, st, q, l, d);
     }
     const size_t sb_lds = ((size_t)cells * C + 5 * C) * sizeof(float) + (size_t)SMALL * 16;
+    totals(d.pgsum, 0, 2);
     hipLaunchKernelGGL(k_trn_stem_bwd<C>, dim3(B), dim3(SMALL), sb_lds, st, d);
     auto join_side = [&]() -> bool {
         if (!fork) return true;
@@ -2877,11 +2928,15 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
     hipLaunchKernelGGL(k_tw_scales<C>, dim3(1), dim3(256), 0, st, d, 1);
     hipLaunchKernelGGL(k_tw_pack<C>, dim3((C * (C / 8) + 255) / 256, L, 2), dim3(256), 0, st, d, t->Ww16f_dev, t->Ww16b_dev);
     hipLaunchKernelGGL(k_trn_stem_fwd<C>, dim3(B), dim3(SMALL), 0, st, d);
+    auto totals = [&](const float2 *part, int l, int k) {         // large batches, see k_trn_totals
+        if (d.presum) hipLaunchKernelGGL(k_trn_totals, dim3(C / 16), dim3(256), 0, st, part + (size_t)l * B * C, B, C, d.sums + (size_t)l * C * 4 + k);
+    };
     for (int l = 0; l < L; ++l) {
         // act_l from raw_l (batch statistics from the per-board partials), then raw_{l+1} = conv(act_l)
         const bool has_res = (l & 1) == 0 && l >= 2;
         const TwAct a = {t->raw[l], has_res ? t->act[l - 2] : nullptr, d.bn_w[l], d.bn_b[l], d.pstat + (size_t)l * B * C,
-                         d.sums + (size_t)l * C * 4, t->act[l], t->A16[l], d.fsc + (l + 1)};
+                         d.sums + (size_t)l * C * 4, t->act[l], t->A16[l], d.fsc + (l + 1), d.presum};
+        totals(d.pstat, l, 0);
         hipLaunchKernelGGL(k_tw_bnact, eg, eb, 0, st, a, cells, C, B, d.invN);
         if (int rc = azx_net_wide_train_conv(N, C, t->Ww16f[l + 1], t->A16[l], t->raw[l + 1], B, &d.fsc[l + 1].y,
                                              d.pstat + (size_t)(l + 1) * B * C, st))
@@ -2889,7 +2944,8 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
     }
     {   // act_L (and BN_L's totals), the head convolutions, the FC layers and the loss
         const TwAct a = {t->raw[L], L >= 2 ? t->act[L - 2] : nullptr, d.bn_w[L], d.bn_b[L], d.pstat + (size_t)L * B * C,
-                         d.sums + (size_t)L * C * 4, t->act[L], nullptr, d.fsc};
+                         d.sums + (size_t)L * C * 4, t->act[L], nullptr, d.fsc, d.presum};
+        totals(d.pstat, L, 0);
         hipLaunchKernelGGL(k_tw_bnact, eg, eb, 0, st, a, cells, C, B, d.invN);
     }
     hipLaunchKernelGGL(k_tw_hconv, dim3(B), dim3(SMALL), 0, st, d);
@@ -2923,7 +2979,8 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
     for (int l = L; l >= 1; --l) {
         // (sum g_l, sum g_l xhat_l) come from the partials of k_tw_heads_bwd (l = L) / the backward convolution's epilogue
         const TwBnBwd bb = {t->g[l], t->raw[l], d.bn_w[l], d.pgsum + (size_t)l * B * C, d.sums + (size_t)l * C * 4, d.gmax + l,
-                            d.fsc + l, t->D16[l], d.bsc + l};
+                            d.fsc + l, t->D16[l], d.bsc + l, d.presum};
+        totals(d.pgsum, l, 2);
         hipLaunchKernelGGL(k_tw_bnbwd, eg, eb, 0, st, bb, cells, C, B, d.invN);
         // draw_l's image is complete: the filter gradient of layer l runs beside the rest of the data chain
         if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
@@ -2944,6 +3001,7 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
                                                  d.gmax + (l - 1), st))
             return tfail(rc, "train: launching a wide backward convolution failed");
     }
+    totals(d.pgsum, 0, 2);
     hipLaunchKernelGGL(k_tw_stem_bwd, eg, eb, 0, st, d);
     if (!join_side()) return tfail(AZX_EHIP, "train: joining the weight-gradient stream failed");
     if (t->n_conv_blocks > 0)

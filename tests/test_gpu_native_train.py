@@ -152,11 +152,12 @@ def test_exact_fp32_kernels_stay_green(monkeypatch, passes):
 
 
 @pytest.mark.parametrize("n,blocks,chans,B", [(11, 1, 64, 200), (7, 2, 32, 300), (3, 1, 16, 1), (11, 2, 16, 131), (2, 1, 64, 3),
-                                              (11, 1, 128, 131), (3, 1, 256, 1), (9, 2, 256, 70), (13, 1, 128, 67)])
+                                              (11, 1, 128, 131), (3, 1, 256, 1), (9, 2, 256, 70), (13, 1, 128, 67),
+                                              (11, 2, 64, 257), (5, 2, 16, 1031), (9, 1, 128, 261), (5, 2, 256, 515)])
 def test_odd_batches_and_boards(n, blocks, chans, B):
     """Batches that are not a multiple of anything the kernels tile by -- more boards than one round of partial-sum
-    loads covers (> 128), filter-gradient groups of unequal size (B not a multiple of 64), a single board -- and the
-    smallest boards: loss, outputs and every parameter gradient against float64 autograd, within a small multiple of
+    loads covers (> 128), more than TRN_PRESUM_BATCH = 256 (the batch sums then come from k_trn_totals behind every
+    producer), filter-gradient groups of unequal size (B not a multiple of 64), a single board -- and the smallest boards: loss, outputs and every parameter gradient against float64 autograd, within a small multiple of
     torch's own fp32 distance."""
     from azalea_amd.native_train import NativeTrainStep
     batch = {k: v.to(DEV) for k, v in _random_batch(n, B, 21).items()}
