@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""The whole loop end to end on one GPU, judged by playing strength: `policy_trainer.train` (the reference's loop,
+policy_trainer.py:23-119: random-mover replay buffer, then a training step + `consume(batch / oversampling)` of fresh
+self-play per step) with everything on the device -- self-play in throughput mode (k_play, device RNG), the HBM replay
+ring, the hand-written training step, the device weight refresh -- and then a tournament (evaluation.py:17-36, all games
+resident on the GPU: evaluate_batched) of the trained network against the network it started from, same search
+settings, temperature-1 sampling for the first `exploration_depth` plies and no root noise.
+
+    python3 tools/train_to_strength.py [--board 7] [--blocks 4] [--chans 32] [--epochs 6] [--rounds 200]
+
+Prints one JSON line: training seconds / steps / steps per second, rows of self-play consumed, and the tally."""
+import argparse
+import copy
+import json
+import logging
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+
+def make_policy(args, seed):
+    from azalea_amd.policy import Policy
+    torch.manual_seed(seed)
+    p = Policy()
+    p.initialize(dict(device="cuda:0", network="HexNetwork", board_size=args.board, num_blocks=args.blocks,
+                      base_chans=args.chans, simulations=args.sims, search_batch_size=10, exploration_coef=args.c,
+                      exploration_depth=args.depth, exploration_noise_alpha=args.alpha, exploration_noise_scale=0.25,
+                      exploration_temperature=1.0, seed=seed))
+    return p
+
+
+def tournament(policies, n, rounds):
+    from azalea_amd import evaluation
+    from azalea_amd.azalea_agent import AzaleaAgent
+    from azalea_amd.game.hex import HexGame
+    agents = []
+    for p in policies:
+        p.settings["move_sampling"] = True
+        p.settings["move_exploration"] = False
+        p.net.eval()
+        agents.append(AzaleaAgent(lambda n=n: HexGame(n), policy=p, device="cuda:0"))
+    out = evaluation.evaluate_batched(agents, rounds)
+    return {"%d-%d" % k: [int(x) for x in v] for k, v in out.items()}
+
+
+class LossLog(logging.Handler):
+    """policy_trainer's "step %d loss %.4f steps/sec %.2f" lines (policy_trainer.py:101-107), kept as numbers."""
+
+    def __init__(self):
+        super().__init__(logging.INFO)
+        self.rows = []
+
+    def emit(self, record):
+        if isinstance(record.msg, str) and record.msg.startswith("step %d loss"):
+            self.rows.append([int(record.args[0]), round(float(record.args[1]), 4), round(float(record.args[2]), 1)])
+
+
+def run(args):
+    from azalea_amd.policy_trainer import train
+    losses = LossLog()
+    logging.getLogger().addHandler(losses)
+    logging.getLogger().setLevel(logging.INFO)
+    policy = make_policy(args, args.seed)
+    start = copy.deepcopy(policy.net.state_dict())
+    config = dict(seed=args.seed, device="cuda:0", game="azalea_amd.game.hex.HexGame", board_size=args.board,
+                  replaybuf_size=args.replay, replaybuf_oversampling=args.oversampling, batch_size=128,
+                  lr_initial=args.lr, lr_decay=0.1, lr_decay_epochs=max(1, args.epochs - 1), momentum=0.9,
+                  l2_regularization=1e-4, total_epochs=args.epochs, selfplay_games=args.games, log_interval=args.log_interval,
+                  model_checkpoint_interval=0)
+    history = {}
+    rundir = tempfile.mkdtemp(prefix="azx_strength_")
+    t0 = time.perf_counter()
+    train(policy, config, rundir, device_replay=True, history=history)
+    torch.cuda.synchronize()
+    secs = time.perf_counter() - t0
+    steps = args.epochs * (args.replay // 128 + (1 if args.replay % 128 else 0))
+    untrained = make_policy(args, args.seed)
+    untrained.net.load_state_dict(start)
+    untrained.net.to("cuda:0")
+    tally = tournament([untrained, policy], args.board, args.rounds)
+    w_old, draws, w_new = tally["0-1"]
+    games = w_old + draws + w_new
+    return {"what": "train() on one GPU, then trained vs starting network (agent 1 vs agent 0), %d games" % games,
+            "net": "%dx%d on %dx%d" % (args.blocks, args.chans, args.board, args.board), "sims": args.sims,
+            "train_step": history.get("train_step"), "epochs": args.epochs, "steps": steps, "train_seconds": secs,
+            "steps_per_sec_incl_selfplay_and_fill": steps / secs, "selfplay_rows_consumed": steps * 128 / args.oversampling,
+            "loss_by_step": losses.rows[1:],          # [step, mean loss over the interval, steps/s incl. self-play]
+            "tally_untrained_draw_trained": [w_old, draws, w_new], "trained_win_rate": w_new / max(1, games)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--board", type=int, default=7)
+    ap.add_argument("--blocks", type=int, default=4)
+    ap.add_argument("--chans", type=int, default=32)
+    ap.add_argument("--sims", type=int, default=100)
+    ap.add_argument("--c", type=float, default=1.0)
+    ap.add_argument("--depth", type=int, default=6)
+    ap.add_argument("--alpha", type=float, default=0.3)
+    ap.add_argument("--epochs", type=int, default=6)
+    ap.add_argument("--replay", type=int, default=60000)
+    ap.add_argument("--oversampling", type=float, default=4.0)
+    ap.add_argument("--games", type=int, default=1024)
+    ap.add_argument("--lr", type=float, default=0.05)
+    ap.add_argument("--rounds", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--log-interval", type=int, default=5000)
+    args = ap.parse_args()
+    print(json.dumps(run(args)))
+
+
+if __name__ == "__main__":
+    main()
