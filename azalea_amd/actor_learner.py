@@ -6,8 +6,8 @@ with the trainer's live network (its CUDA-IPC tensors).  One process per GPU giv
 
 * rank 0 is the LEARNER: it runs the optimizer and, with more than one rank, never plays.  When its replay buffer's
   fresh-example counter asks for rows (replay_buffer.py:121-132) it PULLS them: one announcement on the control group
-  (gloo, host side), then the two record collectives of the lock-step path (counts, records: RCCL over xGMI), to which
-  it contributes nothing.  Every `weight_sync_steps` optimizer steps it broadcasts its network (parameters and
+  (gloo, host side), then two record collectives (RCCL over xGMI): the per-rank counts, and a GATHER of the records to
+  rank 0 -- each actor's block travels once, on its own link into the learner; no actor receives another's rows.  Every `weight_sync_steps` optimizer steps it broadcasts its network (parameters and
   BatchNorm statistics, one flat tensor) -- asynchronously, from a snapshot: the training stream does not wait for the
   actors to join.
 * ranks != 0 are ACTORS: they play whole games continuously into a BACKLOG of packed record chunks in HBM
@@ -106,7 +106,7 @@ class Learner:
         contract in the reference, whose trainer waits the same way when the generator is behind."""
         t0 = time.perf_counter()
         azdist.lead(azdist.OP_PULL, int(np.ceil(size)))
-        parts, counts = azdist.all_gather_records(torch.empty((0, record_bytes), dtype=torch.uint8, device=device))
+        parts, counts = azdist.gather_records(torch.empty((0, record_bytes), dtype=torch.uint8, device=device), dst=0)
         metrics = azdist.all_reduce_metrics({})
         self.pulls += 1
         world = len(counts)
@@ -186,7 +186,7 @@ def serve_selfplay_ahead(player, *, ahead_rows: Optional[int] = None, poll_plies
                     produce()
                 recs, m = backlog.take(quota)
                 rec = torch.cat(recs) if recs else torch.empty((0, eng.record_bytes), dtype=torch.uint8, device=device)
-                azdist.all_gather_records(rec)
+                azdist.gather_records(rec, dst=0)
                 azdist.all_reduce_metrics(m)
                 stats["pulls"] += 1
             else:

@@ -117,6 +117,38 @@ def all_gather_records(rec: torch.Tensor) -> Tuple[List[torch.Tensor], List[int]
     return [out[r * most:r * most + c] for r, c in enumerate(counts)], counts
 
 
+@_data_collective
+def gather_records(rec: torch.Tensor, dst: int = 0) -> Tuple[List[torch.Tensor], List[int]]:
+    """The actor / learner pull: only rank `dst` needs the records, so each rank SENDS its block to it -- over xGMI
+    that is one point-to-point transfer per actor, each on its own link into `dst`, instead of an all-gather that
+    lands every actor's rows on every other actor as well ((W - 1) x the bytes, and a W x buffer on ranks that drop
+    it).  Same two collectives: the per-rank counts (all ranks learn the padding), then the padded blocks.  Returns
+    (per-rank record tensors, counts) on `dst` and ([], counts) elsewhere."""
+    world = dist.get_world_size()
+    if rec.is_cuda and dist.get_backend() != "nccl":          # gloo over device tensors (tests): a host round trip
+        parts, counts = gather_records(rec.cpu(), dst)
+        return [p.to(rec.device) for p in parts], counts
+    dev = rec.device
+    counts_t = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts_t, torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev))
+    counts = [int(c) for c in counts_t.tolist()]
+    most = max(counts)
+    me = dist.get_rank()
+    if most == 0:
+        return ([rec[:0] for _ in range(world)] if me == dst else []), counts
+    if rec.shape[0] == most:
+        padded = rec.contiguous()
+    else:
+        padded = torch.zeros((most, rec.shape[1]), dtype=torch.uint8, device=dev)
+        padded[:rec.shape[0]] = rec
+    if me != dst:
+        dist.gather(padded, None, dst=dst)
+        return [], counts
+    blocks = [torch.empty((most, rec.shape[1]), dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.gather(padded, blocks, dst=dst)
+    return [b[:c] for b, c in zip(blocks, counts)], counts
+
+
 def all_gather_rows(rows: Dict[str, np.ndarray], board_size: int) -> Dict[str, np.ndarray]:
     """Host rows (Player.read's frame path): every rank contributes its rows -- possibly none -- and every
     rank gets all rows, in rank order."""

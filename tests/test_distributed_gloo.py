@@ -214,6 +214,19 @@ def _worker(rank, world, port, out):
     fails += [] if (all(np.array_equal(got[k], want[k]) for k in got)) else [1]
     m = azd.all_reduce_metrics({"games": 1 + rank, "reward": 0.5})
     fails += [] if (m == {"games": 3.0, "reward": 1.0}) else [2]
+    # the actor / learner pull: records gathered to rank 0 only (ragged counts, an empty contribution)
+    cells = 25
+    mine = torch.from_numpy(azd.pack_rows(_rows(rank, counts[rank]), cells))
+    for dst, give in ((0, [mine, mine]), (1, [mine, mine]), (0, [mine[:0], mine])):
+        parts, cnt = azd.gather_records(give[rank], dst=dst)
+        want_cnt = [0 if (dst == 0 and give[0].shape[0] == 0 and r == 0) else counts[r] for r in range(world)]
+        ok = cnt == want_cnt
+        if rank == dst:
+            for r in range(world):
+                ok = ok and np.array_equal(parts[r].numpy(), azd.pack_rows(_rows(r, counts[r]), cells)[:want_cnt[r]])
+        else:
+            ok = ok and parts == []
+        fails += [] if ok else [20 + dst]
     fails += [] if ([azd.shard_quota(25, r, 2) for r in range(2)] == [13, 12]) else [3]
     torch.manual_seed(rank)
     net = HexNetwork(board_size=5, num_blocks=1, base_chans=8)

@@ -278,6 +278,8 @@ def test_rccl_single_rank_carries_the_records_and_the_weights():
         assert counts == [37] and torch.equal(parts[0], rec) and parts[0].is_cuda
         empty, c0 = azd.all_gather_records(rec[:0])
         assert c0 == [0] and empty[0].shape[0] == 0
+        parts, counts = azd.gather_records(rec, dst=0)              # the actor / learner pull's gather to the learner
+        assert counts == [37] and torch.equal(parts[0], rec) and parts[0].is_cuda
         t = torch.tensor([azd.OP_REFILL, 77], dtype=torch.int64, device="cuda:0")
         dist.broadcast(t, src=0)
         assert t.tolist() == [azd.OP_REFILL, 77]
