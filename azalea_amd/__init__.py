@@ -16,6 +16,7 @@ _LAZY = {
     "HexGame": ("game.hex", "HexGame"),
     "HexNetwork": ("network", "HexNetwork"),
     "SearchTreeFull": ("policy", "SearchTreeFull"),
+    "compute_ranking": ("ranking", "compute_ranking"),
 }
 
 

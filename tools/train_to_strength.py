@@ -86,12 +86,20 @@ def run(args):
     tally = tournament([untrained, policy], args.board, args.rounds)
     w_old, draws, w_new = tally["0-1"]
     games = w_old + draws + w_new
+    from azalea_amd import ranking
+    try:                                   # ranking.py:46-58 on evaluate's tallies, as compare_cli.py:76 does
+        elo = float(ranking.compute_ranking(2, {(0, 1): (w_old, draws, w_new)})[1])
+    except ranking.RankingError:
+        elo = None                         # a clean sweep has no finite maximum-likelihood score
+    if elo is not None and (w_old == 0 or w_new == 0):
+        elo = None
     return {"what": "train() on one GPU, then trained vs starting network (agent 1 vs agent 0), %d games" % games,
             "net": "%dx%d on %dx%d" % (args.blocks, args.chans, args.board, args.board), "sims": args.sims,
             "train_step": history.get("train_step"), "epochs": args.epochs, "steps": steps, "train_seconds": secs,
             "steps_per_sec_incl_selfplay_and_fill": steps / secs, "selfplay_rows_consumed": steps * 128 / args.oversampling,
             "loss_by_step": losses.rows[1:],          # [step, mean loss over the interval, steps/s incl. self-play]
-            "tally_untrained_draw_trained": [w_old, draws, w_new], "trained_win_rate": w_new / max(1, games)}
+            "tally_untrained_draw_trained": [w_old, draws, w_new], "trained_win_rate": w_new / max(1, games),
+            "trained_elo_over_start": elo}
 
 
 def main():
