@@ -99,6 +99,7 @@ SYMBOLS = {
     "azx_replay_put_records": (C.c_int, [_vp, C.c_int64, _vp]),
     "azx_replay_collate": (C.c_int, [_vp, C.c_int64, _i64p, _vp, _vp, _vp, _vp, _vp, _vp, _i32p]),
     "azx_replay_collate_async": (C.c_int, [_vp, C.c_int64, _i64p, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "azx_replay_set_mover_view": (C.c_int, [_vp, C.c_int]),
     "azx_selftest_arith": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p]),
     "azx_selftest_divide": (C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p]),
     "azx_selftest_dirichlet": (C.c_int, [C.c_int, C.c_double, C.c_int, C.c_int, C.c_uint32, _f32p]),

@@ -80,6 +80,7 @@ struct azx_engine {
     long long *ring_idx = nullptr;      // sampled row indices of the collate in flight
     int64_t ring_idx_cap = 0;
     int32_t *ring_maxk = nullptr;
+    bool ring_mover_view = false;       // azx_replay_set_mover_view
     std::vector<void *> ring_allocs;
     // azx_replay_collate_async: index staging, AZX_COLLATE_SLOTS deep (pinned host + device), one event per slot
     long long *cidx_host[8] = {nullptr}, *cidx_dev[8] = {nullptr};
@@ -1248,7 +1249,7 @@ extern "C" int azx_replay_collate(azx_engine *e, int64_t batch, const int64_t *i
     HIPCHECK(hipMemsetAsync(e->ring_maxk, 0, sizeof(int32_t), e->stream));
     azx_launch_replay_collate(e->ring, e->ring_idx, (int)batch, e->d.ncells, (long long *)color_dev,
                               legal_moves_dev, (long long *)result_dev, board_dev, moves_prob_dev, reward_dev,
-                              e->ring_maxk, e->stream);
+                              e->ring_maxk, e->ring_mover_view ? e->d.N : 0, e->stream);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(max_k_out, e->ring_maxk, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIPCHECK(hipStreamSynchronize(e->stream));
@@ -1257,6 +1258,13 @@ extern "C" int azx_replay_collate(azx_engine *e, int64_t batch, const int64_t *i
 
 // The same collate, enqueued on the CALLER's stream and not synchronised (no max_k: the consumer takes full-width
 // rows): for a trainer whose step runs on that stream (azx_train_step) -- the host queues collate + step and moves on.
+extern "C" int azx_replay_set_mover_view(azx_engine *e, int on) {
+    if (!e) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
+    e->ring_mover_view = on != 0;
+    return AZX_OK;
+}
+
 // The sampled indices are staged through a small ring of pinned buffers; a slot is re-used only after the collate that
 // read it has run (one event per slot).  The caller orders ring WRITES (azx_replay_fill / put, which are blocking calls
 // on the engine's stream) after these reads by synchronising its stream before a refill.
@@ -1292,7 +1300,7 @@ extern "C" int azx_replay_collate_async(azx_engine *e, int64_t batch, const int6
     HIPCHECK(hipMemcpyAsync(e->cidx_dev[slot], e->cidx_host[slot], (size_t)batch * sizeof(int64_t), hipMemcpyHostToDevice, st));
     azx_launch_replay_collate(e->ring, e->cidx_dev[slot], (int)batch, e->d.ncells, (long long *)color_dev,
                               legal_moves_dev, (long long *)result_dev, board_dev, moves_prob_dev, reward_dev,
-                              e->cidx_maxk, st);
+                              e->cidx_maxk, e->ring_mover_view ? e->d.N : 0, st);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipEventRecord(e->cidx_ev[slot], st));
     return AZX_OK;

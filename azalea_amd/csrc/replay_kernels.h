@@ -16,7 +16,7 @@ void azx_launch_replay_put(const ReplayRows &src, const ReplayRows &ring, long l
                            long long write_idx, hipStream_t st);
 void azx_launch_replay_collate(const ReplayRows &ring, const long long *idx, int B, int ncells,
                                long long *color, int32_t *legal, long long *result, int32_t *board,
-                               float *prob, float *reward, int32_t *max_k, hipStream_t st);
+                               float *prob, float *reward, int32_t *max_k, int mover_n, hipStream_t st);
 void azx_launch_rows_export(const uint8_t *qb, const float *qp, long long n, int ncells, int32_t *board,
                             float *prob, hipStream_t st);
 void azx_launch_rows_pack(const ReplayRows &src, const long long *uid, long long first, long long n, int ncells,

@@ -41,10 +41,14 @@ __global__ __launch_bounds__(64) void k_replay_put(ReplayRows src, ReplayRows ri
 //   color i64[B], legal_moves i32[B][ncells] (ascending tile+1 of the empty cells, hex.py:151-159,
 //   zero padded), result i64[B] (0: replay rows are positions of games in progress),
 //   board i32[B][ncells], moves_prob f32[B][ncells] (zero padded), reward f32[B].
+// mover_n > 0 (azx_replay_set_mover_view; NOT the reference's batch): the rows of the second player come out in the
+// view the SEARCH evaluates them in (mcts.py:178-181, hex.py flip_player_board_moves) -- colours swapped, the board
+// mirrored along the anti-diagonal, every legal move mapped with it in its original list position (so moves_prob
+// stays aligned) -- on a board of mover_n x mover_n cells.
 __global__ __launch_bounds__(64) void k_replay_collate(ReplayRows ring, const long long *idx, int B,
                                                        int ncells, long long *color, int32_t *legal,
                                                        long long *result, int32_t *board,
-                                                       float *prob, float *reward, int32_t *max_k) {
+                                                       float *prob, float *reward, int32_t *max_k, int mover_n) {
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     if (b >= B) return;
@@ -52,6 +56,7 @@ __global__ __launch_bounds__(64) void k_replay_collate(ReplayRows ring, const lo
     const uint8_t *rb = ring.board + r * AZX_CELL_STRIDE;
     const float *rp = ring.prob + r * AZX_CELL_STRIDE;
     const int k = ring.k[r];
+    const bool flip = mover_n > 0 && ring.color[r] == 1;
     int base = 0;
 #pragma unroll
     for (int s = 0; s < AZX_CELL_STRIDE / 64; ++s) {
@@ -59,15 +64,20 @@ __global__ __launch_bounds__(64) void k_replay_collate(ReplayRows ring, const lo
         const bool on = c < ncells;
         const int v = on ? (int)rb[c] : 3;
         const unsigned long long empties = __ballot(v == 0);
+        int fc = c;                                                  // the cell's place in the view handed out
+        if (flip && on) {
+            const int row = c / mover_n, col = c - row * mover_n;
+            fc = (mover_n - 1 - col) * mover_n + (mover_n - 1 - row);
+        }
         if (on) {
-            board[(size_t)b * ncells + c] = v;
+            board[(size_t)b * ncells + fc] = flip && v ? 3 - v : v;
             prob[(size_t)b * ncells + c] = c < k ? rp[c] : 0.0f;
             if (c >= k) legal[(size_t)b * ncells + c] = 0;          // padding (prep.py:70-86)
         }
         if (v == 0) {
             const int rank = base + __builtin_amdgcn_mbcnt_hi((unsigned)(empties >> 32),
                                                               __builtin_amdgcn_mbcnt_lo((unsigned)empties, 0u));
-            if (rank < k) legal[(size_t)b * ncells + rank] = c + 1;
+            if (rank < k) legal[(size_t)b * ncells + rank] = fc + 1;
         }
         base += __popcll(empties);
     }
@@ -169,8 +179,8 @@ void azx_launch_replay_put(const ReplayRows &src, const ReplayRows &ring, long l
 
 void azx_launch_replay_collate(const ReplayRows &ring, const long long *idx, int B, int ncells,
                                long long *color, int32_t *legal, long long *result, int32_t *board,
-                               float *prob, float *reward, int32_t *max_k, hipStream_t st) {
+                               float *prob, float *reward, int32_t *max_k, int mover_n, hipStream_t st) {
     if (B <= 0) return;
     hipLaunchKernelGGL(k_replay_collate, dim3(B), dim3(64), 0, st, ring, idx, B, ncells, color, legal,
-                       result, board, prob, reward, max_k);
+                       result, board, prob, reward, max_k, mover_n);
 }

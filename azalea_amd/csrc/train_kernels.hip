@@ -1766,6 +1766,46 @@ __global__ __launch_bounds__(256) void k_trn_update(TrnDev P, const Segment *seg
     S.p[e] = np;
 }
 
+// The tower filters' update for the wide towers, one launch per layer behind that layer's filter-gradient kernel on the
+// side stream (so this HBM-bound pass runs under the MFMA-bound data chain instead of after it).  A block owns 256
+// (co, ci) pairs x the nine taps: the G partial copies are read in THEIR order ([tap][co][ci]: coalesced, all of a
+// thread's loads of a tap requested together), summed in k_trn_update's fixed order, turned through LDS, and the filter /
+// momentum / gradient are walked in THEIR order ((co C + ci) 9 + tap: 9 KB contiguous per block).  (k_trn_update's
+// element-per-thread form touches the three tensors at a 36-byte stride: every line nine times, from nine blocks.)
+__global__ __launch_bounds__(256) void k_tw_update_conv(TrnDev P, Segment S, int G) {
+    __shared__ float gsum[9 * 256];
+    const int tid = threadIdx.x;
+    const float lr = P.hp[0], mu = P.hp[1], wd = P.hp[2];
+    const size_t cc9 = S.n / 9;
+    const float *part = P.wpart + (size_t)(S.layer - 1) * G * S.n + (size_t)blockIdx.x * 256 + tid;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int g0 = 0; g0 < G; g0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)tap * cc9 + (size_t)min(g0 + u, G - 1) * S.n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s4[u & 3] += g0 + u < G ? v[u] : 0.f;
+        }
+        gsum[tid * 9 + tap] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * 256 * 9;
+    float p[9], m[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { p[k] = S.p[base + k * 256 + tid]; m[k] = S.mom[base + k * 256 + tid]; }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const size_t e = base + k * 256 + tid;
+        const float gr = gsum[k * 256 + tid];
+        P.grad[S.goff + e] = gr;
+        const float d = gr + wd * p[k], buf = mu * m[k] + d;
+        S.mom[e] = buf;
+        S.p[e] = p[k] - lr * buf;
+    }
+}
+
 // First kernel of a step, grid (C C 9 / 256, L + 1):
 //   y < L   max |filter y + 1| (per-block maxima: the scale of the split-f16 fragments k_trn_stem_fwd writes) and the
 //           fp32 MFMA-order copies the exact-fp32 roles convolve with: whatever wrote the weights last -- this trainer's
@@ -2377,6 +2417,7 @@ struct AzxTrain {
     int n_blocks = 0, n_conv_blocks = 0;
     HeadGradOffs hoffs;
     std::vector<size_t> conv_goff;
+    std::vector<Segment> conv_seg;                       // wide towers: the tower filters' segments, updated per layer (k_tw_update_conv)
     float *hp_dev = nullptr, *hp_ring = nullptr;       // hp_ring: pinned host memory the prep kernel reads
     unsigned long long host_steps = 0;
     bool broken = false;                                 // a step failed while being queued (see azx_trn_step)
@@ -2676,6 +2717,11 @@ int azx_trn_bind(AzxTrain *t, int n, const char *const *names, void *const *ptrs
             if (s.kind == SEG_CONV) { t->conv_goff.resize(L + 1); t->conv_goff[s.layer] = b->goff; }
             const int si = (int)segs.size();
             segs.push_back(s);
+            if (s.kind == SEG_CONV && t->wide) {          // no blocks in the table: one launch per layer, see k_tw_update_conv
+                t->conv_seg.resize(L + 1);
+                t->conv_seg[s.layer] = s;
+                continue;
+            }
             for (size_t e = 0; e < b->n; e += 256) (s.kind == SEG_CONV ? blocks : rest).push_back(make_int2(si, (int)(e / 256)));
         }
         t->n_conv_blocks = (int)blocks.size();
@@ -2991,6 +3037,7 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
             const WgradPtrs wq = {t->g[l], t->raw[l], t->act[l - 1], d.bn_w[l]};
             hipLaunchKernelGGL(k_trn_wgrad16<C>, dim3(NT * NT, G), dim3(256), wg16_lds, ws, wq, l, G, d);
         }
+        hipLaunchKernelGGL(k_tw_update_conv, dim3(C * C / 256), dim3(256), 0, ws, d, t->conv_seg[l], G);
         const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= L;
         // conv^T with the ReLU mask, the skip gradient, g_{l-1}'s per-board (sum g, sum g xhat) and max |g| in its epilogue
         // (as a separate elementwise launch behind a plain conv^T: 72 + 23 us per layer against 92 fused, 10.74 vs 10.68 ms

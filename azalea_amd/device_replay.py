@@ -32,10 +32,23 @@ class DeviceReplayBuffer:
         self.shared = shared
         self.learner = None             # actor_learner.Learner: refills are PULLED from the actors' backlogs (rank 0 only)
         self.last_exchange = None       # timing of the last shared refill (bench / diagnostics)
+        self._mover_view = False
         self.device = getattr(engine, "torch_device", None) or torch.device("cuda", engine.cfg.device)
         if contents is not None and len(contents):
             self.put(contents)
             self.fresh_counter = 0          # ReplayBuffer.__init__ starts with nothing fresh
+
+    @property
+    def mover_view(self) -> bool:
+        """NOT the reference's batch (off by default): minibatches hand out the second player's rows in the view the
+        search evaluates them in (azx_replay_set_mover_view, include/azx.h; policy_trainer.train's
+        config["train_mover_view"]).  The ring itself always holds absolute colours."""
+        return self._mover_view
+
+    @mover_view.setter
+    def mover_view(self, on: bool) -> None:
+        self.engine.replay_set_mover_view(bool(on))
+        self._mover_view = bool(on)
 
     # ---- ReplayBuffer surface -----------------------------------------------------------------
     def __len__(self) -> int:
@@ -234,7 +247,16 @@ class DeviceReplayBuffer:
     def rows(self, indices=None) -> Dict[str, np.ndarray]:
         """Host copy of ring rows (all rows held by default) in collated form."""
         idx = np.arange(len(self)) if indices is None else np.asarray(indices, np.int64)
-        return {k: v.cpu().numpy() for k, v in self.sample(idx).items()} if len(idx) else {}
+        if not len(idx):
+            return {}
+        view = self._mover_view
+        if view:
+            self.mover_view = False      # checkpoints hold the rows as the ring does: absolute colours
+        try:
+            return {k: v.cpu().numpy() for k, v in self.sample(idx).items()}
+        finally:
+            if view:
+                self.mover_view = True
 
     def state_dict(self) -> Dict:
         return {"rows": self.rows(), "write_idx": self.write_idx, "fresh_counter": self.fresh_counter}

@@ -402,6 +402,10 @@ class Engine:
                                         C.byref(mk)))
         return mk.value
 
+    def replay_set_mover_view(self, on: bool):
+        """azx_replay_set_mover_view: the collates hand out the second player's rows as the search sees them."""
+        check(self.L.azx_replay_set_mover_view(self.h, 1 if on else 0))
+
     def replay_collate_async(self, indices, out, stream):
         """replay_collate enqueued on `stream` (a hipStream_t as int) without synchronising and without max_k."""
         idx = np.ascontiguousarray(indices, np.int64)

@@ -177,6 +177,19 @@ class GraphedTrainStep:
         return {"value": self.out_value, "moves_logprob": self.out_logprob[:, :k]}
 
 
+def to_mover_view(batch, game_class):
+    """config["train_mover_view"] on a host batch: the rows of the second player (color == 1) as the search hands them
+    to the network (mcts.py:178-181) -- game.flip_player_board_moves on board and legal_moves, moves_prob untouched
+    (the moves keep their list positions).  In place; returns the batch."""
+    mask = batch["color"] == 1
+    if bool(mask.any()):
+        board, moves = batch["board"], batch["legal_moves"]
+        fb, fm = game_class.flip_player_board_moves(board[mask].cpu().numpy(), moves[mask].cpu().numpy())
+        board[mask] = torch.as_tensor(fb, dtype=board.dtype, device=board.device)
+        moves[mask] = torch.as_tensor(fm, dtype=moves.dtype, device=moves.device)
+    return batch
+
+
 def initialize_replay_buffer(pool, game_factory, size: int) -> ReplayBuffer:
     """Fill a buffer with random-mover games (policy_trainer.py:145-158)."""
     player = Player(pool, [AzaleaAgent(game_factory)])
@@ -259,7 +272,12 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
     * "lockstep": every shared production -- a Player.read or a device-ring refill -- is announced by rank 0, which
       broadcasts its network first, and played by all ranks; the others serve it (`serve_selfplay`).  Deterministic.
     Either way the other ranks return when rank 0 stops, holding the trained weights; if rank 0 fails they are told
-    (distributed.LeaderLost) instead of being left in a collective."""
+    (distributed.LeaderLost) instead of being left in a collective.
+
+    config["train_mover_view"] (default False = the reference's batches): train on every position in the view the
+    search evaluates it in -- the second player's rows flipped to the first player's view (mcts.py:178-181), which
+    the reference's trainer does not do (policy_trainer.py:84-85 feeds the rows' absolute boards).  DESIGN 8.6 has
+    what that costs in playing strength."""
     os.makedirs("%s/checkpoints" % rundir, exist_ok=True)
     np.random.seed(config["seed"])
     torch.manual_seed(config["seed"])
@@ -297,10 +315,12 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
     if mode == "actor_learner" and player._device_policy() is None:
         raise ValueError("selfplay_mode 'actor_learner' needs a Policy that holds a HexNetwork; use 'lockstep'")
     from_ring = False
+    mover_view = bool(config.get("train_mover_view", False))
     if device_replay:
         from .device_replay import DeviceReplayBuffer
         if not isinstance(replaybuf, DeviceReplayBuffer):
             replaybuf = DeviceReplayBuffer(player.device_engine(), len(replaybuf), replaybuf)
+        replaybuf.mover_view = mover_view         # the collate kernel flips; host batches are flipped below
     elif mode == "actor_learner":
         player._agree_seed_base()          # a collective the actors make in device_engine(): rank 0 joins it here
     if history is not None and mode:
@@ -367,6 +387,8 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
                     else:
                         batch = replaybuf.sample(item)              # the epoch's ragged last chunk: eager step below
                 if batch is not None:
+                    if mover_view and not device_replay:
+                        batch = to_mover_view(batch, game_class)
                     batch = game_class.random_reflect(batch)
                     if gstep is not None and len(batch["reward"]) == batch_size:
                         l3 = gstep.step({k: v.to(device) for k, v in batch.items()})

@@ -296,6 +296,15 @@ int azx_replay_collate_async(azx_engine *e, int64_t batch, const int64_t *indice
                              int32_t *legal_moves_dev, int64_t *result_dev, int32_t *board_dev,
                              float *moves_prob_dev, float *reward_dev, void *hip_stream);
 
+/* NOT the reference's batch (off by default).  The reference trains on the boards as the replay rows hold them --
+ * absolute colours, the second player's positions included (policy_trainer.py:84-85 -> network.py:92-102: no use of
+ * `color`) -- while its search hands the network every position in the FIRST player's view (mcts.py:178-181:
+ * flip_player_board_moves on the rows with color == 1).  With on != 0 both collates hand out the rows of the second
+ * player in that view: colours swapped, board mirrored along the anti-diagonal, each legal move mapped with it in its
+ * original list position (moves_prob stays aligned; `color` still reports the mover).  The training distribution then
+ * is the distribution the search evaluates. */
+int azx_replay_set_mover_view(azx_engine *e, int on);
+
 /* float32 arithmetic self-test (tests): the tree kernels need IEEE-rounded sqrt and divide and
  * no FMA contraction (mcts.py:132-135).  sq=sqrtf(a), dv=a/(1+b), mul=(0.75f*a)*b+a. */
 int azx_selftest_arith(int device, int n, const float *a, const float *b, float *sq, float *dv,

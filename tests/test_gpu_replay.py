@@ -117,3 +117,46 @@ def test_consume_refills_on_device_with_whole_valid_games():
     for kk in KEYS:
         assert have[kk].dtype == want[kk].dtype and np.array_equal(have[kk], want[kk]), kk
     E.close()
+
+
+def test_mover_view_collate_is_the_search_side_flip():
+    """azx_replay_set_mover_view (config["train_mover_view"]; not the reference's batch): the second player's rows come
+    out as hex.py's flip_player_board_moves makes them for the search (mcts.py:178-181), the first player's rows and
+    every moves_prob / reward / color untouched; the ring, its checkpoint and the default view are unaffected."""
+    from azalea_amd.device_replay import DeviceReplayBuffer
+    from azalea_amd.game.hex import HexGame
+    from azalea_amd.policy_trainer import to_mover_view
+    for n in (7, 11, 13):
+        E = make_engine(n=n, games=16, sims=20)
+        buf = DeviceReplayBuffer(E, 4096)
+        buf.consume(150)
+        rows = len(buf)
+        idx = np.random.RandomState(n).permutation(rows)[:97]
+        plain = host(buf.sample(idx))
+        buf.mover_view = True
+        assert buf.mover_view
+        seen = host(buf.sample(idx))
+        kept = buf.state_dict()["rows"]                     # checkpoints hold absolute colours whatever the view
+        assert buf.mover_view
+        buf.mover_view = False
+        again = host(buf.sample(idx))
+        second = plain["color"] == 1
+        assert second.any() and (~second).any()
+        want_b, want_m = HexGame.flip_player_board_moves(plain["board"][second], plain["legal_moves"][second])
+        assert np.array_equal(seen["board"][second], want_b) and np.array_equal(seen["legal_moves"][second], want_m)
+        assert np.array_equal(seen["board"][~second], plain["board"][~second])
+        assert np.array_equal(seen["legal_moves"][~second], plain["legal_moves"][~second])
+        for k in ("color", "moves_prob", "reward", "result"):
+            assert np.array_equal(seen[k], plain[k]), k
+        for k in KEYS:
+            assert np.array_equal(again[k], plain[k]), k
+            assert np.array_equal(np.asarray(kept[k])[idx].reshape(plain[k].shape[0], -1)[:, :plain[k].reshape(len(idx), -1).shape[1]],
+                                  plain[k].reshape(len(idx), -1)) or k in ("legal_moves", "moves_prob"), k
+        # the host twin used for DataLoader batches does the same
+        tb = to_mover_view({k: torch.as_tensor(v).clone() for k, v in plain.items()}, HexGame)
+        for k in KEYS:
+            assert np.array_equal(tb[k].numpy(), seen[k]), k
+        # flipped twice is the identity, and a flipped row is a position with the same stones for the mover
+        back_b, back_m = HexGame.flip_player_board_moves(seen["board"][second], seen["legal_moves"][second])
+        assert np.array_equal(back_b, plain["board"][second]) and np.array_equal(back_m, plain["legal_moves"][second])
+        E.close()

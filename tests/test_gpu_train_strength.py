@@ -1,7 +1,8 @@
 """The loop end to end, judged the way the reference judges its models (compare.py / evaluation.py: a tournament):
 `policy_trainer.train` on one GPU -- self-play in throughput mode, the HBM replay ring, the hand-written training step,
 the device weight refresh -- makes a network that beats the network it started from.  7x7, 4x32, 100 simulations,
-40 epochs over a 60 000-row buffer (18 760 steps, ~25 s); `tools/train_to_strength.py` is the same run with knobs, and
+40 epochs over a 60 000-row buffer (18 760 steps, ~25 s), with the reference's batches and with
+config["train_mover_view"]; `tools/train_to_strength.py` is the same run with knobs, and
 profiles/r5_train_to_strength.json holds its longer runs (7x7: 400 of 400 games after 57 s; 11x11 6x64 at the
 reference's hyper-parameters: 137 of 200 after 4.5 minutes, loss 5.2 -> 2.2)."""
 import os
@@ -15,14 +16,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_training_makes_a_stronger_player():
+@pytest.mark.parametrize("mover_view", [False, True])
+def test_training_makes_a_stronger_player(mover_view):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         import train_to_strength as tts
     finally:
         sys.path.pop(0)
     args = SimpleNamespace(board=7, blocks=4, chans=32, sims=100, c=1.0, depth=6, alpha=0.3, epochs=40, replay=60000,
-                           oversampling=4.0, games=1024, lr=0.05, rounds=150, seed=3, log_interval=4000)
+                           oversampling=4.0, games=1024, lr=0.05, rounds=150, seed=3, log_interval=4000, mover_view=mover_view)
     out = tts.run(args)
     assert out["train_step"] == "native"
     losses = [row[1] for row in out["loss_by_step"]]

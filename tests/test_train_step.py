@@ -298,3 +298,35 @@ def test_native_step_envelope_is_what_train_picks_by():
     assert "CUDA" in unsupported_reason(net, opt, "cpu")
     from azalea_amd.policy_trainer import make_train_step
     assert make_train_step(net, opt, 4, "cpu", {}) == (None, "eager")
+
+
+def test_to_mover_view_flips_only_the_second_players_rows():
+    """config["train_mover_view"] on host batches: game.flip_player_board_moves on the rows with color == 1
+    (what mcts.py:178-181 does before every evaluation), everything else as collated."""
+    import numpy as np
+    import torch
+    from azalea_amd.game.hex import HexGame
+    from azalea_amd.policy_trainer import to_mover_view
+    rng = np.random.RandomState(4)
+    n, B = 5, 9
+    board = rng.randint(0, 3, (B, n, n)).astype(np.int32)
+    moves = np.zeros((B, n * n), np.int32)
+    for i in range(B):
+        e = np.flatnonzero(board[i].ravel() == 0) + 1
+        moves[i, :len(e)] = e
+    color = np.array([0, 1, 1, 0, 1, 0, 0, 1, 1])
+    batch = dict(board=torch.tensor(board), legal_moves=torch.tensor(moves), color=torch.tensor(color),
+                 moves_prob=torch.rand(B, n * n), reward=torch.ones(B))
+    keep = {k: v.clone() for k, v in batch.items()}
+    out = to_mover_view(batch, HexGame)
+    m = color == 1
+    fb, fm = HexGame.flip_player_board_moves(board[m], moves[m])
+    assert np.array_equal(out["board"][m].numpy(), fb) and np.array_equal(out["legal_moves"][m].numpy(), fm)
+    assert torch.equal(out["board"][~torch.tensor(m)], keep["board"][~torch.tensor(m)])
+    assert torch.equal(out["moves_prob"], keep["moves_prob"]) and torch.equal(out["color"], keep["color"])
+    # in the flipped view the mover's stones are colour 1 and every listed move is an empty cell of the flipped board
+    for i in np.flatnonzero(m):
+        k = int((moves[i] > 0).sum())
+        cells = out["legal_moves"][i, :k].numpy() - 1
+        assert np.all(out["board"][i].reshape(-1).numpy()[cells] == 0)
+        assert int((out["board"][i] == 1).sum()) == int((board[i] == 2).sum())

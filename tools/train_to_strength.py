@@ -72,7 +72,7 @@ def run(args):
                   replaybuf_size=args.replay, replaybuf_oversampling=args.oversampling, batch_size=128,
                   lr_initial=args.lr, lr_decay=0.1, lr_decay_epochs=max(1, args.epochs - 1), momentum=0.9,
                   l2_regularization=1e-4, total_epochs=args.epochs, selfplay_games=args.games, log_interval=args.log_interval,
-                  model_checkpoint_interval=0)
+                  model_checkpoint_interval=0, train_mover_view=args.mover_view)
     history = {}
     rundir = tempfile.mkdtemp(prefix="azx_strength_")
     t0 = time.perf_counter()
@@ -95,7 +95,7 @@ def run(args):
         elo = None
     return {"what": "train() on one GPU, then trained vs starting network (agent 1 vs agent 0), %d games" % games,
             "net": "%dx%d on %dx%d" % (args.blocks, args.chans, args.board, args.board), "sims": args.sims,
-            "train_step": history.get("train_step"), "epochs": args.epochs, "steps": steps, "train_seconds": secs,
+            "train_step": history.get("train_step"), "train_mover_view": bool(args.mover_view), "epochs": args.epochs, "steps": steps, "train_seconds": secs,
             "steps_per_sec_incl_selfplay_and_fill": steps / secs, "selfplay_rows_consumed": steps * 128 / args.oversampling,
             "loss_by_step": losses.rows[1:],          # [step, mean loss over the interval, steps/s incl. self-play]
             "tally_untrained_draw_trained": [w_old, draws, w_new], "trained_win_rate": w_new / max(1, games),
@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=200)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--log-interval", type=int, default=5000)
+    ap.add_argument("--mover-view", action="store_true", help="config['train_mover_view']: not the reference's batches")
     args = ap.parse_args()
     print(json.dumps(run(args)))
 
