@@ -55,7 +55,7 @@ def main():
     t0 = mark = time.perf_counter()
     for i in range(20, args.steps + 20):
         gs.step_from_ring(buf, order[i] % len(buf))
-        if B / 10.0 > buf.fresh_counter:                     # the consume below will refill: close the steps' interval first
+        if buf.fresh_counter - B / 10.0 < B / 10.0:          # the consume below will refill (replay_buffer.py:121-132): close the steps' interval first
             torch.cuda.synchronize()
             a = time.perf_counter()
             t_steps += a - mark
