@@ -316,6 +316,10 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
         raise ValueError("selfplay_mode 'actor_learner' needs a Policy that holds a HexNetwork; use 'lockstep'")
     from_ring = False
     mover_view = bool(config.get("train_mover_view", False))
+    if leader:
+        logging.info("training batches: %s", "second player's rows flipped to the search's view (train_mover_view)"
+                     if mover_view else "absolute boards, as the reference trains (config['train_mover_view'] = True "
+                     "trains in the view the search evaluates in: DESIGN 8.6)")
     if device_replay:
         from .device_replay import DeviceReplayBuffer
         if not isinstance(replaybuf, DeviceReplayBuffer):
