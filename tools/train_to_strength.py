@@ -8,6 +8,10 @@ settings, temperature-1 sampling for the first `exploration_depth` plies and no 
 
     python3 tools/train_to_strength.py [--board 7] [--blocks 4] [--chans 32] [--epochs 6] [--rounds 200]
 
+    ... --checkpoints 4     also: the reference's compare workflow (compare_cli.py:60-80) -- `train` saves a checkpoint
+                            every steps / 4, `Policy.load` brings them back, a round robin (evaluate_batched) among
+                            [start, checkpoints..., final] is ranked by `ranking.compute_ranking`: an Elo curve
+
 Prints one JSON line: training seconds / steps / steps per second, rows of self-play consumed, and the tally."""
 import argparse
 import copy
@@ -73,13 +77,15 @@ def run(args):
                   lr_initial=args.lr, lr_decay=0.1, lr_decay_epochs=max(1, args.epochs - 1), momentum=0.9,
                   l2_regularization=1e-4, total_epochs=args.epochs, selfplay_games=args.games, log_interval=args.log_interval,
                   model_checkpoint_interval=0, train_mover_view=args.mover_view)
+    steps = args.epochs * (args.replay // 128 + (1 if args.replay % 128 else 0))
+    every = steps // args.checkpoints if args.checkpoints else 0
+    config["model_checkpoint_interval"] = every
     history = {}
     rundir = tempfile.mkdtemp(prefix="azx_strength_")
     t0 = time.perf_counter()
     train(policy, config, rundir, device_replay=True, history=history)
     torch.cuda.synchronize()
     secs = time.perf_counter() - t0
-    steps = args.epochs * (args.replay // 128 + (1 if args.replay % 128 else 0))
     untrained = make_policy(args, args.seed)
     untrained.net.load_state_dict(start)
     untrained.net.to("cuda:0")
@@ -93,13 +99,26 @@ def run(args):
         elo = None                         # a clean sweep has no finite maximum-likelihood score
     if elo is not None and (w_old == 0 or w_new == 0):
         elo = None
+    curve = None
+    if args.checkpoints:
+        from azalea_amd.policy import Policy
+        marks = [k * every for k in range(1, args.checkpoints) if k * every < steps]
+        loaded = [Policy.load("%s/checkpoints/checkpoint.%d.policy.pth" % (rundir, m), device="cuda:0") for m in marks]
+        field = [untrained] + loaded + [policy]
+        tallies = tournament(field, args.board, args.curve_rounds)
+        outcomes = {tuple(int(x) for x in k.split("-")): tuple(v) for k, v in tallies.items()}
+        try:
+            elos = [round(float(x), 1) for x in ranking.compute_ranking(len(field), outcomes)]
+        except ranking.RankingError:
+            elos = None
+        curve = {"steps": [0] + marks + [steps], "elo": elos, "games_per_pair": args.curve_rounds, "tallies": tallies}
     return {"what": "train() on one GPU, then trained vs starting network (agent 1 vs agent 0), %d games" % games,
             "net": "%dx%d on %dx%d" % (args.blocks, args.chans, args.board, args.board), "sims": args.sims,
             "train_step": history.get("train_step"), "train_mover_view": bool(args.mover_view), "epochs": args.epochs, "steps": steps, "train_seconds": secs,
             "steps_per_sec_incl_selfplay_and_fill": steps / secs, "selfplay_rows_consumed": steps * 128 / args.oversampling,
             "loss_by_step": losses.rows[1:],          # [step, mean loss over the interval, steps/s incl. self-play]
             "tally_untrained_draw_trained": [w_old, draws, w_new], "trained_win_rate": w_new / max(1, games),
-            "trained_elo_over_start": elo}
+            "trained_elo_over_start": elo, "elo_curve": curve}
 
 
 def main():
@@ -119,6 +138,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=200)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--log-interval", type=int, default=5000)
+    ap.add_argument("--checkpoints", type=int, default=0, help="save this many evenly spaced checkpoints and rank them")
+    ap.add_argument("--curve-rounds", type=int, default=40, help="games per pair of the ranking round robin")
     ap.add_argument("--mover-view", action="store_true", help="config['train_mover_view']: not the reference's batches")
     args = ap.parse_args()
     print(json.dumps(run(args)))
