@@ -12,6 +12,9 @@ settings, temperature-1 sampling for the first `exploration_depth` plies and no 
                             every steps / 4, `Policy.load` brings them back, a round robin (evaluate_batched) among
                             [start, checkpoints..., final] is ranked by `ranking.compute_ranking`: an Elo curve
 
+    ... --world 3           the same under torch.distributed with 3 processes ON THIS ONE GPU (gloo; a functional soak of
+                            the actor / learner topology, not a benchmark): rank 0 trains and pulls, ranks 1-2 play ahead
+
 Prints one JSON line: training seconds / steps / steps per second, rows of self-play consumed, and the tally."""
 import argparse
 import copy
@@ -83,9 +86,15 @@ def run(args):
     history = {}
     rundir = tempfile.mkdtemp(prefix="azx_strength_")
     t0 = time.perf_counter()
+    if args.world > 1:
+        config.update(selfplay_mode=args.selfplay_mode, weight_sync_steps=args.weight_sync_steps)
     train(policy, config, rundir, device_replay=True, history=history)
     torch.cuda.synchronize()
     secs = time.perf_counter() - t0
+    if args.world > 1:
+        import torch.distributed as dist
+        if dist.get_rank() != 0:
+            return {"rank": dist.get_rank(), "actor": history.get("actor")}
     untrained = make_policy(args, args.seed)
     untrained.net.load_state_dict(start)
     untrained.net.to("cuda:0")
@@ -118,7 +127,8 @@ def run(args):
             "steps_per_sec_incl_selfplay_and_fill": steps / secs, "selfplay_rows_consumed": steps * 128 / args.oversampling,
             "loss_by_step": losses.rows[1:],          # [step, mean loss over the interval, steps/s incl. self-play]
             "tally_untrained_draw_trained": [w_old, draws, w_new], "trained_win_rate": w_new / max(1, games),
-            "trained_elo_over_start": elo, "elo_curve": curve}
+            "trained_elo_over_start": elo, "elo_curve": curve,
+            "world": args.world, "selfplay_mode": history.get("selfplay_mode"), "learner": history.get("learner")}
 
 
 def main():
@@ -141,8 +151,30 @@ def main():
     ap.add_argument("--checkpoints", type=int, default=0, help="save this many evenly spaced checkpoints and rank them")
     ap.add_argument("--curve-rounds", type=int, default=40, help="games per pair of the ranking round robin")
     ap.add_argument("--mover-view", action="store_true", help="config['train_mover_view']: not the reference's batches")
+    ap.add_argument("--world", type=int, default=1)
+    ap.add_argument("--selfplay-mode", default="actor_learner")
+    ap.add_argument("--weight-sync-steps", type=int, default=50)
     args = ap.parse_args()
-    print(json.dumps(run(args)))
+    if args.world == 1:
+        print(json.dumps(run(args)))
+        return
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_rank_main, args=(args, port), nprocs=args.world, join=True)
+
+
+def _rank_main(rank, args, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=args.world)
+    out = run(args)
+    print(json.dumps(out), file=(sys.stdout if rank == 0 else sys.stderr), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":
