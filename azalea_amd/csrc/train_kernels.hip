@@ -878,10 +878,13 @@ __device__ __forceinline__ void trn_wgrad_body(const WgradPtrs &W_, const TrnDev
         if (b + G < P.B) request(b + G);                 // travels under this board's k-loop
         TS_MARK(1)
         // this wave's k-steps s = wave, wave + 4, ...; the operands of step s + 4 are requested before step s's MFMAs
-        int s = wave < S ? wave : S - 1;
-        float a_c = D[(size_t)(2 * s + lh) * 32 + li], b_c[9];
+        // (a 2x2 board has two k-steps: waves 2 and 3 have none -- their first operands are read at a clamped step
+        // and never used)
+        int s = wave;
+        const int s0 = min(s, S - 1);
+        float a_c = D[(size_t)(2 * s0 + lh) * 32 + li], b_c[9];
         {
-            const float *bp = A + (size_t)prow[2 * s + lh] * 32 + li;
+            const float *bp = A + (size_t)prow[2 * s0 + lh] * 32 + li;
 #pragma unroll
             for (int t = 0; t < 9; ++t) b_c[t] = bp[((t / 3 - 1) * NP + (t % 3 - 1)) * 32];
         }

@@ -149,6 +149,10 @@ def test_exact_fp32_kernels_stay_green(monkeypatch, passes):
         monkeypatch.setenv("AZX_TRAIN_" + name, "fp32")
     test_every_intermediate_matches_autograd(11, 2, 64, 8)
     test_every_intermediate_matches_autograd(9, 2, 32, 7)
+    # the smallest boards: 2x2 has two k-steps for the filter gradient's four waves, 3x3 five
+    test_odd_batches_and_boards(2, 1, 64, 3)
+    test_odd_batches_and_boards(3, 1, 16, 1)
+    test_odd_batches_and_boards(7, 2, 32, 300)
 
 
 @pytest.mark.parametrize("n,blocks,chans,B", [(11, 1, 64, 200), (7, 2, 32, 300), (3, 1, 16, 1), (11, 2, 16, 131), (2, 1, 64, 3),
