@@ -226,14 +226,25 @@ def test_many_games_vs_oracle_with_compaction(eng, orc, nodes_per_game, hashed):
     engine and the CPU oracle (reference never-free tree) must agree bit-exactly on every game's
     kept subtree after every search -- with a roomy arena (moves re-root in place) and with one so
     tight that the kept subtree has to be compacted into the other arena every other move."""
-    n, G, sims = 11, 64, 100
+    _many_games_vs_oracle(eng, orc, 11, 64, 100, nodes_per_game, hashed)
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 6, 7, 8, 9, 10, 12, 13])
+def test_every_board_size_vs_oracle(eng, orc, n):
+    """The same game-by-game comparison on every other board size the engine accepts (the fixtures and the test above
+    are 5x5 / 11x11 / 13x13): 24 games from random positions, four searches + moves each, the generic and the FAST
+    instantiation on alternating sizes, bit for bit."""
+    _many_games_vs_oracle(eng, orc, n, 24, 60, 0, hashed=bool(n & 1), max_prefix=max(1, n * n - 2 * n))
+
+
+def _many_games_vs_oracle(eng, orc, n, G, sims, nodes_per_game, hashed, max_prefix=95):
     rng = np.random.RandomState(5)
     table = (np.float32(1.0) / np.arange(0, n * n + 1).clip(1).astype(np.float32)).astype(np.float32)
     prefixes = []
     for g in range(G):
         h = orc.Hex(n)
         mv = []
-        for _ in range(int(rng.randint(0, 95))):
+        for _ in range(int(rng.randint(0, max_prefix))):
             lm = h.legal_moves()
             m = int(lm[rng.randint(len(lm))])
             h2 = h.copy()
