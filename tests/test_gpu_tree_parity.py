@@ -390,15 +390,17 @@ def test_tree_full_sets_status(eng):
     E.close()
 
 
-def test_play_mode_whole_games(eng):
+@pytest.mark.parametrize("n", [7, 2, 3, 4, 13])
+def test_play_mode_whole_games(eng, n):
     """Player.read semantics: whole finished games, rewards alternate from the last mover,
-    rows are legal positions with normalised move distributions."""
-    n = 7
+    rows are legal positions with normalised move distributions -- throughput mode (device RNG) on the
+    smallest and the largest boards too."""
     E = eng.Engine(board_size=n, n_games=32, simulations=30, search_batch_size=10,
                    exploration_depth=6, evaluator=eng.EVAL_UNIFORM, seed=123)
-    rows, st = E.play(200)
+    want = 200 if n >= 4 else 60
+    rows, st = E.play(want)
     P = len(rows["board"])
-    assert P >= 200 and st["games"] >= 1 and st["positions"] == P
+    assert P >= want and st["games"] >= 1 and st["positions"] == P
     uid = rows["game_uid"]
     for u in np.unique(uid):
         idx = np.flatnonzero(uid == u)
