@@ -168,3 +168,35 @@ def test_trainer_style_loop_consumes_the_engine():
             break
     player.stop()
     assert fresh_games >= 1 and len(buf) == size0   # FIFO keeps its size; new rows overwrote old
+
+
+@pytest.mark.parametrize("n,mode,sims,sampling", [(2, "hashprior", 20, True), (3, "uniformhash", 30, True),
+                                                  (4, "hashprior", 30, False), (6, "hashprior", 40, True),
+                                                  (8, "uniformhash", 40, True), (10, "hashprior", 30, True),
+                                                  (12, "uniformhash", 20, True), (13, "hashprior", 20, True)])
+def test_whole_games_on_the_other_board_sizes_match_the_oracle(n, mode, sims, sampling):
+    """G5 holds the reference's games on 5x5 / 7x7 / 9x9 / 11x11; here the same surface (Policy -> AzaleaAgent ->
+    play_game, stub network on the host, tree and rules on the GPU, numpy RNG) plays whole games on every other size
+    and the oracle's play_game -- pinned to the reference by G5 and G11 -- must produce the same game bit for bit."""
+    from test_oracle_golden import _stub_eval
+    from azalea_amd import AzaleaAgent, HexGame
+    from azalea_amd.play_game import play_game
+    from oracle import oracle as orc
+    cfg = dict(mode=mode, cfg_n=n, cfg_sims=sims, cfg_batch=10, cfg_c=0.5, cfg_depth=min(6, n), cfg_alpha=0.3, cfg_eps=0.25,
+               cfg_temp=1.0, cfg_sampling=sampling, cfg_explore=sampling)
+    seed = 1000 + n
+    agent = AzaleaAgent(lambda: HexGame(n), policy=make_policy(cfg), device="cpu")
+    agent.seed(seed)
+    result, frame, metrics = play_game([agent], collect_data=True)
+    o_result, rows, reward = orc.play_game(n, _stub_eval(mode), simulations=sims, batch_size=10, c_puct=0.5,
+                                           exploration_depth=cfg["cfg_depth"], noise_alpha=0.3, noise_scale=0.25,
+                                           temperature=1.0, seed=seed, move_sampling=sampling, move_exploration=sampling)
+    assert result == o_result and len(frame) == len(rows)
+    for i, r in enumerate(rows):
+        st = frame.state[i]
+        assert np.array_equal(st.board, r["board"]) and st.color == r["color"], i
+        assert np.array_equal(st.legal_moves, r["legal_moves"]), i
+        assert np.array_equal(bits(frame.moves_prob[i]), bits(r["moves_prob"])), i
+    assert np.array_equal(np.array(frame.reward, np.float32), reward)
+    assert metrics["moves_per_game"] == len(rows)
+    assert abs(metrics["search_tree_nodes"] - np.mean([r["num_nodes"] for r in rows])) < 1e-6
