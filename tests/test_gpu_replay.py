@@ -160,3 +160,39 @@ def test_mover_view_collate_is_the_search_side_flip():
         back_b, back_m = HexGame.flip_player_board_moves(seen["board"][second], seen["legal_moves"][second])
         assert np.array_equal(back_b, plain["board"][second]) and np.array_equal(back_m, plain["legal_moves"][second])
         E.close()
+
+
+@pytest.mark.parametrize("n", [2, 3, 8, 12, 13])
+def test_record_exchange_round_trip_on_other_board_sizes(n):
+    """The multi-GPU exchange unit (AZX_RECORD_BYTES, k_rows_pack -> k_records_put) on the smallest and largest boards:
+    rows harvested on the device, packed into records, unpacked by the host twin (distributed.unpack_rows) and -- put
+    into a ring from the records -- collated: the same boards, move lists, distributions, rewards, colours."""
+    from azalea_amd import distributed as azd
+    from azalea_amd.device_replay import DeviceReplayBuffer
+    E = make_engine(n=n, games=16, sims=20)
+    rows, st = E.play_device(40)
+    assert rows >= 40
+    rec = torch.empty((rows, E.record_bytes), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    E.rows_pack(0, rows, rec.data_ptr())
+    assert E.record_bytes == azd.record_bytes(n * n) and E.record_bytes % 16 == 0
+    host_rows = azd.unpack_rows(rec.cpu().numpy(), n)
+    buf = DeviceReplayBuffer(E, rows + 3)
+    E.replay_put_records(rows, rec.data_ptr())
+    assert len(buf) == rows
+    got = host(buf.sample(np.arange(rows)))
+    cells = n * n
+    board = got["board"].reshape(rows, cells)
+    assert np.array_equal(board, host_rows["board"].reshape(rows, cells))
+    assert np.array_equal(got["color"], host_rows["color"]) and np.array_equal(got["reward"], host_rows["reward"])
+    k = host_rows["nlegal"]
+    assert np.array_equal(k, (board == 0).sum(1)) and np.array_equal(got["color"], (board > 0).sum(1) & 1)
+    K = got["moves_prob"].shape[1]
+    assert K == k.max() and np.array_equal(got["moves_prob"], host_rows["moves_prob"][:, :K])
+    for i in range(rows):
+        assert np.array_equal(got["legal_moves"][i, :k[i]], np.flatnonzero(board[i] == 0) + 1)
+        assert abs(got["moves_prob"][i].sum() - 1.0) < 1e-5
+    assert len(np.unique(host_rows["game_uid"])) >= 1 and set(np.unique(got["reward"])) <= {-1.0, 1.0}
+    # the host twin packs what it unpacked
+    assert np.array_equal(azd.pack_rows(host_rows, cells), rec.cpu().numpy())
+    E.close()
