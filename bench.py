@@ -610,6 +610,32 @@ def pick(d, keys):
     return {k: d[k] for k in keys if isinstance(d, dict) and d.get(k) is not None}
 
 
+def box_calibration(torch):
+    """How fast THIS box is, by a yardstick that is not this repo's code: a hipBLASLt f16 GEMM (8192^3, torch.matmul),
+    best of three bursts of 30.  Leases of this pool differ by ~14 % in it (1 150 vs 1 310 TFLOP/s an hour apart) and
+    the tower's launch time moves with it one to one (tests/test_gpu_perf_floor.py), so a headline read beside
+    `box.gemm_f16_8192_tflops` can be compared across runs.  Outside every timed region."""
+    n, iters = 8192, 30
+    a = torch.randn(n, n, device="cuda", dtype=torch.float16)
+    b = torch.randn(n, n, device="cuda", dtype=torch.float16)
+    for _ in range(5):
+        a @ b
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            a @ b
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, iters * 2.0 * n ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    del a, b
+    torch.cuda.empty_cache()
+    return {"gemm_f16_8192_tflops": best, "usual_on_this_pool": 1310.0, "relative": best / 1310.0,
+            "what": "library f16 GEMM on this box (not this repo's code): a yardstick for box-to-box differences"}
+
+
 def fold_legs(line):
     """The driver's record keeps `roofline`, `cpu_baseline` and `config` whole and every other nested dict by name
     only, so the essentials of every nested leg are repeated inside those two: enough to recompute each kernel's
@@ -648,6 +674,8 @@ def fold_legs(line):
     api = line.get("api")
     if isinstance(api, dict):
         legs["api"] = pick(api, ("rows_per_sec", "plies_per_sec", "rows_over_plies", "host_overhead_frac", "error"))
+    if isinstance(line.get("box"), dict):
+        legs["box"] = pick(line["box"], ("gemm_f16_8192_tflops", "usual_on_this_pool", "relative", "error"))
     roof["legs"] = legs
     if isinstance(cpu, dict):
         CK = ("value", "unit", "cores", "per_core", "kind", "sample", "seconds", "error")
@@ -791,6 +819,11 @@ def main():
             if exchange is not None:
                 line["replay_allgather"] = exchange
         line["config"] = dict(workload=wl, **common_cfg)
+        if world == 1:
+            try:
+                line["box"] = box_calibration(torch)
+            except Exception as exc:
+                line["box"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args, headline, ex["net_state"])

@@ -17,8 +17,45 @@ pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(os.environ.get("AZX_PERF_FLOOR") == "0",
                                  reason="AZX_PERF_FLOOR=0: wall-clock floors switched off (a shared or throttled box)")]
 # Every floor is DEVICE time (HIP events on the stream the kernels run on), best of three measurements: host jitter
-# and a neighbour's burst do not reach it, which is what lets the bounds sit 7-15 % above the measured values.
+# and a neighbour's burst do not reach it, which is what lets the bounds sit 7-15 % above the measured values
+# -- on a box of the usual speed; see box_factor below for the others.
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# Boxes of this pool differ by more than the margins: the same library measured 7.93 ms per 40 960 positions on one
+# lease and 9.07 on another an hour later -- and a plain hipBLASLt f16 GEMM (8192^3, torch.matmul) ran at 1 310 and
+# 1 150 TFLOP/s on the same two (ratio 1.14 both ways: a power / clock difference of the box, not of the code).  So each
+# floor is scaled by how far THIS box's GEMM falls short of the usual rate; on a box at or above it the floors are the
+# plain numbers.  A box more than 35 % short is not measured at all.
+TYPICAL_GEMM_TFLOPS = 1310.0
+_box = {}
+
+
+def box_factor():
+    if "factor" not in _box:
+        n, iters = 8192, 30
+        a = torch.randn(n, n, device="cuda:0", dtype=torch.float16)
+        b = torch.randn(n, n, device="cuda:0", dtype=torch.float16)
+        for _ in range(5):
+            a @ b
+        torch.cuda.synchronize()
+        best = 0.0
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                a @ b
+            e1.record()
+            torch.cuda.synchronize()
+            best = max(best, iters * 2.0 * n ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+        del a, b
+        torch.cuda.empty_cache()
+        _box["gemm_tflops"] = best
+        _box["factor"] = max(1.0, TYPICAL_GEMM_TFLOPS / best)
+        _record("box", {"gemm_f16_8192_tflops": best, "typical": TYPICAL_GEMM_TFLOPS, "floor_scale": _box["factor"]})
+    if _box["factor"] > 1.35:
+        pytest.skip("this box runs a library GEMM at %.0f TFLOP/s (usually %.0f): too throttled to hold a floor against"
+                    % (_box["gemm_tflops"], TYPICAL_GEMM_TFLOPS))
+    return _box["factor"]
 
 
 def _record(name, value):
@@ -38,6 +75,7 @@ def _pool(evaluator, **kw):
 
 
 def test_tower_and_heads_floor():
+    f = box_factor()
     E = _pool(eng.EVAL_RESNET, num_blocks=6, base_chans=64)
     torch.manual_seed(0)
     net = HexNetwork(board_size=11, num_blocks=6, base_chans=64).eval().to("cuda:0")
@@ -55,10 +93,11 @@ def test_tower_and_heads_floor():
                             "ms_per_40960_positions": ms_40960, "kernels": E.kernel_info()})
     E.close()
     assert positions > 30000
-    assert ms_40960 <= 8.6, (per_launch_ms, positions)
+    assert ms_40960 <= 8.6 * f, (per_launch_ms, positions, f)
 
 
 def test_tree_move_floor():
+    f = box_factor()
     E = _pool(eng.EVAL_UNIFORM)
     E.play_steps(120)                                                   # settle: the pool spreads over all plies
     ms_per_move = 1e9
@@ -69,13 +108,14 @@ def test_tree_move_floor():
                      "kernels": E.kernel_info()})
     E.close()
     assert st["mcts_kernel_launches"] < st["mcts_launches"]            # the persistent k_play path was taken
-    assert ms_per_move <= 1.45, ms_per_move
+    assert ms_per_move <= 1.45 * f, (ms_per_move, f)
 
 
 def test_native_training_step_floor():
     """The hand-written training step at the reference's shape (6x64, 11x11, batch 128): <= 0.55 ms per step with the
     inputs resident (measured 0.48-0.51 box to box; 0.83 before the split-f16 kernels; the stock kernels captured as a
     HIP graph take 2.1)."""
+    f = box_factor()
     import time
     from azalea_amd.native_train import NativeTrainStep
     dev = "cuda:0"
@@ -111,4 +151,4 @@ def test_native_training_step_floor():
         ms = min(ms, e0.elapsed_time(e1) / 200)
     _record("train_step", {"ms_per_step": ms, "steps_per_sec": 1e3 / ms, "host_clock_ms_per_step": host_ms})
     step.close()
-    assert ms <= 0.55, (ms, host_ms)
+    assert ms <= 0.55 * f, (ms, host_ms, f)
