@@ -24,7 +24,7 @@ def test_training_makes_a_stronger_player(mover_view):
     finally:
         sys.path.pop(0)
     args = SimpleNamespace(board=7, blocks=4, chans=32, sims=100, c=1.0, depth=6, alpha=0.3, epochs=40, replay=60000,
-                           oversampling=4.0, games=1024, lr=0.05, rounds=150, seed=3, log_interval=4000, mover_view=mover_view, checkpoints=0, curve_rounds=0, world=1)
+                           oversampling=4.0, games=1024, lr=0.05, rounds=150, seed=3, log_interval=4000, mover_view=mover_view, checkpoints=0, curve_rounds=0, world=1, vs_shipped=False, lr_decay=0.1, lr_decay_epochs=0)
     out = tts.run(args)
     assert out["train_step"] == "native"
     losses = [row[1] for row in out["loss_by_step"]]
