@@ -237,7 +237,15 @@ def test_every_board_size_vs_oracle(eng, orc, n):
     _many_games_vs_oracle(eng, orc, n, 24, 60, 0, hashed=bool(n & 1), max_prefix=max(1, n * n - 2 * n))
 
 
-def _many_games_vs_oracle(eng, orc, n, G, sims, nodes_per_game, hashed, max_prefix=95):
+@pytest.mark.parametrize("sims,batch,c,G", [(60, 1, 0.5, 8), (55, 7, 1.0, 8), (64, 16, 0.25, 5), (100, 13, 2.0, 3),
+                                            (33, 10, 0.5, 1), (10, 10, 0.5, 70), (9, 10, 0.5, 33), (200, 16, 0.75, 4)])
+def test_search_shapes_vs_oracle(eng, orc, sims, batch, c, G):
+    """search_batch_size from 1 to 16 (the engine's envelope, include/azx.h; the reference runs 10), simulation counts that are / are not multiples of it (mcts.py:62-92 rounds up to
+    sims // bs + 1 batches), exploration coefficients, pool sizes that do not fill a launch: bit for bit."""
+    _many_games_vs_oracle(eng, orc, 9, G, sims, 0, hashed=bool(batch & 1), max_prefix=60, batch=batch, c=c)
+
+
+def _many_games_vs_oracle(eng, orc, n, G, sims, nodes_per_game, hashed, max_prefix=95, batch=10, c=0.5):
     rng = np.random.RandomState(5)
     table = (np.float32(1.0) / np.arange(0, n * n + 1).clip(1).astype(np.float32)).astype(np.float32)
     prefixes = []
@@ -256,8 +264,8 @@ def _many_games_vs_oracle(eng, orc, n, G, sims, nodes_per_game, hashed, max_pref
         prefixes.append(mv)
     # hashed: values from the fnv1a stub, explicit prior table -> the generic k_mcts instantiation;
     # not hashed: value 0, the built-in 1/k table -> the FAST instantiation bench.py runs
-    E = eng.Engine(board_size=n, n_games=G, simulations=sims, search_batch_size=10,
-                   exploration_coef=0.5, evaluator=eng.EVAL_UNIFORM_HASH if hashed else eng.EVAL_UNIFORM,
+    E = eng.Engine(board_size=n, n_games=G, simulations=sims, search_batch_size=batch,
+                   exploration_coef=c, evaluator=eng.EVAL_UNIFORM_HASH if hashed else eng.EVAL_UNIFORM,
                    nodes_per_game=nodes_per_game)
     if hashed:
         E.set_prior_table(table)
@@ -280,7 +288,7 @@ def _many_games_vs_oracle(eng, orc, n, G, sims, nodes_per_game, hashed, max_pref
         for g in range(G):
             if not alive[g]:
                 continue
-            st = orc.search(trees[g], games[g], ev, sims, 10, 0.5)
+            st = orc.search(trees[g], games[g], ev, sims, batch, c)
             assert st.status == 0
             a, b = canonical(E.tree_dump(g)), canonical(trees[g].dump())
             for x, y in zip(a, b):
