@@ -78,12 +78,13 @@ def net_agents(n=5):
     return agents
 
 
-def test_batched_tournament_plays_the_same_games():
+@pytest.mark.parametrize("n", [5, 3, 8])
+def test_batched_tournament_plays_the_same_games(n):
     """All games of the round robin resident on the GPU at once (per-agent engines, only the slots
     to move are searched) give the tallies of the one-game-at-a-time schedule: same seeds, same
     per-game random streams, same network outputs per board whatever the batch."""
     from azalea_amd import evaluation
-    agents = net_agents()
+    agents = net_agents(n)
     seq = evaluation.evaluate(agents, 4)
     bat = evaluation.evaluate_batched(agents, 4)
     assert set(seq) == set(bat) == set(evaluation.gen_pairs(3))
