@@ -28,6 +28,10 @@ def _check_common(d, steps, warmup):
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert r["achieved"] > 0 and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert "traffic" in r
+    # the box's own speed by a library GEMM, in the line and inside the dict the driver keeps whole
+    assert 100.0 < d["box"]["gemm_f16_8192_tflops"] < 2500.0
+    if "legs" in r:
+        assert r["legs"]["box"]["gemm_f16_8192_tflops"] == d["box"]["gemm_f16_8192_tflops"]
 
 
 def test_default_line_is_the_selfplay_headline_with_the_tree_numbers_nested():
