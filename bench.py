@@ -15,7 +15,7 @@ heads launch pair).  The tree-only sub-benchmark, configs[1] (uniform priors, no
 SURVEY 8(d)), is measured the same way right after it and nested in the same line as "tree".
 `--workload resnet` / `--workload tree` run one of the two alone (profiling).  Two more legs are nested in the
 default line: "config5" -- BASELINE configs[4]'s shape on this one GPU (13x13, 19x256 resnet, 800 -> 810 sims,
-`--c5-games` games, one warm-up and one timed move) with its own `roofline` (the wide tower's per-layer MFMA
+`--c5-games` games, one warm-up and `--c5-steps` timed moves) with its own `roofline` (the wide tower's per-layer MFMA
 kernel) and `cpu_baseline` -- and "api": the product surface the trainer calls (Player.read, parallel_player.py:
 24-28) driven for `--api-moves` engine moves after the pool transplant, rows/s over the last 60 of them beside
 the plies/s the engine played in the same window.  A last nested leg stands beside the path, not on it:
@@ -636,57 +636,108 @@ def box_calibration(torch):
             "what": "library f16 GEMM on this box (not this repo's code): a yardstick for box-to-box differences"}
 
 
-def fold_legs(line):
-    """The driver's record keeps `roofline`, `cpu_baseline` and `config` whole and every other nested dict by name
-    only, so the essentials of every nested leg are repeated inside those two: enough to recompute each kernel's
-    fraction (achieved = flop_or_bytes_per_launch / avg_launch_ms) from the driver-held record alone."""
+def _scalar(v):
+    return v is not None and isinstance(v, (bool, int, float, str))
+
+
+def put_flat(dst, prefix, src, keys):
+    """Copy the scalar entries `keys` of `src` into `dst` under `prefix` (`key` or `(key, new_name)`)."""
+    if not isinstance(src, dict):
+        return
+    for k in keys:
+        k, name = (k, k) if isinstance(k, str) else k
+        if _scalar(src.get(k)):
+            dst[prefix + name] = src[k]
+
+
+def flatten_legs(line):
+    """The driver's record keeps the SCALAR entries of `roofline`, `cpu_baseline` and `config` and nothing nested inside them
+    (BENCH_r05.parsed: a nested `legs` dict was dropped), and every other nested dict of the line by name only.  So every
+    leg is repeated here as flat scalar keys of those two dicts -- `tree_*` (configs[1]), `c5_*` (configs[4]'s shape on one
+    GPU), `train_*`, `loop_*`, `api_*`, `box_*` -- enough that the record alone recomputes each fraction:
+        tree_frac        = tree_bytes_per_launch / (tree_avg_launch_ms * 1e-3) / 1e9 / tree_peak_gbs
+        tree_achieved_hbm_frac = tree_traffic / (tree_avg_launch_ms * 1e-3) / 1e9 / tree_peak_gbs
+        c5_frac          = c5_flop_per_launch / (c5_avg_launch_ms * 1e-3) / 1e12 / c5_peak_tflops
+        train_native_frac      = train_flop_per_step / (train_native_step_only_ms * 1e-3) / 1e12 / 2500
+        train_wide_frac        = train_wide_flop_per_step / (train_wide_native_step_only_ms * 1e-3) / 1e12 / 2500
+    A leg that failed leaves `<leg>_error`."""
     roof, cpu = line.get("roofline"), line.get("cpu_baseline")
     if not isinstance(roof, dict):
         return
-    RK = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_tower", "traffic_heads",
-          "issued_frac", "avg_launch_ms", "launches", "positions_per_launch", "flop_per_launch", "bytes_per_launch",
-          "moves_per_launch", "ms_per_move", "bytes_per_sim", "mean_depth", "achieved_hbm_gbs", "achieved_hbm_frac",
-          "limiter")
-    TK = ("value", "unit", "games_per_sec", "plies_per_sec", "ms_per_step", "steps", "warmup", "elapsed_s", "evals")
-    legs = {"headline": dict(pick(line, TK), workload="configs[2]")}
-    for name, tag in (("tree", "configs[1]"), ("config5", "configs[4] shape, one GPU")):
+    TK = (("value", "sims_per_sec"), "games_per_sec", "plies_per_sec", "ms_per_step", "steps", "warmup", "elapsed_s", "evals")
+    for name, pre in (("tree", "tree_"), ("config5", "c5_")):
         leg = line.get(name)
-        if isinstance(leg, dict) and "roofline" in leg:
-            legs[name] = dict(pick(leg, TK), workload=tag, **pick(leg["roofline"], RK))
-            if isinstance(leg.get("config"), dict):
-                legs[name].update(pick(leg["config"], ("games_per_gpu", "board", "simulations")))
-        elif isinstance(leg, dict) and "error" in leg:
-            legs[name] = {"error": leg["error"]}
+        if not isinstance(leg, dict):
+            continue
+        if "error" in leg:
+            roof[pre + "error"] = str(leg["error"])[:120]
+            continue
+        put_flat(roof, pre, leg, TK)
+        r = leg.get("roofline") or {}
+        put_flat(roof, pre, r, ("frac", "achieved", "traffic", "traffic_tower", "traffic_heads", "issued_frac", "avg_launch_ms",
+                                "launches", "positions_per_launch", "flop_per_launch", "bytes_per_launch", "moves_per_launch",
+                                "ms_per_move", "bytes_per_sim", "mean_depth", "achieved_hbm_gbs", "achieved_hbm_frac",
+                                "net_share_of_step", ("unit", "achieved_unit"), ("bound", "bound")))
+        if _scalar(r.get("peak")):
+            roof[pre + ("peak_gbs" if r.get("bound") == "hbm" else "peak_tflops")] = r["peak"]
+        put_flat(roof, pre, leg.get("config"), (("games_per_gpu", "games"), "board", "simulations"))
     ts = line.get("train_step")
     if isinstance(ts, dict):
-        t = {"batch": ts.get("batch")}
-        for mode in ("eager", "eager_nosync", "hip_graph", "native_fp32", "native"):
-            if isinstance(ts.get(mode), dict):
-                t[mode] = pick(ts[mode], ("steps_per_sec", "ms_per_step", "step_only_ms", "flop_per_step",
-                                          "algorithmic_tflops", "frac_of_f16_mfma_peak", "issued_frac_of_f16_mfma_peak"))
-        if isinstance(ts.get("wide"), dict):
-            t["wide"] = {m: (pick(v, ("steps_per_sec", "ms_per_step", "step_only_ms", "flop_per_step", "algorithmic_tflops",
-                                      "frac_of_f16_mfma_peak", "issued_frac_of_f16_mfma_peak", "error")) if isinstance(v, dict) else v)
-                         for m, v in ts["wide"].items() if m != "what"}
         if ts.get("error") is not None:
-            t["error"] = ts["error"]
-        legs["train_step"] = t
-    api = line.get("api")
-    if isinstance(api, dict):
-        legs["api"] = pick(api, ("rows_per_sec", "plies_per_sec", "rows_over_plies", "host_overhead_frac", "error"))
-    if isinstance(line.get("box"), dict):
-        legs["box"] = pick(line["box"], ("gemm_f16_8192_tflops", "usual_on_this_pool", "relative", "error"))
-    roof["legs"] = legs
+            roof["train_error"] = str(ts["error"])[:120]
+        put_flat(roof, "train_", ts, ("batch", "speedup_native_vs_hip_graph"))
+        for mode, tag in (("eager", "eager"), ("eager_nosync", "eager_nosync"), ("hip_graph", "hipgraph"),
+                          ("native_fp32", "native_fp32"), ("native", "native")):
+            m = ts.get(mode)
+            if isinstance(m, dict) and "error" in m:
+                roof["train_%s_error" % tag] = str(m["error"])[:120]
+            put_flat(roof, "train_%s_" % tag, m, (("ms_per_step", "ms"), "step_only_ms", ("frac_of_f16_mfma_peak", "frac"),
+                                                  ("issued_frac_of_f16_mfma_peak", "issued_frac")))
+        put_flat(roof, "train_", ts.get("native"), ("flop_per_step",))
+        w = ts.get("wide")
+        if isinstance(w, dict):
+            put_flat(roof, "train_wide_", w, ("batch", "speedup_native_vs_hip_graph"))
+            for mode, tag in (("hip_graph", "hipgraph"), ("native", "native")):
+                m = w.get(mode)
+                if isinstance(m, dict) and "error" in m:
+                    roof["train_wide_%s_error" % tag] = str(m["error"])[:120]
+                put_flat(roof, "train_wide_%s_" % tag, m, (("ms_per_step", "ms"), "step_only_ms",
+                                                           ("issued_frac_of_f16_mfma_peak", "issued_frac")))
+            put_flat(roof, "train_wide_", w.get("native"), ("flop_per_step", ("frac_of_f16_mfma_peak", "frac")))
+    put_flat(roof, "loop_", line.get("train_loop"), ("inline_steps_per_sec", "overlapped_steps_per_sec", "overlap_speedup",
+                                                     "inline_selfplay_share", "overlapped_wait_share", "max_staleness_steps",
+                                                     "games", "simulations", "steps", "error"))
+    put_flat(roof, "api_", line.get("api"), ("rows_per_sec", "plies_per_sec", "rows_over_plies", "host_overhead_frac", "error"))
+    put_flat(roof, "box_", line.get("box"), (("gemm_f16_8192_tflops", "gemm_tflops"), ("usual_on_this_pool", "usual_tflops"),
+                                             "relative", "error"))
+    put_flat(roof, "", line, ("games_per_sec", "plies_per_sec", "games_per_sec_steady", "mean_game_length", "evals", "elapsed_s"))
     if isinstance(cpu, dict):
-        CK = ("value", "unit", "cores", "per_core", "kind", "sample", "seconds", "error")
-        cl = {}
-        for name in ("tree", "config5"):
+        CK = ("value", "unit", "cores", "per_core", "seconds", "sample", "error", "port_vs_reference_per_core")
+        for name, pre in (("tree", "tree_"), ("config5", "c5_")):
             c = (line.get(name) or {}).get("cpu_baseline") if isinstance(line.get(name), dict) else None
+            put_flat(cpu, pre, c, CK)
             if isinstance(c, dict):
-                cl[name] = pick(c, CK)
-                if isinstance(c.get("reference_shim"), dict):
-                    cl[name]["reference_per_core"] = c["reference_shim"].get("per_core")
-        cpu["legs"] = cl
+                put_flat(cpu, pre + "reference_", c.get("reference_shim"), ("per_core", "cores", "sims_per_s"))
+                put_flat(cpu, pre + "reference_scaled_", c.get("reference_scaled"), ("value",))
+        put_flat(cpu, "reference_", cpu.get("reference_shim"), ("per_core", "cores", "sims_per_s", "games_per_s"))
+        put_flat(cpu, "reference_scaled_", cpu.get("reference_scaled"), ("value", "cores"))
+        put_flat(cpu, "same_container_", cpu.get("same_container"), (("port_per_core_8", "port_per_core"),
+                                                                     ("reference_per_core_8", "reference_per_core")))
+
+
+def strip_to_driver_record(line):
+    """What the driver's BENCH_rNN.parsed keeps of a line: the contract's top-level scalars, and of `roofline` /
+    `cpu_baseline` / `config` only the scalar entries (strings cut at 128 characters).  tests/test_bench_helpers.py
+    recomputes every leg from this."""
+    TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+           "vs_baseline", "dtype", "data")
+    out = {k: line[k] for k in TOP if k in line}
+    for name in ("config", "roofline", "cpu_baseline"):
+        d = line.get(name)
+        if isinstance(d, dict):
+            out[name] = {k: (v[:128] if isinstance(v, str) else v) for k, v in d.items()
+                         if v is None or isinstance(v, (bool, int, float, str))}
+    return out
 
 
 def main():
@@ -715,6 +766,7 @@ def main():
     ap.add_argument("--nodes-per-game", type=int, default=0,
                     help="tree arena capacity per game (0 = engine default)")
     ap.add_argument("--c5-games", type=int, default=512, help="concurrent games of the nested configs[4]-shape leg")
+    ap.add_argument("--c5-steps", type=int, default=3, help="timed moves of the nested configs[4]-shape leg (one warm-up move)")
     ap.add_argument("--no-config5", action="store_true", help="skip the nested configs[4]-shape leg")
     ap.add_argument("--api-moves", type=int, default=190,
                     help="engine moves the nested product-surface leg (Player.read) is driven for; 0 = skip")
@@ -852,11 +904,11 @@ def main():
                     tree["cpu_baseline"] = {"error": repr(exc)}
             line["tree"] = tree
 
-    # ---- nested configs[4]-shape leg: 13x13, 19x256, 810 selects, one warm-up + one timed move --------------
+    # ---- nested configs[4]-shape leg: 13x13, 19x256, 810 selects, one warm-up + `--c5-steps` timed moves --------------
     if args.workload == "selfplay" and not args.no_config5 and (args.board, args.blocks, args.chans) == (11, 6, 64):
         a5 = config5_args(args)
         try:
-            st5, el5, ex5 = run_workload("resnet", a5, rank, world, local_rank, 1, 1, sync, torch)
+            st5, el5, ex5 = run_workload("resnet", a5, rank, world, local_rank, args.c5_steps, 1, sync, torch)
         except Exception as exc:      # a nested leg must not take the headline down (one process: no peer is left waiting)
             if world > 1:
                 raise
@@ -866,9 +918,9 @@ def main():
             el5, sums5 = reduce_over_ranks(dist, torch, el5, [float(st5[k]) for k in SUM_KEYS])
             ex5["engine"].close()
         if rank == 0 and st5 is not None:
-            c5 = {"metric": "mcts_sims_per_sec", "steps": 1, "warmup": 1,
+            c5 = {"metric": "mcts_sims_per_sec", "steps": args.c5_steps, "warmup": 1,
                   "dtype": "f16x3 (fp32 operands split hi+lo f16, fp32 accumulate)"}
-            c5.update(throughput_fields(sums5, el5, 1))
+            c5.update(throughput_fields(sums5, el5, args.c5_steps))
             sel5 = (a5.sims // a5.batch + 1) * a5.batch
             c5["config"] = {"workload": ("BASELINE configs[4] shape on one GPU: %d concurrent 13x13 Hex games, %d sims/move "
                                          "(%d select_leaf calls), 19x256 resnet forward on split-f16 MFMA, random-init "
@@ -876,7 +928,7 @@ def main():
                             "games_per_gpu": a5.games, "board": 13, "simulations": a5.sims, "search_batch_size": a5.batch,
                             "start": "steady-state pool as the headline's (0..%d plies, %d settle moves), 1 warm-up move"
                                      % (a5.desync, a5.settle)}
-            c5["roofline"] = resnet_roofline(st5, a5, 1, 1, ex5["kernels"])
+            c5["roofline"] = resnet_roofline(st5, a5, args.c5_steps, 1, ex5["kernels"])
             c5["kernels"] = ex5["kernels"]
             if world == 1 and not args.no_cpu_baseline:
                 try:      # 19x256 on the host: ~0.2 s per position and thread -> one ply of a 20-sim search per thread
@@ -902,7 +954,7 @@ def main():
             line["train_step"] = {"error": repr(exc)}
 
     if rank == 0:
-        fold_legs(line)
+        flatten_legs(line)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -75,22 +75,60 @@ def test_cpu_baseline_carries_the_reference_shim_context():
     assert bench.REFERENCE_SHIM["tree"]["sims_per_s"] == 870.0
 
 
-def test_every_leg_s_fraction_can_be_recomputed_from_the_dicts_the_driver_keeps():
-    """The driver's record keeps `roofline` / `cpu_baseline` / `config` whole and other nested dicts by name only
-    (VERDICT r4 weak #9): after fold_legs, `roofline` alone must carry what recomputes each leg's fraction."""
-    line = json.load(open(os.path.join(ROOT, "profiles", "r4_selfplay_bench.json")))
-    bench.fold_legs(line)
-    kept = {"roofline": line["roofline"], "cpu_baseline": line["cpu_baseline"]}      # what survives
-    legs = kept["roofline"]["legs"]
-    t = legs["tree"]
-    assert abs(t["bytes_per_launch"] / (t["avg_launch_ms"] * 1e-3) / 1e9 / t["peak"] - line["tree"]["roofline"]["frac"]) < 1e-9
-    assert t["achieved_hbm_frac"] == line["tree"]["roofline"]["achieved_hbm_frac"] and t["value"] == line["tree"]["value"]
-    c = legs["config5"]
-    assert abs(c["flop_per_launch"] / (c["avg_launch_ms"] * 1e-3) / 1e12 / c["peak"] - line["config5"]["roofline"]["frac"]) < 1e-9
-    assert c["traffic"] == line["config5"]["roofline"]["traffic"] and c["positions_per_launch"] > 0
-    tr = legs["train_step"]
-    assert tr["native"]["steps_per_sec"] == line["train_step"]["native"]["steps_per_sec"]
-    assert tr["native"]["step_only_ms"] and tr["hip_graph"]["steps_per_sec"] and tr["eager"]["steps_per_sec"]
-    assert legs["api"]["rows_over_plies"] == line["api"]["rows_over_plies"]
-    cl = kept["cpu_baseline"]["legs"]
-    assert cl["tree"]["value"] == line["tree"]["cpu_baseline"]["value"] and cl["config5"]["cores"] == 64
+def _is_scalar(v):
+    return v is None or isinstance(v, (bool, int, float, str))
+
+
+def test_every_leg_s_fraction_can_be_recomputed_from_the_scalars_the_driver_keeps():
+    """BENCH_r05.parsed showed what the driver keeps: the contract's top-level keys, and of `roofline` / `cpu_baseline` /
+    `config` the SCALAR entries only (a nested `legs` dict was dropped).  So every non-scalar is
+    stripped BEFORE anything is recomputed: the flat tree_* / c5_* / train_* / api_* / box_* keys must do alone."""
+    line = json.load(open(os.path.join(ROOT, "profiles", "r5_selfplay_bench.json")))
+    line["roofline"].pop("legs", None)           # the r5 line carried the nested form
+    line["cpu_baseline"].pop("legs", None)
+    bench.flatten_legs(line)
+    kept = bench.strip_to_driver_record(line)
+    assert set(kept) <= {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                         "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+    for name in ("config", "roofline", "cpu_baseline"):
+        assert all(_is_scalar(v) for v in kept[name].values()), name
+    r, c = kept["roofline"], kept["cpu_baseline"]
+    # headline (as before)
+    assert abs(r["flop_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12 / r["peak"] - r["frac"]) < 1e-9
+    assert kept["unit"] == "sims/s" and r["unit"] == "TFLOP/s"
+    # configs[1]: model bytes and counter bytes over the launch time, against the HBM peak
+    t = line["tree"]
+    assert abs(r["tree_bytes_per_launch"] / (r["tree_avg_launch_ms"] * 1e-3) / 1e9 / r["tree_peak_gbs"] - t["roofline"]["frac"]) < 1e-9
+    assert abs(r["tree_traffic"] / (r["tree_avg_launch_ms"] * 1e-3) / 1e9 / r["tree_peak_gbs"] - t["roofline"]["achieved_hbm_frac"]) < 1e-9
+    assert r["tree_frac"] == t["roofline"]["frac"] and r["tree_sims_per_sec"] == t["value"] and r["tree_achieved_unit"] == "GB/s"
+    assert r["tree_ms_per_move"] == t["roofline"]["ms_per_move"] and r["tree_steps"] == t["steps"]
+    # configs[4]'s shape on one GPU
+    c5 = line["config5"]
+    assert abs(r["c5_flop_per_launch"] / (r["c5_avg_launch_ms"] * 1e-3) / 1e12 / r["c5_peak_tflops"] - c5["roofline"]["frac"]) < 1e-9
+    assert r["c5_frac"] == c5["roofline"]["frac"] and r["c5_sims_per_sec"] == c5["value"] and r["c5_traffic"] == c5["roofline"]["traffic"]
+    assert r["c5_positions_per_launch"] > 0 and r["c5_board"] == 13 and r["c5_games"] == 512 and r["c5_achieved_unit"] == "TFLOP/s"
+    # both training steps
+    ts = line["train_step"]
+    assert abs(r["train_flop_per_step"] / (r["train_native_step_only_ms"] * 1e-3) / 1e12 / 2500.0 - r["train_native_frac"]) < 1e-9
+    assert abs(r["train_wide_flop_per_step"] / (r["train_wide_native_step_only_ms"] * 1e-3) / 1e12 / 2500.0 - r["train_wide_frac"]) < 1e-9
+    assert r["train_native_ms"] == ts["native"]["ms_per_step"] and r["train_hipgraph_ms"] == ts["hip_graph"]["ms_per_step"]
+    assert r["train_eager_ms"] == ts["eager"]["ms_per_step"] and r["train_wide_hipgraph_ms"] == ts["wide"]["hip_graph"]["ms_per_step"]
+    assert r["train_wide_native_ms"] == ts["wide"]["native"]["ms_per_step"]
+    # product surface and the box yardstick
+    assert r["api_rows_over_plies"] == line["api"]["rows_over_plies"] and r["api_rows_per_sec"] == line["api"]["rows_per_sec"]
+    assert r["box_gemm_tflops"] == line["box"]["gemm_f16_8192_tflops"] and abs(r["box_relative"] - r["box_gemm_tflops"] / r["box_usual_tflops"]) < 1e-12
+    assert r["games_per_sec"] == line["games_per_sec"]
+    # the CPU side: every leg's baseline and the context that fixes its reading
+    assert c["tree_value"] == t["cpu_baseline"]["value"] and c["tree_cores"] == 64 and c["tree_unit"] == "sims/s"
+    assert c["c5_value"] == c5["cpu_baseline"]["value"] and c["c5_cores"] == 64
+    assert c["reference_per_core"] == 376.4 and c["reference_scaled_value"] == 376.4 * c["cores"]
+    assert c["same_container_port_per_core"] == 380.8 and c["same_container_reference_per_core"] == 376.4
+    assert c["tree_reference_per_core"] == 870.0
+
+
+def test_a_failed_leg_leaves_a_scalar_error():
+    line = {"roofline": {"frac": 0.2}, "cpu_baseline": {"value": 1.0}, "config5": {"error": "RuntimeError('x')"},
+            "train_step": {"error": "boom"}, "api": {"error": "nope"}}
+    bench.flatten_legs(line)
+    r = line["roofline"]
+    assert r["c5_error"].startswith("RuntimeError") and r["train_error"] == "boom" and r["api_error"] == "nope"

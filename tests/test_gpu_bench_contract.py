@@ -8,6 +8,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
 
 
 def _run(*args):
@@ -30,8 +32,16 @@ def _check_common(d, steps, warmup):
     assert "traffic" in r
     # the box's own speed by a library GEMM, in the line and inside the dict the driver keeps whole
     assert 100.0 < d["box"]["gemm_f16_8192_tflops"] < 2500.0
-    if "legs" in r:
-        assert r["legs"]["box"]["gemm_f16_8192_tflops"] == d["box"]["gemm_f16_8192_tflops"]
+    assert "legs" not in r and r["box_gemm_tflops"] == d["box"]["gemm_f16_8192_tflops"]
+    # the driver keeps only the scalars of roofline / cpu_baseline: every leg of the line is repeated there, flat
+    kept = bench.strip_to_driver_record(d)
+    for name in ("tree", "config5"):
+        pre = {"tree": "tree_", "config5": "c5_"}[name]
+        if name in d and "roofline" in d[name]:
+            assert kept["roofline"][pre + "frac"] == d[name]["roofline"]["frac"]
+            assert kept["roofline"][pre + "sims_per_sec"] == d[name]["value"]
+            if "cpu_baseline" in d[name] and "cpu_baseline" in kept:
+                assert kept["cpu_baseline"][pre + "value"] == d[name]["cpu_baseline"]["value"]
 
 
 def test_default_line_is_the_selfplay_headline_with_the_tree_numbers_nested():
@@ -68,7 +78,7 @@ def test_default_line_is_the_selfplay_headline_with_the_tree_numbers_nested():
 
 def test_default_line_nests_the_config5_shape_with_roofline_and_cpu_baseline():
     """Under the real headline shape (11x11, 6x64) the line also carries BASELINE configs[4]'s shape on one GPU as
-    "config5" -- 13x13, 19x256, 810 select_leaf calls, one warm-up + one timed move -- with its own roofline and
+    "config5" -- 13x13, 19x256, 810 select_leaf calls, one warm-up + three timed moves -- with its own roofline and
     cpu_baseline (few games here)."""
     d = _run("--steps", "1", "--warmup", "1", "--games", "32", "--tree-steps", "4", "--tree-warmup", "1",
              "--c5-games", "8", "--api-moves", "0", "--settle", "30")
@@ -78,8 +88,8 @@ def test_default_line_nests_the_config5_shape_with_roofline_and_cpu_baseline():
     assert c["reference_shim"]["sims_per_s"] == 3011.0 and c["reference_shim"]["cores"] == 8
     assert abs(c["port_vs_reference_per_core"] - c["per_core"] / c["reference_shim"]["per_core"]) < 1e-9
     c5 = d["config5"]
-    assert c5["config"]["workload"].startswith("BASELINE configs[4] shape") and c5["steps"] == 1 and c5["warmup"] == 1
-    assert round(c5["value"] * c5["elapsed_s"]) == 8 * 810 and c5["plies"] == 8
+    assert c5["config"]["workload"].startswith("BASELINE configs[4] shape") and c5["steps"] == 3 and c5["warmup"] == 1
+    assert round(c5["value"] * c5["elapsed_s"]) == 3 * 8 * 810 and c5["plies"] == 3 * 8
     r = c5["roofline"]
     assert r["bound"] == "mfma" and "k_conv_wide_f16x3_s16 x 38" in r["kernel"] and r["peak"] == 2500.0
     assert abs(r["flop_per_launch"] / r["positions_per_launch"] - 7.58e9) < 0.01e9
@@ -97,6 +107,12 @@ def test_default_line_nests_the_config5_shape_with_roofline_and_cpu_baseline():
     assert ts["native"]["steps_per_sec"] > 2.5 * ts["hip_graph"]["steps_per_sec"]      # measured 3.7-3.9x
     assert ts["native"]["steps_per_sec"] > 1.1 * ts["native_fp32"]["steps_per_sec"]    # the split-f16 kernels: measured 1.3-1.5x
     assert "fp32" in ts["native_fp32"]["arithmetic"] and "split f16" in ts["native"]["arithmetic"]
+    kr = bench.strip_to_driver_record(d)["roofline"]      # ... and the same from the scalars the driver keeps
+    assert abs(kr["train_flop_per_step"] / (kr["train_native_step_only_ms"] * 1e-3) / 1e12 / 2500.0 - kr["train_native_frac"]) < 1e-9
+    assert abs(kr["train_wide_flop_per_step"] / (kr["train_wide_native_step_only_ms"] * 1e-3) / 1e12 / 2500.0 - kr["train_wide_frac"]) < 1e-9
+    assert kr["train_hipgraph_ms"] == ts["hip_graph"]["ms_per_step"] and kr["train_wide_hipgraph_ms"] > kr["train_wide_native_ms"]
+    assert abs(kr["c5_flop_per_launch"] / (kr["c5_avg_launch_ms"] * 1e-3) / 1e12 / kr["c5_peak_tflops"] - kr["c5_frac"]) < 1e-9
+    assert abs(kr["tree_bytes_per_launch"] / (kr["tree_avg_launch_ms"] * 1e-3) / 1e9 / kr["tree_peak_gbs"] - kr["tree_frac"]) < 1e-9
 
 
 def test_tree_bench_line():
