@@ -24,6 +24,9 @@ sys.path.insert(0, os.path.dirname(HERE))
 CONFIGS = {   # tag: (n, sims, batch, c, depth, alpha, eps, temp, games)
     "7": (7, 60, 10, 0.5, 6, 0.3, 0.25, 1.0, 96),
     "11": (11, 100, 10, 0.5, 6, 0.3, 0.25, 1.0, 12),
+    # the headline's own search hyper-parameters (config/hex11_train_config.yml:19-36: alpha 0.03, depth 15), where a
+    # Dirichlet row over ~100 children is one or two spikes and the rest underflows
+    "11h": (11, 100, 10, 0.5, 15, 0.03, 0.25, 1.0, 16),
 }
 
 

@@ -45,9 +45,14 @@ CASES = {
     "11": (11, 100, 512, [0, 1, 2, 3, 4, 5, 6, 8, 12, 20, 30, 40, 50], 150),
 }
 CFG = dict(batch=10, c=0.5, depth=6, alpha=0.3, eps=0.25, temp=1.0)
+# the configuration every reported number runs on (config/hex11_train_config.yml:19-36, bench.py make_engine): alpha 0.03 is
+# where a Dirichlet row over ~100 children is one or two spikes above a float-underflow tail -- the regime the device's
+# Gamma-by-CDF-inversion sampler (log2 domain) was built for
+CFG_HEADLINE = dict(batch=10, c=0.5, depth=15, alpha=0.03, eps=0.25, temp=1.0)
+HEADLINE_PLIES = [0, 1, 2, 3, 4, 5, 6, 8, 10, 12, 14, 15, 16, 18, 20, 30, 40, 50]
 
 
-def oracle_sample(tmp_path, n, sims, games, seed0, extra=()):
+def oracle_sample(tmp_path, n, sims, games, seed0, extra=(), CFG=CFG):
     out = str(tmp_path / ("oracle_%d_%d_%d%s.npz" % (n, games, seed0, "_w" if "--noise-until" in extra else "")))
     cmd = [sys.executable, os.path.join(HERE, "oracle_games.py"), "--n", str(n), "--sims", str(sims),
            "--games", str(games), "--seed0", str(seed0), "--out", out]
@@ -57,7 +62,7 @@ def oracle_sample(tmp_path, n, sims, games, seed0, extra=()):
     return dict(np.load(out))
 
 
-def engine_sample(n, sims, games, seed, net=None):
+def engine_sample(n, sims, games, seed, net=None, CFG=CFG):
     """The first `games` games (uids 0..games-1: the first generation of the pool, so no length bias from taking
     whichever games finish first) of a throughput-mode engine, summarised like tests/oracle_games.py.  `net`:
     (blocks, chans, state_dict as numpy) -> the device network evaluates the leaves (the headline's kernels: k_mcts
@@ -122,32 +127,90 @@ def engine_sample(n, sims, games, seed, net=None):
     return out
 
 
-@pytest.mark.parametrize("tag", ["7", "11"])
-def test_throughput_mode_plays_the_reference_game_distribution(tag, tmp_path):
-    n, sims, games, plies, min_games = CASES[tag]
-    a = oracle_sample(tmp_path, n, sims, games, 0)
-    b = oracle_sample(tmp_path, n, sims, games, 100000)
-    same = gs.compare(a, b, CFG["depth"], plies, min_games)
-    e = engine_sample(n, sims, games, seed=20261003)
+def compare_with_oracle(tag, tmp_path, n, sims, games, plies, min_games, cfg, seed, net=None, extra=(), oracle=None):
+    """Engine sample against two pooled oracle samples (disjoint seeds), with the oracle-vs-oracle comparison as the
+    calibration of the thresholds.  `oracle`: (a, b) already loaded (tests/golden/g13_*: the oracle's network games
+    take minutes on the host, so they are recorded once by tests/golden/make_oracle_net_games.py)."""
+    from scipy import stats as sps
+    a, b = oracle if oracle is not None else (oracle_sample(tmp_path, n, sims, games, 0, extra, cfg),
+                                               oracle_sample(tmp_path, n, sims, games, 100000, extra, cfg))
+    same = gs.compare(a, b, cfg["depth"], plies, min_games)
+    e = engine_sample(n, sims, games, seed=seed, net=net, CFG=cfg)
     if os.environ.get("AZX_DIST_DUMP"):      # keep the three samples for offline analysis
         for name, smp in (("engine", e), ("oracle_a", a), ("oracle_b", b)):
             np.savez_compressed(os.path.join(os.environ["AZX_DIST_DUMP"], "dist_%s_%s.npz" % (tag, name)), **smp)
-    ref = {k: np.concatenate([a[k], b[k]]) for k in a}       # the reference sample: both oracle runs, 2 x the engine's
-    res = gs.compare(e, ref, CFG["depth"], plies, min_games)
+    ref = {k: np.concatenate([a[k], b[k]]) for k in e}       # the reference sample: both oracle runs, 2 x the engine's
+    res = gs.compare(e, ref, cfg["depth"], plies, min_games)
     low, low_same = sum(v < 0.05 for v in res.values()), sum(v < 0.05 for v in same.values())
-    print("oracle vs oracle: %d tests, worst %s p=%.3g, %d below 0.05" % ((len(same),) + gs.worst(same) + (low_same,)))
-    print("engine vs oracle: %d tests, worst %s p=%.3g, %d below 0.05" % ((len(res),) + gs.worst(res) + (low,)))
-    print("lengths: engine %.2f oracle %.2f / %.2f; first player wins: %.4f vs %.4f / %.4f" % (
-        e["length"].mean(), a["length"].mean(), b["length"].mean(),
+    print("[%s] oracle vs oracle: %d tests, worst %s p=%.3g, %d below 0.05" % ((tag, len(same)) + gs.worst(same) + (low_same,)))
+    print("[%s] engine vs oracle: %d tests, worst %s p=%.3g, %d below 0.05" % ((tag, len(res)) + gs.worst(res) + (low,)))
+    print("[%s] lengths: engine %.2f oracle %.2f / %.2f; first player wins: %.4f vs %.4f / %.4f" % (
+        tag, e["length"].mean(), a["length"].mean(), b["length"].mean(),
         e["first_wins"].mean(), a["first_wins"].mean(), b["first_wins"].mean()))
     # every statistic the oracle's games have is tested on the engine's (entropy: below the depth, where the rows carry it)
-    assert len(res) >= len(same) - sum(p >= CFG["depth"] for p in plies) and len(res) >= 50
+    assert len(res) >= len(same) - sum(p >= cfg["depth"] for p in plies) and len(res) >= 50
     assert gs.worst(same)[1] > gs.P_MIN, gs.worst(same)
     bad = {k: v for k, v in res.items() if v <= gs.P_MIN}
     assert not bad, bad
     # ... and no drift too small for any single test: the count of p < 0.05 stays binomial (99.9 % quantile)
-    from scipy import stats as sps
     assert low <= sps.binom.ppf(0.999, len(res), 0.05), (low, len(res))
+    return res, same
+
+
+@pytest.mark.parametrize("tag", ["7", "11"])
+def test_throughput_mode_plays_the_reference_game_distribution(tag, tmp_path):
+    n, sims, games, plies, min_games = CASES[tag]
+    compare_with_oracle(tag, tmp_path, n, sims, games, plies, min_games, CFG, seed=20261003)
+
+
+def test_throughput_mode_at_the_headline_hyper_parameters(tmp_path):
+    """The configuration every reported number runs on: 11x11, Dirichlet alpha 0.03, eps 0.25,
+    exploration_depth 15, c_puct 0.5, search batch 10 (config/hex11_train_config.yml:19-36) -- 512 games of 100 -> 110
+    selects with the uniform-prior / board-hash evaluator in k_play, against the oracle under numpy's
+    `RandomState.dirichlet` (mcts.py:126-131), whose sampler is pinned to the REFERENCE's own games at exactly these
+    hyper-parameters by G11's "11h" set (tests/test_oracle_golden.py)."""
+    compare_with_oracle("11h", tmp_path, 11, 100, 512, HEADLINE_PLIES, 150, CFG_HEADLINE, seed=20261005)
+
+
+def golden_oracle_games(name):
+    """(a, b): the two oracle samples of tests/golden/<name> expanded to the [games, cells] columns gs.compare reads."""
+    z = np.load(os.path.join(HERE, "golden", name))
+    cells, plies = int(z["cells"]), z["plies"]
+    out = []
+    for half in ("a", "b"):
+        smp = dict(length=z["length_" + half], first_wins=z["first_wins_" + half])
+        for c in og.COLUMNS:
+            full = np.full((len(smp["length"]), cells), np.nan, np.float32)
+            full[:, plies] = z[c + "_" + half]
+            smp[c] = full
+        out.append(smp)
+    return tuple(out), z
+
+
+def test_headline_kernels_at_the_headline_hyper_parameters(tmp_path):
+    """The headline itself, whole games: 11x11, the 6x64 DEVICE network (k_tower_f16x3_s16 + k_heads_mfma on G3's seeded
+    weights with non-trivial BatchNorm statistics), alpha 0.03 / eps 0.25 / depth 15 / c 0.5 / batch 10, 256 games of
+    60 -> 70 selects in k_mcts's phases + k_choose + k_advance -- against the oracle playing with ITS fp32 forward of the
+    same weights under numpy's RNG.  The oracle's 2 x 256 games cost ~20 core-minutes, so they are a committed fixture
+    (tests/golden/g13_oracle_net_games_11h.npz, written by tests/golden/make_oracle_net_games.py from
+    tests/oracle_games.py; tests/test_oracle_golden.py replays its first games live), regenerated here when absent."""
+    n, sims, games, blocks, chans = 11, 60, 256, 6, 64
+    z = np.load(os.path.join(HERE, "golden", "g3_forward_11_6x64.npz"))
+    state = {k[2:]: z[k] for k in z.files if k.startswith("w:") and z[k].dtype.kind == "f"}
+    path = os.path.join(HERE, "golden", "g13_oracle_net_games_11h.npz")
+    oracle = None
+    extra = ()
+    if os.path.exists(path):
+        oracle, meta = golden_oracle_games("g13_oracle_net_games_11h.npz")
+        assert (int(meta["n"]), int(meta["sims"]), int(meta["games"])) == (n, sims, games)
+        assert set(HEADLINE_PLIES) <= set(meta["plies"].tolist())
+        assert all(float(meta["cfg_" + k]) == float(v) for k, v in CFG_HEADLINE.items())
+    else:
+        wpath = str(tmp_path / "weights.npz")
+        np.savez(wpath, **state)
+        extra = ["--weights", wpath, "--blocks", str(blocks), "--chans", str(chans)]
+    compare_with_oracle("net11h", tmp_path, n, sims, games, HEADLINE_PLIES, 80, CFG_HEADLINE, seed=20261006,
+                        net=(blocks, chans, state), extra=extra, oracle=oracle)
 
 
 def test_distribution_test_has_the_power_to_see_a_wrong_noise_gate(tmp_path):
@@ -182,23 +245,5 @@ def test_throughput_mode_with_the_device_network_plays_the_reference_game_distri
     wpath = str(tmp_path / "weights.npz")
     np.savez(wpath, **state)
     extra = ["--weights", wpath, "--blocks", str(blocks), "--chans", str(chans)]
-    a = oracle_sample(tmp_path, n, sims, games, 0, extra)
-    b = oracle_sample(tmp_path, n, sims, games, 100000, extra)
-    same = gs.compare(a, b, CFG["depth"], plies, min_games)
-    e = engine_sample(n, sims, games, seed=20261004, net=(blocks, chans, state))
-    if os.environ.get("AZX_DIST_DUMP"):
-        for name, smp in (("engine", e), ("oracle_a", a), ("oracle_b", b)):
-            np.savez_compressed(os.path.join(os.environ["AZX_DIST_DUMP"], "dist_net7_%s.npz" % name), **smp)
-    ref = {k: np.concatenate([a[k], b[k]]) for k in a}
-    res = gs.compare(e, ref, CFG["depth"], plies, min_games)
-    low = sum(v < 0.05 for v in res.values())
-    print("oracle vs oracle: %d tests, worst %s p=%.3g" % ((len(same),) + gs.worst(same)))
-    print("engine vs oracle: %d tests, worst %s p=%.3g, %d below 0.05" % ((len(res),) + gs.worst(res) + (low,)))
-    print("lengths: engine %.2f oracle %.2f / %.2f; first player wins: %.4f vs %.4f / %.4f" % (
-        e["length"].mean(), a["length"].mean(), b["length"].mean(),
-        e["first_wins"].mean(), a["first_wins"].mean(), b["first_wins"].mean()))
-    assert len(res) >= 50 and gs.worst(same)[1] > gs.P_MIN, gs.worst(same)
-    bad = {k: v for k, v in res.items() if v <= gs.P_MIN}
-    assert not bad, bad
-    from scipy import stats as sps
-    assert low <= sps.binom.ppf(0.999, len(res), 0.05), (low, len(res))
+    compare_with_oracle("net7", tmp_path, n, sims, games, plies, min_games, CFG, seed=20261004,
+                        net=(blocks, chans, state), extra=extra)

@@ -280,7 +280,7 @@ def test_timed_network_path_matches_the_parity_path():
         assert np.abs(v - vf).max() <= 1e-5 and np.abs(lp - lpf)[lm > 0].max() <= 1e-5, (n, blocks, chans)
 
 
-@pytest.mark.parametrize("tag", ["7", "11"])
+@pytest.mark.parametrize("tag", ["7", "11", "11h"])
 def test_oracle_game_sampler_replays_the_reference_games_g11(tag):
     """tests/oracle_games.py -- the reference side of the GPU whole-game distribution test -- plays, seed for seed, the
     games the REFERENCE played in that test's configurations (G11: tests/golden/make_game_stats.py): the same moves,
