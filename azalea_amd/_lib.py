@@ -97,6 +97,8 @@ SYMBOLS = {
     "azx_play_device": (C.c_int, [_vp, C.c_int64, C.c_int64, _i64p, C.POINTER(PlayStats)]),
     "azx_rows_pack": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
     "azx_replay_put_records": (C.c_int, [_vp, C.c_int64, _vp]),
+    "azx_replay_put_records_async": (C.c_int, [_vp, C.c_int64, _vp, _vp]),
+    "azx_reserve_cus": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     "azx_replay_collate": (C.c_int, [_vp, C.c_int64, _i64p, _vp, _vp, _vp, _vp, _vp, _vp, _i32p]),
     "azx_replay_collate_async": (C.c_int, [_vp, C.c_int64, _i64p, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "azx_replay_set_mover_view": (C.c_int, [_vp, C.c_int]),

@@ -147,31 +147,45 @@ def serve_selfplay_ahead(player, *, ahead_rows: Optional[int] = None, poll_plies
     stats = dict(productions=0, rows=0, pulls=0, weight_syncs=0, max_productions_between_announcements=0, waited=0)
     since = 0
     have_weights = False
+    carry = {}                      # seconds / plies of productions that finished no game: added to the next chunk's metrics
+    failure = []                    # the error of a production that raised: reported at the next pull (PeerFailed on all ranks)
 
     def produce():
-        n, st = eng.play_device(ahead, max_plies=poll_plies)
-        stats["productions"] += 1
-        if not n:
+        if failure:
             return
-        rec = torch.empty((n, eng.record_bytes), dtype=torch.uint8, device=device)
-        if device.type == "cuda":
-            torch.cuda.synchronize(device)          # the caching allocator may recycle memory torch kernels still use
-        eng.rows_pack(0, n, rec.data_ptr())
-        m = {k: float(st.get(k, 0.0)) for k in _SUM_KEYS}
-        if game_sums is not None:
-            m.update({"game_" + k: float(v) for k, v in game_sums(n).items()})
-        backlog.push(rec, m)
-        stats["rows"] += n
+        try:
+            n, st = eng.play_device(ahead, max_plies=poll_plies)
+            stats["productions"] += 1
+            for k in _SUM_KEYS:
+                carry[k] = carry.get(k, 0.0) + float(st.get(k, 0.0))
+            if not n:
+                return
+            rec = torch.empty((n, eng.record_bytes), dtype=torch.uint8, device=device)
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)          # the caching allocator may recycle memory torch kernels still use
+            eng.rows_pack(0, n, rec.data_ptr())
+            m = dict(carry)
+            carry.clear()
+            if game_sums is not None:
+                m.update({"game_" + k: float(v) for k, v in game_sums(n).items()})
+            backlog.push(rec, m)
+            stats["rows"] += n
+        except Exception as exc:      # keep answering announcements: the learner must not be left in a collective
+            logging.exception("actor %d: self-play failed; reporting it at the next pull", rank)
+            failure.append(exc)
 
     pending = azdist.Pending()
     while True:
-        if pending.ready() or not have_weights or backlog.rows >= ahead:
+        if pending.ready() or not have_weights or backlog.rows >= ahead or failure:
             if not pending.ready():
                 stats["waited"] += 1
             op, arg = pending.result(timeout)
             stats["max_productions_between_announcements"] = max(stats["max_productions_between_announcements"], since)
             since = 0
             if op == azdist.OP_STOP:
+                if failure:
+                    azdist.broadcast_weights(pol.net, src=0)     # the collective rank 0 is about to enter
+                    raise failure[0]
                 break
             if op == azdist.OP_WEIGHTS:
                 azdist.broadcast_weights(pol.net, src=0)
@@ -182,11 +196,16 @@ def serve_selfplay_ahead(player, *, ahead_rows: Optional[int] = None, poll_plies
                 have_weights = True
             elif op == azdist.OP_PULL:
                 quota = actor_quota(arg, rank, world)
-                while backlog.rows < quota:                      # fallen behind: the learner waits for us
+                while backlog.rows < quota and not failure:      # fallen behind: the learner waits for us
                     produce()
-                recs, m = backlog.take(quota)
+                recs, m = ([], {}) if failure else backlog.take(quota)
                 rec = torch.cat(recs) if recs else torch.empty((0, eng.record_bytes), dtype=torch.uint8, device=device)
-                azdist.gather_records(rec, dst=0)
+                try:
+                    azdist.gather_records(rec, dst=0, failed=bool(failure))
+                except azdist.PeerFailed:
+                    if failure:
+                        raise failure[0]
+                    raise
                 azdist.all_reduce_metrics(m)
                 stats["pulls"] += 1
             else:

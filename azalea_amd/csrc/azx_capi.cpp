@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,8 @@ struct azx_engine {
     azx_config cfg;
     DevEngine d;
     hipStream_t stream = nullptr;
+    int reserved_cus = 0;               // azx_reserve_cus: CUs of the device the engine's streams stay off
+    std::mutex alloc_mu;                // dev_alloc from the trainer's thread (collate staging) beside the play thread's
     int num_batches = 0;
     int selects_per_search = 0;
     std::vector<void *> allocs;
@@ -111,6 +114,7 @@ static int dev_alloc(azx_engine *e, T **p, size_t count, bool zero = true) {
         err = hipMemsetAsync(q, 0, bytes, e->stream);
         if (err != hipSuccess) return fail(AZX_EHIP, "hipMemset failed: %s", hipGetErrorString(err));
     }
+    std::lock_guard<std::mutex> lock(e->alloc_mu);
     e->allocs.push_back(q);
     *p = reinterpret_cast<T *>(q);
     return AZX_OK;
@@ -268,6 +272,38 @@ extern "C" void azx_destroy(azx_engine *e) {
 
 extern "C" void *azx_stream(azx_engine *e) { return e ? (void *)e->stream : nullptr; }
 
+// CU mask layout of gfx950, measured (tools/microbench/cu_mask.hip, profiles/r6_cu_mask_microbench.txt): bit b of the
+// mask is XCD b % 8, shader engine (b / 8) % 4, so bits [0, 8 r) are r CUs of every XCD, dealt one per shader engine.
+extern "C" int azx_reserve_cus(azx_engine *e, int cus_per_xcd, int *reserved_out) {
+    if (!e) return fail(AZX_EINVAL, "null engine");
+    ENGINE_GUARD(e);
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, e->cfg.device));
+    const int ncu = prop.multiProcessorCount, xcds = 8, ses = 4;
+    if (cus_per_xcd < 0 || cus_per_xcd * xcds >= ncu)
+        return fail(AZX_EINVAL, "cus_per_xcd %d outside [0, %d)", cus_per_xcd, ncu / xcds);
+    if (cus_per_xcd > 0 && ncu % (xcds * ses))
+        return fail(AZX_ESTATE, "CU reservation is laid out for 8 XCDs x 4 shader engines; this device has %d CUs", ncu);
+    const int per = (cus_per_xcd + ses - 1) / ses * ses;
+    const int words = (ncu + 31) / 32;
+    std::vector<uint32_t> mask((size_t)words, 0u);
+    for (int b = 0; b < ncu; ++b)
+        if (b >= per * xcds) mask[b / 32] |= 1u << (b % 32);
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    hipStream_t fresh = nullptr;
+    if (per == 0) HIPCHECK(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+    else HIPCHECK(hipExtStreamCreateWithCUMask(&fresh, (uint32_t)words, mask.data()));
+    hipStream_t old = e->stream;
+    e->stream = fresh;
+    if (e->net) azx_net_set_stream(e->net, fresh, per ? mask.data() : nullptr, per ? words : 0);
+    (void)hipStreamDestroy(old);
+    e->reserved_cus = per * xcds;
+    if (!e->cidx_maxk) TRY(dev_alloc(e, &e->cidx_maxk, 4));     // (so that the trainer's thread never allocates beside a play)
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    if (reserved_out) *reserved_out = e->reserved_cus;
+    return AZX_OK;
+}
+
 extern "C" int azx_kernel_info(azx_engine *e, char *buf, int cap) {
     if (!e || !buf || cap < 1) return fail(AZX_EINVAL, "null argument");
     const DevEngine &d = e->d;
@@ -289,6 +325,7 @@ extern "C" int azx_kernel_info(azx_engine *e, char *buf, int cap) {
                        (e->net ? azx_net_kernel_info(e->net) : "none") +
                        "; switches: AZX_MCTS_GENERIC=" + (e->force_generic ? "1" : "0") +
                        " AZX_NO_PERSISTENT=" + (e->no_persistent ? "1" : "0") +
+                       " reserved_cus=" + std::to_string(e->reserved_cus) +
                        "; src=" AZX_SRC_SHA;       // sha256 (16 hex digits) over the kernel sources this library was built from
     snprintf(buf, (size_t)cap, "%s", text.c_str());
     return (int)text.size();
@@ -1110,6 +1147,20 @@ extern "C" int azx_replay_put_records(azx_engine *e, int64_t n, const void *reco
     e->ring_write = (e->ring_write + n) % e->ring_cap;
     e->ring_size = std::min<int64_t>(e->ring_cap, e->ring_size + n);
     HIPCHECK(hipStreamSynchronize(e->stream));
+    return AZX_OK;
+}
+
+extern "C" int azx_replay_put_records_async(azx_engine *e, int64_t n, const void *records_dev, void *hip_stream) {
+    if (!e || (n > 0 && !records_dev)) return fail(AZX_EINVAL, "null argument");
+    ENGINE_GUARD(e);
+    if (e->ring_cap == 0) return fail(AZX_ESTATE, "no replay ring: call azx_replay_create first");
+    if (n < 0) return fail(AZX_EINVAL, "n must be >= 0");
+    if (n == 0) return AZX_OK;
+    // only ring state and the caller's stream: nothing the play thread (azx_play_device on e->stream) touches
+    azx_launch_records_put((const uint8_t *)records_dev, e->ring, n, e->ring_cap, e->ring_write, e->d.ncells, (hipStream_t)hip_stream);
+    HIPCHECK(hipGetLastError());
+    e->ring_write = (e->ring_write + n) % e->ring_cap;
+    e->ring_size = std::min<int64_t>(e->ring_cap, e->ring_size + n);
     return AZX_OK;
 }
 

@@ -9,6 +9,9 @@ struct AzxNet;
 
 int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hipStream_t st);
 void azx_net_destroy(AzxNet *net);
+// the engine re-made its stream (azx_reserve_cus): use `st` from now on and make the wide tower's side streams on the
+// same CU mask (`mask` words, 0 words = all CUs); the old side streams are drained and dropped
+void azx_net_set_stream(AzxNet *net, hipStream_t st, const uint32_t *mask, int words);
 const char *azx_net_error();
 int azx_net_set_weights(AzxNet *net, int n, const char *const *names, const void *const *ptrs,
                         const int64_t *counts, int on_device);

@@ -1788,6 +1788,21 @@ int azx_net_create(AzxNet **out, int N, int blocks, int chans, int max_evals, hi
     return AZX_OK;
 }
 
+void azx_net_set_stream(AzxNet *net, hipStream_t st, const uint32_t *mask, int words) {
+    if (!net) return;
+    for (int i = 0; i < 3; ++i) {
+        if (net->stream2[i]) { (void)hipStreamSynchronize(net->stream2[i]); (void)hipStreamDestroy(net->stream2[i]); }
+        if (net->ev_join[i]) (void)hipEventDestroy(net->ev_join[i]);
+        net->stream2[i] = nullptr;
+        net->ev_join[i] = nullptr;
+    }
+    if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
+    net->ev_fork = nullptr;           // run_net makes the side streams again on first use
+    net->streams_ok = false;
+    net->cu_mask.assign(mask, mask + (mask ? words : 0));
+    net->stream = st;
+}
+
 void azx_net_destroy(AzxNet *net) {
     if (net) {
         for (int i = 0; i < 3; ++i) {
@@ -1899,7 +1914,8 @@ static void run_net(AzxNet *net, const uint8_t *boards, const int32_t *flip, con
                 if (parts > 1 && !net->ev_fork) {
                     bool ok = hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) == hipSuccess;
                     for (int i = 0; i < 3 && ok; ++i)
-                        ok = hipStreamCreateWithFlags(&net->stream2[i], hipStreamNonBlocking) == hipSuccess &&
+                        ok = (net->cu_mask.empty() ? hipStreamCreateWithFlags(&net->stream2[i], hipStreamNonBlocking)
+                                                   : hipExtStreamCreateWithCUMask(&net->stream2[i], (uint32_t)net->cu_mask.size(), net->cu_mask.data())) == hipSuccess &&
                              hipEventCreateWithFlags(&net->ev_join[i], hipEventDisableTiming) == hipSuccess;
                     net->streams_ok = ok;
                 }

@@ -69,6 +69,7 @@ struct AzxNet {
     int tower_variant = 0;
     // wide tower: the second half of a batch's boards runs its layer launches on a second stream
     hipStream_t stream2[3] = {nullptr, nullptr, nullptr};
+    std::vector<uint32_t> cu_mask;   // azx_net_set_stream: the side streams are made on the engine's CU mask (empty = all CUs)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     bool streams_ok = false;
     // diagnostic switches, read once per engine by azx_net_create (azx_net_kernel_info reports the outcome)

@@ -3125,8 +3125,12 @@ int azx_trn_step(AzxTrain *t, float lr, float momentum, float weight_decay, hipS
     if (t->broken) return tfail(AZX_ESTATE, "train: an earlier step failed while it was being queued; create a new trainer");
     if (!t->cap) {
         if (int rc = raise_limits(t->d.C, t->d.cells, t->d.N)) return rc;
+        // the side stream (filter gradients) takes the priority of the stream the first step is queued on: a trainer that
+        // runs beside self-play on a high-priority stream (azalea_amd/play_ahead.py) gets both of its streams ahead
+        int prio = 0;
+        if (hipStreamGetPriority(st, &prio) != hipSuccess) prio = 0;
         if (hipStreamCreateWithFlags(&t->cap, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) != hipSuccess)
+            hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, prio) != hipSuccess)
             return tfail(AZX_EHIP, "train: creating the capture streams failed");
     }
     // The hyper-parameters travel through a ring in pinned host memory that the step's first kernel reads (slot = steps

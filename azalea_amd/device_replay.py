@@ -9,6 +9,7 @@ prep.torch_batch_replays.  `loader(batch_size)` yields the batches a
 random permutation (RandomSampler seeds a private generator from the global torch RNG), the same
 keys, dtypes and zero padding to the batch's widest row, as device tensors.
 """
+from collections import deque
 from typing import Dict, Iterator
 
 import numpy as np
@@ -31,6 +32,8 @@ class DeviceReplayBuffer:
         self.fresh_counter = 0
         self.shared = shared
         self.learner = None             # actor_learner.Learner: refills are PULLED from the actors' backlogs (rank 0 only)
+        self.ahead = None               # play_ahead.PlayAhead: refills are TAKEN from this process's own play thread
+        self._retired = deque()         # (record chunks, event): chunks whose ring put may still be in flight
         self.last_exchange = None       # timing of the last shared refill (bench / diagnostics)
         self._mover_view = False
         self.device = getattr(engine, "torch_device", None) or torch.device("cuda", engine.cfg.device)
@@ -79,10 +82,12 @@ class DeviceReplayBuffer:
         refill = max(0, num_examples - self.fresh_counter)
         if not refill:
             return {}
-        if getattr(self, "_async_reads", False):       # collate_async reads queued on torch's stream come first
-            torch.cuda.synchronize(self.device)
+        if self.ahead is None and getattr(self, "_async_reads", False):
+            torch.cuda.synchronize(self.device)        # collate_async reads queued on torch's stream come first
             self._async_reads = False
-        if self.learner is not None:
+        if self.ahead is not None:                     # (its put is queued on the stream those reads are on: ordered)
+            rows, st = self._take_ahead(int(np.ceil(refill)))
+        elif self.learner is not None:
             rows, st = self._pull(int(np.ceil(refill)))
         elif self.shared and azdist.is_distributed():
             rows, st = self.refill_shared(int(np.ceil(refill)), player)
@@ -132,6 +137,30 @@ class DeviceReplayBuffer:
         self.last_exchange = dict(self.learner.last_pull)
         return int(sum(counts)), st
 
+    def _take_ahead(self, refill: int):
+        """Play-ahead mode (azalea_amd/play_ahead.py): whole chunks out of this process's own backlog -- waiting only when
+        it is short -- appended to the ring by a kernel queued on the CURRENT (training) stream: behind the collate reads
+        already queued there, ahead of the next ones, and never on the engine's stream, which the play thread keeps busy.
+        A chunk's memory is released once the stream has passed its put."""
+        chunks, st = self.ahead.take(refill)
+        cuda = self.device.type == "cuda"
+        stream = torch.cuda.current_stream(self.device) if cuda else None
+        rows = 0
+        for rec in chunks:
+            n = int(rec.shape[0])
+            if cuda:
+                self.engine.replay_put_records_async(n, rec.data_ptr(), stream.cuda_stream)
+            else:
+                self.engine.replay_put_records(n, rec.data_ptr())
+            rows += n
+        if cuda and chunks:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self._retired.append((chunks, ev))
+            while self._retired and self._retired[0][1].query():
+                self._retired.popleft()
+        return rows, st
+
     def _fill_shared(self, refill: int):
         """One refill played by all ranks: each rank plays its share of whole games into its harvest
         queue, packs the rows into fixed-size records ON THE DEVICE (k_rows_pack), the ranks all-gather
@@ -143,18 +172,31 @@ class DeviceReplayBuffer:
         eng = self.engine
         quota = azdist.shard_quota(refill)
         t0 = time.perf_counter()
-        if quota > 0:
-            n_local, st = eng.play_device(quota)
-        else:
-            n_local, st = 0, {}
-        t1 = time.perf_counter()
-        rec = torch.empty((n_local, eng.record_bytes), dtype=torch.uint8, device=self.device)
-        if n_local:
-            if self.device.type == "cuda":
-                torch.cuda.synchronize(self.device)     # the caching allocator may recycle memory torch kernels still use
-            eng.rows_pack(0, n_local, rec.data_ptr())
+        failure = None
+        n_local, st = 0, {}
+        t1 = t0
+        try:
+            if quota > 0:
+                n_local, st = eng.play_device(quota)
+            t1 = time.perf_counter()
+            rec = torch.empty((n_local, eng.record_bytes), dtype=torch.uint8, device=self.device)
+            if n_local:
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)     # the caching allocator may recycle memory torch kernels still use
+                eng.rows_pack(0, n_local, rec.data_ptr())
+        except Exception as exc:
+            # AZX_ERANGE, a full tree arena, a HIP error: the other ranks are already on their way into the record
+            # collectives of this announced refill -- join the first with the failure mark, so that every rank leaves it
+            # with PeerFailed instead of hanging until the RCCL watchdog (distributed.PeerFailed)
+            failure = exc
+            rec = torch.empty((0, eng.record_bytes), dtype=torch.uint8, device=self.device)
         t2 = time.perf_counter()
-        parts, counts = azdist.all_gather_records(rec)
+        try:
+            parts, counts = azdist.all_gather_records(rec, failed=failure is not None)
+        except azdist.PeerFailed:
+            if failure is not None:
+                raise failure
+            raise
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         t3 = time.perf_counter()
@@ -177,6 +219,8 @@ class DeviceReplayBuffer:
         idx = np.asarray(indices, np.int64).reshape(-1)
         B, cells = len(idx), self.engine.n * self.engine.n
         dev = self.device
+        if self.ahead is not None:
+            return self._sample_on_stream(idx)
         out = dict(color=torch.empty(B, dtype=torch.int64, device=dev),
                    legal_moves=torch.empty((B, cells), dtype=torch.int32, device=dev),
                    result=torch.empty(B, dtype=torch.int64, device=dev),
@@ -186,6 +230,24 @@ class DeviceReplayBuffer:
         torch.cuda.synchronize(dev)      # the allocator may hand back memory torch kernels still use
         k = self.engine.replay_collate(idx, {name: t.data_ptr() for name, t in out.items()})
         n = self.engine.n
+        out["legal_moves"] = out["legal_moves"][:, :k].contiguous()
+        out["moves_prob"] = out["moves_prob"][:, :k].contiguous()
+        out["board"] = out["board"].view(B, n, n)
+        return out
+
+    def _sample_on_stream(self, idx) -> Dict[str, torch.Tensor]:
+        """`sample` while a play thread keeps the engine's stream busy: the collate runs on the current stream (where the
+        ring puts of play-ahead mode are), the batch's widest row is found on the host side of it."""
+        B, n = len(idx), self.engine.n
+        cells, dev = n * n, self.device
+        out = dict(color=torch.empty(B, dtype=torch.int64, device=dev),
+                   legal_moves=torch.empty((B, cells), dtype=torch.int32, device=dev),
+                   result=torch.empty(B, dtype=torch.int64, device=dev),
+                   board=torch.empty((B, cells), dtype=torch.int32, device=dev),
+                   moves_prob=torch.empty((B, cells), dtype=torch.float32, device=dev),
+                   reward=torch.empty(B, dtype=torch.float32, device=dev))
+        self.collate_async(idx, out)
+        k = max(1, int((out["legal_moves"] > 0).sum(1).max().item())) if B else 0
         out["legal_moves"] = out["legal_moves"][:, :k].contiguous()
         out["moves_prob"] = out["moves_prob"][:, :k].contiguous()
         out["board"] = out["board"].view(B, n, n)

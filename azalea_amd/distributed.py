@@ -88,22 +88,41 @@ def empty_rows(board_size: int) -> Dict[str, np.ndarray]:
     return unpack_rows(np.zeros((0, record_bytes(board_size * board_size)), np.uint8), board_size)
 
 
+class PeerFailed(RuntimeError):
+    """Some rank's production failed between an announcement and its record collective.  The failed rank still joins
+    the counts all-gather -- with -1 for its count -- and EVERY rank raises this right after it, at the same point of the
+    protocol: nobody is left waiting in the payload collective (or in the metric one behind it) for a rank that will
+    never arrive.  The failed rank re-raises its own error instead (DeviceReplayBuffer._fill_shared, Player.read,
+    actor_learner.serve_selfplay_ahead)."""
+
+
+def _gather_counts(n_local: int, dev: torch.device, failed: bool) -> List[int]:
+    world = dist.get_world_size()
+    counts_t = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts_t, torch.tensor([-1 if failed else int(n_local)], dtype=torch.int64, device=dev))
+    counts = [int(c) for c in counts_t.tolist()]
+    bad = [r for r, c in enumerate(counts) if c < 0]
+    if bad:
+        raise PeerFailed("self-play failed on rank%s %s: the production is abandoned on every rank"
+                         % ("s" if len(bad) > 1 else "", ", ".join(str(r) for r in bad)))
+    return counts
+
+
 @_data_collective
-def all_gather_records(rec: torch.Tensor) -> Tuple[List[torch.Tensor], List[int]]:
+def all_gather_records(rec: torch.Tensor, failed: bool = False) -> Tuple[List[torch.Tensor], List[int]]:
     """rec: uint8 [P, record_bytes] on the communication device (HBM under RCCL).  Two collectives:
     the per-rank counts, then the records padded to the largest count -- a direct all-gather over
     xGMI.  Returns the per-rank record tensors (views trimmed to their counts) and the counts, in rank
-    order; nothing touches the host except the W counts."""
+    order; nothing touches the host except the W counts.  `failed`: this rank has nothing to give because its
+    production raised -- every rank then raises PeerFailed after the counts."""
     world = dist.get_world_size()
     if rec.is_cuda and dist.get_backend() != "nccl":
         # functional fallback (tests, bench.py with AZX_BENCH_BACKEND=gloo): the CPU backend cannot gather
         # device tensors, so the records make a host round trip; RCCL gathers them in HBM
-        parts, counts = all_gather_records(rec.cpu())
+        parts, counts = all_gather_records(rec.cpu(), failed)
         return [p.to(rec.device) for p in parts], counts
     dev = rec.device
-    counts_t = torch.zeros(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts_t, torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev))
-    counts = [int(c) for c in counts_t.tolist()]
+    counts = _gather_counts(rec.shape[0], dev, failed)
     most = max(counts)
     if most == 0:
         return [rec[:0] for _ in range(world)], counts
@@ -118,20 +137,18 @@ def all_gather_records(rec: torch.Tensor) -> Tuple[List[torch.Tensor], List[int]
 
 
 @_data_collective
-def gather_records(rec: torch.Tensor, dst: int = 0) -> Tuple[List[torch.Tensor], List[int]]:
+def gather_records(rec: torch.Tensor, dst: int = 0, failed: bool = False) -> Tuple[List[torch.Tensor], List[int]]:
     """The actor / learner pull: only rank `dst` needs the records, so each rank SENDS its block to it -- over xGMI
     that is one point-to-point transfer per actor, each on its own link into `dst`, instead of an all-gather that
     lands every actor's rows on every other actor as well ((W - 1) x the bytes, and a W x buffer on ranks that drop
     it).  Same two collectives: the per-rank counts (all ranks learn the padding), then the padded blocks.  Returns
-    (per-rank record tensors, counts) on `dst` and ([], counts) elsewhere."""
+    (per-rank record tensors, counts) on `dst` and ([], counts) elsewhere.  `failed`: as in all_gather_records."""
     world = dist.get_world_size()
     if rec.is_cuda and dist.get_backend() != "nccl":          # gloo over device tensors (tests): a host round trip
-        parts, counts = gather_records(rec.cpu(), dst)
+        parts, counts = gather_records(rec.cpu(), dst, failed)
         return [p.to(rec.device) for p in parts], counts
     dev = rec.device
-    counts_t = torch.zeros(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts_t, torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev))
-    counts = [int(c) for c in counts_t.tolist()]
+    counts = _gather_counts(rec.shape[0], dev, failed)
     most = max(counts)
     me = dist.get_rank()
     if most == 0:
@@ -149,14 +166,14 @@ def gather_records(rec: torch.Tensor, dst: int = 0) -> Tuple[List[torch.Tensor],
     return [b[:c] for b, c in zip(blocks, counts)], counts
 
 
-def all_gather_rows(rows: Dict[str, np.ndarray], board_size: int) -> Dict[str, np.ndarray]:
+def all_gather_rows(rows: Dict[str, np.ndarray], board_size: int, failed: bool = False) -> Dict[str, np.ndarray]:
     """Host rows (Player.read's frame path): every rank contributes its rows -- possibly none -- and every
-    rank gets all rows, in rank order."""
+    rank gets all rows, in rank order.  `failed`: as in all_gather_records."""
     if not is_distributed():
         return rows
     cells = board_size * board_size
     local = torch.from_numpy(pack_rows(rows, cells)).to(_comm_device())
-    parts, _ = all_gather_records(local)
+    parts, _ = all_gather_records(local, failed)
     rec = torch.cat(parts).cpu().numpy() if parts else np.zeros((0, record_bytes(cells)), np.uint8)
     return unpack_rows(rec, board_size)
 
@@ -211,7 +228,11 @@ def control_group():
     control_group() call at the same point (train() does, right after the ranks split)."""
     global _control
     if _control is None:
-        _control = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+        if dist.get_backend() == "gloo":
+            _control = dist.group.WORLD
+        else:        # gloo's own timeout must not fire before ours (AZX_FOLLOW_TIMEOUT may exceed its 30 min default)
+            from datetime import timedelta
+            _control = dist.new_group(backend="gloo", timeout=timedelta(seconds=follow_timeout() + 300.0))
     return _control
 
 
@@ -270,7 +291,10 @@ class Pending:
                 raise LeaderLost("no announcement from rank 0 within %.0f s" % limit)
             time.sleep(pause)
             pause = min(0.01, pause * 2)
-        self.work.wait()
+        try:
+            self.work.wait()
+        except RuntimeError as exc:         # the control group itself failed (rank 0 died, gloo's own timeout)
+            raise LeaderLost("control group failed: %s" % exc) from exc
         op, arg = (int(x) for x in self.t.tolist())
         if op == OP_ABORT:
             raise LeaderLost("rank 0 aborted the run")

@@ -53,12 +53,13 @@ class Engine:
         t = np.ascontiguousarray(table, np.float32)
         check(self.L.azx_set_prior_table(self.h, _p(t, C.c_float), t.size))
 
-    def set_weights(self, tensors, on_device=False):
+    def set_weights(self, tensors, on_device=False, sync=True):
         """tensors: {state_dict name: contiguous fp32 numpy array} or {name: (ptr, count)}.
         `on_device`: the pointers are device memory of this GPU (torch tensors).  The engine copies them through its
         own HIP runtime, which knows nothing of torch's streams, so whatever last wrote them -- an optimizer step
-        still in flight, a graph replay -- is waited for here."""
-        if on_device:
+        still in flight, a graph replay -- is waited for here (`sync=False`: the caller has already waited for the
+        writer, e.g. on an event; play_ahead.PlayAhead)."""
+        if on_device and sync:
             import torch
             torch.cuda.synchronize(self.cfg.device)
         names, ptrs, counts, keep = [], [], [], []
@@ -349,6 +350,18 @@ class Engine:
     def replay_put_records(self, n, records_ptr):
         """n records from a device buffer into the replay ring (FIFO)."""
         check(self.L.azx_replay_put_records(self.h, int(n), C.c_void_p(int(records_ptr))))
+
+    def replay_put_records_async(self, n, records_ptr, stream):
+        """The same put enqueued on `stream` (a hipStream_t value) and not synchronised: the one engine call that may
+        run on another host thread than a play in progress (include/azx.h)."""
+        check(self.L.azx_replay_put_records_async(self.h, int(n), C.c_void_p(int(records_ptr)), C.c_void_p(int(stream))))
+
+    def reserve_cus(self, cus_per_xcd):
+        """Keep `cus_per_xcd` CUs of every XCD (rounded up to 4: one per shader engine) free of this engine's kernels;
+        0 = use all.  Returns the CUs left free on the whole device."""
+        out = C.c_int(0)
+        check(self.L.azx_reserve_cus(self.h, int(cus_per_xcd), C.byref(out)))
+        return out.value
 
     @property
     def record_bytes(self):

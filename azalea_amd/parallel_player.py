@@ -97,19 +97,28 @@ class Player:
         quota = azdist.shard_quota(size) if shared else size
         rows_list, metrics = [], defaultdict(float)
         have, barren = 0, 0
-        while have < quota:
-            if not self._games:
-                self._produce(quota - have)
+        failure = None
+        try:
+            while have < quota:
                 if not self._games:
-                    barren += 1
-                    if barren > self.MAX_BARREN_PRODUCTIONS:
-                        raise RuntimeError("self-play produced no finished game in %d attempts" % barren)
-                    continue
-            rows, gm = self._games.popleft()
-            rows_list.append(rows)
-            have += len(rows["reward"])
-            for name, v in gm.items():
-                metrics[name] += v
+                    self._produce(quota - have)
+                    if not self._games:
+                        barren += 1
+                        if barren > self.MAX_BARREN_PRODUCTIONS:
+                            raise RuntimeError("self-play produced no finished game in %d attempts" % barren)
+                        continue
+                rows, gm = self._games.popleft()
+                rows_list.append(rows)
+                have += len(rows["reward"])
+                for name, v in gm.items():
+                    metrics[name] += v
+        except Exception as exc:
+            if not shared:
+                raise
+            # the other ranks are on their way into this read's record collectives: join the first one with the
+            # failure mark so that every rank leaves it (distributed.PeerFailed), then raise what happened here
+            failure = exc
+            rows_list = []
         if self._skipped:
             metrics["game_error"] += self._skipped
             self._skipped = 0
@@ -119,7 +128,12 @@ class Player:
         else:
             rows = azdist.empty_rows(n)       # quota 0 (size < world): still join the collectives
         if shared:
-            rows = azdist.all_gather_rows(rows, n)
+            try:
+                rows = azdist.all_gather_rows(rows, n, failed=failure is not None)
+            except azdist.PeerFailed:
+                if failure is not None:
+                    raise failure
+                raise
             metrics = azdist.all_reduce_metrics(dict(metrics))
         return rows_to_frame(rows), dict(metrics)
 

@@ -7,6 +7,7 @@ checkpoints in the reference schema) and can keep the replay buffer in HBM
 (`device_replay=True`: DeviceReplayBuffer, minibatches collated on the GPU); logging goes through
 `logging` instead of the reference's tensorboard monitor, which is out of scope.
 """
+import contextlib
 import logging
 import os
 import time
@@ -345,6 +346,9 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
     # runs inside try: a failure -- a train step outside its envelope, AZX_ERANGE from a refill, SearchTreeFull, an
     # out-of-memory -- is announced (OP_ABORT) so that the other ranks leave instead of waiting in a broadcast
     learner = None
+    ahead = None
+    side = None
+    stream_ctx = None
     try:
         if mode == "actor_learner":
             from .actor_learner import Learner
@@ -370,6 +374,26 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
             batches = lambda: iter(loader)
         if learner is not None:
             learner.sync_weights()         # the actors start playing with rank 0's network, whatever they were built with
+        if config.get("selfplay_overlap"):
+            # one GPU, one process: self-play runs WHILE the steps run (azalea_amd/play_ahead.py) -- a host thread keeps
+            # the engine playing into a bounded backlog on a CU mask that leaves some CUs free, the steps run on a
+            # high-priority stream and `consume` only waits when the backlog is short (process_pool.py:29-47 +
+            # replay_buffer.py:121-132).  Not deterministic; the inline refill (the default) is.
+            if shared or not device_replay or device.type != "cuda":
+                raise ValueError("selfplay_overlap needs device_replay=True on one CUDA (ROCm) device, one process")
+            from .play_ahead import PlayAhead
+            ahead = PlayAhead(player, replaybuf.engine, ahead_rows=config.get("selfplay_ahead_rows"),
+                              weight_sync_steps=config.get("weight_sync_steps", 50),
+                              poll_plies=config.get("selfplay_poll_plies", 1),
+                              reserve_cus=config.get("selfplay_reserve_cus", 4))
+            replaybuf.ahead = ahead
+            ahead.start()
+            side = torch.cuda.Stream(device, priority=-1)
+            side.wait_stream(torch.cuda.current_stream(device))
+            if history is not None:
+                history["selfplay_overlap"] = True
+        stream_ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+        stream_ctx.__enter__()
         loss_dev = None
         loss, step, start_time = 0.0, 0, time.time()
         for epoch in range(1, config["total_epochs"] + 1):
@@ -402,6 +426,8 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
                         loss += loss_
                 if learner is not None:
                     learner.after_step()
+                if ahead is not None:
+                    ahead.after_step()
                 replaybuf.consume(batch_size / oversampling, player)
                 if config.get("log_interval") and step % config["log_interval"] == 0:
                     if loss_dev is not None:
@@ -412,13 +438,27 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
                 if config.get("model_checkpoint_interval") and step % config["model_checkpoint_interval"] == 0:
                     save_checkpoint(policy, "%s/checkpoints/checkpoint.%d" % (rundir, step), optimizer=optimizer)
                 step += 1
+        stream_ctx.__exit__(None, None, None)
+        stream_ctx = None
+        if side is not None:
+            torch.cuda.current_stream(device).wait_stream(side)
     except BaseException:
+        if stream_ctx is not None:
+            stream_ctx.__exit__(None, None, None)
+        if ahead is not None:
+            ahead.stop()
+            replaybuf.ahead = None
         if shared:
             try:
                 azdist.abort()
             except Exception:               # the control group itself is gone: the followers' timeout ends them
                 logging.exception("could not announce the abort")
         raise
+    if ahead is not None:
+        ahead.stop()
+        replaybuf.ahead = None
+        if history is not None:
+            history["play_ahead"] = ahead.counters()
     if history is not None and learner is not None:
         history["learner"] = dict(steps=learner.steps, pulls=learner.pulls, weight_syncs=learner.weight_syncs)
     if learner is not None:

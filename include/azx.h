@@ -86,7 +86,8 @@ typedef struct {
 typedef struct azx_engine azx_engine;
 
 const char *azx_last_error(void);
-int azx_version(void);            /* ABI revision: 5 = AZX_ERANGE, azx_debug_weights, weights packed on the device
+int azx_version(void);            /* ABI revision: 6 = azx_reserve_cus, azx_replay_put_records_async (self-play beside training);
+                                   * 5 = AZX_ERANGE, azx_debug_weights, weights packed on the device
                                    * (4 = 8-float row metrics, azx_kernel_info, azx_debug_set_queue_cap;
                                    *  3 = azx_config.game_index_*, azx_play_stats.sum_game_length) */
 
@@ -276,6 +277,19 @@ int azx_rows_pack(azx_engine *e, int64_t first, int64_t n, void *records_dev);
 /* ReplayBuffer.put of n records held in a DEVICE buffer: FIFO with the wrap-around / overflow behaviour
  * of azx_replay_put.  Blocking. */
 int azx_replay_put_records(azx_engine *e, int64_t n, const void *records_dev);
+/* The same put ENQUEUED on the caller's stream (a hipStream_t) and not synchronised: ordered with the
+ * azx_replay_collate_async reads and the training step on that stream, and independent of the engine's own stream --
+ * so a trainer thread can take rows into the ring while another host thread is inside azx_play_device on the same
+ * handle (the one pairing of concurrent calls a handle allows; play-ahead self-play, replay_buffer.py:121-132 over
+ * process_pool.py:29-47).  records_dev must stay valid until the stream has passed this point. */
+int azx_replay_put_records_async(azx_engine *e, int64_t n, const void *records_dev, void *hip_stream);
+/* Leave `cus_per_xcd` compute units of every XCD free of this engine's kernels (0 = use all): the engine's streams are
+ * re-made with a CU mask (hipExtStreamCreateWithCUMask), so a training step on another stream finds empty CUs at
+ * once instead of queueing behind resident tower blocks.  Rounded up to a multiple of 4: an XCD deals workgroups
+ * round-robin to its 4 shader engines, so taking CUs from fewer than all of them costs the same throughput as taking
+ * one from each (tools/microbench/cu_mask.hip).  Call between plays (the streams are drained).  *reserved_out = CUs
+ * actually left free on the whole device. */
+int azx_reserve_cus(azx_engine *e, int cus_per_xcd, int *reserved_out);
 
 /* prep.batch_replays of the rows `indices[0..batch)` (host array; each < rows held) into DEVICE
  * buffers with row stride board_size^2: color i64[batch], legal_moves i32[batch][cells] (ascending

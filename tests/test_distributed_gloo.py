@@ -698,3 +698,82 @@ def _pull_ring_worker(rank, world, port, out):
     out[rank] = fails
     azd_reset()
     dist.destroy_process_group()
+
+
+# ---- a production that fails AFTER its announcement: carried through the counts collective ---------------
+
+class FailingActorEngine(ActorEngine):
+    """ActorEngine whose `fail_rank`'s `fail_call`-th production raises (AZX_ERANGE / a full arena / a HIP error)."""
+    fail_rank, fail_call = None, 4
+
+    def play_device(self, min_positions, max_plies=0):
+        self.calls = getattr(self, "calls", 0) + 1
+        if dist.get_rank() == self.fail_rank and self.calls == self.fail_call:
+            raise RuntimeError("injected self-play failure")
+        return super().play_device(min_positions, max_plies)
+
+
+def _production_failure_worker(rank, world, port, rundir, mode, fail_rank, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["AZX_FOLLOW_TIMEOUT"] = "60"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+    from azalea_amd import distributed as azd
+    from azalea_amd import parallel_player as pp
+    from azalea_amd import policy_trainer as pt
+    real = pp._eng.Engine
+    FailingActorEngine.fail_rank = fail_rank
+    raised = None
+    t0 = time.monotonic()
+    try:
+        if mode == "actor_learner":
+            pp._eng.Engine = FailingActorEngine
+            cfg = dict(_train_config(), total_epochs=40, weight_sync_steps=3, selfplay_ahead_rows=40)
+            del cfg["selfplay_mode"]
+            pt.train(_policy(100 + rank), cfg, rundir)
+        else:
+            # lock-step device refill, without train(): rank 0 announces, every rank plays its share -- one of them fails
+            from azalea_amd.device_replay import DeviceReplayBuffer
+            azd.control_group()
+            E = StubEngine(4, seed=50 + rank)
+            real_play = E.play_device
+            calls = [0]
+
+            def play(min_positions, max_plies=0):
+                calls[0] += 1
+                if rank == fail_rank and calls[0] == 2:
+                    raise RuntimeError("injected self-play failure")
+                return real_play(min_positions, max_plies)
+            E.play_device = play
+            buf = DeviceReplayBuffer(E, capacity=500)
+            for _ in range(3):
+                if rank == 0:
+                    azd.lead(azd.OP_REFILL, 40)
+                else:
+                    op, arg = azd.follow(30)
+                    assert (op, arg) == (azd.OP_REFILL, 40)
+                buf.consume(40)
+                buf.fresh_counter = 0
+    except Exception as exc:                           # noqa: BLE001
+        raised = exc
+    finally:
+        pp._eng.Engine = real
+    took = time.monotonic() - t0
+    # the failed rank raises ITS error; every other rank leaves the counts collective with PeerFailed, at once
+    want = RuntimeError if rank == fail_rank else azd.PeerFailed
+    ok = isinstance(raised, want) and (rank != fail_rank or "injected" in str(raised)) and took < 45
+    out[rank] = [] if ok else [800 + rank, repr(raised), took]
+    azd_reset()
+    dist.destroy_process_group()
+
+
+def test_a_failed_production_is_carried_through_the_counts_collective(tmp_path):
+    """rank 0 announces a refill and then ITS share fails (AZX_ERANGE, SearchTreeFull ...) -- the
+    followers are already on their way into the record all-gather and would wait there for the RCCL watchdog.  The
+    failed rank joins the counts collective with -1 and every rank raises distributed.PeerFailed right after it; the
+    same when a follower's share fails, and when an actor's production fails between two pulls of an actor / learner
+    run (the learner's next pull raises PeerFailed, the healthy actor too, the failed actor its own error)."""
+    for mode, world, fail_rank in (("lockstep", 2, 0), ("lockstep", 3, 2), ("actor_learner", 3, 2)):
+        out = _spawn(_production_failure_worker, world, str(tmp_path / ("%s_%d" % (mode, fail_rank))), mode, fail_rank)
+        assert out == {r: [] for r in range(world)}, (mode, fail_rank, out)

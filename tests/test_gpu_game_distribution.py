@@ -149,7 +149,10 @@ def compare_with_oracle(tag, tmp_path, n, sims, games, plies, min_games, cfg, se
         e["first_wins"].mean(), a["first_wins"].mean(), b["first_wins"].mean()))
     # every statistic the oracle's games have is tested on the engine's (entropy: below the depth, where the rows carry it)
     assert len(res) >= len(same) - sum(p >= cfg["depth"] for p in plies) and len(res) >= 50
-    assert gs.worst(same)[1] > gs.P_MIN, gs.worst(same)
+    # calibration: the oracle against itself.  Over ~90 tests the smallest of that many uniform p-values is below 1e-3
+    # nine times in a hundred (the 11h pair of seeds: entropy@3 at 6.6e-4, the engine's own worst 0.013), so it is held to
+    # the family-wise 5 % bound; the engine is held to the fixed, stricter-per-test P_MIN
+    assert gs.worst(same)[1] > min(gs.P_MIN, 0.05 / len(same)), gs.worst(same)
     bad = {k: v for k, v in res.items() if v <= gs.P_MIN}
     assert not bad, bad
     # ... and no drift too small for any single test: the count of p < 0.05 stays binomial (99.9 % quantile)

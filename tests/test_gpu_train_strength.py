@@ -2,7 +2,7 @@
 `policy_trainer.train` on one GPU -- self-play in throughput mode, the HBM replay ring, the hand-written training step,
 the device weight refresh -- makes a network that beats the network it started from.  7x7, 4x32, 100 simulations,
 40 epochs over a 60 000-row buffer (18 760 steps, ~25 s), with the reference's batches and with
-config["train_mover_view"]; `tools/train_to_strength.py` is the same run with knobs, and
+config["train_mover_view"], and with config["selfplay_overlap"] (self-play beside the steps); `tools/train_to_strength.py` is the same run with knobs, and
 profiles/r5_train_to_strength.json holds its longer runs (7x7: 400 of 400 games after 57 s; 11x11 6x64 at the
 reference's hyper-parameters: 137 of 200 after 4.5 minutes, loss 5.2 -> 2.2)."""
 import os
@@ -16,17 +16,23 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mover_view", [False, True])
-def test_training_makes_a_stronger_player(mover_view):
+@pytest.mark.parametrize("mover_view,overlap", [(False, False), (True, False), (False, True)])
+def test_training_makes_a_stronger_player(mover_view, overlap):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         import train_to_strength as tts
     finally:
         sys.path.pop(0)
     args = SimpleNamespace(board=7, blocks=4, chans=32, sims=100, c=1.0, depth=6, alpha=0.3, epochs=40, replay=60000,
-                           oversampling=4.0, games=1024, lr=0.05, rounds=150, seed=3, log_interval=4000, mover_view=mover_view, checkpoints=0, curve_rounds=0, world=1, vs_shipped=False, lr_decay=0.1, lr_decay_epochs=0)
+                           oversampling=4.0, games=1024, lr=0.05, rounds=150, seed=3, log_interval=4000, mover_view=mover_view, overlap=overlap, weight_sync_steps=50, checkpoints=0, curve_rounds=0, world=1, vs_shipped=False, lr_decay=0.1, lr_decay_epochs=0)
     out = tts.run(args)
     assert out["train_step"] == "native"
+    if overlap:      # config["selfplay_overlap"]: self-play ran beside the steps (azalea_amd/play_ahead.py), with fresh weights
+        pa = out["play_ahead"]
+        assert pa["productions"] > 50 and pa["weight_syncs"] > 20 and pa["reserved_cus"] == 32 and pa["takes"] > 5
+        assert pa["max_backlog_rows"] < 2 * 1024 + 49 * 1024 // 8      # the bound: ahead_rows + about one harvest
+    else:
+        assert out["play_ahead"] is None
     losses = [row[1] for row in out["loss_by_step"]]
     assert losses[-1] < losses[0] - 0.05, losses                # the network follows its self-play targets
     old, draws, new = out["tally_untrained_draw_trained"]

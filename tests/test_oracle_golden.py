@@ -301,3 +301,31 @@ def test_oracle_game_sampler_replays_the_reference_games_g11(tag):
             assert np.array_equal(got[k][g, :L], z[k + "_" + tag][g, :L].astype(np.float32)), (k, g)
         for k in ("mean_visits", "search_value", "action_prob"):
             assert np.array_equal(got[k][g, :L].view(np.uint32), z[k + "_" + tag][g, :L].view(np.uint32)), (k, g)
+
+
+def test_oracle_network_games_fixture_g13_is_what_the_sampler_plays():
+    """G13 (tests/golden/make_oracle_net_games.py): the oracle's 2 x 256 whole games with its fp32 6x64 network at the
+    headline's hyper-parameters, the reference side of the GPU test of the headline's kernels.  The fixture is ORACLE
+    output, recorded because it costs ~20 core-minutes; the first game of each half is replayed here live -- same moves,
+    same per-ply columns at the plies the fixture keeps -- so the file cannot drift from tests/oracle_games.py (which G11
+    holds to the reference's own games at these hyper-parameters, uniform evaluator)."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    try:
+        import make_oracle_net_games as mk
+    finally:
+        sys.path.pop(0)
+    import oracle_games as og
+    z = np.load(os.path.join(GOLDEN, "g13_oracle_net_games_11h.npz"))
+    assert (int(z["n"]), int(z["sims"]), int(z["games"])) == (mk.N, mk.SIMS, mk.GAMES)
+    assert all(float(z["cfg_" + k]) == float(v) for k, v in mk.CFG.items()) and z["plies"].tolist() == mk.PLIES
+    cfg = mk.config(mk.weights_file())
+    got = og.sample(cfg, [mk.SEED0["a"], mk.SEED0["b"]], procs=2)
+    for i, half in enumerate(("a", "b")):
+        L = int(got["length"][i])
+        assert L == int(z["length_" + half][0]) and int(got["first_wins"][i]) == int(z["first_wins_" + half][0])
+        assert np.array_equal(got["moves"][i], z["moves_" + half][0])
+        for c in og.COLUMNS:
+            want, have = z[c + "_" + half][0], got[c][i][mk.PLIES]
+            assert np.array_equal(np.isnan(want), np.isnan(have)), (c, half)
+            assert np.array_equal(want[~np.isnan(want)].view(np.uint32), have[~np.isnan(have)].view(np.uint32)), (c, half)

@@ -6,8 +6,12 @@ the refills played inline (DeviceReplayBuffer.consume), and the same steps witho
 step (NativeTrainStep) and with the stock kernels captured as a HIP graph (GraphedTrainStep).
 Reports steps/s and the rows the refills brought.  (Round 3 also measured the refills played UNDER the steps by a
 background thread on a second engine handle: 344.7 vs 339.6 steps/s, profiles/r3_train_loop_bench.json -- the tower
-fills every CU's registers and LDS, so the training kernels queue behind its blocks; that variant was removed.)
-    python tools/bench_train_loop.py [--steps 1200] [--games 4096] [--sims 400]"""
+fills every CU's registers and LDS, so the training kernels queue behind its blocks.)  Round 6: `overlapped` -- the
+play-ahead mode of azalea_amd/play_ahead.py: a host thread keeps the engine playing into a bounded backlog on a CU mask
+that leaves `--reserve-cus` CUs of every XCD free, the steps run on a high-priority stream beside it and `consume` takes
+chunks out of the backlog, waiting only when it is short.
+    python tools/bench_train_loop.py [--steps 1200] [--games 4096] [--sims 400] [--modes inline,steps,overlapped]
+                                     [--reserve-cus 4] [--priority high|normal]"""
 import argparse
 import json
 import os
@@ -51,21 +55,44 @@ def run(mode, args, step_kind="native"):
     gs = (NativeTrainStep if step_kind == "native" else GraphedTrainStep)(policy.net, opt, B, torch.device(dev))
     refills, rows = [], 0
     order = np.random.RandomState(0).randint(0, len(buf), (args.steps + 20, B))
-    for i in range(args.steps + 20):
-        if i == 20:
+    ahead, ctx = None, None
+    if mode == "overlapped":
+        from azalea_amd.play_ahead import PlayAhead
+        ahead = PlayAhead(player, E, ahead_rows=args.ahead_rows or None, weight_sync_steps=args.weight_sync_steps,
+                          reserve_cus=args.reserve_cus)
+        buf.ahead = ahead
+        ahead.start()
+        side = torch.cuda.Stream(dev, priority=-1 if args.priority == "high" else 0)
+        side.wait_stream(torch.cuda.current_stream())
+        ctx = torch.cuda.stream(side)
+        ctx.__enter__()
+    warm = 20 if mode != "overlapped" else 400          # overlapped: past the first takes, the backlog in its steady state
+    waits0 = 0.0
+    for i in range(args.steps + warm):
+        if i == warm:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             refills, rows = [], 0
-        gs.step_from_ring(buf, order[i] % len(buf))
-        m = buf.consume(B / 10.0, player) if mode == "inline" else None
+            waits0 = ahead.stats["wait_seconds"] if ahead else 0.0
+        gs.step_from_ring(buf, order[i % len(order)] % len(buf))
+        if ahead is not None:
+            ahead.after_step()
+        m = buf.consume(B / 10.0, player) if mode in ("inline", "overlapped") else None
         if m:
             refills.append(time.perf_counter())
             rows += int(m["moves_per_game"])
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    player.stop()
     out = {"mode": mode, "step": step_kind, "steps": args.steps, "seconds": t1 - t0, "steps_per_sec": args.steps / (t1 - t0),
            "refills": len(refills), "rows_refilled": rows}
+    if ahead is not None:
+        ctx.__exit__(None, None, None)
+        ahead.stop()
+        buf.ahead = None
+        c = ahead.counters()
+        out.update({"play_ahead": c, "wait_share": (c["wait_seconds"] - waits0) / (t1 - t0), "reserve_cus_per_xcd": args.reserve_cus,
+                    "priority": args.priority})
+    player.stop()
     return out
 
 
@@ -75,14 +102,27 @@ def main():
     ap.add_argument("--games", type=int, default=4096)
     ap.add_argument("--sims", type=int, default=400)
     ap.add_argument("--fill", type=int, default=60000, help="rows of the untimed initial fill")
+    ap.add_argument("--modes", default="inline,steps,overlapped,inline_graph,steps_graph")
+    ap.add_argument("--reserve-cus", type=int, default=4, help="overlapped: CUs of every XCD the engine leaves free")
+    ap.add_argument("--priority", choices=["high", "normal"], default="high", help="overlapped: the training stream's priority")
+    ap.add_argument("--ahead-rows", type=int, default=0, help="overlapped: backlog bound (default: one row per pool slot)")
+    ap.add_argument("--weight-sync-steps", type=int, default=50)
     args = ap.parse_args()
-    res = [run("inline", args, "native"), run("steps only", args, "native"),
-           run("inline", args, "hip_graph"), run("steps only", args, "hip_graph")]
-    print(json.dumps({"what": "training step (batch 128; hand-written / stock kernels captured as a HIP graph) + consume(12.8) per "
-                              "step; 6x64 resnet self-play, %d games, %d sims" % (args.games, args.sims), "runs": res,
-                      "selfplay_share_of_loop_native": 1.0 - res[0]["steps_per_sec"] / res[1]["steps_per_sec"],
-                      "selfplay_share_of_loop_hip_graph": 1.0 - res[2]["steps_per_sec"] / res[3]["steps_per_sec"],
-                      "loop_speedup_native_vs_hip_graph": res[0]["steps_per_sec"] / res[2]["steps_per_sec"]}))
+    table = {"inline": ("inline", "native"), "steps": ("steps only", "native"), "overlapped": ("overlapped", "native"),
+             "inline_graph": ("inline", "hip_graph"), "steps_graph": ("steps only", "hip_graph")}
+    res = {m: run(table[m][0], args, table[m][1]) for m in args.modes.split(",")}
+    out = {"what": "training step (batch 128; hand-written / stock kernels captured as a HIP graph) + consume(12.8) per "
+                   "step; 6x64 resnet self-play, %d games, %d sims" % (args.games, args.sims), "runs": list(res.values())}
+    sps = {m: r["steps_per_sec"] for m, r in res.items()}
+    if "inline" in sps and "steps" in sps:
+        out["selfplay_share_of_loop_native"] = 1.0 - sps["inline"] / sps["steps"]
+    if "inline_graph" in sps and "steps_graph" in sps:
+        out["selfplay_share_of_loop_hip_graph"] = 1.0 - sps["inline_graph"] / sps["steps_graph"]
+    if "inline" in sps and "inline_graph" in sps:
+        out["loop_speedup_native_vs_hip_graph"] = sps["inline"] / sps["inline_graph"]
+    if "inline" in sps and "overlapped" in sps:
+        out["overlap_speedup"] = sps["overlapped"] / sps["inline"]
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

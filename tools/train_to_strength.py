@@ -92,6 +92,8 @@ def run(args):
     t0 = time.perf_counter()
     if args.world > 1:
         config.update(selfplay_mode=args.selfplay_mode, weight_sync_steps=args.weight_sync_steps)
+    if getattr(args, "overlap", False):        # self-play beside the steps on this one GPU (azalea_amd/play_ahead.py)
+        config.update(selfplay_overlap=True, weight_sync_steps=args.weight_sync_steps)
     train(policy, config, rundir, device_replay=True, history=history)
     torch.cuda.synchronize()
     secs = time.perf_counter() - t0
@@ -151,7 +153,8 @@ def run(args):
             "loss_by_step": losses.rows[1:],          # [step, mean loss over the interval, steps/s incl. self-play]
             "tally_untrained_draw_trained": [w_old, draws, w_new], "trained_win_rate": w_new / max(1, games),
             "trained_elo_over_start": elo, "elo_curve": curve, "vs_shipped_model": shipped,
-            "world": args.world, "selfplay_mode": history.get("selfplay_mode"), "learner": history.get("learner")}
+            "world": args.world, "selfplay_mode": history.get("selfplay_mode"), "learner": history.get("learner"),
+            "play_ahead": history.get("play_ahead")}
 
 
 def main():
@@ -177,6 +180,7 @@ def main():
     ap.add_argument("--lr-decay", type=float, default=0.1)
     ap.add_argument("--lr-decay-epochs", type=int, default=0, help="StepLR period in epochs (default: only the last epoch decays)")
     ap.add_argument("--mover-view", action="store_true", help="config['train_mover_view']: not the reference's batches")
+    ap.add_argument("--overlap", action="store_true", help="config['selfplay_overlap']: self-play runs while the steps run")
     ap.add_argument("--world", type=int, default=1)
     ap.add_argument("--selfplay-mode", default="actor_learner")
     ap.add_argument("--weight-sync-steps", type=int, default=50)
