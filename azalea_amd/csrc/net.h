@@ -35,9 +35,9 @@ int azx_net_forward_host(AzxNet *net, int B, int K, const int32_t *boards,
 int azx_net_wide_train_conv(int N, int C, const unsigned short *w16, const unsigned short *in, float *out32, int n_boards,
                             const float *unscale, float2 *stat, hipStream_t st);
 // The backward-data convolution of the same step with the next elementwise pass fused into its epilogue: writes
-// g_{l-1} = (conv^T product [+ skip]) masked by act_{l-1} > 0, this board's (sum g, sum g xhat_{l-1}) pairs to pgsum
+// g_{l-1} = (conv^T product [+ skip]) masked by act_{l-1} > 0 (`mask`: one bit per element, [boards][cells][C / 8] bytes, k_tw_bnact's), this board's (sum g, sum g xhat_{l-1}) pairs to pgsum
 // [boards][C] (xhat from raw_{l-1} and BN_{l-1}'s batch sums `sums` [C][4 doubles], invN = 1 / (boards x cells)) and
 // max |g| into *gmax (atomicMax on the float's bits).
 int azx_net_wide_train_conv_bwd(int N, int C, const unsigned short *w16, const unsigned short *in, float *g_out, int n_boards,
-                                const float *unscale, float2 *pgsum, const float *act, const float *raw, const float *skip,
+                                const float *unscale, float2 *pgsum, const unsigned char *mask, const float *raw, const float *skip,
                                 const double *sums, float invN, unsigned int *gmax, hipStream_t st);

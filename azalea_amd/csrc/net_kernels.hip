@@ -626,7 +626,9 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
 // TRAIN = 2: the backward-data convolution with the step's next elementwise pass in its epilogue (WideBwdFuse): the product
 // is dL/dact_{l-1}; what is written is g_{l-1} = (product [+ skip]) where act_{l-1} > 0, else 0; `stat` receives this
 // board's (sum g, sum g xhat_{l-1}) per channel (xhat from raw_{l-1} and BN_{l-1}'s batch sums) and *gmax max |g|.
-struct WideBwdFuse { const float *act, *raw, *skip; const double *sums; float invN; unsigned int *gmax; };
+// (`mask`: act_{l-1} > 0 as one bit per element, a byte per 8 consecutive channels -- 0.7 MB per layer at 19x256 / 13x13 /
+// B = 128 where the fp32 activations were a 22 MB read)
+struct WideBwdFuse { const unsigned char *mask; const float *raw, *skip; const double *sums; float invN; unsigned int *gmax; };
 // NTW = 16-channel tiles per wave: 4 (a block = board x 128 channels: the inference decomposition) or, TRAIN only, 2 (a
 // block = board x 64 channels).  A training batch of 128 boards is 256 of the former -- one workgroup per CU, one wave per
 // SIMD, nobody to run while a block stages its next chunk -- and 512 of the latter: two independent workgroups per CU, the
@@ -929,7 +931,8 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
         // the join -- six memory round trips at the end of a kernel that has nothing left to hide them under.
 #pragma unroll
         for (int m0 = 0; m0 < MT; m0 += 3) {
-            float4 ea[3][NP][2], er[3][NP][2], ek[3][NP][2];
+            float4 er[3][NP][2], ek[3][NP][2];
+            unsigned int ea[3][NP];
             if (TRAIN == 2) {
 #pragma unroll
                 for (int mm = 0; mm < 3; ++mm)
@@ -937,8 +940,7 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
                     for (int np = 0; np < NP; ++np) {
                         const int rc = min(row0 + 16 * (m0 + mm) + lrow, ncells - 1);
                         const size_t o = ((size_t)e * ncells + rc) * C + chan0(np);
-                        ea[mm][np][0] = *reinterpret_cast<const float4 *>(F.act + o);
-                        ea[mm][np][1] = *reinterpret_cast<const float4 *>(F.act + o + 4);
+                        ea[mm][np] = F.mask[o >> 3];
                         er[mm][np][0] = *reinterpret_cast<const float4 *>(F.raw + o);
                         er[mm][np][1] = *reinterpret_cast<const float4 *>(F.raw + o + 4);
                         if (F.skip) {        // (wave-uniform: a kernel argument)
@@ -961,14 +963,15 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
                         const size_t o = ((size_t)e * ncells + r) * C + chan0(np);
                         float vv[8];
                         if (TRAIN == 2) {
-                            const float4 a0 = ea[mm][np][0], a1 = ea[mm][np][1], r0 = er[mm][np][0], r1 = er[mm][np][1];
+                            const float4 r0 = er[mm][np][0], r1 = er[mm][np][1];
                             const float4 k0 = ek[mm][np][0], k1 = ek[mm][np][1];
-                            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+                            const unsigned int bits = ea[mm][np];
+                            const float rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
                             const float kv[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
                                 const bool ok = (j >> 2) ? ok1 : ok0;
-                                vv[j] = av[j] > 0.f ? acc[m][2 * np + (j >> 2)][j & 3] * unscale + kv[j] : 0.f;
+                                vv[j] = ((bits >> j) & 1u) ? acc[m][2 * np + (j >> 2)][j & 3] * unscale + kv[j] : 0.f;
                                 if (ok) {
                                     vmax = fmaxf(vmax, fabsf(vv[j]));
                                     s1[np][j] += vv[j];
@@ -1103,7 +1106,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_train_bwd(int N, int C, co
 // 73 vs 61-64 us forward, 10.8-11.0 vs 10.4-10.6 ms per step, and was removed)
 
 int azx_net_wide_train_conv_bwd(int N, int C, const unsigned short *w16, const unsigned short *in, float *g_out, int n_boards,
-                                const float *unscale, float2 *pgsum, const float *act, const float *raw, const float *skip,
+                                const float *unscale, float2 *pgsum, const unsigned char *mask, const float *raw, const float *skip,
                                 const double *sums, float invN, unsigned int *gmax, hipStream_t st) {
     static bool raised = false;
     const size_t lds = (size_t)(N * N + 2) * WIDE_ROWB;
@@ -1112,7 +1115,7 @@ int azx_net_wide_train_conv_bwd(int N, int C, const unsigned short *w16, const u
             return AZX_EHIP;
         raised = true;
     }
-    const WideBwdFuse F = {act, raw, skip, sums, invN, gmax};
+    const WideBwdFuse F = {mask, raw, skip, sums, invN, gmax};
     hipLaunchKernelGGL(k_conv_wide_train_bwd<2>, dim3(8 * (C / 64), (n_boards + 7) / 8), dim3(256), lds, st, N, C, w16, in, g_out, n_boards, unscale, pgsum, F);
     return AZX_OK;
 }

@@ -1885,7 +1885,7 @@ __global__ __launch_bounds__(256) void k_trn_prep(TrnDev P) {
 int azx_net_wide_train_conv(int N, int C, const unsigned short *w16, const unsigned short *in, float *out32, int n_boards,
                             const float *unscale, float2 *stat, hipStream_t st);      // net_kernels.hip
 int azx_net_wide_train_conv_bwd(int N, int C, const unsigned short *w16, const unsigned short *in, float *g_out, int n_boards,
-                                const float *unscale, float2 *pgsum, const float *act, const float *raw, const float *skip,
+                                const float *unscale, float2 *pgsum, const unsigned char *mask, const float *raw, const float *skip,
                                 const double *sums, float invN, unsigned int *gmax, hipStream_t st);
 
 // per-layer scales (the narrow path makes them in k_trn_stem_fwd): filter scale from k_trn_prep's per-block maxima,
@@ -2012,7 +2012,8 @@ __device__ __forceinline__ void tw_slice_totals(const float2 *part, int B, int C
     }
 }
 
-struct TwAct { const float *raw, *skip, *bnw, *bnb; const float2 *pstat; double *sums; float *act; unsigned short *img; const float4 *fsc; int presum; };
+struct TwAct { const float *raw, *skip, *bnw, *bnb; const float2 *pstat; double *sums; float *act; unsigned short *img; const float4 *fsc; int presum;
+               unsigned char *mask; };      // [B][cells][C / 8]: bit j of a byte = (act of channel 8 k + j) > 0, all the backward pass reads of act_l
 __global__ __launch_bounds__(256) void k_tw_bnact(TwAct A, int cells, int C, int B, float invN) {
     __shared__ float cA[64], cB[64];
     __shared__ double2 sh[256];
@@ -2039,10 +2040,12 @@ __global__ __launch_bounds__(256) void k_tw_bnact(TwAct A, int cells, int C, int
         if (A.skip) { s0 = *reinterpret_cast<const float4 *>(A.skip + o); s1 = *reinterpret_cast<const float4 *>(A.skip + o + 4); }
         const float x[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w}, k[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
         float v[8], vs[8];
+        unsigned int bits = 0u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { v[j] = fmaxf(x[j] * cA[cl + j] + cB[cl + j] + k[j], 0.f); vs[j] = v[j] * sa; }
+        for (int j = 0; j < 8; ++j) { v[j] = fmaxf(x[j] * cA[cl + j] + cB[cl + j] + k[j], 0.f); vs[j] = v[j] * sa; bits |= (v[j] > 0.f ? 1u : 0u) << j; }
         *reinterpret_cast<float4 *>(A.act + o) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4 *>(A.act + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        if (A.mask) A.mask[o >> 3] = (unsigned char)bits;
         if (A.img) image_store(A.img, (size_t)b * cells + pos, C, c, vs);
     }
 }
@@ -2444,6 +2447,7 @@ struct AzxTrain {
     std::vector<unsigned short *> Ww16f, Ww16b, A16;       // per layer: the wide filter packs, the activations' images
     unsigned short **Ww16f_dev = nullptr, **Ww16b_dev = nullptr;
     std::vector<unsigned short *> D16;                      // per layer: the BatchNorm-backward images (k_tw_wgrad reads them later)
+    std::vector<unsigned char *> relu_mask;                 // per layer: act_l > 0, one bit per element (the backward convolution's epilogue)
 };
 
 template <typename T>
@@ -2510,6 +2514,8 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
         for (int l = 0; l < L && ok; ++l) ok = (t->A16[l] = talloc<unsigned short>(t, 2 * A)) != nullptr;
         t->D16.assign(L + 1, nullptr);
         for (int l = 1; l <= L && ok; ++l) ok = (t->D16[l] = talloc<unsigned short>(t, 2 * A)) != nullptr;
+        t->relu_mask.assign(L + 1, nullptr);
+        for (int l = 0; l < L && ok; ++l) ok = (t->relu_mask[l] = talloc<unsigned char>(t, A / 8)) != nullptr;
         ok = ok &&
              (t->Ww16f_dev = upload_table(t, t->Ww16f)) && (t->Ww16b_dev = upload_table(t, t->Ww16b)) &&
              (d.bsc = talloc<float2>(t, TRN_MAXL + 2));
@@ -2984,7 +2990,7 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
         // act_l from raw_l (batch statistics from the per-board partials), then raw_{l+1} = conv(act_l)
         const bool has_res = (l & 1) == 0 && l >= 2;
         const TwAct a = {t->raw[l], has_res ? t->act[l - 2] : nullptr, d.bn_w[l], d.bn_b[l], d.pstat + (size_t)l * B * C,
-                         d.sums + (size_t)l * C * 4, t->act[l], t->A16[l], d.fsc + (l + 1), d.presum};
+                         d.sums + (size_t)l * C * 4, t->act[l], t->A16[l], d.fsc + (l + 1), d.presum, t->relu_mask[l]};
         totals(d.pstat, l, 0);
         hipLaunchKernelGGL(k_tw_bnact, eg, eb, 0, st, a, cells, C, B, d.invN);
         if (int rc = azx_net_wide_train_conv(N, C, t->Ww16f[l + 1], t->A16[l], t->raw[l + 1], B, &d.fsc[l + 1].y,
@@ -2993,7 +2999,7 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
     }
     {   // act_L (and BN_L's totals), the head convolutions, the FC layers and the loss
         const TwAct a = {t->raw[L], L >= 2 ? t->act[L - 2] : nullptr, d.bn_w[L], d.bn_b[L], d.pstat + (size_t)L * B * C,
-                         d.sums + (size_t)L * C * 4, t->act[L], nullptr, d.fsc, d.presum};
+                         d.sums + (size_t)L * C * 4, t->act[L], nullptr, d.fsc, d.presum, nullptr};
         totals(d.pstat, L, 0);
         hipLaunchKernelGGL(k_tw_bnact, eg, eb, 0, st, a, cells, C, B, d.invN);
     }
@@ -3046,7 +3052,7 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
         // (as a separate elementwise launch behind a plain conv^T: 72 + 23 us per layer against 92 fused, 10.74 vs 10.68 ms
         // per step -- the fused form saves a tensor's round trip, not time)
         if (int rc = azx_net_wide_train_conv_bwd(N, C, t->Ww16b[l], t->D16[l], t->g[l - 1], B, &d.bsc[l].y,
-                                                 d.pgsum + (size_t)(l - 1) * B * C, t->act[l - 1], t->raw[l - 1],
+                                                 d.pgsum + (size_t)(l - 1) * B * C, t->relu_mask[l - 1], t->raw[l - 1],
                                                  has_skip ? t->g[l + 1] : nullptr, d.sums + (size_t)(l - 1) * C * 4, d.invN,
                                                  d.gmax + (l - 1), st))
             return tfail(rc, "train: launching a wide backward convolution failed");

@@ -443,6 +443,40 @@ def run_api(args, rank, world, local_rank, start, torch):
             "host_overhead_frac": (wall - dev_s) / wall, "metric_keys": sorted(metrics_keys)}
 
 
+def rank_report(dist, torch, local_rank, st, elapsed):
+    """N > 1: what every rank measured by itself, gathered as objects -- its device's identity (so that the line can say on
+    how many DISTINCT GPUs the job ran), its own sims/s over its own clock.  None at N = 1."""
+    if dist is None:
+        return None
+    p = torch.cuda.get_device_properties(local_rank)
+    ident = "%s|%s|%s" % (os.uname().nodename, getattr(p, "uuid", None), getattr(p, "pci_bus_id", local_rank))
+    mine = {"rank": dist.get_rank(), "device": ident, "local_rank": local_rank, "sims_per_sec": st["selects"] / elapsed,
+            "seconds": elapsed}
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, mine)
+    return parts
+
+
+def world_fields(per_rank, value, exchange, ref_n1, backend):
+    """Flat scalars of an N > 1 line (they go into `roofline`, which the driver's record keeps): distinct devices, the
+    per-rank spread, the replay all-gather's rate and -- when the N = 1 value is given -- the weak-scaling efficiency."""
+    w = len(per_rank)
+    rates = [r["sims_per_sec"] for r in per_rank]
+    out = {"world_ranks": w, "world_backend": backend, "world_distinct_devices": len({r["device"] for r in per_rank}),
+           "world_rank_sims_per_sec_min": min(rates), "world_rank_sims_per_sec_max": max(rates),
+           "world_rank_sims_per_sec_sum": sum(rates), "world_slowest_over_fastest": min(rates) / max(rates)}
+    # RCCL carried the job only if every rank had a GPU of its own
+    out["rccl_ranks"] = out["world_distinct_devices"] if backend == "nccl" else 0
+    if exchange is not None and exchange.get("allgather_seconds"):
+        out["replay_allgather_gbs"] = exchange["bytes_gathered"] / exchange["allgather_seconds"] / 1e9
+        out["replay_allgather_ms"] = 1e3 * exchange["allgather_seconds"]
+        out["replay_allgather_bytes"] = exchange["bytes_gathered"]
+    if ref_n1:
+        out["world_ref_n1_sims_per_sec"] = ref_n1
+        out["weak_scaling_eff"] = value / (w * ref_n1)
+    return out
+
+
 def reduce_over_ranks(dist, torch, elapsed, sums):
     if dist is None:
         return elapsed, sums
@@ -776,6 +810,10 @@ def main():
                     help="internal: run ONE mode of the training-step leg in this process and print its JSON")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-replay-exchange", action="store_true")
+    ap.add_argument("--ref-n1", type=float, default=None,
+                    help="N > 1: the N = 1 value (sims/s) this job's weak-scaling efficiency is quoted against in `world_*`")
+    ap.add_argument("--all-legs", action="store_true",
+                    help="N > 1: also run the nested tree / configs[4]-shape legs on every rank (default: headline + exchange only)")
     ap.add_argument("--exchange-plies", type=int, default=0,
                     help="replay exchange after exactly this many further moves of every slot (default: a short top-up "
                          "until the first game finishes)")
@@ -827,6 +865,7 @@ def main():
 
     # ---- headline workload --------------------------------------------------------------------
     st, elapsed, ex = run_workload(headline, args, rank, world, local_rank, args.steps, args.warmup, sync, torch)
+    per_rank = rank_report(dist, torch, local_rank, st, elapsed)      # before the max-over-ranks reduction
     elapsed, sums = reduce_over_ranks(dist, torch, elapsed, [float(st[k]) for k in SUM_KEYS])
     E = ex["engine"]
     exchange = None
@@ -871,6 +910,10 @@ def main():
             if exchange is not None:
                 line["replay_allgather"] = exchange
         line["config"] = dict(workload=wl, **common_cfg)
+        if per_rank is not None:
+            line["world"]["per_rank"] = per_rank
+            line["roofline"].update(world_fields(per_rank, line["value"], exchange, args.ref_n1,
+                                                 dist.get_backend() if dist is not None else None))
         if world == 1:
             try:
                 line["box"] = box_calibration(torch)
@@ -883,7 +926,8 @@ def main():
                 line["cpu_baseline"] = {"error": repr(exc)}
 
     # ---- nested tree-only sub-benchmark (configs[1]), measured the same way ---------------------
-    if args.workload == "selfplay":
+    nested = args.workload == "selfplay" and (world == 1 or args.all_legs)    # N > 1: eight ranks each settling three engines
+    if nested:                                                                # is the slow part of a SCALE run
         st_t, el_t, ex_t = run_workload("tree", args, rank, world, local_rank, args.tree_steps, args.tree_warmup,
                                         sync, torch)
         el_t, sums_t = reduce_over_ranks(dist, torch, el_t, [float(st_t[k]) for k in SUM_KEYS])
@@ -905,7 +949,7 @@ def main():
             line["tree"] = tree
 
     # ---- nested configs[4]-shape leg: 13x13, 19x256, 810 selects, one warm-up + `--c5-steps` timed moves --------------
-    if args.workload == "selfplay" and not args.no_config5 and (args.board, args.blocks, args.chans) == (11, 6, 64):
+    if nested and not args.no_config5 and (args.board, args.blocks, args.chans) == (11, 6, 64):
         a5 = config5_args(args)
         try:
             st5, el5, ex5 = run_workload("resnet", a5, rank, world, local_rank, args.c5_steps, 1, sync, torch)

@@ -132,3 +132,16 @@ def test_a_failed_leg_leaves_a_scalar_error():
     bench.flatten_legs(line)
     r = line["roofline"]
     assert r["c5_error"].startswith("RuntimeError") and r["train_error"] == "boom" and r["api_error"] == "nope"
+
+
+def test_world_fields_of_an_n_gpu_line():
+    """N > 1 (VERDICT r5 #5): distinct devices, per-rank spread, all-gather rate and efficiency as flat scalars."""
+    per_rank = [{"rank": r, "device": "box|uuid-%d|%d" % (r % 4, r % 4), "sims_per_sec": 100.0 + r, "seconds": 1.0} for r in range(8)]
+    x = {"bytes_gathered": 4096000, "allgather_seconds": 0.002}
+    f = bench.world_fields(per_rank, 800.0, x, 110.0, "nccl")
+    assert f["world_ranks"] == 8 and f["world_distinct_devices"] == 4 and f["rccl_ranks"] == 4      # two ranks per GPU: visible
+    assert f["world_rank_sims_per_sec_min"] == 100.0 and f["world_rank_sims_per_sec_max"] == 107.0
+    assert abs(f["weak_scaling_eff"] - 800.0 / (8 * 110.0)) < 1e-12 and abs(f["replay_allgather_gbs"] - 2.048) < 1e-9
+    g = bench.world_fields(per_rank, 800.0, None, None, "gloo")
+    assert g["rccl_ranks"] == 0 and "weak_scaling_eff" not in g and "replay_allgather_gbs" not in g
+    assert all(v is None or isinstance(v, (bool, int, float, str)) for v in f.values())

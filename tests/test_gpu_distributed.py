@@ -140,8 +140,18 @@ def test_bench_eight_ranks_dry_run():
     common = ["--steps", "3", "--warmup", "1", "--sims", "40", "--board", "7", "--blocks", "1", "--workload", "resnet",
               "--no-cpu-baseline", "--exchange-plies", "12", "--settle", "40"]
     one = _bench(common + ["--games", "64"], 1)
-    eight = _bench(common + ["--games", "8"], 8)
+    eight = _bench(common + ["--games", "8", "--ref-n1", repr(one["value"])], 8)
     assert eight["n_gpus"] == 8 and eight["world"]["ranks"] == 8 and eight["world"]["backend"] == "gloo"
+    # the N > 1 line checks itself, as scalars of the dict the driver's record keeps: how many DISTINCT
+    # devices the ranks ran on (here one, shared, over gloo -> rccl_ranks 0: no scaling claim can be read off this run),
+    # the per-rank spread, the all-gather's rate, the efficiency against the N = 1 value handed in
+    r = eight["roofline"]
+    assert r["world_ranks"] == 8 and r["world_backend"] == "gloo" and r["world_distinct_devices"] == 1 and r["rccl_ranks"] == 0
+    assert 0 < r["world_rank_sims_per_sec_min"] <= r["world_rank_sims_per_sec_max"] and 0 < r["world_slowest_over_fastest"] <= 1
+    assert r["world_rank_sims_per_sec_sum"] >= eight["value"] * (1 - 1e-9)      # whole-job value: total work / slowest rank's time
+    assert r["replay_allgather_bytes"] == eight["replay_allgather"]["bytes_gathered"] and r["replay_allgather_gbs"] > 0
+    assert abs(r["weak_scaling_eff"] - eight["value"] / (8 * one["value"])) < 1e-9 and r["world_ref_n1_sims_per_sec"] == one["value"]
+    assert len(eight["world"]["per_rank"]) == 8 and "tree" not in eight and "config5" not in eight
     x1, x8 = one["replay_allgather"], eight["replay_allgather"]
     assert x8["ranks"] == 8 and len(x8["rows_per_rank"]) == 8 and eight["world"]["rows_per_rank"] == x8["rows_per_rank"]
     assert x1["games"] >= 4 and x1["game_uids"] == x8["game_uids"]
