@@ -616,6 +616,7 @@ __global__ __launch_bounds__(F16X3_BPB * 128, 2) void k_tower_f16x3_s16(NetDev P
 #ifndef AZX_WIDE_ABLATE
 #define AZX_WIDE_ABLATE 0
 #endif
+
 #define WIDE16_MT 6
 #define WIDE16_NT 4
 // TRAIN = 1 (csrc/train_wide.hip, the training step's forward and backward-data convolutions of a wide tower): the same
@@ -767,8 +768,14 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
 
     // the chunk loop, instantiated per wm (which tile product is the other wave's is a compile-time
     // pattern: straight-line code either way; both paths pass the same barriers)
+    // (Measured and dropped, round 6: requesting chunk c + 1's pieces into registers before chunk c's k-loop -- a
+    // training batch is ONE round of blocks, nobody else's k-loop covers a block's staging -- 63.1 vs 62.5 us forward,
+    // 82.0 vs 82.2 backward: the staging round trips are not what the kernel waits for.  profiles/r6_train_wide_ab.txt)
     auto main_loop = [&](auto wm_tag) __attribute__((always_inline)) {
     constexpr int WM = decltype(wm_tag)::value;
+    // (Measured and dropped, round 6: three weight register sets, k-step g's fragments requested during k-step g - 2 and
+    // across chunk boundaries -- a two-tile k-step is 576 matrix-pipe cycles, about an L2 round trip: 67.5 vs 60.9 us
+    // forward, 85.9 vs 80.0 backward; the weights are not late, the 50 extra registers cost.  profiles/r6_train_wide_ab.txt)
     for (int chunk = 0; chunk < NCH; ++chunk) {
 #if AZX_WIDE_ABLATE & 1
         if (chunk == 0)
@@ -900,6 +907,33 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
     }
 
     };
+    // TRAIN = 2: the epilogue's operands (raw_{l-1}, the skip gradient, the mask bytes) of all six position tiles are
+    // requested together at the top of the epilogue.  (Measured and dropped, round 6: the first three tiles' 51 registers
+    // requested before the k-loop, so that they arrive under it: 82.7 vs 83.4 us -- their round trip is not what the
+    // epilogue costs.  profiles/r6_train_wide_ab.txt)
+    constexpr int NPF = NT / 2;
+    f32x4 er0[3][NPF][2], ek0[3][NPF][2];       // (the native vector type: arrays of HIP's float4 STRUCT handed to a lambda stay in scratch)
+    unsigned int ea0[3][NPF];
+    auto epi_request = [&](int m0, f32x4 (&er)[3][NPF][2], f32x4 (&ek)[3][NPF][2], unsigned int (&ea)[3][NPF]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mm = 0; mm < 3; ++mm)
+#pragma unroll
+            for (int np = 0; np < NPF; ++np) {
+                const int rc = min(row0 + 16 * (m0 + mm) + lrow, ncells - 1);
+                const size_t o = ((size_t)e * ncells + rc) * C + chan0(np);
+                ea[mm][np] = F.mask[o >> 3];
+                er[mm][np][0] = *reinterpret_cast<const f32x4 *>(F.raw + o);
+                er[mm][np][1] = *reinterpret_cast<const f32x4 *>(F.raw + o + 4);
+                if (F.skip) {        // (wave-uniform: a kernel argument)
+                    ek[mm][np][0] = *reinterpret_cast<const f32x4 *>(F.skip + o);
+                    ek[mm][np][1] = *reinterpret_cast<const f32x4 *>(F.skip + o + 4);
+                } else {
+                    ek[mm][np][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    ek[mm][np][1] = ek[mm][np][0];
+                }
+            }
+    };
+
     if (wm == 0) main_loop(std::integral_constant<int, 0>{});
     else main_loop(std::integral_constant<int, 1>{});
 
@@ -929,29 +963,15 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
         // Three position tiles at a time, and (TRAIN = 2) all of their mask / xhat / skip pieces requested before the first
         // is used, unconditionally at a clamped row: behind `if (row is mine)` the compiler waits for each tile's loads at
         // the join -- six memory round trips at the end of a kernel that has nothing left to hide them under.
-#pragma unroll
-        for (int m0 = 0; m0 < MT; m0 += 3) {
-            float4 er[3][NP][2], ek[3][NP][2];
-            unsigned int ea[3][NP];
-            if (TRAIN == 2) {
-#pragma unroll
-                for (int mm = 0; mm < 3; ++mm)
-#pragma unroll
-                    for (int np = 0; np < NP; ++np) {
-                        const int rc = min(row0 + 16 * (m0 + mm) + lrow, ncells - 1);
-                        const size_t o = ((size_t)e * ncells + rc) * C + chan0(np);
-                        ea[mm][np] = F.mask[o >> 3];
-                        er[mm][np][0] = *reinterpret_cast<const float4 *>(F.raw + o);
-                        er[mm][np][1] = *reinterpret_cast<const float4 *>(F.raw + o + 4);
-                        if (F.skip) {        // (wave-uniform: a kernel argument)
-                            ek[mm][np][0] = *reinterpret_cast<const float4 *>(F.skip + o);
-                            ek[mm][np][1] = *reinterpret_cast<const float4 *>(F.skip + o + 4);
-                        } else {
-                            ek[mm][np][0] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            ek[mm][np][1] = ek[mm][np][0];
-                        }
-                    }
-            }
+        f32x4 er1[3][NP][2], ek1[3][NP][2];
+        unsigned int ea1[3][NP];
+        if constexpr (TRAIN == 2) {
+            epi_request(0, er0, ek0, ea0);
+            epi_request(3, er1, ek1, ea1);
+        }
+        auto epi_group = [&](auto m0_tag, const f32x4 (&er)[3][NP][2], const f32x4 (&ek)[3][NP][2],
+                             const unsigned int (&ea)[3][NP]) __attribute__((always_inline)) {
+            constexpr int m0 = decltype(m0_tag)::value;
 #pragma unroll
             for (int mm = 0; mm < 3; ++mm) {
                 const int m = m0 + mm;
@@ -963,11 +983,11 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
                         const size_t o = ((size_t)e * ncells + r) * C + chan0(np);
                         float vv[8];
                         if (TRAIN == 2) {
-                            const float4 r0 = er[mm][np][0], r1 = er[mm][np][1];
-                            const float4 k0 = ek[mm][np][0], k1 = ek[mm][np][1];
+                            const f32x4 r0 = er[mm][np][0], r1 = er[mm][np][1];
+                            const f32x4 k0 = ek[mm][np][0], k1 = ek[mm][np][1];
                             const unsigned int bits = ea[mm][np];
-                            const float rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-                            const float kv[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+                            const float rv[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+                            const float kv[8] = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
                                 const bool ok = (j >> 2) ? ok1 : ok0;
@@ -995,7 +1015,9 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
                     }
                 }
             }
-        }
+        };
+        epi_group(std::integral_constant<int, 0>{}, er0, ek0, ea0);
+        epi_group(std::integral_constant<int, 3>{}, er1, ek1, ea1);
         if (TRAIN == 2) {
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));

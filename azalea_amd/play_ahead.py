@@ -14,10 +14,20 @@ GPU and one process:
   `azx_replay_put_records_async` ON THE TRAINING STREAM, where they are ordered with the collate reads and the step;
 * every `weight_sync_steps` optimizer steps the trainer snapshots its network on the training stream (parameters and
   BatchNorm statistics); the play thread packs the snapshot into the engine before its next pool move.  No collective.
-* the two kinds of work meet on the device, not on the host: the engine's streams carry a CU mask that leaves
-  `reserve_cus` compute units of every XCD free (`azx_reserve_cus`), so the training step's ~31 small dependent kernels
-  find empty CUs at once instead of queueing behind resident tower blocks (which fill a CU's registers and LDS for
-  ~200 us each), and the trainer's streams are created at the high stream priority.
+* the two kinds of work meet on the device, not on the host: the trainer's streams are created at the high stream
+  priority, so a workgroup slot a retiring tower block frees goes to a waiting training kernel first.  Optionally
+  (`reserve_cus`, off by default) the engine's streams carry a CU mask that leaves some compute units of every XCD free
+  (`azx_reserve_cus`).
+
+What it buys, measured (6x64 on 11x11, 4096 games, 400 sims, batch 128, 10x oversampling; tools/bench_train_loop.py,
+profiles/r6_train_loop_overlap.json): inline 657 steps/s -> **727-730 with play-ahead at high priority (1.11x)**; 638 at
+normal priority; 686 / 693 with 4 / 8 CUs of every XCD reserved.  The step's ~31 dependent kernels have 256 workgroups
+each, an XCD deals workgroups to its shader engines round-robin whatever is free elsewhere
+(tools/microbench/cu_mask.hip), and a tower block holds its CU's registers and LDS for ~200 us: under the tower a
+training kernel waits ~44 us for its slots (16 us alone; the step 1.37 ms against 0.50), reserved CUs only serve the
+few workgroups dealt to their own shader engine, and what they cost the tower (14 % for one CU per shader engine:
+an SE with 7 of 8 CUs sets the pace) is more than they give.  The tower itself loses 4 %.  In this mode the loop is
+bound by the (slowed) trainer, not by self-play: the backlog is never short (`waits` 0), the play thread parks ~20 %.
 
 Staleness: a move is searched with the last snapshot packed, taken at most `weight_sync_steps` steps before the move
 started (plus the snapshot the thread was busy packing); a row then waits in the backlog for at most
@@ -39,7 +49,7 @@ from .actor_learner import _SUM_KEYS, RecordBacklog
 
 class PlayAhead:
     def __init__(self, player, engine, *, ahead_rows: Optional[int] = None, weight_sync_steps: int = 50,
-                 poll_plies: int = 1, reserve_cus: int = 4):
+                 poll_plies: int = 1, reserve_cus: int = 0):
         if weight_sync_steps < 1:
             raise ValueError("weight_sync_steps must be >= 1")
         self.player, self.engine = player, engine

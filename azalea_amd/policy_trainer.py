@@ -385,7 +385,7 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
             ahead = PlayAhead(player, replaybuf.engine, ahead_rows=config.get("selfplay_ahead_rows"),
                               weight_sync_steps=config.get("weight_sync_steps", 50),
                               poll_plies=config.get("selfplay_poll_plies", 1),
-                              reserve_cus=config.get("selfplay_reserve_cus", 4))
+                              reserve_cus=config.get("selfplay_reserve_cus", 0))
             replaybuf.ahead = ahead
             ahead.start()
             side = torch.cuda.Stream(device, priority=-1)

@@ -45,7 +45,7 @@ def test_reserved_cus_change_where_the_engine_runs_not_what_it_plays(kind):
         order = np.argsort(r["game_uid"], kind="stable")
         rows.append({k: v[order] for k, v in r.items()})
         E.close()
-    assert len(np.unique(rows[0]["game_uid"])) >= 64
+    assert len(np.unique(rows[0]["game_uid"])) >= 4 and len(rows[0]["reward"]) >= 100
     for k in rows[0]:
         assert np.array_equal(rows[0][k], rows[1][k]), k
         assert np.array_equal(rows[0][k], rows[2][k]), k

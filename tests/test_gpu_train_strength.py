@@ -29,7 +29,7 @@ def test_training_makes_a_stronger_player(mover_view, overlap):
     assert out["train_step"] == "native"
     if overlap:      # config["selfplay_overlap"]: self-play ran beside the steps (azalea_amd/play_ahead.py), with fresh weights
         pa = out["play_ahead"]
-        assert pa["productions"] > 50 and pa["weight_syncs"] > 20 and pa["reserved_cus"] == 32 and pa["takes"] > 5
+        assert pa["productions"] > 50 and pa["weight_syncs"] > 20 and pa["reserved_cus"] == 0 and pa["takes"] > 5
         assert pa["max_backlog_rows"] < 2 * 1024 + 49 * 1024 // 8      # the bound: ahead_rows + about one harvest
     else:
         assert out["play_ahead"] is None

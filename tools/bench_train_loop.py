@@ -103,14 +103,28 @@ def main():
     ap.add_argument("--sims", type=int, default=400)
     ap.add_argument("--fill", type=int, default=60000, help="rows of the untimed initial fill")
     ap.add_argument("--modes", default="inline,steps,overlapped,inline_graph,steps_graph")
-    ap.add_argument("--reserve-cus", type=int, default=4, help="overlapped: CUs of every XCD the engine leaves free")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="overlapped: CUs of every XCD the engine leaves free")
     ap.add_argument("--priority", choices=["high", "normal"], default="high", help="overlapped: the training stream's priority")
     ap.add_argument("--ahead-rows", type=int, default=0, help="overlapped: backlog bound (default: one row per pool slot)")
     ap.add_argument("--weight-sync-steps", type=int, default=50)
+    ap.add_argument("--one", default=None, help="internal: run this one mode in this process")
     args = ap.parse_args()
     table = {"inline": ("inline", "native"), "steps": ("steps only", "native"), "overlapped": ("overlapped", "native"),
              "inline_graph": ("inline", "hip_graph"), "steps_graph": ("steps only", "hip_graph")}
-    res = {m: run(table[m][0], args, table[m][1]) for m in args.modes.split(",")}
+    if args.one:          # internal: ONE mode in this process
+        print(json.dumps(run(table[args.one][0], args, table[args.one][1])))
+        return
+    # every mode in a process of its own: a mode leaves state behind (side streams, allocator pools, a trainer's graph)
+    # that costs whichever runs next up to 2x (an inline run behind an overlapped one in one process: 346 vs 657 steps/s)
+    import subprocess
+    res = {}
+    for m in args.modes.split(","):
+        cmd = [sys.executable, os.path.abspath(__file__), "--one", m] + [a for a in sys.argv[1:]]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode or not lines:
+            raise SystemExit("mode %s failed: %s" % (m, (r.stderr or r.stdout)[-800:]))
+        res[m] = json.loads(lines[-1])
     out = {"what": "training step (batch 128; hand-written / stock kernels captured as a HIP graph) + consume(12.8) per "
                    "step; 6x64 resnet self-play, %d games, %d sims" % (args.games, args.sims), "runs": list(res.values())}
     sps = {m: r["steps_per_sec"] for m, r in res.items()}
