@@ -768,6 +768,10 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
 
     // the chunk loop, instantiated per wm (which tile product is the other wave's is a compile-time
     // pattern: straight-line code either way; both paths pass the same barriers)
+    // (Measured and dropped, round 6: a phase shift between the two co-resident blocks of a CU -- a training launch is ONE
+    // round of blocks, two per CU, started together; every second arrival on a CU (an atomic per XCC_ID / HW_ID) slept half
+    // a chunk's period so that one block would stage under the other's k-loop: 65.3 vs 62.5 us forward, 84.1 vs 82.7
+    // backward, the filter gradient 95.3 vs 93.7 -- the blocks do not run in lock-step, the sleep is simply paid.)
     // (Measured and dropped, round 6: requesting chunk c + 1's pieces into registers before chunk c's k-loop -- a
     // training batch is ONE round of blocks, nobody else's k-loop covers a block's staging -- 63.1 vs 62.5 us forward,
     // 82.0 vs 82.2 backward: the staging round trips are not what the kernel waits for.  profiles/r6_train_wide_ab.txt)
