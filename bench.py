@@ -20,7 +20,8 @@ kernel) and `cpu_baseline` -- and "api": the product surface the trainer calls (
 24-28) driven for `--api-moves` engine moves after the pool transplant, rows/s over the last 60 of them beside
 the plies/s the engine played in the same window.  A last nested leg stands beside the path, not on it:
 "train_step" -- the reference's training step at its own batch size on the HBM replay ring, eager and captured as a
-HIP graph (`--no-train-step` skips it).
+HIP graph (`--no-train-step` skips it) -- and "train_loop": the trainer's loop on this GPU with the refills
+played inline against self-play running beside the steps (azalea_amd/play_ahead.py; `--loop-steps 0` skips it).
 
 Steady state: a pool that restarts finished games in place is, after its first game, spread over
 all plies.  Starting every slot from the empty board would time the opening only (no game can end
@@ -386,6 +387,38 @@ def run_train_step(args, local_rank, torch):
     return out
 
 
+def run_train_loop(args, local_rank):
+    """The trainer's loop on this one GPU (policy_trainer.py:82-90: a step, then `consume(batch / oversampling)`), at the
+    headline's configuration, two ways -- the refills played inline (the deterministic mode) and self-play running beside
+    the steps (azalea_amd/play_ahead.py: process_pool.py:29-47's in-flight games) -- each in a process of its own
+    (tools/bench_train_loop.py).  steps/s of both, their ratio, and how much of the overlapped run the trainer waited."""
+    import subprocess
+    out = {"what": "NativeTrainStep (batch 128) + DeviceReplayBuffer.consume(12.8) per step, %dx%d on %dx%d, %d games, %d sims"
+                   % (args.blocks, args.chans, args.board, args.board, args.games, args.sims),
+           "games": args.games, "simulations": args.sims, "steps": args.loop_steps}
+    tool = os.path.join(ROOT, "tools", "bench_train_loop.py")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank)))
+    for mode in ("inline", "overlapped"):
+        cmd = [sys.executable, tool, "--one", mode, "--steps", str(args.loop_steps), "--games", str(args.games), "--sims", str(args.sims)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode or not lines:
+            out["error"] = "%s: %s" % (mode, (r.stderr or r.stdout)[-300:])
+            return out
+        out[mode] = json.loads(lines[-1])
+    out["inline_steps_per_sec"] = out["inline"]["steps_per_sec"]
+    out["overlapped_steps_per_sec"] = out["overlapped"]["steps_per_sec"]
+    out["overlap_speedup"] = out["overlapped_steps_per_sec"] / out["inline_steps_per_sec"]
+    out["overlapped_wait_share"] = out["overlapped"].get("wait_share")
+    pa = out["overlapped"].get("play_ahead") or {}
+    out["overlapped_weight_syncs"] = pa.get("weight_syncs")
+    out["overlapped_max_backlog_rows"] = pa.get("max_backlog_rows")
+    # staleness bound (azalea_amd/play_ahead.py): weight_sync_steps + (ahead_rows + one harvest) / rows consumed per step
+    if pa.get("max_backlog_rows"):
+        out["max_staleness_steps"] = pa.get("weight_sync_steps", 50) + pa["max_backlog_rows"] / 12.8
+    return out
+
+
 def run_api(args, rank, world, local_rank, start, torch):
     """The product surface for a whole game length: Player.read (parallel_player.py:24-28 -- what
     ReplayBuffer.consume calls, replay_buffer.py:121-132) on a device-policy Player at the headline's
@@ -739,7 +772,8 @@ def flatten_legs(line):
                                                            ("issued_frac_of_f16_mfma_peak", "issued_frac")))
             put_flat(roof, "train_wide_", w.get("native"), ("flop_per_step", ("frac_of_f16_mfma_peak", "frac")))
     put_flat(roof, "loop_", line.get("train_loop"), ("inline_steps_per_sec", "overlapped_steps_per_sec", "overlap_speedup",
-                                                     "inline_selfplay_share", "overlapped_wait_share", "max_staleness_steps",
+                                                     "overlapped_wait_share", "overlapped_weight_syncs",
+                                                     "overlapped_max_backlog_rows", "max_staleness_steps",
                                                      "games", "simulations", "steps", "error"))
     put_flat(roof, "api_", line.get("api"), ("rows_per_sec", "plies_per_sec", "rows_over_plies", "host_overhead_frac", "error"))
     put_flat(roof, "box_", line.get("box"), (("gemm_f16_8192_tflops", "gemm_tflops"), ("usual_on_this_pool", "usual_tflops"),
@@ -805,6 +839,7 @@ def main():
     ap.add_argument("--api-moves", type=int, default=190,
                     help="engine moves the nested product-surface leg (Player.read) is driven for; 0 = skip")
     ap.add_argument("--no-train-step", action="store_true", help="skip the nested training-step leg (SURVEY 8(f).4)")
+    ap.add_argument("--loop-steps", type=int, default=1600, help="timed steps of the nested train-loop leg (inline / overlapped); 0 = skip")
     ap.add_argument("--train-steps", type=int, default=200, help="internal: timed steps of a --train-step-only run")
     ap.add_argument("--train-step-only", choices=list(TRAIN_MODES), default=None,
                     help="internal: run ONE mode of the training-step leg in this process and print its JSON")
@@ -996,6 +1031,14 @@ def main():
             line["train_step"] = run_train_step(args, local_rank, torch)
         except Exception as exc:
             line["train_step"] = {"error": repr(exc)}
+
+    # ---- nested leg beside the path: the trainer's loop, refills inline against self-play beside the steps ---------
+    if (args.workload == "selfplay" and not args.no_train_step and args.loop_steps > 0 and world == 1
+            and (args.board, args.blocks, args.chans) == (11, 6, 64)):
+        try:
+            line["train_loop"] = run_train_loop(args, local_rank)
+        except Exception as exc:
+            line["train_loop"] = {"error": repr(exc)}
 
     if rank == 0:
         flatten_legs(line)

@@ -81,9 +81,9 @@ def test_default_line_nests_the_config5_shape_with_roofline_and_cpu_baseline():
     "config5" -- 13x13, 19x256, 810 select_leaf calls, one warm-up + three timed moves -- with its own roofline and
     cpu_baseline (few games here)."""
     d = _run("--steps", "1", "--warmup", "1", "--games", "32", "--tree-steps", "4", "--tree-warmup", "1",
-             "--c5-games", "8", "--api-moves", "0", "--settle", "30")
+             "--c5-games", "8", "--api-moves", "0", "--settle", "30", "--loop-steps", "0")
     _check_common(d, 1, 1)
-    assert d["config"]["workload"].startswith("BASELINE configs[2]") and "api" not in d
+    assert d["config"]["workload"].startswith("BASELINE configs[2]") and "api" not in d and "train_loop" not in d
     c = d["cpu_baseline"]
     assert c["reference_shim"]["sims_per_s"] == 3011.0 and c["reference_shim"]["cores"] == 8
     assert abs(c["port_vs_reference_per_core"] - c["per_core"] / c["reference_shim"]["per_core"]) < 1e-9
