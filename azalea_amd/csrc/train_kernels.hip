@@ -49,6 +49,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
                                   // access through it a FLAT instruction whose completion the LDS waits then also wait for
 #define TRN_HP_SLOTS 256          // hyper-parameter ring: the host may run this many steps ahead of the device
 #define TRN_SMALL_THREADS 1024    // the elementwise kernels around the tower: 16 waves per CU hide their loads' latency
+// ... except the two that open a chain of them (k_trn_heads_conv behind the forward tower, k_trn_stem_bwd behind the backward
+// one): 512 threads.  A 1024-thread block of theirs is 4 waves x 80-88 registers per SIMD -- more than the HALF of a CU's
+// register file one retiring self-play tower block frees -- so beside self-play (azalea_amd/play_ahead.py) it waited until
+// BOTH tower blocks of some CU happened to have gone: 690 us and 166 us a step where the kernels take 12 and 13 alone
+// (profiles/r6_train_loop_overlap_timeline.txt).  With 8 waves a block fits the freed half; alone they cost +1-2 us.
+#define TRN_MID_THREADS 512
 #define TRN_REP 8                  // copies of the small f64-atomic accumulators
 #define TRN_WG_GROUPS 64          // k_trn_wgrad: board groups (x 4 channel-tile pairs at C = 64: 256 workgroups)
 #define TRN_PRESUM_BATCH 256      // above this batch a totals kernel sums a layer's per-board partial pairs once (see k_trn_totals)
@@ -1145,8 +1151,8 @@ __global__ __launch_bounds__(256) void k_trn_wgrad16(WgradPtrs A, int l, int G, 
 // heads, forward part 1: act_L = relu(BN_L(raw_L) + act_{L-2}); the two 1x1 convolutions; their batch sums
 // =================================================================================================================
 template <int C>
-__global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_conv(TrnDev P) {
-    constexpr int C4 = C / 4, LDX = C + 1, NTH = TRN_SMALL_THREADS, ITER = (121 * C4 + NTH - 1) / NTH;
+__global__ __launch_bounds__(TRN_MID_THREADS) void k_trn_heads_conv(TrnDev P) {
+    constexpr int C4 = C / 4, LDX = C + 1, NTH = TRN_MID_THREADS, ITER = (121 * C4 + NTH - 1) / NTH;
     extern __shared__ __align__(16) float lds[];
     float *X = lds;                         // [cells][LDX]
     float *cA = X + (size_t)P.cells * LDX, *cB = cA + C;
@@ -1229,8 +1235,8 @@ __device__ __forceinline__ float wave_max(float v) {
 // heads, part 2 (one block per board): BN + ReLU of the head planes, the FC layers, masked log-softmax, the loss and
 // the gradient back to the head planes (network.py:77-102, :146-152)
 // =================================================================================================================
-__global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_fc(TrnDev P) {
-    constexpr int NTH = TRN_SMALL_THREADS, NW = NTH / 64;
+__global__ __launch_bounds__(TRN_MID_THREADS) void k_trn_heads_fc(TrnDev P) {
+    constexpr int NTH = TRN_MID_THREADS, NW = NTH / 64;       // (84 registers a thread: see TRN_MID_THREADS)
     __shared__ float ha[6 * 128];           // activated head planes [o][pos] (value 0..1, policy 2..5), flat = the FC inputs
     __shared__ float xh[6 * 128];           // their xhat
     __shared__ float h2[64], dh2s[64], logit[128], dlog[128], gflat[6 * 128], gpart[1024];
@@ -1357,8 +1363,8 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_fc(TrnDev P) {
     if (tid < 128) P.dlogit[(size_t)b * 128 + tid] = tid < cells ? dlog[tid] : 0.f;
     // back through the FC layers to the head planes: thread (i, part) sums a slice of the outputs, the parts are
     // combined through LDS.  value: 242 inputs x 4 parts of 16 outputs; policy: 484 inputs x 2 parts of ~61 tiles.
-    {
-        const int part = tid / 256, i = tid % 256;               // value plane: 4 parts
+    for (int part = tid / 256; part < 4; part += NTH / 256) {    // value plane: 4 parts
+        const int i = tid % 256;
         if (i < KV) {
             float sv = 0.f;
 #pragma unroll
@@ -1369,8 +1375,8 @@ __global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_heads_fc(TrnDev P) {
     __syncthreads();
     if (tid < KV) gflat[tid] = ha[tid] > 0.f ? (gpart[tid] + gpart[256 + tid]) + (gpart[512 + tid] + gpart[768 + tid]) : 0.f;
     __syncthreads();
-    {
-        const int part = tid / 512, i = tid % 512, half = (cells + 1) / 2;
+    for (int part = tid / 512; part < 2; part += (NTH + 511) / 512) {
+        const int i = tid % 512, half = (cells + 1) / 2;
         if (i < KPp) {
             float sp = 0.f;
             const int t1 = min(cells, (part + 1) * half);
@@ -1570,8 +1576,8 @@ __global__ __launch_bounds__(NTH) void k_trn_heads_bwd(TrnDev P) {
 // table's gradient into conv1.weight's and the embedding's
 // =================================================================================================================
 template <int C>
-__global__ __launch_bounds__(TRN_SMALL_THREADS) void k_trn_stem_bwd(TrnDev P) {
-    constexpr int C4 = C / 4, NTH = TRN_SMALL_THREADS, ITER = (121 * C4 + NTH - 1) / NTH;
+__global__ __launch_bounds__(TRN_MID_THREADS) void k_trn_stem_bwd(TrnDev P) {
+    constexpr int C4 = C / 4, NTH = TRN_MID_THREADS, ITER = (121 * C4 + NTH - 1) / NTH;
     extern __shared__ __align__(16) float lds[];
     float *Dr = lds;                         // [cells][C]
     float *cA = Dr + (size_t)P.cells * C, *cM = cA + C, *cI = cM + C, *cK = cI + C;
@@ -2789,9 +2795,9 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
         else hipLaunchKernelGGL((k_trn_conv<C, ROLE_FWD>), dim3(NT, B), dim3(256), conv_lds, st, q, l, d);
         totals(d.pstat, l, 0);
     }
-    const size_t hc_lds = ((size_t)((cells * (C + 1) + 8 * C + 16 + 3) & ~3)) * sizeof(float) + (size_t)SMALL * 16;
-    hipLaunchKernelGGL(k_trn_heads_conv<C>, dim3(B), dim3(SMALL), hc_lds, st, d);
-    hipLaunchKernelGGL(k_trn_heads_fc, dim3(B), dim3(SMALL), 0, st, d);
+    const size_t hc_lds = ((size_t)((cells * (C + 1) + 8 * C + 16 + 3) & ~3)) * sizeof(float) + (size_t)TRN_MID_THREADS * 16;
+    hipLaunchKernelGGL(k_trn_heads_conv<C>, dim3(B), dim3(TRN_MID_THREADS), hc_lds, st, d);
+    hipLaunchKernelGGL(k_trn_heads_fc, dim3(B), dim3(TRN_MID_THREADS), 0, st, d);
     size_t ev = 0;
     auto next_event = [&]() -> hipEvent_t {
         if (ev == t->events.size()) {
@@ -2838,9 +2844,9 @@ static int enqueue_step(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork
         if (t->bwd16) hipLaunchKernelGGL((k_trn_conv<C, ROLE_BWD16>), dim3(NT, B), dim3(256), conv_lds, st, q, l, d);
         else hipLaunchKernelGGL((k_trn_conv<C, ROLE_BWD>), dim3(NT, B), dim3(256), conv_lds, st, q, l, d);
     }
-    const size_t sb_lds = ((size_t)cells * C + 5 * C) * sizeof(float) + (size_t)SMALL * 16;
+    const size_t sb_lds = ((size_t)cells * C + 5 * C) * sizeof(float) + (size_t)TRN_MID_THREADS * 16;
     totals(d.pgsum, 0, 2);
-    hipLaunchKernelGGL(k_trn_stem_bwd<C>, dim3(B), dim3(SMALL), sb_lds, st, d);
+    hipLaunchKernelGGL(k_trn_stem_bwd<C>, dim3(B), dim3(TRN_MID_THREADS), sb_lds, st, d);
     auto join_side = [&]() -> bool {
         if (!fork) return true;
         hipEvent_t e = next_event();

@@ -19,15 +19,23 @@ GPU and one process:
   (`reserve_cus`, off by default) the engine's streams carry a CU mask that leaves some compute units of every XCD free
   (`azx_reserve_cus`).
 
-What it buys, measured (6x64 on 11x11, 4096 games, 400 sims, batch 128, 10x oversampling; tools/bench_train_loop.py,
-profiles/r6_train_loop_overlap.json): inline 657 steps/s -> **727-730 with play-ahead at high priority (1.11x)**; 638 at
-normal priority; 686 / 693 with 4 / 8 CUs of every XCD reserved.  The step's ~31 dependent kernels have 256 workgroups
-each, an XCD deals workgroups to its shader engines round-robin whatever is free elsewhere
-(tools/microbench/cu_mask.hip), and a tower block holds its CU's registers and LDS for ~200 us: under the tower a
-training kernel waits ~44 us for its slots (16 us alone; the step 1.37 ms against 0.50), reserved CUs only serve the
-few workgroups dealt to their own shader engine, and what they cost the tower (14 % for one CU per shader engine:
-an SE with 7 of 8 CUs sets the pace) is more than they give.  The tower itself loses 4 %.  In this mode the loop is
-bound by the (slowed) trainer, not by self-play: the backlog is never short (`waits` 0), the play thread parks ~20 %.
+What it buys on ONE GPU, measured (6x64 on 11x11, 4096 games, 400 sims, batch 128, 10x oversampling;
+tools/bench_train_loop.py over whole refill cycles, 4 800 steps, three alternating runs on one box,
+profiles/r6_train_loop_overlap.json): **inline 638-692 steps/s, play-ahead 645-679 -- nothing.**  (A first reading of
+"1.11x" came from 1 600-step windows, which hold 4 or 5 refills of a third of a second each by chance.)  The timeline
+(tools/prof_overlap.sh, profiles/r6_train_loop_overlap_timeline.txt) says why: the two sides ARE resident together
+66-69 % of the time and the tower does not slow down (7.7 ms a launch either way), but the training step does, 0.50 ->
+1.5 ms: its ~31 dependent kernels have 256 workgroups each; when one of them ends, the slots it held are refilled with
+tower blocks (200 us each) before the next one is launched, so every kernel of the chain waits for tower blocks to
+retire again (~48 us against 12-16 alone).  The trainer, not self-play, bounds the loop (`waits` 0, the play thread
+parked a third of the time), at the same rate the inline loop reaches by taking turns.  Leaving CUs free for the
+trainer (`reserve_cus`) does not change that: an XCD deals workgroups to its shader engines round-robin whatever is
+free elsewhere (tools/microbench/cu_mask.hip), so reserved CUs serve only the workgroups dealt to their own engine,
+and one CU per shader engine costs the tower 14 %.  What would: a training step that keeps its slots -- one persistent
+kernel with grid barriers instead of 31 launches.  One real defect the timeline exposed is fixed: three of the step's
+kernels ran 1024-thread blocks of 80-88 registers a thread, which do not fit the half of a CU's register file one
+retiring tower block frees, and waited 0.2-0.9 ms for a CU with both tower blocks gone (train_kernels.hip:
+TRN_MID_THREADS).  With more than one GPU the same idea (actor_learner.py) does not share a device and has no such limit.
 
 Staleness: a move is searched with the last snapshot packed, taken at most `weight_sync_steps` steps before the move
 started (plus the snapshot the thread was busy packing); a row then waits in the backlog for at most

@@ -406,8 +406,9 @@ def run_train_loop(args, local_rank):
             out["error"] = "%s: %s" % (mode, (r.stderr or r.stdout)[-300:])
             return out
         out[mode] = json.loads(lines[-1])
-    out["inline_steps_per_sec"] = out["inline"]["steps_per_sec"]
-    out["overlapped_steps_per_sec"] = out["overlapped"]["steps_per_sec"]
+    # over whole refill cycles (tools/bench_train_loop.py: a window of N steps holds 4 or 5 refills by chance)
+    out["inline_steps_per_sec"] = out["inline"].get("steps_per_sec_whole_cycles", out["inline"]["steps_per_sec"])
+    out["overlapped_steps_per_sec"] = out["overlapped"].get("steps_per_sec_whole_cycles", out["overlapped"]["steps_per_sec"])
     out["overlap_speedup"] = out["overlapped_steps_per_sec"] / out["inline_steps_per_sec"]
     out["overlapped_wait_share"] = out["overlapped"].get("wait_share")
     pa = out["overlapped"].get("play_ahead") or {}
@@ -839,7 +840,7 @@ def main():
     ap.add_argument("--api-moves", type=int, default=190,
                     help="engine moves the nested product-surface leg (Player.read) is driven for; 0 = skip")
     ap.add_argument("--no-train-step", action="store_true", help="skip the nested training-step leg (SURVEY 8(f).4)")
-    ap.add_argument("--loop-steps", type=int, default=1600, help="timed steps of the nested train-loop leg (inline / overlapped); 0 = skip")
+    ap.add_argument("--loop-steps", type=int, default=4000, help="timed steps of the nested train-loop leg (inline / overlapped); 0 = skip")
     ap.add_argument("--train-steps", type=int, default=200, help="internal: timed steps of a --train-step-only run")
     ap.add_argument("--train-step-only", choices=list(TRAIN_MODES), default=None,
                     help="internal: run ONE mode of the training-step leg in this process and print its JSON")
