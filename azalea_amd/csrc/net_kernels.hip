@@ -1134,13 +1134,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wide_train_bwd(int N, int C, co
 int azx_net_wide_train_conv_bwd(int N, int C, const unsigned short *w16, const unsigned short *in, float *g_out, int n_boards,
                                 const float *unscale, float2 *pgsum, const unsigned char *mask, const float *raw, const float *skip,
                                 const double *sums, float invN, unsigned int *gmax, hipStream_t st) {
-    static bool raised = false;
+    // (N * N + 2) * 272 bytes: 46.5 KB at 13x13, inside the 48 KB a kernel may ask for without raising its limit -- no
+    // per-process "raised" flag to go stale on a second device
     const size_t lds = (size_t)(N * N + 2) * WIDE_ROWB;
-    if (!raised) {
-        if (hipFuncSetAttribute((const void *)k_conv_wide_train_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
-            return AZX_EHIP;
-        raised = true;
-    }
+    if (lds > 48 * 1024) return AZX_EINVAL;
     const WideBwdFuse F = {mask, raw, skip, sums, invN, gmax};
     hipLaunchKernelGGL(k_conv_wide_train_bwd<2>, dim3(8 * (C / 64), (n_boards + 7) / 8), dim3(256), lds, st, N, C, w16, in, g_out, n_boards, unscale, pgsum, F);
     return AZX_OK;
@@ -1148,13 +1145,8 @@ int azx_net_wide_train_conv_bwd(int N, int C, const unsigned short *w16, const u
 
 int azx_net_wide_train_conv(int N, int C, const unsigned short *w16, const unsigned short *in, float *out32, int n_boards,
                             const float *unscale, float2 *stat, hipStream_t st) {
-    static bool raised = false;
-    const size_t lds = (size_t)(N * N + 2) * WIDE_ROWB;
-    if (!raised) {
-        if (hipFuncSetAttribute((const void *)k_conv_wide_train<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
-            return AZX_EHIP;
-        raised = true;
-    }
+    const size_t lds = (size_t)(N * N + 2) * WIDE_ROWB;      // <= 46.5 KB (see azx_net_wide_train_conv_bwd)
+    if (lds > 48 * 1024) return AZX_EINVAL;
     hipLaunchKernelGGL(k_conv_wide_train<2>, dim3(8 * (C / 64), (n_boards + 7) / 8), dim3(256), lds, st, N, C, w16, in, out32, n_boards, unscale, stat);
     return AZX_OK;
 }
