@@ -22,6 +22,9 @@ _KEYS = ("color", "legal_moves", "result", "board", "moves_prob", "reward")
 
 
 class DeviceReplayBuffer:
+    learner = None      # (class defaults: a buffer built around an existing ring without __init__ plays its refills inline)
+    ahead = None
+
     def __init__(self, engine, capacity: int, contents: ReplayDataFrame = None, shared: bool = True):
         """`engine`: azalea_amd.engine.Engine whose self-play feeds the buffer (Player._get_engine).
         `contents`: initial rows, like ReplayBuffer(contents).  `shared`: under torch.distributed every
