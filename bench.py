@@ -51,8 +51,8 @@ sys.path.insert(0, ROOT)
 
 # committed rocprofv3 --pmc summaries of this round (tools/prof.sh); attached only when their bench_key matches AND they
 # were recorded on the kernel sources this library was built from (src_sha, azx_kernel_info's `src=`)
-PMC_FILES = {"resnet": "r5_resnet_pmc_traffic.json", "tree": "r5_tree_pmc_traffic.json",
-             "config5": "r5_config5_pmc_traffic.json"}
+PMC_FILES = {"resnet": "r6_resnet_pmc_traffic.json", "tree": "r6_tree_pmc_traffic.json",
+             "config5": "r6_config5_pmc_traffic.json"}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TF = 157.3   # dense fp32 MFMA peak
 F16_MFMA_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline is 2:1 sparse)
