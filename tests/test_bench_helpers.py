@@ -145,3 +145,27 @@ def test_world_fields_of_an_n_gpu_line():
     g = bench.world_fields(per_rank, 800.0, None, None, "gloo")
     assert g["rccl_ranks"] == 0 and "weak_scaling_eff" not in g and "replay_allgather_gbs" not in g
     assert all(v is None or isinstance(v, (bool, int, float, str)) for v in f.values())
+
+
+def test_the_committed_round6_line_reproduces_every_leg_from_its_scalars():
+    """profiles/r6_selfplay_bench.json is the line `python bench.py` printed on the MI355X box with the final library: cut
+    down to what the driver's record keeps, it alone must reproduce the headline, tree, config5 and both training fractions,
+    carry HBM traffic for all three kernel legs (PMC files keyed to the same kernel sources) and the train-loop leg."""
+    line = json.load(open(os.path.join(ROOT, "profiles", "r6_selfplay_bench.json")))
+    kept = bench.strip_to_driver_record(line)
+    r, c = kept["roofline"], kept["cpu_baseline"]
+    assert abs(r["flop_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12 / r["peak"] - r["frac"]) < 1e-9 and 0.2 < r["frac"] < 1 / 3
+    assert abs(r["tree_bytes_per_launch"] / (r["tree_avg_launch_ms"] * 1e-3) / 1e9 / r["tree_peak_gbs"] - r["tree_frac"]) < 1e-9
+    assert abs(r["tree_traffic"] / (r["tree_avg_launch_ms"] * 1e-3) / 1e9 / r["tree_peak_gbs"] - r["tree_achieved_hbm_frac"]) < 1e-9
+    assert abs(r["c5_flop_per_launch"] / (r["c5_avg_launch_ms"] * 1e-3) / 1e12 / r["c5_peak_tflops"] - r["c5_frac"]) < 1e-9
+    assert r["c5_steps"] == 3 and r["c5_positions_per_launch"] > 4000
+    assert abs(r["train_flop_per_step"] / (r["train_native_step_only_ms"] * 1e-3) / 1e12 / 2500.0 - r["train_native_frac"]) < 1e-9
+    assert abs(r["train_wide_flop_per_step"] / (r["train_wide_native_step_only_ms"] * 1e-3) / 1e12 / 2500.0 - r["train_wide_frac"]) < 1e-9
+    assert r["traffic"] > 0 and r["tree_traffic"] > 0 and r["c5_traffic"] > 0          # counters attached: same kernel sources
+    assert r["traffic"] == r["traffic_tower"] + r["traffic_heads"]
+    assert r["loop_inline_steps_per_sec"] > 0 and abs(r["loop_overlap_speedup"] - r["loop_overlapped_steps_per_sec"] / r["loop_inline_steps_per_sec"]) < 1e-9
+    assert r["box_gemm_tflops"] > 0 and r["api_rows_over_plies"] > 0.9
+    assert c["tree_value"] > 0 and c["c5_value"] > 0 and c["reference_scaled_value"] == c["reference_per_core"] * c["cores"]
+    src = bench.src_sha(line["kernels"])
+    for leg in ("resnet", "tree", "config5"):
+        assert json.load(open(os.path.join(ROOT, "profiles", bench.PMC_FILES[leg])))["src_sha"] == src
