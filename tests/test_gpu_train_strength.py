@@ -30,7 +30,9 @@ def test_training_makes_a_stronger_player(mover_view, overlap):
     if overlap:      # config["selfplay_overlap"]: self-play ran beside the steps (azalea_amd/play_ahead.py), with fresh weights
         pa = out["play_ahead"]
         assert pa["productions"] > 50 and pa["weight_syncs"] > 20 and pa["reserved_cus"] == 0 and pa["takes"] > 5
-        assert pa["max_backlog_rows"] < 2 * 1024 + 49 * 1024 // 8      # the bound: ahead_rows + about one harvest
+        # the bound: ahead_rows (one per pool slot) + ONE harvest -- which is at most every slot's whole game (the first
+        # generation starts together and finishes within a few moves of each other)
+        assert pa["max_backlog_rows"] <= 1024 + 1024 * 49
     else:
         assert out["play_ahead"] is None
     losses = [row[1] for row in out["loss_by_step"]]
