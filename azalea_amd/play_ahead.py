@@ -125,6 +125,7 @@ class PlayAhead:
     _due = False
     _wanted = 0
     _holding = False
+    _failure_raised = False
 
     def take(self, quota: int):
         """Whole chunks, oldest first, until >= quota rows: (list of record tensors, summed production metrics).
@@ -143,6 +144,7 @@ class PlayAhead:
                 self._wanted = 0
                 self.stats["wait_seconds"] += time.perf_counter() - t0
             if self._failure is not None:
+                self._failure_raised = True
                 raise self._failure
             recs, m = self.backlog.take(quota)
             self._cv.notify_all()               # room in the backlog again
@@ -156,6 +158,8 @@ class PlayAhead:
         if self._thread is not None:
             self._thread.join()
             self._thread = None
+        if self._failure is not None and not self._failure_raised:
+            logging.warning("play-ahead: the play thread had failed (%r); no take() was left to raise it", self._failure)
         if self.reserved_cus and self._holding and hasattr(self.engine, "reserve_cus"):
             try:
                 self.engine.reserve_cus(0)
