@@ -2476,10 +2476,12 @@ static T *upload_table(AzxTrain *t, const std::vector<T> &v) {
 int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int device) {
     if (chans != 16 && chans != 32 && chans != 64 && chans != 128 && chans != 256)
         return tfail(AZX_EINVAL, "train: base_chans must be 16, 32, 64, 128 or 256");
-    const bool wide = chans >= 128;
+    // 64 channels on 12x12 / 13x13 take the wide step too (its kernels tile a board as 176 position rows and need C to be
+    // a multiple of 64): the reference's width on BASELINE configs[4]'s board
+    const bool wide = chans >= 128 || (chans == 64 && N > 11);
     if (N < 2 || N > (wide ? 13 : 11))
-        return tfail(AZX_EINVAL, "train: the native step covers boards up to 11x11 with 16 / 32 / 64 channels (121 cells = four 32-row "
-                                 "MFMA tiles) and up to 13x13 with 128 / 256");
+        return tfail(AZX_EINVAL, "train: the native step covers boards up to 11x11 with 16 / 32 channels (121 cells = four 32-row "
+                                 "MFMA tiles) and up to 13x13 with 64 / 128 / 256");
     if (wide && N < 3) return tfail(AZX_EINVAL, "train: the wide towers (128 / 256 channels) need a board of 3x3 or more");
     if (blocks < 1 || batch < 1 || 2 * blocks > TRN_MAXL) return tfail(AZX_EINVAL, "train: num_blocks must be 1..19 and the batch positive");
     AzxTrain *t = new AzxTrain();
@@ -3093,6 +3095,7 @@ static int raise_limits_wide(int cells, int N) {
 static int raise_limits(int C, int cells = 0, int N = 0) {
     if (C == 128) return raise_limits_wide<128>(cells, N);
     if (C == 256) return raise_limits_wide<256>(cells, N);
+    if (C == 64 && N > 11) return raise_limits_wide<64>(cells, N);
     const int cap = 128 * 1024;     // the largest user (k_trn_wgrad<64>) takes 94 KB; some kernels add static LDS on top
     const void *f64[] = {(const void *)k_trn_conv<64, ROLE_FWD>, (const void *)k_trn_conv<64, ROLE_FWD16>, (const void *)k_trn_conv<64, ROLE_BWD>, (const void *)k_trn_conv<64, ROLE_BWD16>, (const void *)k_trn_wgrad<64>, (const void *)k_trn_wgrad16<64>,
                          (const void *)k_trn_heads_conv<64>, (const void *)k_trn_stem_bwd<64>, (const void *)k_trn_heads_bwd<64>};
@@ -3111,7 +3114,7 @@ static int enqueue_any(AzxTrain *t, hipStream_t st, hipStream_t side, bool fork)
     switch (t->d.C) {
         case 256: return enqueue_step_wide<256>(t, st, side, fork);
         case 128: return enqueue_step_wide<128>(t, st, side, fork);
-        case 64: return enqueue_step<64>(t, st, side, fork);
+        case 64: return t->wide ? enqueue_step_wide<64>(t, st, side, fork) : enqueue_step<64>(t, st, side, fork);
         case 32: return enqueue_step<32>(t, st, side, fork);
         default: return enqueue_step<16>(t, st, side, fork);
     }

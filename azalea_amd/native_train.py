@@ -47,7 +47,7 @@ def unsupported_reason(model, optimizer, device):
         return "NativeTrainStep: the optimizer must hold exactly the module's parameters"
     chans = model.conv1.weight.shape[0]
     if (model.board_size, chans) not in SUPPORTED_SHAPES:
-        return ("NativeTrainStep covers boards up to 11x11 with 16 / 32 / 64 channels and 3x3 .. 13x13 with 128 / 256; got %dx%d, %d channels"
+        return ("NativeTrainStep covers boards up to 11x11 with 16 / 32 / 64 channels, 12x12 / 13x13 with 64, and 3x3 .. 13x13 with 128 / 256; got %dx%d, %d channels"
                 % (model.board_size, model.board_size, chans))
     return None
 
@@ -57,7 +57,7 @@ class _Shapes:
 
     def __contains__(self, key):
         n, c = key
-        return (2 <= n <= 11 and c in (16, 32, 64)) or (3 <= n <= 13 and c in (128, 256))
+        return (2 <= n <= 11 and c in (16, 32, 64)) or (3 <= n <= 13 and c in (128, 256)) or (12 <= n <= 13 and c == 64)
 
 
 SUPPORTED_SHAPES = _Shapes()

@@ -367,14 +367,15 @@ int azx_debug_set_queue_cap(azx_engine *e, int64_t rows);
  * split-f16 arithmetic of the self-play tower, fp32 accumulate, operands scaled per layer by powers of two: results
  * at fp32 accuracy whatever the magnitudes; environment AZX_TRAIN_FWD / _BWD / _WGRAD=fp32 selects exact-fp32 MFMA
  * kernels per pass).  The trainer keeps owning its tensors (PyTorch holds them); this handle owns the activations
- * and scratch.  16 / 32 / 64 channels on boards up to 11x11, and 128 / 256 channels on boards from 3x3 to 13x13 (the
- * wide step: the self-play wide convolution kernel in its TRAIN modes for forward and backward-data, elementwise
+ * and scratch.  16 / 32 / 64 channels on boards up to 11x11, and 128 / 256 channels on boards from 3x3 to 13x13 -- and
+ * 64 channels on 12x12 / 13x13 -- through the
+ * wide step (the self-play wide convolution kernel in its TRAIN modes for forward and backward-data, elementwise
  * BatchNorm / ReLU passes on split-f16 images); any batch (built for the reference's 128); other shapes are
- * AZX_EINVAL.  PERMANENT LIMIT of this ABI revision: 16 / 32 / 64 channels on 12x12 / 13x13 boards -- the narrow kernels
- * tile a board as 128 position rows and keep it whole in LDS beside 1024-wide head planes, 144 / 169 cells need the wide
- * step's 176-row tiling; policy_trainer.train runs the stock PyTorch step there (the reference's own, shape-agnostic:
- * policy_trainer.py:123-142), correct and ~4x slower.  BASELINE's configs train 6x64 on 11x11 and 19x256 on 13x13: both
- * covered. */
+ * AZX_EINVAL.  PERMANENT LIMIT of this ABI revision: 16 / 32 channels on 12x12 / 13x13 boards -- the narrow kernels
+ * tile a board as 128 position rows and keep it whole in LDS beside 1024-wide head planes; 144 / 169 cells need the wide
+ * step's 176-row tiling, whose convolution blocks are 64 output channels wide.  policy_trainer.train runs the stock
+ * PyTorch step there (the reference's own, shape-agnostic: policy_trainer.py:123-142), correct and ~4x slower.  The
+ * reference's width (64) and BASELINE's configs (6x64 on 11x11, 19x256 on 13x13) are covered on every board. */
 typedef struct {
     int32_t board_size, num_blocks, base_chans;   /* policy.py:51-53 */
     int32_t batch_size;                           /* config batch_size (hex11_train_config.yml: 128) */

@@ -51,7 +51,8 @@ def _net(n, blocks, chans, seed=0):
 
 @pytest.mark.parametrize("n,blocks,chans,B", [(11, 2, 64, 8), (11, 1, 16, 5), (9, 2, 32, 7), (11, 6, 64, 128),
                                               (5, 1, 128, 4), (7, 2, 256, 6), (11, 2, 128, 9), (11, 3, 256, 16),
-                                              (13, 1, 128, 5), (13, 2, 256, 7), (12, 1, 256, 3)])
+                                              (13, 1, 128, 5), (13, 2, 256, 7), (12, 1, 256, 3),
+                                              (13, 2, 64, 6), (12, 1, 64, 5), (13, 6, 64, 128)])      # 64 channels on 12x12 / 13x13: the wide step
 def test_every_intermediate_matches_autograd(n, blocks, chans, B):
     from azalea_amd.native_train import NativeTrainStep
     net, ref = _net(n, blocks, chans), _net(n, blocks, chans)

@@ -284,11 +284,12 @@ def test_native_train_step_refuses_what_it_does_not_cover():
 
 
 def test_native_step_envelope_is_what_train_picks_by():
-    """native_train.unsupported_reason (no GPU needed for the shape logic): 16 / 32 / 64 channels up to 11x11, 128 / 256
-    from 3x3 to 13x13; anything else names the reason -- train() then takes the stock step (make_train_step)."""
+    """native_train.unsupported_reason (no GPU needed for the shape logic): 16 / 32 / 64 channels up to 11x11, 64 also on
+    12x12 / 13x13 (through the wide step), 128 / 256 from 3x3 to 13x13; anything else names the reason -- train() then
+    takes the stock step (make_train_step)."""
     from azalea_amd.native_train import SUPPORTED_SHAPES
-    ok = [(11, 64), (2, 16), (9, 32), (13, 256), (13, 128), (3, 128), (11, 256)]
-    bad = [(13, 64), (12, 32), (2, 128), (14, 256), (11, 48), (11, 512)]
+    ok = [(11, 64), (2, 16), (9, 32), (13, 256), (13, 128), (3, 128), (11, 256), (13, 64), (12, 64)]
+    bad = [(13, 32), (12, 16), (2, 128), (14, 256), (14, 64), (11, 48), (11, 512)]
     assert all(k in SUPPORTED_SHAPES for k in ok) and not any(k in SUPPORTED_SHAPES for k in bad)
     import torch
     from azalea_amd.network import HexNetwork
