@@ -1870,7 +1870,7 @@ __global__ __launch_bounds__(256) void k_trn_prep(TrnDev P) {
 }
 
 // =================================================================================================================
-// wide towers: C = 128 / 256 (BASELINE configs[4]'s width), boards up to 11x11
+// wide towers: C = 128 / 256 (BASELINE configs[4]'s width) on boards up to 13x13 -- and C = 64 on 12x12 / 13x13
 //
 // A 6x64 step is a chain of launches whose matrix work is ~1.5 us each: everything above is built around latency.  At
 // 256 channels a layer pass is 18 GFLOP: throughput-bound, and a (board, 32 channels) workgroup that stages the whole
@@ -2973,6 +2973,12 @@ __global__ __launch_bounds__(256) void k_tw_wgrad(TwWgrad A, int N, int B, int G
     }
 }
 
+// (Measured and dropped, round 6 -- the hypothesis: one board ahead, a request has ONE k-loop (117 MFMAs = 1.5 us) to come
+// back in while all 64 tile pairs of a board group ask for the same board at once, so the first to ask pays an HBM round
+// trip the k-loop does not cover.  (1) A second 44-register set, boards requested TWO ahead: the compiler takes 256
+// registers and spills 136 bytes a lane, 120 vs 91 us.  (2) One dword of each piece of the board two ahead touched so
+// that the real request hits L2, 11 registers: 156 vs 92 us (the touches sit in the same in-order vmcnt queue as the
+// pieces the staging waits for).  profiles/r6_train_wide_ab.txt)
 // (Measured and dropped, round 5: a 64 x 64 tile per block -- four waves = (co half, ci half), each with all nine taps in
 // 144 accumulator registers, every SIMD with matrix work, the two 64-channel image slices staged once for four tile
 // pairs, one block per CU: 80 vs 92 us per launch, but the blocks that fill the chip once need 16 board groups instead
