@@ -67,8 +67,9 @@ class NativeTrainStep:
     """Same surface as policy_trainer.GraphedTrainStep: `step(batch)`, `step_from_ring(replaybuf, indices)`,
     `outputs(k)`, `.loss` (three device floats: total, value, moves).
 
-    Covers HexNetwork on boards up to 11x11 with 16 / 32 / 64 channels under SGD (one parameter group, no dampening, no
-    nesterov); anything else raises ValueError -- use GraphedTrainStep or the eager step there."""
+    Covers HexNetwork under SGD (one parameter group, no dampening, no nesterov) on the shapes of SUPPORTED_SHAPES: 16 / 32 /
+    64 channels up to 11x11, 64 / 128 / 256 up to 13x13; anything else raises ValueError -- use GraphedTrainStep or the
+    eager step there."""
 
     def __init__(self, model, optimizer, batch_size: int, device):
         from .network import HexNetwork
