@@ -387,7 +387,7 @@ def test_c_abi_error_behaviour_of_the_trainer():
         h = C.c_void_p()
         cfg = _lib.TrainConfig(n, blocks, chans, batch, 0)
         return L.azx_train_create(C.byref(cfg), C.byref(h)), h
-    for bad in ((13, 6, 64, 8), (11, 6, 48, 8), (11, 0, 64, 8), (11, 6, 64, 0), (11, 20, 64, 8)):
+    for bad in ((13, 6, 32, 8), (14, 6, 64, 8), (11, 6, 48, 8), (11, 0, 64, 8), (11, 6, 64, 0), (11, 20, 64, 8)):
         rc, _ = create(*bad)
         assert rc == -1, bad                                      # AZX_EINVAL
     rc, h = create(5, 1, 16, 4)
