@@ -21,6 +21,13 @@ measured min p 1.5e-3 / 0.056, 3 / 0 of them below 0.05); an oracle that (wrongl
 fails the same tests at p < 1e-100 (power check below).  The engine's games are a deterministic function of its seed,
 so the verdict does not flicker from run to run.
 
+Round 6 adds the configuration every reported number runs on (11x11, Dirichlet alpha 0.03, eps 0.25, exploration_depth 15,
+c_puct 0.5, batch 10: config/hex11_train_config.yml:19-36) -- with the uniform-hash evaluator (512 games, 100 -> 110
+selects) and on the headline's own kernels (the 6x64 device network, 256 games of 60 -> 70 selects, against the oracle's
+fp32 forward: fixture G13).  G11's "11h" set pins the oracle sampler to the REFERENCE's games at exactly these
+hyper-parameters.  Measured: 85 tests each, min p 0.013 / 0.0048, 4 / 4 below 0.05; the oracle against itself (92 tests)
+min p 6.6e-4 -- inside the family-wise 5 % bound the calibration is held to.
+
 What this test found when it was first run (round 5): the per-ply `search_value` metric of throughput mode was the
 raw sum of the leaf values, not divided by num_batches * batch_size as mcts.py:291 does (KS p = 0 at every ply;
 everything else agreed) -- fixed in k_choose.
