@@ -223,7 +223,9 @@ def _train_worker(rank, world, port, rundir, native, mode, out):
     if mode == "lockstep":
         # 20 steps x 8 rows consumed: several shared refills, each searched with rank 0's weights of that moment on BOTH
         # ranks (the digests are of the engines' packed operands), and those weights moved as rank 0 trained
-        fails += [] if (len(digests) >= 3 and alld[0] == alld[1]) else [1]
+        # (how many refills 20 steps need depends on the lengths of the games played, i.e. on weights that carry the
+        # native step's last-bit run-to-run differences -- its head sums are float atomics: usually 3-4, once in a while 2)
+        fails += [] if (len(digests) >= 2 and alld[0] == alld[1]) else [1]
     else:
         # 20 steps, a broadcast before the first and after every 4th: the module rank 1 packed after each broadcast is
         # the one rank 0 had just sent; rank 1 played between announcements and handed its rows over when asked
@@ -238,7 +240,7 @@ def _train_worker(rank, world, port, rundir, native, mode, out):
             A = hist["actor"]
             fails += [] if (A["pulls"] >= 2 and A["rows"] >= 100 and A["max_productions_between_announcements"] >= 1) else [7]
             fails += [] if len(set(packed)) == len(packed) >= 3 else [8]     # the packed operands moved with every broadcast
-    fails += [] if len(set(alld[0])) >= 3 else [2]
+    fails += [] if len(set(alld[0])) >= (2 if mode == "lockstep" else 3) else [2]
     sd = torch.cat([t.detach().reshape(-1).double().cpu() for t in policy.net.state_dict().values() if t.is_floating_point()])
     sums = [None] * world
     dist.all_gather_object(sums, float(sd.sum()))
