@@ -348,7 +348,7 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
     learner = None
     ahead = None
     side = None
-    stream_ctx = None
+    streams = contextlib.ExitStack()       # the play-ahead mode's training stream is current from the first step to the last
     try:
         if mode == "actor_learner":
             from .actor_learner import Learner
@@ -392,8 +392,8 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
             side.wait_stream(torch.cuda.current_stream(device))
             if history is not None:
                 history["selfplay_overlap"] = True
-        stream_ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
-        stream_ctx.__enter__()
+        if side is not None:
+            streams.enter_context(torch.cuda.stream(side))
         loss_dev = None
         loss, step, start_time = 0.0, 0, time.time()
         for epoch in range(1, config["total_epochs"] + 1):
@@ -438,13 +438,11 @@ def train(policy, config, rundir, *, replaybuf=None, device_replay: bool = False
                 if config.get("model_checkpoint_interval") and step % config["model_checkpoint_interval"] == 0:
                     save_checkpoint(policy, "%s/checkpoints/checkpoint.%d" % (rundir, step), optimizer=optimizer)
                 step += 1
-        stream_ctx.__exit__(None, None, None)
-        stream_ctx = None
+        streams.close()
         if side is not None:
             torch.cuda.current_stream(device).wait_stream(side)
     except BaseException:
-        if stream_ctx is not None:
-            stream_ctx.__exit__(None, None, None)
+        streams.close()
         if ahead is not None:
             ahead.stop()
             replaybuf.ahead = None
