@@ -2450,6 +2450,7 @@ struct AzxTrain {
     bool fork = true;            // AZX_TRAIN_FORK=0: the weight-gradient passes in line with the data chain (profiling)
     // wide towers (C = 128 / 256)
     bool wide = false;
+    bool wgrad2 = false;         // 256 channels: the two-ci-tile, six-owner-wave filter gradient (k_tw_wgrad2); AZX_TRAIN_WGRAD2=0 / 1 overrides
     std::vector<unsigned short *> Ww16f, Ww16b, A16;       // per layer: the wide filter packs, the activations' images
     unsigned short **Ww16f_dev = nullptr, **Ww16b_dev = nullptr;
     std::vector<unsigned short *> D16;                      // per layer: the BatchNorm-backward images (k_tw_wgrad reads them later)
@@ -2497,6 +2498,9 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     d.presum = d.B > TRN_PRESUM_BATCH;
     t->G = std::min(batch, TRN_WG_GROUPS);
     t->wide = wide;
+    // 256 channels only: at 128 the two are equal on 13x13 (4.84 vs 4.85 ms a step) and the new one loses on small boards
+    // (10x128 on 9x9: 2.30 vs 2.12 ms) -- AZX_TRAIN_WGRAD2=1 forces it there, =0 switches it off
+    t->wgrad2 = wide && chans >= 128 && (getenv("AZX_TRAIN_WGRAD2") ? atoi(getenv("AZX_TRAIN_WGRAD2")) != 0 : chans == 256);
     // wide: (C / 32)^2 tile pairs already fill the chip with few board groups, and a group costs a partial copy of C C 9
     if (wide) t->G = std::min(batch, chans == 256 ? 8 : 32);      // (C = 256: 8 groups measured 10.7 ms per step against 11.1 with 16)
     if (getenv("AZX_TRAIN_WG_GROUPS")) t->G = std::max(1, std::min(t->G, atoi(getenv("AZX_TRAIN_WG_GROUPS"))));
@@ -2973,6 +2977,119 @@ __global__ __launch_bounds__(256) void k_tw_wgrad(TwWgrad A, int N, int B, int G
     }
 }
 
+// k_tw_wgrad with TWO ci tiles per block and SIX owner waves (VERDICT r5 #4a): a block is (32 co, 64 ci) x a group of
+// boards, 512 threads -- waves 0..5 own (ci tile w / 3, tap column w % 3) with three accumulator tiles each, waves 6 and 7
+// only stage; draw's slice is staged ONCE for both ci tiles (92 KB of LDS: one block per CU, six matrix waves on its four
+// SIMDs where two resident blocks of k_tw_wgrad have six with a SIMD left idle).  Same operand layout, k-loop and partial
+// copies as k_tw_wgrad; (C / 32) x (C / 64) tile pairs per board group.  Measured (19x256 on 13x13, batch 128; profiles/
+// r6_train_wide_ab.txt 8): the kernel alone 86.9 vs 90.6 us -- and the STEP on its two streams 9.6 vs 10.4 ms: one 92 KB
+// block with 8 waves leaves a CU room for a data-chain block (46.5 KB, 4 waves) beside it, two 59 KB blocks did not, so the
+// filter gradients now really run UNDER the backward chain.  The default at 256 channels (AZX_TRAIN_WGRAD2=0 / 1 overrides;
+// k_tw_wgrad stays the kernel of 64 and 128 channels).  Capped at 168 registers (so that two of its waves and a 167-register
+// data-chain wave would fit a SIMD together) it spills 12 bytes a lane and the step is no faster: 9.89 vs 9.82 ms.  Same box,
+// three alternating runs: 9.65 ms with it against 10.33 with k_tw_wgrad (and 9.76 / 10.02 with the backward convolution's
+// epilogue operands requested three tiles at a time, 167 instead of 214 registers -- the combination that ships is the best).
+template <int C>
+__global__ __launch_bounds__(512) void k_tw_wgrad2(TwWgrad A, int N, int B, int G) {
+    constexpr int NT = C / 32, NT2 = C / 64, PPP = 24, ITER = (169 * PPP + 511) / 512;      // pieces per position: 8 draw + 2 x 8 input
+    extern __shared__ __align__(16) float lds[];
+    const int cells = N * N, KR = N * 16, BR = (N + 3) * 16;
+    unsigned char *Dh = reinterpret_cast<unsigned char *>(lds), *Dl = Dh + (size_t)KR * 64;      // [KR][32] f16 draw hi / lo
+    unsigned char *Bb = Dl + (size_t)KR * 64;                                                    // [ci tile][hi, lo][BR][32] f16 input
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int pair = blockIdx.x, grp = blockIdx.y;
+    if ((G & 7) == 0) {       // a board group on ONE XCD (see k_tw_wgrad)
+        const int id = blockIdx.y * gridDim.x + blockIdx.x, xcd = id & 7, slot = id >> 3, np = gridDim.x;
+        grp = 8 * (slot / np) + xcd;
+        pair = slot % np;
+    }
+    const int tm = pair / NT2, tn2 = pair % NT2;
+    const int total = cells * PPP;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v[ITER];
+    auto request = [&](int b) {
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) {
+            const int i = min(tid + 512 * k, total - 1), pos = i / PPP, q = i - pos * PPP;
+            const bool inp = q >= 8;
+            const int qq = inp ? q - 8 : q, j = qq >> 3, hl = (qq >> 2) & 1;          // (draw: j = 0)
+            const unsigned short *src = (inp ? A.aimg : A.dimg) + ((size_t)b * cells + pos) * (2 * C) + hl * C +
+                                        (inp ? tn2 * 64 + j * 32 : tm * 32) + (qq & 3) * 8;
+            v[k] = *reinterpret_cast<const u32x4 *>(src);
+        }
+    };
+    request(grp);
+    const float unscale = 1.f / (A.bsc->x * A.fsc->x);
+    {
+        float4 *z = reinterpret_cast<float4 *>(lds);
+        for (int i = tid; i < (2 * KR + 4 * BR) * 64 / 16; i += 512) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const bool owner = wv < 6;
+    const int oj = owner ? wv / 3 : 0, oc = owner ? wv % 3 : 1;       // this wave's ci tile and tap column
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    __syncthreads();
+    const int frag_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const unsigned char *Bh = Bb + (size_t)(2 * oj) * BR * 64, *Bl = Bh + (size_t)BR * 64;
+    const int col_off = (17 + (oc - 1)) * 64 + frag_off;
+    for (int b = grp; b < B; b += G) {
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) {
+            const int i = tid + 512 * k;
+            if (i >= total) break;
+            const int pos = i / PPP, q = i - pos * PPP, y = pos / N, krow = y * 16 + (pos - y * N);
+            const bool inp = q >= 8;
+            const int qq = inp ? q - 8 : q, j = qq >> 3, hl = (qq >> 2) & 1;
+            unsigned char *dst = inp ? Bb + (size_t)(2 * j + hl) * BR * 64 + (size_t)(krow + 17) * 64
+                                     : (hl ? Dl : Dh) + (size_t)krow * 64;
+            *reinterpret_cast<u32x4 *>(dst + (qq & 3) * 16) = v[k];
+        }
+        __syncthreads();
+        if (b + G < B) request(b + G);                 // travels under this board's k-loop
+        if (owner) {
+            f16x8 dhi = tr_frag(Dh + frag_off), dlo = tr_frag(Dl + frag_off);
+            f16x8 h0 = tr_frag(Bh + col_off - 16 * 64), l0 = tr_frag(Bl + col_off - 16 * 64);
+            f16x8 h1 = tr_frag(Bh + col_off), l1 = tr_frag(Bl + col_off);
+            f16x8 h2 = tr_frag(Bh + col_off + 16 * 64), l2 = tr_frag(Bl + col_off + 16 * 64);
+            for (int s = 0; s < N; ++s) {
+                const int sn = s + 1 < N ? s + 1 : s;
+                const f16x8 ndhi = tr_frag(Dh + frag_off + (size_t)sn * 16 * 64), ndlo = tr_frag(Dl + frag_off + (size_t)sn * 16 * 64);
+                const size_t r3 = (size_t)(s + 2 <= N ? s + 2 : N) * 16 * 64;
+                const f16x8 h3 = tr_frag(Bh + col_off + r3), l3 = tr_frag(Bl + col_off + r3);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, h0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, h1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, h2, acc[2], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, l0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, l1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dhi, l2, acc[2], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, h0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, h1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dlo, h2, acc[2], 0, 0, 0);
+                dhi = ndhi; dlo = ndlo;
+                h0 = h1; l0 = l1; h1 = h2; l1 = l2; h2 = h3; l2 = l3;
+            }
+        }
+        __syncthreads();
+    }
+    float *part = A.part + (size_t)grp * ((size_t)C * C * 9);
+    const int li = lane & 31, lh = lane >> 5, ci = tn2 * 64 + oj * 32 + li;
+    if (owner) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int t = 3 * u + oc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = tm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                part[((size_t)t * C + co) * C + ci] = acc[u][i] * unscale;
+            }
+        }
+    }
+}
+
 // (Measured and dropped, round 6 -- the hypothesis: one board ahead, a request has ONE k-loop (117 MFMAs = 1.5 us) to come
 // back in while all 64 tile pairs of a board group ask for the same board at once, so the first to ask pays an HBM round
 // trip the k-loop does not cover.  (1) A second 44-register set, boards requested TWO ahead: the compiler takes 256
@@ -3055,7 +3172,8 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
         if (!fork_side()) return tfail(AZX_EHIP, "train: forking the weight-gradient stream failed");
         if (t->wgrad16) {
             const TwWgrad wq = {t->D16[l], t->A16[l - 1], d.bsc + l, d.fsc + l, d.wpart + (size_t)(l - 1) * G * ((size_t)C * C * 9)};
-            hipLaunchKernelGGL(k_tw_wgrad<C>, dim3(NT * NT, G), dim3(256), wgi_lds, ws, wq, N, B, G);
+            if (t->wgrad2) hipLaunchKernelGGL(k_tw_wgrad2<C>, dim3(NT * (NT / 2), G), dim3(512), (size_t)(2 * N * 16 + 4 * (N + 3) * 16) * 64, ws, wq, N, B, G);
+            else hipLaunchKernelGGL(k_tw_wgrad<C>, dim3(NT * NT, G), dim3(256), wgi_lds, ws, wq, N, B, G);
         } else {      // AZX_TRAIN_WGRAD=fp32 here: the filter gradient from the fp32 tensors (k_trn_wgrad16, BatchNorm backward on the way in)
             const WgradPtrs wq = {t->g[l], t->raw[l], t->act[l - 1], d.bn_w[l]};
             hipLaunchKernelGGL(k_trn_wgrad16<C>, dim3(NT * NT, G), dim3(256), wg16_lds, ws, wq, l, G, d);
@@ -3088,10 +3206,10 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
 template <int C>
 static int raise_limits_wide(int cells, int N) {
     (void)cells;
-    const size_t need[2] = {(size_t)(N * 16 + (N + 3) * 16) * 128 + (1024 + 5 * 32 + 2) * sizeof(float),
-                            (size_t)(N * 16 + (N + 3) * 16) * 128};
-    const void *f[2] = {(const void *)k_trn_wgrad16<C>, (const void *)k_tw_wgrad<C>};
-    for (int i = 0; i < 2; ++i)
+    const size_t need[3] = {(size_t)(N * 16 + (N + 3) * 16) * 128 + (1024 + 5 * 32 + 2) * sizeof(float),
+                            (size_t)(N * 16 + (N + 3) * 16) * 128, (size_t)(2 * N * 16 + 4 * (N + 3) * 16) * 64};
+    const void *f[3] = {(const void *)k_trn_wgrad16<C>, (const void *)k_tw_wgrad<C>, (const void *)k_tw_wgrad2<C>};
+    for (int i = 0; i < 3; ++i)
         if (need[i] > 48 * 1024 && hipFuncSetAttribute(f[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)need[i]) != hipSuccess)
             return tfail(AZX_EHIP, "train: raising a kernel's dynamic LDS limit failed (kernel " + std::to_string(i) + ", " +
                                    std::to_string(need[i]) + " bytes)");
