@@ -156,6 +156,20 @@ def test_exact_fp32_kernels_stay_green(monkeypatch, passes):
     test_odd_batches_and_boards(7, 2, 32, 300)
 
 
+@pytest.mark.parametrize("on", ["0", "1"])
+def test_both_wide_filter_gradient_kernels_stay_green(monkeypatch, on):
+    """AZX_TRAIN_WGRAD2 (read when the trainer is created): k_tw_wgrad2 is the default at 256 channels, k_tw_wgrad at 128 --
+    each is also held to autograd where the other is the default (0: k_tw_wgrad at 256 channels; 1: k_tw_wgrad2 at 128)."""
+    monkeypatch.setenv("AZX_TRAIN_WGRAD2", on)
+    if on == "0":
+        test_every_intermediate_matches_autograd(13, 2, 256, 7)
+        test_odd_batches_and_boards(9, 2, 256, 70)
+    else:
+        test_every_intermediate_matches_autograd(13, 1, 128, 5)
+        test_every_intermediate_matches_autograd(11, 2, 128, 9)
+        test_odd_batches_and_boards(13, 1, 128, 67)
+
+
 @pytest.mark.parametrize("n,blocks,chans,B", [(11, 1, 64, 200), (7, 2, 32, 300), (3, 1, 16, 1), (11, 2, 16, 131), (2, 1, 64, 3),
                                               (11, 1, 128, 131), (3, 1, 256, 1), (9, 2, 256, 70), (13, 1, 128, 67),
                                               (11, 2, 64, 257), (5, 2, 16, 1031), (9, 1, 128, 261), (5, 2, 256, 515)])
