@@ -158,8 +158,9 @@ def test_native_training_step_floor():
 
 
 def test_wide_training_step_floor():
-    """The hand-written step at BASELINE configs[4]'s network (19x256 on 13x13, batch 128): <= 11.6 ms per step with the
-    inputs resident (measured 10.1-10.6 box to box on two streams; the stock kernels captured as a HIP graph take 33)."""
+    """The hand-written step at BASELINE configs[4]'s network (19x256 on 13x13, batch 128): <= 10.9 ms per step with the
+    inputs resident (measured 9.6-10.0 box to box on two streams with k_tw_wgrad2, 10.2-10.4 with k_tw_wgrad; the stock
+    kernels captured as a HIP graph take 33)."""
     f = box_factor()
     from azalea_amd.native_train import NativeTrainStep
     dev = "cuda:0"
@@ -194,4 +195,4 @@ def test_wide_training_step_floor():
         ms = min(ms, e0.elapsed_time(e1) / 10)
     _record("train_step_wide", {"ms_per_step": ms, "shape": "19x256 on 13x13, batch 128"})
     step.close()
-    assert ms <= 11.6 * f, (ms, f)
+    assert ms <= 10.9 * f, (ms, f)
