@@ -1025,7 +1025,10 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
         if (TRAIN == 2) {
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-            if (lane == 0) atomicMax(F.gmax, __float_as_uint(vmax));
+            // ONE atomic per block, below (through LDS with the channel sums).  One per WAVE -- 2 048 atomics on one word at
+            // the end of a launch whose blocks all finish together -- was 16 of this kernel's 80 us (round 6, ablation:
+            // profiles/r6_train_wide_ab.txt 9)
+            if (!stat && lane == 0) atomicMax(F.gmax + ((blockIdx.y * gridDim.x + blockIdx.x) & 31), __float_as_uint(vmax));
         }
         if (stat) {
             // a channel's rows sit in the 16 lanes li of one lane group lh and in both position waves: lanes first
@@ -1049,11 +1052,15 @@ __device__ __forceinline__ void conv_wide_s16_body(const NetDev &P, int layer, c
                     for (int j = 0; j < 8; ++j)
                         sst[wm * BC + 16 * NT * wn + 32 * np + 8 * lh + j] = make_float2(s1[np][j], s2[np][j]);
             }
+            float *wmax = reinterpret_cast<float *>(sst + 2 * BC);     // [4]: the waves' max |g|
+            if (TRAIN == 2 && lane == 0) wmax[wave] = vmax;
             __syncthreads();
             if (tid < BC) {
                 const float2 a = sst[tid], b = sst[BC + tid];
                 stat[(size_t)e * C + co_base + tid] = make_float2(a.x + b.x, a.y + b.y);
             }
+            if (TRAIN == 2 && tid == 0)      // F.gmax: 32 slots of this layer (train_kernels.hip: TW_GSLOTS) -- 512 blocks, 16 atomics a word
+                atomicMax(F.gmax + ((blockIdx.y * gridDim.x + blockIdx.x) & 31), __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
         }
         return;
     } else {

@@ -55,6 +55,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // BOTH tower blocks of some CU happened to have gone: 690 us and 166 us a step where the kernels take 12 and 13 alone
 // (profiles/r6_train_loop_overlap_timeline.txt).  With 8 waves a block fits the freed half; alone they cost +1-2 us.
 #define TRN_MID_THREADS 512
+#define TW_GSLOTS 32
 #define TRN_REP 8                  // copies of the small f64-atomic accumulators
 #define TRN_WG_GROUPS 64          // k_trn_wgrad: board groups (x 4 channel-tile pairs at C = 64: 256 workgroups)
 #define TRN_PRESUM_BATCH 256      // above this batch a totals kernel sums a layer's per-board partial pairs once (see k_trn_totals)
@@ -107,6 +108,8 @@ struct TrnDev {
     unsigned short *Wf16[TRN_MAXL + 1];   // (index 1..L) forward filters as hi / lo f16 MFMA fragments (ROLE_FWD16)
     unsigned short *Wb16[TRN_MAXL + 1];   // the same for the backward-data pass (transposed, taps flipped)
     unsigned int *gmax;                   // [L + 1] bits of max |g_l| (non-negative floats order as their bits)
+    unsigned int *gslots;                 // wide step: [L + 1][TW_GSLOTS] -- the backward convolution's blocks file max |g_{l-1}| by
+                                          // atomicMax on slot (block & 31) instead of all on one word; k_tw_bnbwd folds them
     // the last tower layer's tensors once more, as plain members: P.raw[P.L] is two dependent scalar loads
     float *rawL, *actL, *actLm2, *gL;
     const float *bnwL, *bnbL;
@@ -766,6 +769,8 @@ __device__ __forceinline__ void trn_conv_body(const ConvPtrs &A, const TrnDev &P
         for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
         if (lane == 0) red[wave] = vmax;
         __syncthreads();
+        // (one atomic per block on ONE word: 256 of them cost ~2 us at the end of a 13 us launch -- but spread over 32 slot
+        // words, as the wide step does, the consumers' slot reads cost more: 0.512 vs 0.503 ms a step, round 6)
         if (tid == 64)           // (a NaN's bits are above every finite float's: the consumers then take scale 1)
             atomicMax(&P.gmax[l - 1], __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
         if (tid < CHo) {
@@ -1838,6 +1843,7 @@ __global__ __launch_bounds__(256) void k_trn_prep(TrnDev P) {
             P.stemT[e] = sum;
         }
         if (e <= (size_t)P.L) P.gmax[e] = 0u;
+        if (P.gslots && e < (size_t)(P.L + 1) * TW_GSLOTS) P.gslots[e] = 0u;
         if (e < (size_t)12 + C * 36) P.embw1_old[e] = e < 12 ? P.emb[e] : P.w1[e - 12];
         if (e == 0) {
             const unsigned int step = *P.step_ctr;
@@ -2056,12 +2062,23 @@ __global__ __launch_bounds__(256) void k_tw_bnact(TwAct A, int cells, int C, int
     }
 }
 
-struct TwBnBwd { const float *g, *raw, *bnw; const float2 *pgsum; double *sums; const unsigned int *gmax; const float4 *fsc; unsigned short *img; float2 *bsc; int presum; };
+struct TwBnBwd { const float *g, *raw, *bnw; const float2 *pgsum; double *sums; unsigned int *gmax; const float4 *fsc; unsigned short *img; float2 *bsc; int presum;
+                 const unsigned int *gslots; };       // [TW_GSLOTS] max |g_l| as the backward convolution's blocks filed it (beside *gmax: the heads' for l = L)
 __global__ __launch_bounds__(256) void k_tw_bnbwd(TwBnBwd A, int cells, int C, int B, float invN) {
     __shared__ float cA[64], cM[64], cI[64], cK0[64], cK1[64], red[4];
     __shared__ double2 sh[256];
     const int tid = threadIdx.x, c0 = blockIdx.x * 64, b = blockIdx.y;
-    const float gmax = __uint_as_float(*A.gmax), sqn = sqrtf((float)B * cells);
+    // max |g_l|: the word the heads' backward files for l = L, and the TW_GSLOTS words the backward convolution's blocks file
+    // (every lane reads slot lane & 31: each wave has all of them); block (0, 0) leaves the result in the word for later readers
+    float gmax = __uint_as_float(*A.gmax);
+    {
+        float gs = __uint_as_float(A.gslots[tid & (TW_GSLOTS - 1)]);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) gs = fmaxf(gs, __shfl_xor(gs, o));
+        gmax = fmaxf(gmax, gs);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *A.gmax = __float_as_uint(gmax);
+    }
+    const float sqn = sqrtf((float)B * cells);
     // The image has ONE scale, so every block needs a bound over all channels.  With the channels' own (mean g, mean g
     // xhat) that would be every channel's partial sums in every block; |mean g| <= max |g| and |mean g xhat| <= max |g|
     // (mean |xhat| <= 1) give |draw| <= |gamma inv| max |g| (2 + sqrt n) from what the forward pass filed -- a bound up
@@ -2498,6 +2515,7 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
     d.presum = d.B > TRN_PRESUM_BATCH;
     t->G = std::min(batch, TRN_WG_GROUPS);
     t->wide = wide;
+    if (wide && chans == 64) t->wgrad16 = true;      // (k_trn_wgrad16<64> stages boards of up to 121 cells: no fp32 filter gradient on 12x12 / 13x13)
     // 256 channels only: at 128 the two are equal on 13x13 (4.84 vs 4.85 ms a step) and the new one loses on small boards
     // (10x128 on 9x9: 2.30 vs 2.12 ms) -- AZX_TRAIN_WGRAD2=1 forces it there, =0 switches it off
     t->wgrad2 = wide && chans >= 128 && (getenv("AZX_TRAIN_WGRAD2") ? atoi(getenv("AZX_TRAIN_WGRAD2")) != 0 : chans == 256);
@@ -2552,7 +2570,8 @@ int azx_trn_create(AzxTrain **out, int N, int blocks, int chans, int batch, int 
          (t->in_board = talloc<int32_t>(t, (size_t)B * cells)) && (t->in_legal = talloc<int32_t>(t, (size_t)B * cells)) &&
          (t->in_prob = talloc<float>(t, (size_t)B * cells)) && (t->in_reward = talloc<float>(t, B)) &&
          (t->hp_dev = talloc<float>(t, 4)) && (d.stemT = talloc<float>(t, (size_t)27 * C)) && (d.step_ctr = talloc<unsigned int>(t, 4)) &&
-         (d.gmax = talloc<unsigned int>(t, 3 * (TRN_MAXL + 2)));
+         (d.gmax = talloc<unsigned int>(t, 3 * (TRN_MAXL + 2))) &&
+         (!wide || (d.gslots = talloc<unsigned int>(t, (size_t)(TRN_MAXL + 2) * TW_GSLOTS)));
     if (ok) ok = hipHostMalloc((void **)&t->hp_ring, (size_t)TRN_HP_SLOTS * 4 * sizeof(float)) == hipSuccess &&
                  hipEventCreateWithFlags(&t->ring_ev[0], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&t->ring_ev[1], hipEventDisableTiming) == hipSuccess;
@@ -2991,7 +3010,7 @@ __global__ __launch_bounds__(256) void k_tw_wgrad(TwWgrad A, int N, int B, int G
 // epilogue operands requested three tiles at a time, 167 instead of 214 registers -- the combination that ships is the best).
 template <int C>
 __global__ __launch_bounds__(512) void k_tw_wgrad2(TwWgrad A, int N, int B, int G) {
-    constexpr int NT = C / 32, NT2 = C / 64, PPP = 24, ITER = (169 * PPP + 511) / 512;      // pieces per position: 8 draw + 2 x 8 input
+    constexpr int NT2 = C / 64, PPP = 24, ITER = (169 * PPP + 511) / 512;      // pieces per position: 8 draw + 2 x 8 input
     extern __shared__ __align__(16) float lds[];
     const int cells = N * N, KR = N * 16, BR = (N + 3) * 16;
     unsigned char *Dh = reinterpret_cast<unsigned char *>(lds), *Dl = Dh + (size_t)KR * 64;      // [KR][32] f16 draw hi / lo
@@ -3165,7 +3184,7 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
     for (int l = L; l >= 1; --l) {
         // (sum g_l, sum g_l xhat_l) come from the partials of k_tw_heads_bwd (l = L) / the backward convolution's epilogue
         const TwBnBwd bb = {t->g[l], t->raw[l], d.bn_w[l], d.pgsum + (size_t)l * B * C, d.sums + (size_t)l * C * 4, d.gmax + l,
-                            d.fsc + l, t->D16[l], d.bsc + l, d.presum};
+                            d.fsc + l, t->D16[l], d.bsc + l, d.presum, d.gslots + (size_t)l * TW_GSLOTS};
         totals(d.pgsum, l, 2);
         hipLaunchKernelGGL(k_tw_bnbwd, eg, eb, 0, st, bb, cells, C, B, d.invN);
         // draw_l's image is complete: the filter gradient of layer l runs beside the rest of the data chain
@@ -3178,6 +3197,8 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
             const WgradPtrs wq = {t->g[l], t->raw[l], t->act[l - 1], d.bn_w[l]};
             hipLaunchKernelGGL(k_trn_wgrad16<C>, dim3(NT * NT, G), dim3(256), wg16_lds, ws, wq, l, G, d);
         }
+        // (the update right behind its filter gradient on that stream: all 38 updates after the last gradient, over both
+        // streams, measured 10.15 vs 9.94 ms a step)
         hipLaunchKernelGGL(k_tw_update_conv, dim3(C * C / 256), dim3(256), 0, ws, d, t->conv_seg[l], G);
         const bool has_skip = ((l - 1) & 1) == 0 && l + 1 <= L;
         // conv^T with the ReLU mask, the skip gradient, g_{l-1}'s per-board (sum g, sum g xhat) and max |g| in its epilogue
@@ -3186,7 +3207,7 @@ static int enqueue_step_wide(AzxTrain *t, hipStream_t st, hipStream_t side, bool
         if (int rc = azx_net_wide_train_conv_bwd(N, C, t->Ww16b[l], t->D16[l], t->g[l - 1], B, &d.bsc[l].y,
                                                  d.pgsum + (size_t)(l - 1) * B * C, t->relu_mask[l - 1], t->raw[l - 1],
                                                  has_skip ? t->g[l + 1] : nullptr, d.sums + (size_t)(l - 1) * C * 4, d.invN,
-                                                 d.gmax + (l - 1), st))
+                                                 d.gslots + (size_t)(l - 1) * TW_GSLOTS, st))
             return tfail(rc, "train: launching a wide backward convolution failed");
     }
     totals(d.pgsum, 0, 2);
