@@ -22,7 +22,7 @@ GPU and one process:
 What it buys on ONE GPU, measured (6x64 on 11x11, 4096 games, 400 sims, batch 128, 10x oversampling;
 tools/bench_train_loop.py over whole refill cycles, 4 800 steps, three alternating runs on one box,
 profiles/r6_train_loop_overlap.json): **inline 638-692 steps/s, play-ahead 645-679; 634 vs 689 and 667 vs 735 on two other
-boxes -- 0.96-1.10x, nothing that survives box variance.**  (A first reading of
+boxes -- 0.95-1.10x, nothing that survives box variance.**  (A first reading of
 "1.11x" came from 1 600-step windows, which hold 4 or 5 refills of a third of a second each by chance.)  The timeline
 (tools/prof_overlap.sh, profiles/r6_train_loop_overlap_timeline.txt) says why: the two sides ARE resident together
 66-69 % of the time and the tower does not slow down (7.7 ms a launch either way), but the training step does, 0.50 ->
