@@ -2996,18 +2996,18 @@ __global__ __launch_bounds__(256) void k_tw_wgrad(TwWgrad A, int N, int B, int G
     }
 }
 
-// k_tw_wgrad with TWO ci tiles per block and SIX owner waves (VERDICT r5 #4a): a block is (32 co, 64 ci) x a group of
-// boards, 512 threads -- waves 0..5 own (ci tile w / 3, tap column w % 3) with three accumulator tiles each, waves 6 and 7
-// only stage; draw's slice is staged ONCE for both ci tiles (92 KB of LDS: one block per CU, six matrix waves on its four
-// SIMDs where two resident blocks of k_tw_wgrad have six with a SIMD left idle).  Same operand layout, k-loop and partial
-// copies as k_tw_wgrad; (C / 32) x (C / 64) tile pairs per board group.  Measured (19x256 on 13x13, batch 128; profiles/
-// r6_train_wide_ab.txt 8): the kernel alone 86.9 vs 90.6 us -- and the STEP on its two streams 9.6 vs 10.4 ms: one 92 KB
-// block with 8 waves leaves a CU room for a data-chain block (46.5 KB, 4 waves) beside it, two 59 KB blocks did not, so the
-// filter gradients now really run UNDER the backward chain.  The default at 256 channels (AZX_TRAIN_WGRAD2=0 / 1 overrides;
-// k_tw_wgrad stays the kernel of 64 and 128 channels).  Capped at 168 registers (so that two of its waves and a 167-register
-// data-chain wave would fit a SIMD together) it spills 12 bytes a lane and the step is no faster: 9.89 vs 9.82 ms.  Same box,
-// three alternating runs: 9.65 ms with it against 10.33 with k_tw_wgrad (and 9.76 / 10.02 with the backward convolution's
-// epilogue operands requested three tiles at a time, 167 instead of 214 registers -- the combination that ships is the best).
+// k_tw_wgrad with TWO ci tiles per block (VERDICT r5 #4a): a block is (32 co, 64 ci) x a group of boards, 512 threads; draw's
+// slice is staged ONCE for both ci tiles (92 KB of LDS: one block per CU).  Waves 0..5 own a (ci tile w / 3, tap column w % 3)
+// unit with three accumulator tiles; waves w and w + 4 share a SIMD, so six whole units would load the SIMDs 26 / 26 / 13 / 13
+// row-steps a board: waves 6 and 7 take the lower rows of waves 0 and 1's units (20 / 20 / 19 / 19) and hand their sums over
+// through LDS at the end.  Same operand layout, k-loop and partial copies as k_tw_wgrad; (C / 32) x (C / 64) tile pairs per
+// board group.  The default at 256 channels (AZX_TRAIN_WGRAD2=0 / 1 overrides; k_tw_wgrad stays the kernel of 64 and 128).
+// Measured (19x256 on 13x13, batch 128; profiles/r6_train_wide_ab.txt 8, 11, 12): the kernel alone 86.9 vs 90.6 us with whole
+// units, 84 with the rows balanced -- and the STEP on its two streams 9.6 vs 10.4 ms.  Not because it shares a SIMD with the
+// backward convolution (2 x 176 + 216 registers exceed 512; a build in which they fit, 2 x 168 + 168, measures the same
+// step): one 8-wave block per CU leaves room for the data chain's elementwise and update blocks and the two chains take
+// turns per CU at block granularity.  The balanced rows gain 7 % alone and nothing in the step (the idle SIMD halves were
+// already used by the other stream's blocks).  Capped at 168 registers it spills 12 bytes a lane: 9.89 vs 9.82 ms.
 template <int C>
 __global__ __launch_bounds__(512) void k_tw_wgrad2(TwWgrad A, int N, int B, int G) {
     constexpr int NT2 = C / 64, PPP = 24, ITER = (169 * PPP + 511) / 512;      // pieces per position: 8 draw + 2 x 8 input
@@ -3044,8 +3044,11 @@ __global__ __launch_bounds__(512) void k_tw_wgrad2(TwWgrad A, int N, int B, int 
         for (int i = tid; i < (2 * KR + 4 * BR) * 64 / 16; i += 512) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const bool owner = wv < 6;
-    const int oj = owner ? wv / 3 : 0, oc = owner ? wv % 3 : 1;       // this wave's ci tile and tap column
+    // waves 0..5 own (ci tile, tap column) = (w / 3, w % 3); waves 6 and 7 take the LOWER rows of waves 0 and 1's units, so
+    // that every SIMD (waves w, w + 4) has 19-20 row-steps of matrix work per board instead of 26 / 26 / 13 / 13
+    const int unit = wv < 6 ? wv : wv - 6;
+    const int oj = unit / 3, oc = unit % 3;       // this wave's ci tile and tap column
+    const int s_lo = wv >= 6 ? (N + 1) / 2 : 0, s_hi = wv < 2 ? (N + 1) / 2 : N;
     f32x16 acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -3069,12 +3072,13 @@ __global__ __launch_bounds__(512) void k_tw_wgrad2(TwWgrad A, int N, int B, int 
         }
         __syncthreads();
         if (b + G < B) request(b + G);                 // travels under this board's k-loop
-        if (owner) {
-            f16x8 dhi = tr_frag(Dh + frag_off), dlo = tr_frag(Dl + frag_off);
-            f16x8 h0 = tr_frag(Bh + col_off - 16 * 64), l0 = tr_frag(Bl + col_off - 16 * 64);
-            f16x8 h1 = tr_frag(Bh + col_off), l1 = tr_frag(Bl + col_off);
-            f16x8 h2 = tr_frag(Bh + col_off + 16 * 64), l2 = tr_frag(Bl + col_off + 16 * 64);
-            for (int s = 0; s < N; ++s) {
+        {
+            const size_t r0 = (size_t)s_lo * 16 * 64;
+            f16x8 dhi = tr_frag(Dh + frag_off + r0), dlo = tr_frag(Dl + frag_off + r0);
+            f16x8 h0 = tr_frag(Bh + col_off - 16 * 64 + r0), l0 = tr_frag(Bl + col_off - 16 * 64 + r0);
+            f16x8 h1 = tr_frag(Bh + col_off + r0), l1 = tr_frag(Bl + col_off + r0);
+            f16x8 h2 = tr_frag(Bh + col_off + 16 * 64 + r0), l2 = tr_frag(Bl + col_off + 16 * 64 + r0);
+            for (int s = s_lo; s < s_hi; ++s) {
                 const int sn = s + 1 < N ? s + 1 : s;
                 const f16x8 ndhi = tr_frag(Dh + frag_off + (size_t)sn * 16 * 64), ndlo = tr_frag(Dl + frag_off + (size_t)sn * 16 * 64);
                 const size_t r3 = (size_t)(s + 2 <= N ? s + 2 : N) * 16 * 64;
@@ -3096,7 +3100,22 @@ __global__ __launch_bounds__(512) void k_tw_wgrad2(TwWgrad A, int N, int B, int 
     }
     float *part = A.part + (size_t)grp * ((size_t)C * C * 9);
     const int li = lane & 31, lh = lane >> 5, ci = tn2 * 64 + oj * 32 + li;
-    if (owner) {
+    // waves 6 and 7 hand their partial sums to waves 0 and 1 through LDS (the operand images are done with)
+    float *hand = lds + (size_t)(wv & 1) * (48 * 64) + lane;
+    if (wv >= 6) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hand[(u * 16 + i) * 64] = acc[u][i];
+    }
+    __syncthreads();
+    if (wv < 2) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[u][i] += hand[(u * 16 + i) * 64];
+    }
+    if (wv < 6) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int t = 3 * u + oc;
