@@ -172,7 +172,8 @@ def test_both_wide_filter_gradient_kernels_stay_green(monkeypatch, on):
 
 @pytest.mark.parametrize("n,blocks,chans,B", [(11, 1, 64, 200), (7, 2, 32, 300), (3, 1, 16, 1), (11, 2, 16, 131), (2, 1, 64, 3),
                                               (11, 1, 128, 131), (3, 1, 256, 1), (9, 2, 256, 70), (13, 1, 128, 67),
-                                              (11, 2, 64, 257), (5, 2, 16, 1031), (9, 1, 128, 261), (5, 2, 256, 515)])
+                                              (11, 2, 64, 257), (5, 2, 16, 1031), (9, 1, 128, 261), (5, 2, 256, 515),
+                                              (12, 1, 256, 9), (4, 1, 256, 3), (6, 1, 256, 20)])     # even boards: k_tw_wgrad2's row halves are N / 2 + N / 2
 def test_odd_batches_and_boards(n, blocks, chans, B):
     """Batches that are not a multiple of anything the kernels tile by -- more boards than one round of partial-sum
     loads covers (> 128), more than TRN_PRESUM_BATCH = 256 (the batch sums then come from k_trn_totals behind every
